@@ -1,0 +1,1026 @@
+/*
+ * gs_oracle.c — CPU ORACLE (test infrastructure; see gs_oracle.h for scope, citations and the
+ * "parity unpinned" statement for rows x1-x5).  Plain C11, single precision, written order,
+ * no contraction.  Build: oracle/Makefile.
+ */
+#include "gs_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------------------------------ */
+/* bit helpers and WGSL built-ins                                                              */
+/* ------------------------------------------------------------------------------------------ */
+
+static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+static inline uint32_t ld_u32(const uint8_t *p) { uint32_t u; memcpy(&u, p, 4); return u; }
+static inline float ld_f32(const uint8_t *p) { float f; memcpy(&f, p, 4); return f; }
+
+/* half 2.7.1 f16::from_f32 (call sites gaussian_config.rs:59,227): IEEE RNE. */
+static uint16_t f32_to_f16(float f) {
+    uint32_t x = f2u(f);
+    uint32_t sign = (x >> 16) & 0x8000u;
+    uint32_t mant = x & 0x7fffffu;
+    int exp = (int)((x >> 23) & 0xffu);
+    if (exp == 0xff) return (uint16_t)(sign | 0x7c00u | (mant ? (0x200u | (mant >> 13)) : 0u));
+    int e = exp - 127 + 15;
+    if (e >= 31) return (uint16_t)(sign | 0x7c00u);
+    if (e <= 0) {
+        if (e < -10) return (uint16_t)sign;
+        mant |= 0x800000u;
+        int shift = 14 - e;
+        uint32_t h = mant >> shift;
+        uint32_t rem = mant & ((1u << shift) - 1u);
+        uint32_t half = 1u << (shift - 1);
+        if (rem > half || (rem == half && (h & 1u))) h++;
+        return (uint16_t)(sign | h);
+    }
+    uint32_t h = ((uint32_t)e << 10) | (mant >> 13);
+    uint32_t rem = mant & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) h++;
+    return (uint16_t)(sign | h);
+}
+
+/* WGSL unpack2x16float component: IEEE binary16 -> binary32, exact. */
+static float f16_to_f32(uint16_t h) {
+    uint32_t sign = ((uint32_t)h & 0x8000u) << 16;
+    uint32_t exp = (h >> 10) & 0x1fu;
+    uint32_t mant = h & 0x3ffu;
+    if (exp == 0) {
+        if (mant == 0) return u2f(sign);
+        /* subnormal: value = mant * 2^-24 */
+        float v = (float)mant * 5.9604644775390625e-08f;
+        return sign ? -v : v;
+    }
+    if (exp == 31) return u2f(sign | 0x7f800000u | (mant << 13));
+    return u2f(sign | ((exp + 112u) << 23) | (mant << 13));
+}
+
+static void unpack2x16float(uint32_t w, float out[2]) {
+    out[0] = f16_to_f32((uint16_t)(w & 0xffffu));
+    out[1] = f16_to_f32((uint16_t)(w >> 16));
+}
+
+/* WGSL unpack4x8snorm: max(i8 / 127, -1) */
+static void unpack4x8snorm(uint32_t w, float out[4]) {
+    for (int i = 0; i < 4; i++) {
+        int8_t b = (int8_t)((w >> (8 * i)) & 0xffu);
+        out[i] = fmaxf((float)b / 127.0f, -1.0f);
+    }
+}
+
+/* WGSL unpack4x8unorm: u8 / 255 */
+static void unpack4x8unorm(uint32_t w, float out[4]) {
+    for (int i = 0; i < 4; i++) out[i] = (float)((w >> (8 * i)) & 0xffu) / 255.0f;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* layouts — src/buffer/gaussian.rs:301-384                                                    */
+/* ------------------------------------------------------------------------------------------ */
+
+size_t gso_sh_bytes(int sh) {
+    switch (sh) {
+    case GSO_SH_SINGLE: return 180; /* [Vec3;15]            gaussian_config.rs:37 */
+    case GSO_SH_HALF: return 92;    /* [f16; 3*15+1]        gaussian_config.rs:54 */
+    case GSO_SH_NORM8: return 48;   /* [i8; 3*15+3]         gaussian_config.rs:90 */
+    default: return 0;              /* ()                   gaussian_config.rs:127 */
+    }
+}
+
+size_t gso_cov_bytes(int cov) {
+    switch (cov) {
+    case GSO_COV_ROT_SCALE: return 28; /* [f32;7] gaussian_config.rs:171 */
+    case GSO_COV_SINGLE: return 24;    /* [f32;6] gaussian_config.rs:193 */
+    default: return 12;                /* [f16;6] gaussian_config.rs:224 */
+    }
+}
+
+/* padding_size table, src/buffer/gaussian.rs:373-384 (in f32 units) */
+static const int k_padding[4][3] = {
+    {0, 1, 0}, /* Single: RotScale, Single, Half */
+    {2, 3, 2}, /* Half */
+    {1, 2, 1}, /* Norm8 */
+    {1, 2, 1}, /* None */
+};
+
+size_t gso_pod_size(int sh, int cov) {
+    return 16 + gso_sh_bytes(sh) + gso_cov_bytes(cov) + 4u * (size_t)k_padding[sh][cov];
+}
+
+/* GaussianPod::features(), src/buffer/gaussian.rs:270-286: order sh_single, sh_half, sh_norm8,
+ * sh_none, cov3d_rot_scale, cov3d_single, cov3d_half */
+void gso_pod_features(int sh, int cov, int out[7]) {
+    for (int i = 0; i < 7; i++) out[i] = 0;
+    out[sh] = 1;
+    out[4 + cov] = 1;
+}
+
+/* glam Mat3::from_quat + from_diagonal + r*s + m*m^T, gaussian_config.rs:195-208 */
+static void cov3d_single_from_rot_scale(const float q[4], const float s[3], float out[6]) {
+    float x = q[0], y = q[1], z = q[2], w = q[3];
+    float x2 = x + x, y2 = y + y, z2 = z + z;
+    float xx = x * x2, xy = x * y2, xz = x * z2;
+    float yy = y * y2, yz = y * z2, zz = z * z2;
+    float wx = w * x2, wy = w * y2, wz = w * z2;
+    /* r columns */
+    float r0[3] = {1.0f - (yy + zz), xy + wz, xz - wy};
+    float r1[3] = {xy - wz, 1.0f - (xx + zz), yz + wx};
+    float r2[3] = {xz + wy, yz - wx, 1.0f - (xx + yy)};
+    /* m = r * diag(s): column j = r_j * s_j */
+    float m0[3], m1[3], m2[3];
+    for (int i = 0; i < 3; i++) {
+        m0[i] = r0[i] * s[0];
+        m1[i] = r1[i] * s[1];
+        m2[i] = r2[i] * s[2];
+    }
+    /* sigma = m * m^T: sigma[col j][row i] = m0[i]*m0[j] + m1[i]*m1[j] + m2[i]*m2[j] */
+#define SIG(i, j) ((m0[i] * m0[j] + m1[i] * m1[j]) + m2[i] * m2[j])
+    out[0] = SIG(0, 0);
+    out[1] = SIG(1, 0);
+    out[2] = SIG(2, 0);
+    out[3] = SIG(1, 1);
+    out[4] = SIG(2, 1);
+    out[5] = SIG(2, 2);
+#undef SIG
+}
+
+void gso_pack(int sh, int cov, const gso_gaussian *in, size_t n, void *out_) {
+    uint8_t *out = (uint8_t *)out_;
+    size_t stride = gso_pod_size(sh, cov);
+    size_t cov_off = 16 + gso_sh_bytes(sh);
+    for (size_t i = 0; i < n; i++) {
+        const gso_gaussian *g = &in[i];
+        uint8_t *p = out + i * stride;
+        memset(p, 0, stride);
+        memcpy(p, g->pos, 12);
+        memcpy(p + 12, g->color, 4);
+        switch (sh) {
+        case GSO_SH_SINGLE: memcpy(p + 16, g->sh, 180); break;
+        case GSO_SH_HALF:
+            for (int k = 0; k < 45; k++) {
+                uint16_t h = f32_to_f16(g->sh[k]);
+                memcpy(p + 16 + 2 * k, &h, 2);
+            }
+            break; /* element 45 = f16(0.0) = 0 */
+        case GSO_SH_NORM8:
+            for (int k = 0; k < 45; k++) {
+                /* (v * 127.0).clamp(-127.0, 127.0) as i8 — truncation toward zero, NaN -> 0 */
+                float v = g->sh[k] * 127.0f;
+                v = v < -127.0f ? -127.0f : (v > 127.0f ? 127.0f : v);
+                int8_t b = (v != v) ? 0 : (int8_t)v;
+                memcpy(p + 16 + k, &b, 1);
+            }
+            break;
+        default: break;
+        }
+        switch (cov) {
+        case GSO_COV_ROT_SCALE:
+            memcpy(p + cov_off, g->rot, 16);
+            memcpy(p + cov_off + 16, g->scale, 12);
+            break;
+        case GSO_COV_SINGLE: {
+            float c6[6];
+            cov3d_single_from_rot_scale(g->rot, g->scale, c6);
+            memcpy(p + cov_off, c6, 24);
+        } break;
+        default: {
+            float c6[6];
+            cov3d_single_from_rot_scale(g->rot, g->scale, c6);
+            for (int k = 0; k < 6; k++) {
+                uint16_t h = f32_to_f16(c6[k]);
+                memcpy(p + cov_off + 2 * k, &h, 2);
+            }
+        } break;
+        }
+    }
+}
+
+/* Into<Gaussian>, src/buffer/gaussian.rs:341-363; lossy configs panic in the reference
+ * (gaussian_config.rs:131-133,211-213,230-232) -> return -1. */
+int gso_unpack_to_gaussian(int sh, int cov, const void *pods, size_t n, gso_gaussian *out) {
+    if (sh == GSO_SH_NONE || cov != GSO_COV_ROT_SCALE) return -1;
+    const uint8_t *in = (const uint8_t *)pods;
+    size_t stride = gso_pod_size(sh, cov);
+    size_t cov_off = 16 + gso_sh_bytes(sh);
+    for (size_t i = 0; i < n; i++) {
+        const uint8_t *p = in + i * stride;
+        gso_gaussian *g = &out[i];
+        memcpy(g->pos, p, 12);
+        memcpy(g->color, p + 12, 4);
+        for (int k = 0; k < 45; k++) {
+            if (sh == GSO_SH_SINGLE) {
+                g->sh[k] = ld_f32(p + 16 + 4 * k);
+            } else if (sh == GSO_SH_HALF) {
+                uint16_t h;
+                memcpy(&h, p + 16 + 2 * k, 2);
+                g->sh[k] = f16_to_f32(h);
+            } else {
+                int8_t b;
+                memcpy(&b, p + 16 + k, 1);
+                g->sh[k] = fmaxf((float)b / 127.0f, -1.0f);
+            }
+        }
+        memcpy(g->rot, p + cov_off, 16);
+        memcpy(g->scale, p + cov_off + 16, 12);
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* WESL: src/shader/gaussian.wesl                                                              */
+/* ------------------------------------------------------------------------------------------ */
+
+/* gaussian.wesl:24-26 */
+void gso_unpack_color(const void *pod, float out[4]) {
+    unpack4x8unorm(ld_u32((const uint8_t *)pod + 12), out);
+}
+
+/* gaussian.wesl:29-77 */
+void gso_unpack_sh(int sh, const void *pod, uint32_t sh_index, float out[3]) {
+    const uint8_t *s = (const uint8_t *)pod + 16;
+    if (sh == GSO_SH_SINGLE) {
+        out[0] = ld_f32(s + 4 * (sh_index * 3));
+        out[1] = ld_f32(s + 4 * (sh_index * 3 + 1));
+        out[2] = ld_f32(s + 4 * (sh_index * 3 + 2));
+    } else if (sh == GSO_SH_HALF) {
+        uint32_t i = sh_index * 3;
+        uint32_t xi = i / 2, yi = (i + 1) / 2, zi = (i + 2) / 2;
+        float a[2], b[2];
+        if (xi == yi) {
+            unpack2x16float(ld_u32(s + 4 * xi), a);
+            unpack2x16float(ld_u32(s + 4 * zi), b);
+            out[0] = a[0];
+            out[1] = a[1];
+            out[2] = b[0];
+        } else {
+            unpack2x16float(ld_u32(s + 4 * xi), a);
+            unpack2x16float(ld_u32(s + 4 * yi), b);
+            out[0] = a[1];
+            out[1] = b[0];
+            out[2] = b[1];
+        }
+    } else if (sh == GSO_SH_NORM8) {
+        uint32_t i = sh_index * 3;
+        float v[4];
+        unpack4x8snorm(ld_u32(s + 4 * (i / 4)), v);
+        out[0] = v[i % 4];
+        unpack4x8snorm(ld_u32(s + 4 * ((i + 1) / 4)), v);
+        out[1] = v[(i + 1) % 4];
+        unpack4x8snorm(ld_u32(s + 4 * ((i + 2) / 4)), v);
+        out[2] = v[(i + 2) % 4];
+    } else {
+        out[0] = out[1] = out[2] = 0.0f;
+    }
+}
+
+/* gaussian.wesl:80-149.  `sigma = m * transpose(m)`: WGSL leaves the summation order to the
+ * implementation; fixed here as ((k=0) + (k=1)) + (k=2), the order the HIP kernels use too. */
+void gso_unpack_cov3d(int sh, int cov, const void *pod, float out[6]) {
+    const uint8_t *c = (const uint8_t *)pod + 16 + gso_sh_bytes(sh);
+    if (cov == GSO_COV_ROT_SCALE) {
+        float rx = ld_f32(c), ry = ld_f32(c + 4), rz = ld_f32(c + 8), rw = ld_f32(c + 12);
+        float sx = ld_f32(c + 16), sy = ld_f32(c + 20), sz = ld_f32(c + 24);
+        float x2 = rx + rx, y2 = ry + ry, z2 = rz + rz;
+        float xx = rx * x2, xy = rx * y2, xz = rx * z2;
+        float yy = ry * y2, yz = ry * z2, zz = rz * z2;
+        float wx = rw * x2, wy = rw * y2, wz = rw * z2;
+        float m0[3] = {(1.0f - (yy + zz)) * sx, (xy + wz) * sx, (xz - wy) * sx};
+        float m1[3] = {(xy - wz) * sy, (1.0f - (xx + zz)) * sy, (yz + wx) * sy};
+        float m2[3] = {(xz + wy) * sz, (yz - wx) * sz, (1.0f - (xx + yy)) * sz};
+        /* sigma[c][r] = sum_k m_k[r] * m_k[c]; returned [0][0],[0][1],[0][2],[1][1],[1][2],[2][2] */
+#define SIG(cc, rr) ((m0[rr] * m0[cc] + m1[rr] * m1[cc]) + m2[rr] * m2[cc])
+        out[0] = SIG(0, 0);
+        out[1] = SIG(0, 1);
+        out[2] = SIG(0, 2);
+        out[3] = SIG(1, 1);
+        out[4] = SIG(1, 2);
+        out[5] = SIG(2, 2);
+#undef SIG
+    } else if (cov == GSO_COV_SINGLE) {
+        for (int k = 0; k < 6; k++) out[k] = ld_f32(c + 4 * k);
+    } else {
+        float x[2], y[2], z[2];
+        unpack2x16float(ld_u32(c), x);
+        unpack2x16float(ld_u32(c + 4), y);
+        unpack2x16float(ld_u32(c + 8), z);
+        out[0] = x[0];
+        out[1] = x[1];
+        out[2] = y[0];
+        out[3] = y[1];
+        out[4] = z[0];
+        out[5] = z[1];
+    }
+}
+
+void gso_shader_test_gaussian(int sh, int cov, const void *pod, float out[56]) {
+    gso_unpack_color(pod, out);
+    for (uint32_t i = 0; i < 15; i++) gso_unpack_sh(sh, pod, i, out + 4 + 3 * i);
+    gso_unpack_cov3d(sh, cov, pod, out + 49);
+    out[55] = 0.0f;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* gaussian transform — buffer/gaussian_transform.rs, shader/gaussian_transform.wesl           */
+/* ------------------------------------------------------------------------------------------ */
+
+/* GaussianMaxStdDev::new, buffer/gaussian_transform.rs:63-68 */
+int gso_max_std_dev_encode(float v, uint8_t *out) {
+    if (!(v >= 0.0f && v <= 3.0f)) return -1;
+    *out = (uint8_t)(v / 3.0f * 255.0f);
+    return 0;
+}
+
+/* GaussianTransformPod::new, :178-194 with the range checks of :25-30 and :63-68 */
+int gso_gaussian_transform_new(float size, uint32_t mode, uint32_t sh_deg, int no_sh0,
+                               float max_std_dev, gso_gaussian_transform *out) {
+    uint8_t sd;
+    if (mode > 2 || sh_deg > 3) return -1;
+    if (gso_max_std_dev_encode(max_std_dev, &sd)) return -1;
+    out->size = size;
+    out->flags[0] = (uint8_t)mode;
+    out->flags[1] = (uint8_t)sh_deg;
+    out->flags[2] = no_sh0 ? 1 : 0;
+    out->flags[3] = sd;
+    return 0;
+}
+
+/* gaussian_transform.wesl:14-31; unpack4xU8: byte i = component i */
+uint32_t gso_transform_display_mode(uint32_t flags) { return flags & 0xffu; }
+uint32_t gso_transform_sh_deg(uint32_t flags) { return (flags >> 8) & 0xffu; }
+uint32_t gso_transform_no_sh0(uint32_t flags) { return ((flags >> 16) & 0xffu) != 0u; }
+float gso_transform_max_std_dev(uint32_t flags) {
+    return (float)((flags >> 24) & 0xffu) / 255.0f * 3.0f;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* model transform — shader/model_transform.wesl                                               */
+/* ------------------------------------------------------------------------------------------ */
+
+void gso_model_transform_new(const float pos[3], const float rot[4], const float scale[3],
+                             gso_model_transform *out) {
+    memset(out, 0, sizeof(*out));
+    memcpy(out->pos, pos, 12);
+    memcpy(out->rot, rot, 16);
+    memcpy(out->scale, scale, 12);
+}
+
+typedef struct { float xx, xy, xz, yy, yz, zz, wx, wy, wz; } quat_terms;
+
+static quat_terms quat_terms_of(const float r[4]) {
+    quat_terms t;
+    float x2 = r[0] + r[0], y2 = r[1] + r[1], z2 = r[2] + r[2];
+    t.xx = r[0] * x2; t.xy = r[0] * y2; t.xz = r[0] * z2;
+    t.yy = r[1] * y2; t.yz = r[1] * z2; t.zz = r[2] * z2;
+    t.wx = r[3] * x2; t.wy = r[3] * y2; t.wz = r[3] * z2;
+    return t;
+}
+
+/* model_transform.wesl:105-143, column-major 3x3: out[3*c + r] */
+void gso_model_scale_rot_mat(const gso_model_transform *m, float out[9]) {
+    quat_terms t = quat_terms_of(m->rot);
+    float sx = m->scale[0], sy = m->scale[1], sz = m->scale[2];
+    out[0] = (1.0f - (t.yy + t.zz)) * sx;
+    out[1] = (t.xy + t.wz) * sx;
+    out[2] = (t.xz - t.wy) * sx;
+    out[3] = (t.xy - t.wz) * sy;
+    out[4] = (1.0f - (t.xx + t.zz)) * sy;
+    out[5] = (t.yz + t.wx) * sy;
+    out[6] = (t.xz + t.wy) * sz;
+    out[7] = (t.yz - t.wx) * sz;
+    out[8] = (1.0f - (t.xx + t.yy)) * sz;
+}
+
+/* model_transform.wesl:64-102 */
+void gso_model_transform_inv_sr_mat(const gso_model_transform *m, float out[9]) {
+    quat_terms t = quat_terms_of(m->rot);
+    float sx = m->scale[0], sy = m->scale[1], sz = m->scale[2];
+    out[0] = (1.0f - (t.yy + t.zz)) / sx;
+    out[1] = (t.xy - t.wz) / sy;
+    out[2] = (t.xz + t.wy) / sz;
+    out[3] = (t.xy + t.wz) / sx;
+    out[4] = (1.0f - (t.xx + t.zz)) / sy;
+    out[5] = (t.yz - t.wx) / sz;
+    out[6] = (t.xz - t.wy) / sx;
+    out[7] = (t.yz + t.wx) / sy;
+    out[8] = (1.0f - (t.xx + t.yy)) / sz;
+}
+
+/* model_transform.wesl:18-61, column-major 4x4: out[4*c + r] */
+void gso_model_transform_mat(const gso_model_transform *m, float out[16]) {
+    float sr[9];
+    gso_model_scale_rot_mat(m, sr);
+    for (int c = 0; c < 3; c++) {
+        out[4 * c + 0] = sr[3 * c + 0];
+        out[4 * c + 1] = sr[3 * c + 1];
+        out[4 * c + 2] = sr[3 * c + 2];
+        out[4 * c + 3] = 0.0f;
+    }
+    out[12] = m->pos[0];
+    out[13] = m->pos[1];
+    out[14] = m->pos[2];
+    out[15] = 1.0f;
+}
+
+/* mat4 * vec4 / mat3 * vec3, order fixed as ((c0 + c1) + c2) + c3 */
+static inline void mat4_mul_point(const float m[16], const float p[3], float out[4]) {
+    for (int r = 0; r < 4; r++)
+        out[r] = ((m[r] * p[0] + m[4 + r] * p[1]) + m[8 + r] * p[2]) + m[12 + r];
+}
+static inline void mat3_mul_vec(const float m[9], const float v[3], float out[3]) {
+    for (int r = 0; r < 3; r++) out[r] = (m[r] * v[0] + m[3 + r] * v[1]) + m[6 + r] * v[2];
+}
+
+/* model_transform.wesl:13-15 */
+void gso_model_to_world(const gso_model_transform *m, const float p[3], float out[4]) {
+    float mat[16];
+    gso_model_transform_mat(m, mat);
+    mat4_mul_point(mat, p, out);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* fixtures                                                                                    */
+/* ------------------------------------------------------------------------------------------ */
+
+/* tests/common/given.rs:48-81 */
+void gso_given_gaussian_with_seed(uint32_t seed, gso_gaussian *out) {
+    float base = (float)seed;
+    float q[4] = {base + 0.1f, base + 0.2f, base + 0.3f, base + 0.4f};
+    float len = sqrtf(((q[0] * q[0] + q[1] * q[1]) + q[2] * q[2]) + q[3] * q[3]);
+    for (int i = 0; i < 4; i++) out->rot[i] = q[i] / len;
+    out->pos[0] = base + 1.1f;
+    out->pos[1] = base + 2.2f;
+    out->pos[2] = base + 3.3f;
+    out->color[0] = (uint8_t)fmodf(base + 11.0f, 256.0f);
+    out->color[1] = (uint8_t)fmodf(base + 22.0f, 256.0f);
+    out->color[2] = (uint8_t)fmodf(base + 33.0f, 256.0f);
+    out->color[3] = (uint8_t)fmodf(base + 44.0f, 256.0f);
+    for (int i = 0; i < 15; i++) {
+        float sh_base = base + ((float)i * 0.3f);
+        out->sh[3 * i + 0] = fmodf(sh_base + 0.1f, 2.0f) - 1.0f;
+        out->sh[3 * i + 1] = fmodf(sh_base + 0.2f, 2.0f) - 1.0f;
+        out->sh[3 * i + 2] = fmodf(sh_base + 0.3f, 2.0f) - 1.0f;
+    }
+    out->scale[0] = base + 0.12f;
+    out->scale[1] = base + 0.34f;
+    out->scale[2] = base + 0.56f;
+}
+
+static uint8_t sat_u8(float v) { /* Rust `as u8`: truncating, saturating, NaN -> 0 */
+    if (!(v > 0.0f)) return 0;
+    if (v >= 255.0f) return 255;
+    return (uint8_t)v;
+}
+
+/* src/gaussian.rs:70-92 */
+void gso_gaussian_from_ply(const gso_ply_pod *ply, gso_gaussian *out) {
+    memcpy(out->pos, ply->pos, 12);
+    float q[4] = {ply->rot[1], ply->rot[2], ply->rot[3], ply->rot[0]};
+    float len = sqrtf(((q[0] * q[0] + q[1] * q[1]) + q[2] * q[2]) + q[3] * q[3]);
+    for (int i = 0; i < 4; i++) out->rot[i] = q[i] / len;
+    for (int i = 0; i < 3; i++) out->scale[i] = expf(ply->scale[i]);
+    for (int i = 0; i < 3; i++) {
+        float v = (ply->color[i] * 0.2820948f + 0.5f) * 255.0f;
+        v = fminf(fmaxf(v, 0.0f), 255.0f);
+        out->color[i] = sat_u8(v);
+    }
+    {
+        float a = (1.0f / (1.0f + expf(-ply->alpha))) * 255.0f;
+        a = fminf(fmaxf(a, 0.0f), 255.0f);
+        out->color[3] = sat_u8(a);
+    }
+    for (int i = 0; i < 15; i++) {
+        out->sh[3 * i + 0] = ply->sh[i];
+        out->sh[3 * i + 1] = ply->sh[i + 15];
+        out->sh[3 * i + 2] = ply->sh[i + 30];
+    }
+}
+
+/* src/gaussian.rs:95-125 */
+void gso_gaussian_to_ply(const gso_gaussian *g, gso_ply_pod *out) {
+    memcpy(out->pos, g->pos, 12);
+    out->rot[0] = g->rot[3];
+    out->rot[1] = g->rot[0];
+    out->rot[2] = g->rot[1];
+    out->rot[3] = g->rot[2];
+    for (int i = 0; i < 3; i++) out->scale[i] = logf(g->scale[i]);
+    float rgba[4];
+    for (int i = 0; i < 4; i++) rgba[i] = (float)g->color[i] / 255.0f;
+    for (int i = 0; i < 3; i++) out->color[i] = (rgba[i] - 0.5f) / 0.2820948f;
+    out->alpha = -logf(1.0f / rgba[3] - 1.0f);
+    for (int i = 0; i < 15; i++) {
+        out->sh[i] = g->sh[3 * i + 0];
+        out->sh[i + 15] = g->sh[3 * i + 1];
+        out->sh[i + 30] = g->sh[3 * i + 2];
+    }
+    out->normal[0] = 0.0f;
+    out->normal[1] = 0.0f;
+    out->normal[2] = 1.0f;
+}
+
+static const char *k_ply_props[62] = {
+    "x", "y", "z", "nx", "ny", "nz", "f_dc_0", "f_dc_1", "f_dc_2",
+    "f_rest_0", "f_rest_1", "f_rest_2", "f_rest_3", "f_rest_4", "f_rest_5", "f_rest_6", "f_rest_7",
+    "f_rest_8", "f_rest_9", "f_rest_10", "f_rest_11", "f_rest_12", "f_rest_13", "f_rest_14",
+    "f_rest_15", "f_rest_16", "f_rest_17", "f_rest_18", "f_rest_19", "f_rest_20", "f_rest_21",
+    "f_rest_22", "f_rest_23", "f_rest_24", "f_rest_25", "f_rest_26", "f_rest_27", "f_rest_28",
+    "f_rest_29", "f_rest_30", "f_rest_31", "f_rest_32", "f_rest_33", "f_rest_34", "f_rest_35",
+    "f_rest_36", "f_rest_37", "f_rest_38", "f_rest_39", "f_rest_40", "f_rest_41", "f_rest_42",
+    "f_rest_43", "f_rest_44", "opacity", "scale_0", "scale_1", "scale_2", "rot_0", "rot_1", "rot_2",
+    "rot_3"};
+
+/* src/source_format/ply.rs:292-384, Inria fast path only (binary_little_endian, 62 float
+ * properties in PLY_PROPERTIES order).  -1 malformed, -2 not the Inria layout, -3 truncated. */
+long gso_read_inria_ply(const uint8_t *bytes, size_t len, gso_ply_pod *out, size_t cap) {
+    size_t pos = 0;
+    long count = -1;
+    int prop = 0, little = 0, in_vertex = 0, line_no = 0, ended = 0;
+    while (pos < len) {
+        size_t eol = pos;
+        while (eol < len && bytes[eol] != '\n') eol++;
+        if (eol >= len) return -1;
+        char line[256];
+        size_t l = eol - pos;
+        if (l >= sizeof(line)) return -1;
+        memcpy(line, bytes + pos, l);
+        line[l] = 0;
+        if (l && line[l - 1] == '\r') line[l - 1] = 0;
+        pos = eol + 1;
+        if (line_no++ == 0) {
+            if (strcmp(line, "ply")) return -1;
+            continue;
+        }
+        if (!strncmp(line, "format ", 7)) {
+            little = !strncmp(line + 7, "binary_little_endian", 20);
+        } else if (!strncmp(line, "element ", 8)) {
+            in_vertex = !strncmp(line + 8, "vertex ", 7);
+            if (in_vertex) count = strtol(line + 15, NULL, 10);
+        } else if (!strncmp(line, "property ", 9)) {
+            if (in_vertex) {
+                if (prop >= 62) return -2;
+                char expect[64];
+                strcpy(expect, "float ");
+                strcat(expect, k_ply_props[prop]);
+                if (strcmp(line + 9, expect)) return -2;
+                prop++;
+            }
+        } else if (!strcmp(line, "end_header")) {
+            ended = 1;
+            break;
+        }
+    }
+    if (!ended || count < 0) return -1;
+    if (!little || prop != 62) return -2;
+    if (!out) return count;
+    if ((size_t)count > cap) count = (long)cap;
+    if (len - pos < (size_t)count * sizeof(gso_ply_pod)) return -3;
+    memcpy(out, bytes + pos, (size_t)count * sizeof(gso_ply_pod));
+    return count;
+}
+
+/* src/compute_bundle.rs:131 */
+uint32_t gso_dispatch_workgroups(uint32_t count, uint32_t workgroup_size) {
+    return count / workgroup_size + (count % workgroup_size != 0u);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* EXTERNAL spec rows x1-x5 (PARITY UNPINNED — normative definition)             */
+/* ------------------------------------------------------------------------------------------ */
+
+/* exp for x <= 0, bit-reproducible on any IEEE machine with fmaf.
+ * max relative error vs exp(): 8e-7 on [-5.6, 0]. */
+float gso_exp(float x) {
+    if (x < -87.0f) return 0.0f;
+    float t = x * 1.44269504088896340736f;
+    float n = rintf(t);
+    float f = t - n;
+    float p = 0x1.5f0896p-10f;
+    p = fmaf(p, f, 0x1.3cbf6cp-7f);
+    p = fmaf(p, f, 0x1.c6af6cp-5f);
+    p = fmaf(p, f, 0x1.ebfa4ap-3f);
+    p = fmaf(p, f, 0x1.62e430p-1f);
+    p = fmaf(p, f, 1.0f);
+    return ldexpf(p, (int)n);
+}
+
+/* glam Mat4::look_at_rh + pinhole intrinsics from a vertical field of view (host-side helper,
+ * evaluated in double then rounded once so that it is not part of the bit-exact contract). */
+void gso_camera_look_at(const float eye[3], const float target[3], const float up[3],
+                        float vfov_rad, uint32_t width, uint32_t height, float near_plane,
+                        float far_plane, gso_camera *out) {
+    double f[3], s[3], u[3];
+    double fl = 0, sl = 0;
+    for (int i = 0; i < 3; i++) { f[i] = (double)target[i] - (double)eye[i]; fl += f[i] * f[i]; }
+    fl = sqrt(fl);
+    for (int i = 0; i < 3; i++) f[i] /= fl;
+    s[0] = f[1] * up[2] - f[2] * up[1];
+    s[1] = f[2] * up[0] - f[0] * up[2];
+    s[2] = f[0] * up[1] - f[1] * up[0];
+    for (int i = 0; i < 3; i++) sl += s[i] * s[i];
+    sl = sqrt(sl);
+    for (int i = 0; i < 3; i++) s[i] /= sl;
+    u[0] = s[1] * f[2] - s[2] * f[1];
+    u[1] = s[2] * f[0] - s[0] * f[2];
+    u[2] = s[0] * f[1] - s[1] * f[0];
+    double e[3] = {eye[0], eye[1], eye[2]};
+    double ds = s[0] * e[0] + s[1] * e[1] + s[2] * e[2];
+    double du = u[0] * e[0] + u[1] * e[1] + u[2] * e[2];
+    double df = f[0] * e[0] + f[1] * e[1] + f[2] * e[2];
+    float *v = out->view;
+    v[0] = (float)s[0]; v[1] = (float)u[0]; v[2] = (float)-f[0]; v[3] = 0.0f;
+    v[4] = (float)s[1]; v[5] = (float)u[1]; v[6] = (float)-f[1]; v[7] = 0.0f;
+    v[8] = (float)s[2]; v[9] = (float)u[2]; v[10] = (float)-f[2]; v[11] = 0.0f;
+    v[12] = (float)-ds; v[13] = (float)-du; v[14] = (float)df; v[15] = 1.0f;
+    memcpy(out->pos, eye, 12);
+    double focal = 0.5 * (double)height / tan(0.5 * (double)vfov_rad);
+    out->fx = (float)focal;
+    out->fy = (float)focal;
+    out->cx = 0.5f * (float)width;
+    out->cy = 0.5f * (float)height;
+    out->near_plane = near_plane;
+    out->far_plane = far_plane;
+    out->width = width;
+    out->height = height;
+    out->background[0] = out->background[1] = out->background[2] = 0.0f;
+}
+
+/* real SH basis (Kerbl et al. 2023), coefficient k of this data model is the
+ * k-th *rest* coefficient (CHANGELOG.md:34,41), DC is pre-baked in color (gaussian.rs:77-81). */
+static void eval_sh(int sh, const void *pod, uint32_t deg, int no_sh0, const float d[3],
+                    float rgb[3]) {
+    float col[4];
+    gso_unpack_color(pod, col);
+    float acc[3];
+    for (int c = 0; c < 3; c++) acc[c] = no_sh0 ? 0.0f : col[c];
+    if (deg >= 1) {
+        float x = d[0], y = d[1], z = d[2];
+        float s0[3], s1[3], s2[3];
+        gso_unpack_sh(sh, pod, 0, s0);
+        gso_unpack_sh(sh, pod, 1, s1);
+        gso_unpack_sh(sh, pod, 2, s2);
+        const float C1 = 0.4886025119029199f;
+        for (int c = 0; c < 3; c++)
+            acc[c] = ((acc[c] - (C1 * y) * s0[c]) + (C1 * z) * s1[c]) - (C1 * x) * s2[c];
+        if (deg >= 2) {
+            float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            float b0 = 1.0925484305920792f * xy;
+            float b1 = -1.0925484305920792f * yz;
+            float b2 = 0.31539156525252005f * ((2.0f * zz - xx) - yy);
+            float b3 = -1.0925484305920792f * xz;
+            float b4 = 0.5462742152960396f * (xx - yy);
+            float t0[3], t1[3], t2[3], t3[3], t4[3];
+            gso_unpack_sh(sh, pod, 3, t0);
+            gso_unpack_sh(sh, pod, 4, t1);
+            gso_unpack_sh(sh, pod, 5, t2);
+            gso_unpack_sh(sh, pod, 6, t3);
+            gso_unpack_sh(sh, pod, 7, t4);
+            for (int c = 0; c < 3; c++)
+                acc[c] = ((((acc[c] + b0 * t0[c]) + b1 * t1[c]) + b2 * t2[c]) + b3 * t3[c]) +
+                         b4 * t4[c];
+            if (deg >= 3) {
+                float c0 = (-0.5900435899266435f * y) * (3.0f * xx - yy);
+                float c1 = (2.890611442640554f * xy) * z;
+                float c2 = (-0.4570457994644658f * y) * ((4.0f * zz - xx) - yy);
+                float c3 = (0.3731763325901154f * z) * ((2.0f * zz - 3.0f * xx) - 3.0f * yy);
+                float c4 = (-0.4570457994644658f * x) * ((4.0f * zz - xx) - yy);
+                float c5 = (1.445305721320277f * z) * (xx - yy);
+                float c6 = (-0.5900435899266435f * x) * (xx - 3.0f * yy);
+                float u0[3], u1[3], u2[3], u3[3], u4[3], u5[3], u6[3];
+                gso_unpack_sh(sh, pod, 8, u0);
+                gso_unpack_sh(sh, pod, 9, u1);
+                gso_unpack_sh(sh, pod, 10, u2);
+                gso_unpack_sh(sh, pod, 11, u3);
+                gso_unpack_sh(sh, pod, 12, u4);
+                gso_unpack_sh(sh, pod, 13, u5);
+                gso_unpack_sh(sh, pod, 14, u6);
+                for (int c = 0; c < 3; c++)
+                    acc[c] = ((((((acc[c] + c0 * u0[c]) + c1 * u1[c]) + c2 * u2[c]) + c3 * u3[c]) +
+                               c4 * u4[c]) + c5 * u5[c]) + c6 * u6[c];
+            }
+        }
+    }
+    for (int c = 0; c < 3; c++) rgb[c] = fmaxf(acc[c], 0.0f);
+}
+
+static inline float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
+
+/* Frame constants derived from the uniforms, evaluated once per frame. */
+typedef struct {
+    float M[16];   /* model_transform_mat */
+    float ISR[9];  /* model_transform_inv_sr_mat */
+    float WS[9];   /* W * (R_m S_m), row-major [r][c]; W = view rotation with rows 1,2 negated */
+    float V[16];
+    float size2;
+    float limx, limy;
+    float max_std_dev;
+    uint32_t sh_deg;
+    int no_sh0;
+} frame_consts;
+
+static void make_frame_consts(const gso_gaussian_transform *gt, const gso_model_transform *mt,
+                              const gso_camera *cam, frame_consts *fc) {
+    uint32_t flags;
+    memcpy(&flags, gt->flags, 4);
+    gso_model_transform_mat(mt, fc->M);
+    gso_model_transform_inv_sr_mat(mt, fc->ISR);
+    float sr[9];
+    gso_model_scale_rot_mat(mt, sr);
+    memcpy(fc->V, cam->view, 64);
+    /* W[r][c] = sign_r * view[4*c + r], sign = (+,-,-).  WS[r][c] = sum_k W[r][k] * SR[k][c]
+     * with SR[k][c] = sr[3*c + k]; order ((k0 + k1) + k2). */
+    for (int r = 0; r < 3; r++) {
+        float sg = r == 0 ? 1.0f : -1.0f;
+        float w0 = sg * cam->view[0 + r], w1 = sg * cam->view[4 + r], w2 = sg * cam->view[8 + r];
+        for (int c = 0; c < 3; c++)
+            fc->WS[3 * r + c] = (w0 * sr[3 * c + 0] + w1 * sr[3 * c + 1]) + w2 * sr[3 * c + 2];
+    }
+    fc->size2 = gt->size * gt->size;
+    fc->limx = 1.3f * ((0.5f * (float)cam->width) / cam->fx);
+    fc->limy = 1.3f * ((0.5f * (float)cam->height) / cam->fy);
+    fc->max_std_dev = gso_transform_max_std_dev(flags);
+    fc->sh_deg = gso_transform_sh_deg(flags);
+    fc->no_sh0 = (int)gso_transform_no_sh0(flags);
+}
+
+/* DESIGN.md §3.3. Returns tiles touched (0 = culled). */
+static uint32_t project_one(int sh, int cov, const uint8_t *pod, const frame_consts *fc,
+                            const gso_camera *cam, uint32_t tiles_x, uint32_t band_ty0,
+                            uint32_t band_ty1, gso_projected *out) {
+    float p[3] = {ld_f32(pod), ld_f32(pod + 4), ld_f32(pod + 8)};
+    float pw[4], t[4];
+    mat4_mul_point(fc->M, p, pw);
+    mat4_mul_point(fc->V, pw, t);
+    float xv = t[0], yv = -t[1], zv = -t[2];
+    if (!(zv > cam->near_plane) || !(zv < cam->far_plane)) return 0;
+
+    float S[6];
+    gso_unpack_cov3d(sh, cov, pod, S);
+    /* J W S rows: T0 = j00*WS[0] + j02*WS[2], T1 = j11*WS[1] + j12*WS[2] */
+    float txz = xv / zv, tyz = yv / zv;
+    float xc = clampf(txz, -fc->limx, fc->limx) * zv;
+    float yc = clampf(tyz, -fc->limy, fc->limy) * zv;
+    float zz = zv * zv;
+    float j00 = cam->fx / zv, j02 = -(cam->fx * xc) / zz;
+    float j11 = cam->fy / zv, j12 = -(cam->fy * yc) / zz;
+    float T0[3], T1[3];
+    for (int c = 0; c < 3; c++) {
+        T0[c] = j00 * fc->WS[0 + c] + j02 * fc->WS[6 + c];
+        T1[c] = j11 * fc->WS[3 + c] + j12 * fc->WS[6 + c];
+    }
+    /* S as symmetric matrix: [0]=xx [1]=xy [2]=xz [3]=yy [4]=yz [5]=zz.  v = S * T^T */
+    float a0 = (S[0] * T0[0] + S[1] * T0[1]) + S[2] * T0[2];
+    float a1 = (S[1] * T0[0] + S[3] * T0[1]) + S[4] * T0[2];
+    float a2 = (S[2] * T0[0] + S[4] * T0[1]) + S[5] * T0[2];
+    float b0 = (S[0] * T1[0] + S[1] * T1[1]) + S[2] * T1[2];
+    float b1 = (S[1] * T1[0] + S[3] * T1[1]) + S[4] * T1[2];
+    float b2 = (S[2] * T1[0] + S[4] * T1[1]) + S[5] * T1[2];
+    float ca = fc->size2 * ((T0[0] * a0 + T0[1] * a1) + T0[2] * a2) + 0.3f;
+    float cb = fc->size2 * ((T0[0] * b0 + T0[1] * b1) + T0[2] * b2);
+    float cc = fc->size2 * ((T1[0] * b0 + T1[1] * b1) + T1[2] * b2) + 0.3f;
+    float det = ca * cc - cb * cb;
+    if (!(det > 0.0f)) return 0;
+    float inv = 1.0f / det;
+    float mid = 0.5f * (ca + cc);
+    float lam = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
+    float radius = ceilf(fc->max_std_dev * sqrtf(lam));
+    if (!(radius > 0.0f)) return 0;
+    float mx = cam->fx * txz + cam->cx;
+    float my = cam->fy * tyz + cam->cy;
+    uint32_t tiles_y_all = (cam->height + 15u) / 16u;
+    float lo_y = (float)band_ty0, hi_y = (float)(band_ty1 < tiles_y_all ? band_ty1 : tiles_y_all);
+    float fx0 = clampf(floorf((mx - radius) * 0.0625f), 0.0f, (float)tiles_x);
+    float fx1 = clampf(floorf((mx + radius) * 0.0625f) + 1.0f, 0.0f, (float)tiles_x);
+    float fy0 = clampf(floorf((my - radius) * 0.0625f), lo_y, hi_y);
+    float fy1 = clampf(floorf((my + radius) * 0.0625f) + 1.0f, lo_y, hi_y);
+    if (!(fx1 > fx0) || !(fy1 > fy0)) return 0;
+    uint32_t tx0 = (uint32_t)fx0, tx1 = (uint32_t)fx1, ty0 = (uint32_t)fy0, ty1 = (uint32_t)fy1;
+
+    /* colour (x1): direction in model space */
+    float dw[3] = {pw[0] - cam->pos[0], pw[1] - cam->pos[1], pw[2] - cam->pos[2]};
+    float dl = sqrtf((dw[0] * dw[0] + dw[1] * dw[1]) + dw[2] * dw[2]);
+    float dn[3] = {dw[0] / dl, dw[1] / dl, dw[2] / dl};
+    float dm[3];
+    mat3_mul_vec(fc->ISR, dn, dm);
+    float ml = sqrtf((dm[0] * dm[0] + dm[1] * dm[1]) + dm[2] * dm[2]);
+    float d[3] = {dm[0] / ml, dm[1] / ml, dm[2] / ml};
+    float rgb[3], col[4];
+    eval_sh(sh, pod, fc->sh_deg, fc->no_sh0, d, rgb);
+    gso_unpack_color(pod, col);
+
+    out->mx = mx;
+    out->my = my;
+    out->ca = -0.5f * (cc * inv);
+    out->cb = (cb * inv); /* = -B of the conic, B = -cb*inv */
+    out->cc = -0.5f * (ca * inv);
+    out->opacity = col[3];
+    out->r = rgb[0];
+    out->g = rgb[1];
+    out->b = rgb[2];
+    out->depth = zv;
+    out->tx0 = (uint16_t)tx0;
+    out->ty0 = (uint16_t)ty0;
+    out->tx1 = (uint16_t)tx1;
+    out->ty1 = (uint16_t)ty1;
+    return (tx1 - tx0) * (ty1 - ty0);
+}
+
+void gso_preprocess(int sh, int cov, const void *pods, size_t n, const gso_gaussian_transform *gt,
+                    const gso_model_transform *mt, const gso_camera *cam, uint32_t band_ty0,
+                    uint32_t band_ty1, gso_projected *proj, uint32_t *tiles_touched) {
+    frame_consts fc;
+    make_frame_consts(gt, mt, cam, &fc);
+    size_t stride = gso_pod_size(sh, cov);
+    uint32_t tiles_x = (cam->width + 15u) / 16u;
+    const uint8_t *base = (const uint8_t *)pods;
+#pragma omp parallel for schedule(static)
+    for (long i = 0; i < (long)n; i++) {
+        gso_projected rec;
+        memset(&rec, 0, sizeof(rec));
+        uint32_t cnt = project_one(sh, cov, base + (size_t)i * stride, &fc, cam, tiles_x, band_ty0,
+                                   band_ty1, &rec);
+        if (!cnt) memset(&rec, 0, sizeof(rec));
+        proj[i] = rec;
+        tiles_touched[i] = cnt;
+    }
+}
+
+/* pairs ordered by Gaussian index, then tile row, then tile column. */
+uint64_t gso_build_keys(const gso_projected *proj, const uint32_t *tiles_touched, size_t n,
+                        uint32_t tiles_x, uint64_t *keys, uint32_t *idx) {
+    uint64_t d = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (!tiles_touched[i]) continue;
+        const gso_projected *p = &proj[i];
+        uint32_t depth_bits = f2u(p->depth);
+        for (uint32_t ty = p->ty0; ty < p->ty1; ty++)
+            for (uint32_t tx = p->tx0; tx < p->tx1; tx++) {
+                if (keys) {
+                    keys[d] = ((uint64_t)(ty * tiles_x + tx) << 32) | depth_bits;
+                    idx[d] = (uint32_t)i;
+                }
+                d++;
+            }
+    }
+    return d;
+}
+
+/* Stable LSD radix sort on the 64-bit key (ties keep emission order = Gaussian index). */
+void gso_sort_pairs(uint64_t *keys, uint32_t *idx, uint64_t d) {
+    if (d < 2) return;
+    uint64_t *k2 = (uint64_t *)malloc(d * sizeof(uint64_t));
+    uint32_t *i2 = (uint32_t *)malloc(d * sizeof(uint32_t));
+    uint64_t *ka = keys, *kb = k2;
+    uint32_t *ia = idx, *ib = i2;
+    for (int pass = 0; pass < 8; pass++) {
+        int shift = pass * 8;
+        size_t hist[256] = {0};
+        for (uint64_t j = 0; j < d; j++) hist[(ka[j] >> shift) & 0xff]++;
+        int trivial = 0;
+        for (int b = 0; b < 256; b++)
+            if (hist[b] == d) trivial = 1;
+        if (trivial) continue;
+        size_t sum = 0;
+        for (int b = 0; b < 256; b++) {
+            size_t c = hist[b];
+            hist[b] = sum;
+            sum += c;
+        }
+        for (uint64_t j = 0; j < d; j++) {
+            size_t dst = hist[(ka[j] >> shift) & 0xff]++;
+            kb[dst] = ka[j];
+            ib[dst] = ia[j];
+        }
+        uint64_t *tk = ka; ka = kb; kb = tk;
+        uint32_t *ti = ia; ia = ib; ib = ti;
+    }
+    if (ka != keys) {
+        memcpy(keys, ka, d * sizeof(uint64_t));
+        memcpy(idx, ia, d * sizeof(uint32_t));
+    }
+    free(k2);
+    free(i2);
+}
+
+void gso_tile_ranges(const uint64_t *keys, uint64_t d, uint32_t num_tiles, uint32_t *ranges) {
+    memset(ranges, 0, (size_t)num_tiles * 2 * sizeof(uint32_t));
+    for (uint64_t j = 0; j < d; j++) {
+        uint32_t tile = (uint32_t)(keys[j] >> 32);
+        if (j == 0 || (uint32_t)(keys[j - 1] >> 32) != tile) ranges[2 * tile] = (uint32_t)j;
+        if (j + 1 == d || (uint32_t)(keys[j + 1] >> 32) != tile) ranges[2 * tile + 1] = (uint32_t)(j + 1);
+    }
+}
+
+/* DESIGN.md §3.5 */
+void gso_blend(const gso_projected *proj, const uint32_t *idx, const uint32_t *ranges,
+               const gso_camera *cam, uint32_t band_ty0, uint32_t band_ty1, float *rgba) {
+    uint32_t W = cam->width, H = cam->height;
+    uint32_t tiles_x = (W + 15u) / 16u, tiles_y = (H + 15u) / 16u;
+    if (band_ty1 > tiles_y) band_ty1 = tiles_y;
+    long ntile = (long)(band_ty1 > band_ty0 ? band_ty1 - band_ty0 : 0) * tiles_x;
+#pragma omp parallel for schedule(dynamic, 4)
+    for (long tt = 0; tt < ntile; tt++) {
+        uint32_t tile = band_ty0 * tiles_x + (uint32_t)tt;
+        uint32_t ty = tile / tiles_x, tx = tile % tiles_x;
+        uint32_t s = ranges[2 * tile], e = ranges[2 * tile + 1];
+        for (uint32_t ly = 0; ly < 16; ly++) {
+            uint32_t py = ty * 16 + ly;
+            if (py >= H) break;
+            for (uint32_t lx = 0; lx < 16; lx++) {
+                uint32_t px = tx * 16 + lx;
+                if (px >= W) break;
+                float pxf = (float)px + 0.5f, pyf = (float)py + 0.5f;
+                float T = 1.0f, C0 = 0.0f, C1 = 0.0f, C2 = 0.0f;
+                for (uint32_t j = s; j < e; j++) {
+                    const gso_projected *g = &proj[idx[j]];
+                    float dx = g->mx - pxf, dy = g->my - pyf;
+                    /* power = ca*dx^2 + cc*dy^2 + cb*dx*dy with the pre-scaled conic */
+                    float u = g->ca * dx, v = g->cc * dy, w = g->cb * dx;
+                    float power = fmaf(u, dx, fmaf(v, dy, w * dy));
+                    if (power > 0.0f) continue;
+                    float alpha = fminf(0.99f, g->opacity * gso_exp(power));
+                    if (alpha < 1.0f / 255.0f) continue;
+                    float test_T = T * (1.0f - alpha);
+                    if (test_T < 0.0001f) break;
+                    float wgt = alpha * T;
+                    C0 = fmaf(g->r, wgt, C0);
+                    C1 = fmaf(g->g, wgt, C1);
+                    C2 = fmaf(g->b, wgt, C2);
+                    T = test_T;
+                }
+                float *o = rgba + ((size_t)py * W + px) * 4;
+                o[0] = fmaf(T, cam->background[0], C0);
+                o[1] = fmaf(T, cam->background[1], C1);
+                o[2] = fmaf(T, cam->background[2], C2);
+                o[3] = 1.0f - T;
+            }
+        }
+    }
+}
+
+static _Thread_local double g_stage[5];
+
+static double now_s(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+uint64_t gso_render(int sh, int cov, const void *pods, size_t n, const gso_gaussian_transform *gt,
+                    const gso_model_transform *mt, const gso_camera *cam, uint32_t band_ty0,
+                    uint32_t band_ty1, float *rgba, uint64_t *visible_out) {
+    uint32_t tiles_x = (cam->width + 15u) / 16u, tiles_y = (cam->height + 15u) / 16u;
+    gso_projected *proj = (gso_projected *)malloc((n ? n : 1) * sizeof(gso_projected));
+    uint32_t *tt = (uint32_t *)malloc((n ? n : 1) * sizeof(uint32_t));
+    double t0 = now_s();
+    gso_preprocess(sh, cov, pods, n, gt, mt, cam, band_ty0, band_ty1, proj, tt);
+    double t1 = now_s();
+    uint64_t d = gso_build_keys(proj, tt, n, tiles_x, NULL, NULL);
+    uint64_t vis = 0;
+    for (size_t i = 0; i < n; i++) vis += tt[i] != 0;
+    uint64_t *keys = (uint64_t *)malloc((d ? d : 1) * sizeof(uint64_t));
+    uint32_t *idx = (uint32_t *)malloc((d ? d : 1) * sizeof(uint32_t));
+    gso_build_keys(proj, tt, n, tiles_x, keys, idx);
+    double t2 = now_s();
+    gso_sort_pairs(keys, idx, d);
+    double t3 = now_s();
+    uint32_t *ranges = (uint32_t *)malloc((size_t)tiles_x * tiles_y * 2 * sizeof(uint32_t));
+    gso_tile_ranges(keys, d, tiles_x * tiles_y, ranges);
+    double t4 = now_s();
+    if (rgba) gso_blend(proj, idx, ranges, cam, band_ty0, band_ty1, rgba);
+    double t5 = now_s();
+    g_stage[0] = t1 - t0;
+    g_stage[1] = t2 - t1;
+    g_stage[2] = t3 - t2;
+    g_stage[3] = t4 - t3;
+    g_stage[4] = t5 - t4;
+    if (visible_out) *visible_out = vis;
+    free(proj);
+    free(tt);
+    free(keys);
+    free(idx);
+    free(ranges);
+    return d;
+}
+
+void gso_last_stage_seconds(double out[5]) { memcpy(out, g_stage, sizeof(g_stage)); }
+
+void gso_set_threads(int n) {
+#ifdef _OPENMP
+    omp_set_num_threads(n > 0 ? n : 1);
+#else
+    (void)n;
+#endif
+}
+
+int gso_get_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
