@@ -1,0 +1,386 @@
+/*
+ * gs3d.h — C ABI of the MI355X-native 3D Gaussian Splatting core (libgs3d_hip.so).
+ *
+ * This is the drop-in boundary for LioQing/wgpu-3dgs-core's render-side API: every entry point
+ * names the reference interface it replaces (paths relative to the reference repository root).
+ * A Rust `extern "C"` block binds these 1:1; there are no C++/torch types in any
+ * signature — only opaque handles, plain pointers and sizes.
+ *
+ * Conventions
+ *   - Every function that can fail returns gs_status (0 = GS_OK, negative = error).  The variant
+ *     fields of the matching Rust error enum (src/error.rs) are available, per thread, from
+ *     gs_last_error().
+ *   - Handles are created/destroyed explicitly.  A handle must not be used from two threads at
+ *     once; distinct handles are independent.
+ *   - Every launch takes a gs_stream (a hipStream_t): the analogue of the reference's
+ *     CommandEncoder + queue.submit (src/compute_bundle.rs:114-132).  Work is asynchronous
+ *     unless the function is documented as blocking.
+ *   - There is no CPU fallback: without a HIP device gs_device_create fails with
+ *     GS_ERR_NO_DEVICE and nothing else can be constructed.
+ */
+#ifndef GS3D_H
+#define GS3D_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GS3D_ABI_VERSION 1
+
+typedef int32_t gs_status;
+
+enum {
+    GS_OK = 0,
+    GS_ERR_INVALID_ARGUMENT = -1,
+    GS_ERR_NO_DEVICE = -2,
+    GS_ERR_HIP = -3,
+    GS_ERR_OUT_OF_MEMORY = -4,
+    /* GaussiansBufferUpdateError::CountMismatch{count, expected_count}      src/error.rs:66-70  */
+    GS_ERR_COUNT_MISMATCH = -10,
+    /* GaussiansBufferUpdateRangeError::CountMismatch{count,start,expected}  src/error.rs:73-81  */
+    GS_ERR_RANGE_COUNT_MISMATCH = -11,
+    /* GaussiansBufferTryFromBufferError::BufferSizeNotMultiple              src/error.rs:85-94  */
+    GS_ERR_BUFFER_SIZE_NOT_MULTIPLE = -12,
+    /* FixedSizeBufferWrapperError::BufferSizeMismatched                     src/error.rs:97-104 */
+    GS_ERR_BUFFER_SIZE_MISMATCHED = -13,
+    /* ComputeBundleCreateError::ResourceCountMismatch                       src/error.rs:109-117 */
+    GS_ERR_RESOURCE_COUNT_MISMATCH = -14,
+    /* ComputeBundleCreateError::WorkgroupSizeExceedsDeviceLimit             src/error.rs:118-125 */
+    GS_ERR_WORKGROUP_SIZE_EXCEEDS_LIMIT = -15,
+    /* ComputeBundleBuildError::{MissingBindGroupLayout, MissingResolver, MissingEntryPoint,
+     * MissingMainShader, Wesl}                                              src/error.rs:129-143 */
+    GS_ERR_MISSING_BIND_GROUP_LAYOUT = -16,
+    GS_ERR_MISSING_RESOLVER = -17,
+    GS_ERR_MISSING_ENTRY_POINT = -18,
+    GS_ERR_MISSING_MAIN_SHADER = -19,
+    GS_ERR_KERNEL_COMPILE = -20,
+    /* the reference panics: gaussian_config.rs:131-133, 211-213, 230-232 */
+    GS_ERR_LOSSY_CONFIG = -21,
+    /* DownloadBufferError                                                   src/error.rs:55-63  */
+    GS_ERR_DOWNLOAD = -22,
+    /* the (key,index) pair buffer was too small for this frame; call again (it was grown) */
+    GS_ERR_PAIR_OVERFLOW = -23
+};
+
+/* Thread-local details of the last failing call on this thread.
+ *   COUNT_MISMATCH:            a = count, b = expected_count
+ *   RANGE_COUNT_MISMATCH:      a = count, b = start, c = expected_count
+ *   BUFFER_SIZE_NOT_MULTIPLE:  a = buffer_size, b = expected_multiple_size
+ *   BUFFER_SIZE_MISMATCHED:    a = buffer_size, b = expected_size
+ *   RESOURCE_COUNT_MISMATCH:   a = resource_count, b = bind_group_layout_count
+ *   WORKGROUP_SIZE_EXCEEDS_LIMIT: a = workgroup_size, b = device_limit
+ *   HIP:                       a = hipError_t                                                   */
+typedef struct gs_error_info {
+    int32_t code;
+    uint64_t a, b, c;
+    char message[256];
+} gs_error_info;
+
+void gs_last_error(gs_error_info *out);
+const char *gs_status_string(gs_status s);
+uint32_t gs_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Data model                                                                                  */
+/* ------------------------------------------------------------------------------------------ */
+
+/* GaussianShConfig / GaussianCov3dConfig families — src/gaussian_config.rs:15-233 */
+typedef enum { GS_SH_SINGLE = 0, GS_SH_HALF = 1, GS_SH_NORM8 = 2, GS_SH_NONE = 3 } gs_sh_config;
+typedef enum { GS_COV3D_ROT_SCALE = 0, GS_COV3D_SINGLE = 1, GS_COV3D_HALF = 2 } gs_cov3d_config;
+
+/* struct Gaussian — src/gaussian.rs:53-60 (rot = xyzw; 224 bytes) */
+typedef struct gs_gaussian {
+    float rot[4];
+    float pos[3];
+    uint8_t color[4];
+    float sh[45];
+    float scale[3];
+} gs_gaussian;
+
+/* GaussianDisplayMode — src/buffer/gaussian_transform.rs:7-14 */
+typedef enum { GS_DISPLAY_SPLAT = 0, GS_DISPLAY_ELLIPSE = 1, GS_DISPLAY_POINT = 2 } gs_display_mode;
+
+/* GaussianTransformPod — src/buffer/gaussian_transform.rs:166-174 (8 bytes) */
+typedef struct gs_gaussian_transform_pod {
+    float size;
+    uint8_t flags[4]; /* display_mode, sh_deg, no_sh0, max_std_dev (u8) */
+} gs_gaussian_transform_pod;
+
+/* ModelTransformPod — src/buffer/model_transform.rs:61-66 (48 bytes) */
+typedef struct gs_model_transform_pod {
+    float pos[3];
+    float _pad0;
+    float rot[4];
+    float scale[3];
+    float _pad1;
+} gs_model_transform_pod;
+
+/* std::mem::size_of::<GaussianPodWithSh{S}Cov3d{C}Configs>() — src/buffer/gaussian.rs:373-384 */
+size_t gs_pod_size(gs_sh_config sh, gs_cov3d_config cov);
+/* GaussianPod::features() — src/buffer/gaussian.rs:270-286; order: sh_single, sh_half, sh_norm8,
+ * sh_none, cov3d_rot_scale, cov3d_single, cov3d_half */
+gs_status gs_pod_features(gs_sh_config sh, gs_cov3d_config cov, uint8_t out[7]);
+const char *gs_feature_name(uint32_t index);
+/* G::from_gaussian — src/buffer/gaussian.rs:314-339 (host, multi-threaded) */
+gs_status gs_pack(gs_sh_config sh, gs_cov3d_config cov, const gs_gaussian *in, size_t n, void *out);
+/* Into<Gaussian> — src/buffer/gaussian.rs:341-363; GS_ERR_LOSSY_CONFIG where Rust panics */
+gs_status gs_unpack_to_gaussian(gs_sh_config sh, gs_cov3d_config cov, const void *pods, size_t n,
+                                gs_gaussian *out);
+
+/* GaussianShDegree::new / GaussianMaxStdDev::new / GaussianTransformPod::new —
+ * src/buffer/gaussian_transform.rs:25-30, 63-68, 178-194.  GS_ERR_INVALID_ARGUMENT where the
+ * Rust constructors return None. */
+gs_status gs_gaussian_transform_pod_new(float size, gs_display_mode mode, uint8_t sh_deg,
+                                        uint8_t no_sh0, float max_std_dev,
+                                        gs_gaussian_transform_pod *out);
+void gs_gaussian_transform_pod_default(gs_gaussian_transform_pod *out);
+gs_status gs_max_std_dev_encode(float max_std_dev, uint8_t *out);
+float gs_max_std_dev_decode(uint8_t v);
+/* ModelTransformPod::new / default — src/buffer/model_transform.rs:68-84 */
+void gs_model_transform_pod_new(const float pos[3], const float rot_xyzw[4], const float scale[3],
+                                gs_model_transform_pod *out);
+void gs_model_transform_pod_default(gs_model_transform_pod *out);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Device, streams                                                                             */
+/* ------------------------------------------------------------------------------------------ */
+
+typedef struct gs_device gs_device;   /* wgpu::Device + wgpu::Queue */
+typedef struct gs_stream gs_stream;   /* wgpu::CommandEncoder + queue.submit */
+
+/* wgpu::Limits fields read by src/compute_bundle.rs:269-272 */
+typedef struct gs_limits {
+    uint32_t max_compute_workgroup_size_x;
+    uint32_t max_compute_invocations_per_workgroup;
+    uint32_t compute_units;
+    uint32_t wavefront_size;
+    uint64_t total_memory_bytes;
+    char arch_name[64];
+} gs_limits;
+
+gs_status gs_device_create(int32_t hip_ordinal, gs_device **out);
+void gs_device_destroy(gs_device *dev);
+gs_status gs_device_limits(const gs_device *dev, gs_limits *out);
+gs_status gs_device_synchronize(gs_device *dev);
+gs_status gs_stream_create(gs_device *dev, gs_stream **out);
+/* borrow an existing hipStream_t (e.g. the stream a caller's framework is using) */
+gs_status gs_stream_wrap(gs_device *dev, void *hip_stream, gs_stream **out);
+void *gs_stream_native(const gs_stream *s);
+gs_status gs_stream_synchronize(gs_stream *s);
+void gs_stream_destroy(gs_stream *s);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Buffers — trait BufferWrapper / FixedSizeBufferWrapper, src/buffer/mod.rs:17-150            */
+/* ------------------------------------------------------------------------------------------ */
+
+typedef struct gs_buffer gs_buffer; /* wgpu::Buffer: ref-counted device allocation */
+
+gs_status gs_buffer_create(gs_device *dev, size_t bytes, const void *init_or_null, gs_buffer **out);
+/* adopt device memory the caller owns (non-owning; the TryFrom<wgpu::Buffer> direction) */
+gs_status gs_buffer_from_raw(gs_device *dev, void *device_ptr, size_t bytes, gs_buffer **out);
+gs_buffer *gs_buffer_retain(gs_buffer *b); /* Clone = handle copy (buffer/gaussian.rs:16) */
+void gs_buffer_release(gs_buffer *b);
+size_t gs_buffer_size(const gs_buffer *b);
+void *gs_buffer_device_ptr(const gs_buffer *b);
+/* queue.write_buffer(buffer, offset, data) */
+gs_status gs_buffer_write(gs_buffer *b, gs_stream *s, size_t offset, const void *src, size_t bytes);
+/* BufferWrapper::download — src/buffer/mod.rs:27-42 (blocking: prepare_download + map + poll) */
+gs_status gs_buffer_download(gs_buffer *b, gs_stream *s, void *dst, size_t bytes);
+
+/* GaussiansBuffer<G> — src/buffer/gaussian.rs:17-229 */
+typedef struct gs_gaussians_buffer gs_gaussians_buffer;
+
+/* new_with_pods (pods != NULL) / new_empty (pods == NULL) — :50-90 */
+gs_status gs_gaussians_buffer_create(gs_device *dev, gs_sh_config sh, gs_cov3d_config cov,
+                                     const void *pods_or_null, size_t len,
+                                     gs_gaussians_buffer **out);
+/* new(device, gaussians): pack on the host then upload — :21-30 */
+gs_status gs_gaussians_buffer_create_from_gaussians(gs_device *dev, gs_sh_config sh,
+                                                    gs_cov3d_config cov, const gs_gaussian *gaussians,
+                                                    size_t len, gs_gaussians_buffer **out);
+/* TryFrom<wgpu::Buffer> — :213-229; the wrapper retains `buffer` */
+gs_status gs_gaussians_buffer_from_buffer(gs_buffer *buffer, gs_sh_config sh, gs_cov3d_config cov,
+                                          gs_gaussians_buffer **out);
+void gs_gaussians_buffer_destroy(gs_gaussians_buffer *g);
+size_t gs_gaussians_buffer_len(const gs_gaussians_buffer *g); /* :93-95 */
+gs_buffer *gs_gaussians_buffer_buffer(const gs_gaussians_buffer *g); /* BufferWrapper::buffer(), borrowed */
+gs_sh_config gs_gaussians_buffer_sh(const gs_gaussians_buffer *g);
+gs_cov3d_config gs_gaussians_buffer_cov3d(const gs_gaussians_buffer *g);
+/* update_with_pod — :122-138 */
+gs_status gs_gaussians_buffer_update(gs_gaussians_buffer *g, gs_stream *s, const void *pods,
+                                     size_t count);
+/* update_range_with_pod — :161-183 */
+gs_status gs_gaussians_buffer_update_range(gs_gaussians_buffer *g, gs_stream *s, size_t start,
+                                           const void *pods, size_t count);
+/* update / update_range with Gaussians (host pack first) — :103-118, :143-158 */
+gs_status gs_gaussians_buffer_update_gaussians(gs_gaussians_buffer *g, gs_stream *s,
+                                               const gs_gaussian *gaussians, size_t count);
+gs_status gs_gaussians_buffer_update_range_gaussians(gs_gaussians_buffer *g, gs_stream *s,
+                                                     size_t start, const gs_gaussian *gaussians,
+                                                     size_t count);
+/* download::<G> (pods) and download_gaussians — :186-195 (blocking) */
+gs_status gs_gaussians_buffer_download(gs_gaussians_buffer *g, gs_stream *s, void *pods_out,
+                                       size_t count);
+gs_status gs_gaussians_buffer_download_gaussians(gs_gaussians_buffer *g, gs_stream *s,
+                                                 gs_gaussian *out, size_t count);
+/* tell the wrapper that device code wrote the underlying buffer (e.g. a compute bundle bound it
+ * read-write), so the renderer's chunk-planar mirror must be rebuilt on the next frame */
+void gs_gaussians_buffer_mark_dirty(gs_gaussians_buffer *g);
+
+/* GaussianTransformBuffer — src/buffer/gaussian_transform.rs:104-163 (8-byte uniform) */
+gs_status gs_gaussian_transform_buffer_create(gs_device *dev, gs_buffer **out);
+gs_status gs_gaussian_transform_buffer_update(gs_buffer *b, gs_stream *s,
+                                              const gs_gaussian_transform_pod *pod);
+gs_status gs_gaussian_transform_buffer_from_buffer(gs_buffer *b); /* size check only */
+/* ModelTransformBuffer — src/buffer/model_transform.rs:10-58 (48-byte uniform) */
+gs_status gs_model_transform_buffer_create(gs_device *dev, gs_buffer **out);
+gs_status gs_model_transform_buffer_update(gs_buffer *b, gs_stream *s,
+                                           const gs_model_transform_pod *pod);
+gs_status gs_model_transform_buffer_from_buffer(gs_buffer *b);
+
+/* ------------------------------------------------------------------------------------------ */
+/* ComputeBundle — src/compute_bundle.rs:49-351                                                */
+/* ------------------------------------------------------------------------------------------ */
+
+/* The kernel registry replaces shader::PACKAGE + wesl feature flags (src/shader.rs:8-56):
+ * "features" select a template instantiation keyed by (sh, cov). */
+typedef enum {
+    /* tests/common/shader/array_map_add.wesl: group0 = {data rw u32[]}, group1 = {uniform u32};
+     * data[i] += uniform + constant("add_constant") */
+    GS_KERNEL_ARRAY_MAP_ADD = 0,
+    /* tests/shader/gaussian.rs:26-59: group0 = {gaussians, output(56 f32)} */
+    GS_KERNEL_TEST_GAUSSIAN = 1,
+    /* tests/shader/gaussian_transform.rs:13-48: group0 = {transform uniform, output(4 u32)} */
+    GS_KERNEL_TEST_GAUSSIAN_TRANSFORM = 2,
+    /* tests/shader/model_transform.rs:14-51: group0 = {model uniform, output(38 f32)} */
+    GS_KERNEL_TEST_MODEL_TRANSFORM = 3,
+    /* AoS pods -> SoA f32 planes (color4, sh45, cov6) for `count` Gaussians: group0 = {gaussians, out} */
+    GS_KERNEL_UNPACK_SOA = 4,
+    GS_KERNEL_COUNT_ = 5
+} gs_kernel_id;
+
+typedef struct gs_bundle gs_bundle;
+
+typedef struct gs_bundle_desc {
+    const char *label;          /* may be NULL ("Compute Bundle") */
+    gs_kernel_id kernel;        /* main_shader + entry_point */
+    gs_sh_config sh;            /* wesl features */
+    gs_cov3d_config cov;
+    uint32_t bind_group_count;  /* bind_group_layouts.len() */
+    const uint32_t *bindings_per_group;
+    uint32_t workgroup_size;    /* 0 = None = device limit (compute_bundle.rs:274) */
+    const char *const *constant_names; /* PipelineCompilationOptions.constants */
+    const double *constant_values;
+    uint32_t constant_count;
+} gs_bundle_desc;
+
+/* ComputeBundle::new_without_bind_groups — :260-341 */
+gs_status gs_bundle_create(gs_device *dev, const gs_bundle_desc *desc, gs_bundle **out);
+/* ComputeBundle::new — :141-188: `resources` = bind_group_count_given arrays of buffers;
+ * GS_ERR_RESOURCE_COUNT_MISMATCH when group counts differ */
+gs_status gs_bundle_create_with_bind_groups(gs_device *dev, const gs_bundle_desc *desc,
+                                            gs_buffer *const *const *resources,
+                                            const uint32_t *resource_counts,
+                                            uint32_t resource_group_count, gs_bundle **out);
+void gs_bundle_destroy(gs_bundle *b);
+uint32_t gs_bundle_workgroup_size(const gs_bundle *b);
+const char *gs_bundle_label(const gs_bundle *b);
+uint32_t gs_bundle_bind_group_layout_count(const gs_bundle *b);
+uint32_t gs_bundle_bind_group_count(const gs_bundle *b);
+/* update_bind_group_with_binding_resources — :222-231; GS_ERR_INVALID_ARGUMENT when the index is
+ * out of bounds (Rust returns None) */
+gs_status gs_bundle_set_bind_group(gs_bundle *b, uint32_t index, gs_buffer *const *buffers,
+                                   uint32_t count);
+/* dispatch — :196-198: ceil(count / workgroup_size) workgroups on `s` */
+gs_status gs_bundle_dispatch(gs_bundle *b, gs_stream *s, uint32_t count);
+/* dispatch_with_bind_groups — :114-132 (ComputeBundle<()>::dispatch :344-351) */
+gs_status gs_bundle_dispatch_with_bind_groups(gs_bundle *b, gs_stream *s, uint32_t count,
+                                              gs_buffer *const *const *groups,
+                                              const uint32_t *group_counts, uint32_t group_count);
+/* number of workgroups the last dispatch launched (launch arithmetic check) */
+uint32_t gs_bundle_last_workgroup_count(const gs_bundle *b);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Render path (absent from the reference crate; see DESIGN.md §3 for its definition)          */
+/* ------------------------------------------------------------------------------------------ */
+
+/* view: column-major world->view, right-handed, camera looks down -Z, +Y up */
+typedef struct gs_camera {
+    float view[16];
+    float pos[3];
+    float fx, fy, cx, cy;
+    float near_plane, far_plane;
+    uint32_t width, height;
+    float background[3];
+} gs_camera;
+
+/* 48-byte projected splat record; conic pre-scaled to (-A/2, -B, -C/2) */
+typedef struct gs_projected {
+    float mx, my;
+    float ca, cb, cc;
+    float opacity;
+    float r, g, b;
+    float depth;
+    uint16_t tx0, ty0, tx1, ty1;
+} gs_projected;
+
+typedef struct gs_frame_stats {
+    uint64_t gaussians;       /* N */
+    uint64_t visible;         /* Gaussians with >= 1 tile */
+    uint64_t pairs;           /* D = (tile, Gaussian) pairs */
+    uint32_t tiles_x, tiles_y;
+    uint32_t sort_passes;
+    uint32_t timed_frames;    /* frames accumulated below since the last reset */
+    /* accumulated stage time in ms (only while timing is enabled):
+     * 0 repack, 1 preprocess, 2 scan, 3 emit, 4 sort, 5 ranges, 6 blend, 7 whole frame */
+    double stage_ms[8];
+} gs_frame_stats;
+
+typedef struct gs_renderer gs_renderer;
+
+void gs_camera_look_at(const float eye[3], const float target[3], const float up[3],
+                       float vfov_radians, uint32_t width, uint32_t height, float near_plane,
+                       float far_plane, gs_camera *out);
+
+gs_status gs_renderer_create(gs_device *dev, gs_renderer **out);
+void gs_renderer_destroy(gs_renderer *r);
+/* stage timing with HIP events on the launch stream (off by default) */
+gs_status gs_renderer_set_timing(gs_renderer *r, int32_t enabled);
+gs_status gs_renderer_reset_stats(gs_renderer *r);
+/* blocking: synchronises the stream of the last frame first */
+gs_status gs_renderer_stats(gs_renderer *r, gs_frame_stats *out);
+
+/* One frame: repack (if the Gaussians changed) -> preprocess -> scan -> key emit -> radix sort ->
+ * tile ranges -> blend.  Renders tile rows [band_ty0, band_ty1) (16-pixel rows; pass 0 and
+ * UINT32_MAX for the whole image) into rgba_out_device, a device pointer to the FULL
+ * height x width x 4 f32 image; only the band's rows are written. */
+gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_buffer *gaussians,
+                          const gs_gaussian_transform_pod *gaussian_transform,
+                          const gs_model_transform_pod *model_transform, const gs_camera *camera,
+                          uint32_t band_ty0, uint32_t band_ty1, float *rgba_out_device);
+
+/* Parity taps on the last frame (blocking).  Sizes: N records / N counts; D keys / D indices;
+ * tiles_x*tiles_y*2 ranges. */
+gs_status gs_renderer_download_projected(gs_renderer *r, gs_projected *proj_out,
+                                         uint32_t *tiles_touched_out, size_t n);
+gs_status gs_renderer_download_sorted(gs_renderer *r, uint64_t *keys_out, uint32_t *idx_out,
+                                      uint64_t capacity, uint64_t *pairs_out);
+gs_status gs_renderer_download_unsorted(gs_renderer *r, uint64_t *keys_out, uint32_t *idx_out,
+                                        uint64_t capacity, uint64_t *pairs_out);
+gs_status gs_renderer_download_ranges(gs_renderer *r, uint32_t *ranges_out, size_t num_tiles);
+
+/* Stand-alone device primitives used by the frame (also exported for tests and callers):
+ * stable LSD radix sort of (u64 key, u32 value) pairs on bits [0, end_bit) — host buffers in/out,
+ * blocking; and exclusive prefix sum of u32. */
+gs_status gs_sort_pairs_u64(gs_device *dev, gs_stream *s, uint64_t *keys, uint32_t *values,
+                            uint64_t count, uint32_t end_bit);
+gs_status gs_exclusive_scan_u32(gs_device *dev, gs_stream *s, const uint32_t *in, uint32_t *out,
+                                uint64_t count, uint64_t *total_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GS3D_H */

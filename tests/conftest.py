@@ -1,0 +1,50 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tools")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    return np.load(os.path.join(ROOT, "tests", "golden", "golden_v1.npz"))
+
+
+@pytest.fixture(scope="session")
+def ob():
+    """The CPU oracle (test infrastructure)."""
+    from oracle import binding
+    binding.build()
+    binding.lib()
+    return binding
+
+
+@pytest.fixture(scope="session")
+def gs():
+    import wgpu_3dgs_core_amd
+    return wgpu_3dgs_core_amd
+
+
+@pytest.fixture(scope="session")
+def device(gs):
+    """A real HIP device.  GPU tests must fail (not skip) when the extension cannot reach one."""
+    dev = gs.Device(0)
+    yield dev
+    dev.close()
+
+
+@pytest.fixture()
+def stream(device):
+    s = device.create_stream()
+    yield s
+    s.synchronize()
+    s.close()

@@ -1,0 +1,754 @@
+"""wgpu_3dgs_core_amd — host-side mirror of LioQing/wgpu-3dgs-core's API over the MI355X C ABI.
+
+The product is libgs3d_hip.so (include/gs3d.h); this package is the thin Python host layer that
+tests, bench.py and torch.distributed plumbing use.  Names, argument meaning and error behaviour
+follow the reference (citations relative to the reference repository):
+
+    Gaussian / GaussianPod configs ...... src/gaussian.rs:53-60, src/buffer/gaussian.rs:239-384
+    GaussiansBuffer ..................... src/buffer/gaussian.rs:17-229
+    GaussianTransformBuffer / Pod ....... src/buffer/gaussian_transform.rs
+    ModelTransformBuffer / Pod .......... src/buffer/model_transform.rs
+    BufferWrapper.download .............. src/buffer/mod.rs:17-102
+    ComputeBundle / ComputeBundleBuilder  src/compute_bundle.rs
+    error enums ......................... src/error.rs:55-143
+
+There is no CPU implementation behind any device call: constructing a Device without a HIP GPU
+raises NoDeviceError, and importing the package without libgs3d_hip.so raises ImportError.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+from ._capi import Camera, FrameStats, GaussianTransformPod, Limits, ModelTransformPod
+
+_L = _capi.load()
+
+# ------------------------------------------------------------------------------------------------
+# data model
+# ------------------------------------------------------------------------------------------------
+
+#: struct Gaussian — src/gaussian.rs:53-60
+GAUSSIAN_DTYPE = np.dtype([("rot", "<f4", 4), ("pos", "<f4", 3), ("color", "u1", 4),
+                           ("sh", "<f4", 45), ("scale", "<f4", 3)])
+#: projected splat record (include/gs3d.h gs_projected)
+PROJECTED_DTYPE = np.dtype([("mx", "<f4"), ("my", "<f4"), ("ca", "<f4"), ("cb", "<f4"),
+                            ("cc", "<f4"), ("opacity", "<f4"), ("r", "<f4"), ("g", "<f4"),
+                            ("b", "<f4"), ("depth", "<f4"), ("tx0", "<u2"), ("ty0", "<u2"),
+                            ("tx1", "<u2"), ("ty1", "<u2")])
+
+SH_SINGLE, SH_HALF, SH_NORM8, SH_NONE = 0, 1, 2, 3
+COV3D_ROT_SCALE, COV3D_SINGLE, COV3D_HALF = 0, 1, 2
+SH_CONFIG_NAMES = ["Single", "Half", "Norm8", "None"]
+COV3D_CONFIG_NAMES = ["RotScale", "Single", "Half"]
+FEATURE_NAMES = [_L.gs_feature_name(i).decode() for i in range(7)]
+
+DISPLAY_SPLAT, DISPLAY_ELLIPSE, DISPLAY_POINT = 0, 1, 2
+
+KERNEL_ARRAY_MAP_ADD = 0
+KERNEL_TEST_GAUSSIAN = 1
+KERNEL_TEST_GAUSSIAN_TRANSFORM = 2
+KERNEL_TEST_MODEL_TRANSFORM = 3
+KERNEL_UNPACK_SOA = 4
+
+
+class GsError(Exception):
+    """Base of every error raised by the C ABI; carries the variant fields of src/error.rs."""
+    code = None
+
+    def __init__(self, info):
+        self.status = info.code
+        self.a, self.b, self.c = info.a, info.b, info.c
+        super().__init__(info.message.decode(errors="replace"))
+
+
+class InvalidArgumentError(GsError): code = -1
+class NoDeviceError(GsError): code = -2
+class HipError(GsError): code = -3
+class OutOfMemoryError(GsError): code = -4
+
+
+class GaussiansBufferUpdateError(GsError):
+    """CountMismatch{count, expected_count} — src/error.rs:66-70"""
+    code = -10
+    count = property(lambda s: s.a)
+    expected_count = property(lambda s: s.b)
+
+
+class GaussiansBufferUpdateRangeError(GsError):
+    """CountMismatch{count, start, expected_count} — src/error.rs:73-81"""
+    code = -11
+    count = property(lambda s: s.a)
+    start = property(lambda s: s.b)
+    expected_count = property(lambda s: s.c)
+
+
+class GaussiansBufferTryFromBufferError(GsError):
+    """BufferSizeNotMultiple{buffer_size, expected_multiple_size} — src/error.rs:85-94"""
+    code = -12
+    buffer_size = property(lambda s: s.a)
+    expected_multiple_size = property(lambda s: s.b)
+
+
+class FixedSizeBufferWrapperError(GsError):
+    """BufferSizeMismatched{buffer_size, expected_size} — src/error.rs:97-104"""
+    code = -13
+    buffer_size = property(lambda s: s.a)
+    expected_size = property(lambda s: s.b)
+
+
+class ComputeBundleCreateError(GsError):
+    """ResourceCountMismatch / WorkgroupSizeExceedsDeviceLimit — src/error.rs:107-126"""
+
+
+class ResourceCountMismatch(ComputeBundleCreateError):
+    code = -14
+    resource_count = property(lambda s: s.a)
+    bind_group_layout_count = property(lambda s: s.b)
+
+
+class WorkgroupSizeExceedsDeviceLimit(ComputeBundleCreateError):
+    code = -15
+    workgroup_size = property(lambda s: s.a)
+    device_limit = property(lambda s: s.b)
+
+
+class ComputeBundleBuildError(Exception):
+    """src/error.rs:129-143; raised by ComputeBundleBuilder.build in the reference's order."""
+
+
+class MissingBindGroupLayout(ComputeBundleBuildError): pass
+class MissingResolver(ComputeBundleBuildError): pass
+class MissingEntryPoint(ComputeBundleBuildError): pass
+class MissingMainShader(ComputeBundleBuildError): pass
+class KernelResolveError(ComputeBundleBuildError): """ComputeBundleBuildError::Wesl analogue"""
+
+
+class LossyConfigError(GsError): code = -21
+class DownloadBufferError(GsError): code = -22
+
+
+_ERRORS = {c.code: c for c in (InvalidArgumentError, NoDeviceError, HipError, OutOfMemoryError,
+                               GaussiansBufferUpdateError, GaussiansBufferUpdateRangeError,
+                               GaussiansBufferTryFromBufferError, FixedSizeBufferWrapperError,
+                               ResourceCountMismatch, WorkgroupSizeExceedsDeviceLimit,
+                               LossyConfigError, DownloadBufferError)}
+
+
+def _check(status):
+    if status == 0:
+        return
+    info = _capi.ErrorInfo()
+    _L.gs_last_error(C.byref(info))
+    if info.code != status:
+        info.code = status
+        info.message = _L.gs_status_string(status)
+    raise _ERRORS.get(status, GsError)(info)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class GaussianPod:
+    """One of the 12 GaussianPodWithSh{S}Cov3d{C}Configs layouts (src/buffer/gaussian.rs:373-384)."""
+
+    def __init__(self, sh, cov):
+        self.sh, self.cov = int(sh), int(cov)
+        self.name = "GaussianPodWithSh%sCov3d%sConfigs" % (SH_CONFIG_NAMES[sh], COV3D_CONFIG_NAMES[cov])
+
+    @property
+    def size(self):
+        return _L.gs_pod_size(self.sh, self.cov)
+
+    def features(self):
+        """GaussianPod::features() — src/buffer/gaussian.rs:270-286"""
+        out = (C.c_uint8 * 7)()
+        _check(_L.gs_pod_features(self.sh, self.cov, out))
+        return [(FEATURE_NAMES[i], bool(out[i])) for i in range(7)]
+
+    def from_gaussian(self, gaussians):
+        """G::from_gaussian over an array of Gaussians -> packed bytes (host)."""
+        g = np.ascontiguousarray(np.atleast_1d(gaussians), dtype=GAUSSIAN_DTYPE)
+        out = np.zeros(len(g) * self.size, dtype=np.uint8)
+        _check(_L.gs_pack(self.sh, self.cov, _ptr(g), len(g), _ptr(out)))
+        return out
+
+    def into_gaussian(self, pods):
+        """Into<Gaussian>; raises LossyConfigError where the reference panics."""
+        pods = np.ascontiguousarray(pods, dtype=np.uint8)
+        n = len(pods) // self.size
+        out = np.zeros(n, dtype=GAUSSIAN_DTYPE)
+        _check(_L.gs_unpack_to_gaussian(self.sh, self.cov, _ptr(pods), n, _ptr(out)))
+        return out
+
+    def __repr__(self):
+        return self.name
+
+    def __eq__(self, o):
+        return isinstance(o, GaussianPod) and (self.sh, self.cov) == (o.sh, o.cov)
+
+    def __hash__(self):
+        return hash((self.sh, self.cov))
+
+
+ALL_PODS = [GaussianPod(s, c) for s in range(4) for c in range(3)]
+for _p in ALL_PODS:
+    globals()[_p.name] = _p
+
+
+class GaussianShDegree:
+    """src/buffer/gaussian_transform.rs:17-52"""
+
+    def __init__(self, v):
+        self.v = int(v)
+
+    @staticmethod
+    def new(sh_deg):
+        return GaussianShDegree(sh_deg) if 0 <= sh_deg <= 3 else None
+
+    def get(self):
+        return self.v
+
+
+class GaussianMaxStdDev:
+    """src/buffer/gaussian_transform.rs:55-98"""
+
+    def __init__(self, u8):
+        self.u8 = int(u8)
+
+    @staticmethod
+    def new(max_std_dev):
+        out = C.c_uint8()
+        if _L.gs_max_std_dev_encode(max_std_dev, C.byref(out)) != 0:
+            return None
+        return GaussianMaxStdDev(out.value)
+
+    def get(self):
+        return _L.gs_max_std_dev_decode(self.u8)
+
+    def as_u8(self):
+        return self.u8
+
+
+def gaussian_transform_pod(size=1.0, display_mode=DISPLAY_SPLAT, sh_deg=3, no_sh0=False,
+                           max_std_dev=3.0):
+    """GaussianTransformPod::new — raises InvalidArgumentError where the Rust newtypes return None."""
+    pod = GaussianTransformPod()
+    _check(_L.gs_gaussian_transform_pod_new(size, display_mode, sh_deg, int(bool(no_sh0)),
+                                            max_std_dev, C.byref(pod)))
+    return pod
+
+
+def model_transform_pod(pos=(0.0, 0.0, 0.0), rot=(0.0, 0.0, 0.0, 1.0), scale=(1.0, 1.0, 1.0)):
+    """ModelTransformPod::new — src/buffer/model_transform.rs:68-77"""
+    pod = ModelTransformPod()
+    _L.gs_model_transform_pod_new(_ptr(np.asarray(pos, np.float32)), _ptr(np.asarray(rot, np.float32)),
+                                  _ptr(np.asarray(scale, np.float32)), C.byref(pod))
+    return pod
+
+
+def camera_look_at(eye, target, up, vfov_radians, width, height, near=0.1, far=100.0,
+                   background=(0.0, 0.0, 0.0)):
+    cam = Camera()
+    _L.gs_camera_look_at(_ptr(np.asarray(eye, np.float32)), _ptr(np.asarray(target, np.float32)),
+                         _ptr(np.asarray(up, np.float32)), vfov_radians, width, height, near, far,
+                         C.byref(cam))
+    cam.background[:] = background
+    return cam
+
+
+# ------------------------------------------------------------------------------------------------
+# device / stream / buffers
+# ------------------------------------------------------------------------------------------------
+
+class Device:
+    """wgpu::Device + wgpu::Queue."""
+
+    def __init__(self, ordinal=0):
+        h = C.c_void_p()
+        _check(_L.gs_device_create(ordinal, C.byref(h)))
+        self._h = h
+        self.ordinal = ordinal
+
+    def limits(self):
+        lim = Limits()
+        _check(_L.gs_device_limits(self._h, C.byref(lim)))
+        return lim
+
+    def synchronize(self):
+        _check(_L.gs_device_synchronize(self._h))
+
+    def create_stream(self):
+        return Stream(self)
+
+    def wrap_stream(self, native_handle):
+        return Stream(self, native=native_handle)
+
+    def close(self):
+        if self._h:
+            _L.gs_device_destroy(self._h)
+            self._h = None
+
+
+class Stream:
+    """CommandEncoder + queue.submit: an ordered HIP stream."""
+
+    def __init__(self, device, native=None):
+        h = C.c_void_p()
+        if native is None:
+            _check(_L.gs_stream_create(device._h, C.byref(h)))
+        else:
+            _check(_L.gs_stream_wrap(device._h, C.c_void_p(native), C.byref(h)))
+        self._h = h
+        self.device = device
+
+    def synchronize(self):
+        _check(_L.gs_stream_synchronize(self._h))
+
+    def native(self):
+        return _L.gs_stream_native(self._h)
+
+    def close(self):
+        if self._h:
+            _L.gs_stream_destroy(self._h)
+            self._h = None
+
+
+class Buffer:
+    """wgpu::Buffer with the BufferWrapper download contract (src/buffer/mod.rs:17-102)."""
+
+    def __init__(self, device, size=None, data=None, _handle=None):
+        self.device = device
+        if _handle is not None:
+            self._h = _handle
+            return
+        h = C.c_void_p()
+        if data is not None:
+            data = np.ascontiguousarray(data)
+            size = data.nbytes
+        _check(_L.gs_buffer_create(device._h, size, _ptr(data) if data is not None else None,
+                                   C.byref(h)))
+        self._h = h
+
+    @staticmethod
+    def from_raw(device, device_ptr, size):
+        h = C.c_void_p()
+        _check(_L.gs_buffer_from_raw(device._h, C.c_void_p(device_ptr), size, C.byref(h)))
+        return Buffer(device, _handle=h)
+
+    def clone(self):
+        return Buffer(self.device, _handle=C.c_void_p(_L.gs_buffer_retain(self._h)))
+
+    def size(self):
+        return _L.gs_buffer_size(self._h)
+
+    def device_ptr(self):
+        return _L.gs_buffer_device_ptr(self._h)
+
+    def write(self, stream, offset, data):
+        data = np.ascontiguousarray(data)
+        _check(_L.gs_buffer_write(self._h, stream._h, offset, _ptr(data), data.nbytes))
+
+    def download(self, stream, dtype=np.uint8):
+        """BufferWrapper::download::<T> — blocking."""
+        out = np.zeros(self.size(), dtype=np.uint8)
+        _check(_L.gs_buffer_download(self._h, stream._h, _ptr(out), out.nbytes))
+        return out.view(dtype)
+
+    def release(self):
+        if self._h:
+            _L.gs_buffer_release(self._h)
+            self._h = None
+
+
+class GaussiansBuffer:
+    """GaussiansBuffer<G> — src/buffer/gaussian.rs:17-229."""
+
+    def __init__(self, device, pod, _handle):
+        self.device, self.pod, self._h = device, pod, _handle
+
+    @staticmethod
+    def new(device, pod, gaussians):
+        g = np.ascontiguousarray(np.atleast_1d(gaussians), dtype=GAUSSIAN_DTYPE)
+        h = C.c_void_p()
+        _check(_L.gs_gaussians_buffer_create_from_gaussians(device._h, pod.sh, pod.cov, _ptr(g),
+                                                            len(g), C.byref(h)))
+        return GaussiansBuffer(device, pod, h)
+
+    @staticmethod
+    def new_with_pods(device, pod, pods):
+        pods = np.ascontiguousarray(pods, dtype=np.uint8)
+        assert pods.nbytes % pod.size == 0
+        h = C.c_void_p()
+        _check(_L.gs_gaussians_buffer_create(device._h, pod.sh, pod.cov, _ptr(pods),
+                                             pods.nbytes // pod.size, C.byref(h)))
+        return GaussiansBuffer(device, pod, h)
+
+    @staticmethod
+    def new_empty(device, pod, length):
+        h = C.c_void_p()
+        _check(_L.gs_gaussians_buffer_create(device._h, pod.sh, pod.cov, None, length, C.byref(h)))
+        return GaussiansBuffer(device, pod, h)
+
+    @staticmethod
+    def try_from(buffer, pod):
+        """TryFrom<wgpu::Buffer> — raises GaussiansBufferTryFromBufferError."""
+        h = C.c_void_p()
+        _check(_L.gs_gaussians_buffer_from_buffer(buffer._h, pod.sh, pod.cov, C.byref(h)))
+        return GaussiansBuffer(buffer.device, pod, h)
+
+    def len(self):
+        return _L.gs_gaussians_buffer_len(self._h)
+
+    __len__ = len
+
+    def is_empty(self):
+        return self.len() == 0
+
+    def buffer(self):
+        """BufferWrapper::buffer() — a new handle to the same device allocation."""
+        return Buffer(self.device, _handle=C.c_void_p(
+            _L.gs_buffer_retain(_L.gs_gaussians_buffer_buffer(self._h))))
+
+    def update(self, stream, gaussians):
+        g = np.ascontiguousarray(np.atleast_1d(gaussians), dtype=GAUSSIAN_DTYPE)
+        _check(_L.gs_gaussians_buffer_update_gaussians(self._h, stream._h, _ptr(g), len(g)))
+
+    def update_with_pod(self, stream, pods):
+        pods = np.ascontiguousarray(pods, dtype=np.uint8)
+        _check(_L.gs_gaussians_buffer_update(self._h, stream._h, _ptr(pods),
+                                             pods.nbytes // self.pod.size))
+
+    def update_range(self, stream, start, gaussians):
+        g = np.ascontiguousarray(np.atleast_1d(gaussians), dtype=GAUSSIAN_DTYPE)
+        _check(_L.gs_gaussians_buffer_update_range_gaussians(self._h, stream._h, start, _ptr(g), len(g)))
+
+    def update_range_with_pod(self, stream, start, pods):
+        pods = np.ascontiguousarray(pods, dtype=np.uint8)
+        _check(_L.gs_gaussians_buffer_update_range(self._h, stream._h, start, _ptr(pods),
+                                                   pods.nbytes // self.pod.size))
+
+    def download(self, stream):
+        out = np.zeros(self.len() * self.pod.size, dtype=np.uint8)
+        _check(_L.gs_gaussians_buffer_download(self._h, stream._h, _ptr(out), self.len()))
+        return out
+
+    def download_gaussians(self, stream):
+        out = np.zeros(self.len(), dtype=GAUSSIAN_DTYPE)
+        _check(_L.gs_gaussians_buffer_download_gaussians(self._h, stream._h, _ptr(out), self.len()))
+        return out
+
+    def mark_dirty(self):
+        _L.gs_gaussians_buffer_mark_dirty(self._h)
+
+    def destroy(self):
+        if self._h:
+            _L.gs_gaussians_buffer_destroy(self._h)
+            self._h = None
+
+
+class GaussianTransformBuffer(Buffer):
+    """src/buffer/gaussian_transform.rs:104-163"""
+
+    def __init__(self, device, _handle=None):
+        if _handle is None:
+            _handle = C.c_void_p()
+            _check(_L.gs_gaussian_transform_buffer_create(device._h, C.byref(_handle)))
+        super().__init__(device, _handle=_handle)
+
+    @staticmethod
+    def try_from(buffer):
+        _check(_L.gs_gaussian_transform_buffer_from_buffer(buffer._h))
+        return GaussianTransformBuffer(buffer.device, _handle=C.c_void_p(_L.gs_buffer_retain(buffer._h)))
+
+    def update(self, stream, size, display_mode, sh_deg, no_sh0, max_std_dev):
+        self.update_with_pod(stream, gaussian_transform_pod(size, display_mode, sh_deg, no_sh0, max_std_dev))
+
+    def update_with_pod(self, stream, pod):
+        _check(_L.gs_gaussian_transform_buffer_update(self._h, stream._h, C.byref(pod)))
+
+
+class ModelTransformBuffer(Buffer):
+    """src/buffer/model_transform.rs:10-58"""
+
+    def __init__(self, device, _handle=None):
+        if _handle is None:
+            _handle = C.c_void_p()
+            _check(_L.gs_model_transform_buffer_create(device._h, C.byref(_handle)))
+        super().__init__(device, _handle=_handle)
+
+    @staticmethod
+    def try_from(buffer):
+        _check(_L.gs_model_transform_buffer_from_buffer(buffer._h))
+        return ModelTransformBuffer(buffer.device, _handle=C.c_void_p(_L.gs_buffer_retain(buffer._h)))
+
+    def update(self, stream, pos, rot, scale):
+        self.update_with_pod(stream, model_transform_pod(pos, rot, scale))
+
+    def update_with_pod(self, stream, pod):
+        _check(_L.gs_model_transform_buffer_update(self._h, stream._h, C.byref(pod)))
+
+
+# ------------------------------------------------------------------------------------------------
+# ComputeBundle
+# ------------------------------------------------------------------------------------------------
+
+class KernelRegistry:
+    """The resolver: maps a module path to a kernel of the built-in library (the HIP analogue of
+    wesl::PkgResolver over shader::PACKAGE, src/shader.rs:8-56)."""
+    MODULES = {"array_map_add": KERNEL_ARRAY_MAP_ADD, "test_gaussian": KERNEL_TEST_GAUSSIAN,
+               "test_gaussian_transform": KERNEL_TEST_GAUSSIAN_TRANSFORM,
+               "test_model_transform": KERNEL_TEST_MODEL_TRANSFORM, "unpack_soa": KERNEL_UNPACK_SOA}
+
+    def resolve(self, path):
+        key = path.split("::")[-1]
+        if key not in self.MODULES:
+            raise KernelResolveError("module not found: %s" % path)
+        return self.MODULES[key]
+
+
+def _buffer_array(buffers):
+    arr = (C.c_void_p * len(buffers))(*[b._h for b in buffers])
+    return arr
+
+
+class ComputeBundle:
+    """src/compute_bundle.rs:49-351.  `layouts` = bindings per bind group."""
+
+    def __init__(self, device, handle, managed):
+        self.device, self._h, self._managed = device, handle, managed
+
+    @staticmethod
+    def _desc(label, kernel, pod, layouts, workgroup_size, constants, keep):
+        d = _capi.BundleDesc()
+        d.label = label.encode() if label else None
+        d.kernel = kernel
+        d.sh, d.cov = (pod.sh, pod.cov) if pod is not None else (0, 0)
+        d.bind_group_count = len(layouts)
+        arr = (C.c_uint32 * max(len(layouts), 1))(*layouts)
+        d.bindings_per_group = arr
+        d.workgroup_size = workgroup_size or 0
+        names = (C.c_char_p * max(len(constants), 1))(*[k.encode() for k in constants])
+        vals = (C.c_double * max(len(constants), 1))(*[float(v) for v in constants.values()])
+        d.constant_names, d.constant_values, d.constant_count = names, vals, len(constants)
+        keep.extend([arr, names, vals])
+        return d
+
+    @staticmethod
+    def new(label, device, layouts, resources, kernel, pod=None, workgroup_size=None, constants=None):
+        """ComputeBundle::new — :141-188"""
+        keep = []
+        d = ComputeBundle._desc(label, kernel, pod, list(layouts), workgroup_size, constants or {}, keep)
+        resources = [list(r) for r in resources]
+        groups = [_buffer_array(r) for r in resources]
+        gp = (C.c_void_p * max(len(groups), 1))(*[C.cast(g, C.c_void_p) for g in groups])
+        counts = (C.c_uint32 * max(len(groups), 1))(*[len(r) for r in resources])
+        h = C.c_void_p()
+        _check(_L.gs_bundle_create_with_bind_groups(device._h, C.byref(d), gp, counts, len(groups),
+                                                    C.byref(h)))
+        return ComputeBundle(device, h, True)
+
+    @staticmethod
+    def new_without_bind_groups(label, device, layouts, kernel, pod=None, workgroup_size=None,
+                                constants=None):
+        """ComputeBundle::new_without_bind_groups — :260-341"""
+        keep = []
+        d = ComputeBundle._desc(label, kernel, pod, list(layouts), workgroup_size, constants or {}, keep)
+        h = C.c_void_p()
+        _check(_L.gs_bundle_create(device._h, C.byref(d), C.byref(h)))
+        return ComputeBundle(device, h, False)
+
+    def workgroup_size(self):
+        return _L.gs_bundle_workgroup_size(self._h)
+
+    def label(self):
+        v = _L.gs_bundle_label(self._h)
+        return v.decode() if v else None
+
+    def bind_group_layouts(self):
+        return _L.gs_bundle_bind_group_layout_count(self._h)
+
+    def bind_groups(self):
+        return _L.gs_bundle_bind_group_count(self._h)
+
+    def update_bind_group_with_binding_resources(self, index, resources):
+        """Returns False when index is out of bounds (Rust: None) — :222-231"""
+        if index >= self.bind_groups():
+            return False
+        resources = list(resources)
+        _check(_L.gs_bundle_set_bind_group(self._h, index, _buffer_array(resources), len(resources)))
+        return True
+
+    def dispatch(self, stream, count, bind_groups=None):
+        """dispatch(encoder, count) / ComputeBundle<()>::dispatch(encoder, count, bind_groups)"""
+        if bind_groups is None:
+            _check(_L.gs_bundle_dispatch(self._h, stream._h, count))
+            return
+        bind_groups = [list(g) for g in bind_groups]
+        groups = [_buffer_array(g) for g in bind_groups]
+        gp = (C.c_void_p * max(len(groups), 1))(*[C.cast(g, C.c_void_p) for g in groups])
+        counts = (C.c_uint32 * max(len(groups), 1))(*[len(g) for g in bind_groups])
+        _check(_L.gs_bundle_dispatch_with_bind_groups(self._h, stream._h, count, gp, counts, len(groups)))
+
+    def last_workgroup_count(self):
+        return _L.gs_bundle_last_workgroup_count(self._h)
+
+    def destroy(self):
+        if self._h:
+            _L.gs_bundle_destroy(self._h)
+            self._h = None
+
+
+class ComputeBundleBuilder:
+    """src/compute_bundle.rs:364-593: same required fields, checked in the same order."""
+
+    def __init__(self):
+        self._label = None
+        self._layouts = []
+        self._constants = {}
+        self._entry_point = None
+        self._main_shader = None
+        self._pod = None
+        self._resolver = None
+        self._workgroup_size = None
+
+    def label(self, label):
+        self._label = label
+        return self
+
+    def bind_group_layout(self, bindings):
+        """`bindings` = number of entries of the BindGroupLayoutDescriptor"""
+        self._layouts.append(int(bindings))
+        return self
+
+    def bind_group_layouts(self, layouts):
+        self._layouts.extend(int(b) for b in layouts)
+        return self
+
+    def pipeline_compile_options(self, constants):
+        self._constants = dict(constants)
+        return self
+
+    def entry_point(self, name):
+        self._entry_point = name
+        return self
+
+    def main_shader(self, module_path):
+        self._main_shader = module_path
+        return self
+
+    def wesl_compile_options(self, features):
+        """`features` = a GaussianPod (its features() select the kernel instantiation)"""
+        self._pod = features
+        return self
+
+    def resolver(self, resolver):
+        self._resolver = resolver
+        return self
+
+    def workgroup_size(self, n):
+        self._workgroup_size = n
+        return self
+
+    def _resolve(self):
+        if not self._layouts:
+            raise MissingBindGroupLayout("missing bind group layout for compute bundle")
+        if self._resolver is None:
+            raise MissingResolver("missing resolver for compute bundle")
+        if self._entry_point is None:
+            raise MissingEntryPoint("missing entry point for compute bundle")
+        if self._main_shader is None:
+            raise MissingMainShader("missing main shader for compute bundle")
+        return self._resolver.resolve(self._main_shader)
+
+    def build(self, device, resources):
+        kernel = self._resolve()
+        return ComputeBundle.new(self._label, device, self._layouts, resources, kernel, self._pod,
+                                 self._workgroup_size, self._constants)
+
+    def build_without_bind_groups(self, device):
+        kernel = self._resolve()
+        return ComputeBundle.new_without_bind_groups(self._label, device, self._layouts, kernel,
+                                                     self._pod, self._workgroup_size, self._constants)
+
+
+# ------------------------------------------------------------------------------------------------
+# renderer
+# ------------------------------------------------------------------------------------------------
+
+STAGE_NAMES = ["repack", "preprocess", "scan", "emit", "sort", "ranges", "blend", "frame"]
+
+
+class Renderer:
+    """One render context (scratch buffers + stats) on a device: gs_render_frame."""
+
+    def __init__(self, device):
+        h = C.c_void_p()
+        _check(_L.gs_renderer_create(device._h, C.byref(h)))
+        self._h, self.device = h, device
+
+    def set_timing(self, enabled):
+        _check(_L.gs_renderer_set_timing(self._h, int(bool(enabled))))
+
+    def reset_stats(self):
+        _check(_L.gs_renderer_reset_stats(self._h))
+
+    def stats(self):
+        st = FrameStats()
+        _check(_L.gs_renderer_stats(self._h, C.byref(st)))
+        return st
+
+    def render(self, stream, gaussians, gaussian_transform, model_transform, camera,
+               rgba_device_ptr, band=None):
+        b0, b1 = band if band is not None else (0, 0xFFFFFFFF)
+        _check(_L.gs_render_frame(self._h, stream._h, gaussians._h, C.byref(gaussian_transform),
+                                  C.byref(model_transform), C.byref(camera), b0, b1,
+                                  C.c_void_p(rgba_device_ptr)))
+
+    def download_projected(self, n):
+        proj = np.zeros(n, dtype=PROJECTED_DTYPE)
+        tiles = np.zeros(n, dtype=np.uint32)
+        _check(_L.gs_renderer_download_projected(self._h, _ptr(proj), _ptr(tiles), n))
+        return proj, tiles
+
+    def _pairs(self, fn):
+        d = C.c_uint64()
+        _check(fn(self._h, None, None, 0, C.byref(d)))
+        keys = np.zeros(max(d.value, 1), dtype=np.uint64)
+        idx = np.zeros(max(d.value, 1), dtype=np.uint32)
+        _check(fn(self._h, _ptr(keys), _ptr(idx), d.value, C.byref(d)))
+        return keys[:d.value], idx[:d.value]
+
+    def download_sorted(self):
+        return self._pairs(_L.gs_renderer_download_sorted)
+
+    def download_unsorted(self):
+        return self._pairs(_L.gs_renderer_download_unsorted)
+
+    def download_ranges(self, num_tiles):
+        r = np.zeros((num_tiles, 2), dtype=np.uint32)
+        _check(_L.gs_renderer_download_ranges(self._h, _ptr(r), num_tiles))
+        return r
+
+    def destroy(self):
+        if self._h:
+            _L.gs_renderer_destroy(self._h)
+            self._h = None
+
+
+def sort_pairs_u64(device, stream, keys, values, end_bit=64):
+    """Device radix sort of host arrays (stable LSD on key bits [0, end_bit)); returns copies."""
+    k = np.ascontiguousarray(keys, dtype=np.uint64).copy()
+    v = np.ascontiguousarray(values, dtype=np.uint32).copy()
+    _check(_L.gs_sort_pairs_u64(device._h, stream._h if stream else None, _ptr(k), _ptr(v), len(k), end_bit))
+    return k, v
+
+
+def exclusive_scan_u32(device, stream, values):
+    a = np.ascontiguousarray(values, dtype=np.uint32)
+    out = np.zeros_like(a)
+    total = C.c_uint64()
+    _check(_L.gs_exclusive_scan_u32(device._h, stream._h if stream else None, _ptr(a), _ptr(out),
+                                    len(a), C.byref(total)))
+    return out, total.value

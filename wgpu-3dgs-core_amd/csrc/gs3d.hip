@@ -1,0 +1,1557 @@
+// gs3d.hip — host side of libgs3d_hip.so: the C ABI of include/gs3d.h over the gfx950 kernels.
+// Built by hipcc --offload-arch=gfx950 -ffp-contract=off (see build.py).  No CPU fallback: every
+// compute entry point needs a HIP device.
+#include "../../include/gs3d.h"
+
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "gs_bundle_kernels.h"
+#include "gs_render_kernels.h"
+
+// ------------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------------
+
+static thread_local gs_error_info t_err = {0, 0, 0, 0, {0}};
+
+static gs_status fail(gs_status code, uint64_t a, uint64_t b, uint64_t c, const char *fmt, ...) {
+    t_err.code = code;
+    t_err.a = a;
+    t_err.b = b;
+    t_err.c = c;
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(t_err.message, sizeof(t_err.message), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define GS_HIP(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return fail(e_ == hipErrorOutOfMemory ? GS_ERR_OUT_OF_MEMORY : GS_ERR_HIP,            \
+                        (uint64_t)e_, 0, 0, "%s failed: %s", #expr, hipGetErrorString(e_));       \
+    } while (0)
+
+#define GS_TRY(expr)                  \
+    do {                              \
+        gs_status s_ = (expr);        \
+        if (s_ != GS_OK) return s_;   \
+    } while (0)
+
+extern "C" void gs_last_error(gs_error_info *out) {
+    if (out) *out = t_err;
+}
+
+extern "C" uint32_t gs_abi_version(void) { return GS3D_ABI_VERSION; }
+
+extern "C" const char *gs_status_string(gs_status s) {
+    switch (s) {
+    case GS_OK: return "ok";
+    case GS_ERR_INVALID_ARGUMENT: return "invalid argument";
+    case GS_ERR_NO_DEVICE: return "no HIP device";
+    case GS_ERR_HIP: return "HIP runtime error";
+    case GS_ERR_OUT_OF_MEMORY: return "out of device memory";
+    case GS_ERR_COUNT_MISMATCH: return "Gaussians count mismatch";
+    case GS_ERR_RANGE_COUNT_MISMATCH: return "Gaussians range count mismatch";
+    case GS_ERR_BUFFER_SIZE_NOT_MULTIPLE: return "buffer size and expected multiple size mismatch";
+    case GS_ERR_BUFFER_SIZE_MISMATCHED: return "buffer size and expected size mismatch";
+    case GS_ERR_RESOURCE_COUNT_MISMATCH: return "resource count and bind group layout count mismatch";
+    case GS_ERR_WORKGROUP_SIZE_EXCEEDS_LIMIT: return "workgroup size exceeds device limit";
+    case GS_ERR_MISSING_BIND_GROUP_LAYOUT: return "missing bind group layout for compute bundle";
+    case GS_ERR_MISSING_RESOLVER: return "missing resolver for compute bundle";
+    case GS_ERR_MISSING_ENTRY_POINT: return "missing entry point for compute bundle";
+    case GS_ERR_MISSING_MAIN_SHADER: return "missing main shader for compute bundle";
+    case GS_ERR_KERNEL_COMPILE: return "kernel compilation failed";
+    case GS_ERR_LOSSY_CONFIG: return "configuration cannot be converted back to a Gaussian";
+    case GS_ERR_DOWNLOAD: return "buffer download failed";
+    case GS_ERR_PAIR_OVERFLOW: return "pair buffer overflow";
+    default: return "unknown";
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host-side data model: packing (G::from_gaussian) — runs on the host in the reference too
+// ------------------------------------------------------------------------------------------------
+
+static bool valid_cfg(int sh, int cov) { return sh >= 0 && sh <= 3 && cov >= 0 && cov <= 2; }
+
+extern "C" size_t gs_pod_size(gs_sh_config sh, gs_cov3d_config cov) {
+    if (!valid_cfg(sh, cov)) return 0;
+    return (size_t)gs::pod_bytes(sh, cov);
+}
+
+static const char *k_feature_names[7] = {"sh_single", "sh_half", "sh_norm8", "sh_none",
+                                         "cov3d_rot_scale", "cov3d_single", "cov3d_half"};
+
+extern "C" const char *gs_feature_name(uint32_t index) {
+    return index < 7 ? k_feature_names[index] : nullptr;
+}
+
+extern "C" gs_status gs_pod_features(gs_sh_config sh, gs_cov3d_config cov, uint8_t out[7]) {
+    if (!valid_cfg(sh, cov) || !out) return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "bad config");
+    for (int i = 0; i < 7; i++) out[i] = (i == (int)sh) || (i == 4 + (int)cov);
+    return GS_OK;
+}
+
+// IEEE binary32 -> binary16, round to nearest even (half::f16::from_f32)
+static uint16_t f32_to_f16_rtne(float value) {
+    union { uint32_t u; float f; } f, magic;
+    f.f = value;
+    const uint32_t f32infty = 255u << 23, f16max = (127u + 16u) << 23;
+    magic.u = ((127u - 15u) + (23u - 10u) + 1u) << 23;
+    uint32_t sign = f.u & 0x80000000u;
+    f.u ^= sign;
+    uint16_t o;
+    if (f.u >= f16max) {
+        o = (f.u > f32infty) ? (uint16_t)(0x7e00u | ((f.u >> 13) & 0x1ffu)) : (uint16_t)0x7c00u;
+    } else if (f.u < (113u << 23)) {
+        f.f += magic.f;
+        o = (uint16_t)(f.u - magic.u);
+    } else {
+        uint32_t odd = (f.u >> 13) & 1u;
+        f.u += ((uint32_t)(15 - 127) << 23) + 0xfffu;
+        f.u += odd;
+        o = (uint16_t)(f.u >> 13);
+    }
+    return (uint16_t)(o | (sign >> 16));
+}
+
+static float f16_to_f32_host(uint16_t h) {
+    union { uint32_t u; float f; } o;
+    uint32_t sign = ((uint32_t)h & 0x8000u) << 16, e = (h >> 10) & 0x1fu, m = h & 0x3ffu;
+    if (e == 0) {
+        o.f = std::ldexp((float)m, -24);
+        o.u |= sign;
+    } else if (e == 31) {
+        o.u = sign | 0x7f800000u | (m << 13);
+    } else {
+        o.u = sign | ((e + 112u) << 23) | (m << 13);
+    }
+    return o.f;
+}
+
+// glam Mat3::from_quat(rot) * Mat3::from_diagonal(scale), then m * m^T (gaussian_config.rs:195-208)
+static void cov3d_from_rot_scale(const float q[4], const float s[3], float out[6]) {
+    gs::ModelTransform mt{};
+    std::memcpy(mt.rot, q, 16);
+    std::memcpy(mt.scale, s, 12);
+    float m[9];
+    gs::model_scale_rot_mat(mt, m);  // same x2/xx/wz formulation, columns scaled by s
+    auto sig = [&](int r, int c) {
+        return (m[0 + r] * m[0 + c] + m[3 + r] * m[3 + c]) + m[6 + r] * m[6 + c];
+    };
+    out[0] = sig(0, 0);
+    out[1] = sig(1, 0);
+    out[2] = sig(2, 0);
+    out[3] = sig(1, 1);
+    out[4] = sig(2, 1);
+    out[5] = sig(2, 2);
+}
+
+template <class F>
+static void parallel_for(size_t n, F fn) {
+    unsigned hw = std::thread::hardware_concurrency();
+    size_t threads = n < 65536 ? 1 : (hw ? (hw > 32 ? 32 : hw) : 4);
+    if (threads <= 1) {
+        fn((size_t)0, n);
+        return;
+    }
+    std::vector<std::thread> pool;
+    size_t per = (n + threads - 1) / threads;
+    for (size_t t = 0; t < threads; t++) {
+        size_t a = t * per, b = a + per < n ? a + per : n;
+        if (a >= b) break;
+        pool.emplace_back([=] { fn(a, b); });
+    }
+    for (auto &th : pool) th.join();
+}
+
+static void pack_one(int sh, int cov, const gs_gaussian &g, uint8_t *p, size_t stride) {
+    std::memset(p, 0, stride);
+    std::memcpy(p, g.pos, 12);
+    std::memcpy(p + 12, g.color, 4);
+    uint8_t *s = p + 16;
+    if (sh == GS_SH_SINGLE) {
+        std::memcpy(s, g.sh, 180);
+    } else if (sh == GS_SH_HALF) {
+        uint16_t h[46];
+        for (int k = 0; k < 45; k++) h[k] = f32_to_f16_rtne(g.sh[k]);
+        h[45] = 0;
+        std::memcpy(s, h, 92);
+    } else if (sh == GS_SH_NORM8) {
+        int8_t b[48];
+        for (int k = 0; k < 45; k++) {
+            float v = g.sh[k] * 127.0f;
+            if (v != v) v = 0.0f;             // Rust `as i8`: NaN -> 0
+            if (v < -127.0f) v = -127.0f;
+            if (v > 127.0f) v = 127.0f;
+            b[k] = (int8_t)v;                 // truncation toward zero
+        }
+        b[45] = b[46] = b[47] = 0;
+        std::memcpy(s, b, 48);
+    }
+    uint8_t *c = s + gs::sh_bytes(sh);
+    if (cov == GS_COV3D_ROT_SCALE) {
+        std::memcpy(c, g.rot, 16);
+        std::memcpy(c + 16, g.scale, 12);
+    } else {
+        float c6[6];
+        cov3d_from_rot_scale(g.rot, g.scale, c6);
+        if (cov == GS_COV3D_SINGLE) {
+            std::memcpy(c, c6, 24);
+        } else {
+            uint16_t h[6];
+            for (int k = 0; k < 6; k++) h[k] = f32_to_f16_rtne(c6[k]);
+            std::memcpy(c, h, 12);
+        }
+    }
+}
+
+extern "C" gs_status gs_pack(gs_sh_config sh, gs_cov3d_config cov, const gs_gaussian *in, size_t n,
+                             void *out) {
+    if (!valid_cfg(sh, cov) || (n && (!in || !out)))
+        return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "gs_pack: bad argument");
+    size_t stride = gs_pod_size(sh, cov);
+    uint8_t *o = (uint8_t *)out;
+    parallel_for(n, [=](size_t a, size_t b) {
+        for (size_t i = a; i < b; i++) pack_one(sh, cov, in[i], o + i * stride, stride);
+    });
+    return GS_OK;
+}
+
+extern "C" gs_status gs_unpack_to_gaussian(gs_sh_config sh, gs_cov3d_config cov, const void *pods,
+                                           size_t n, gs_gaussian *out) {
+    if (!valid_cfg(sh, cov) || (n && (!pods || !out)))
+        return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "gs_unpack_to_gaussian: bad argument");
+    if (sh == GS_SH_NONE)
+        return fail(GS_ERR_LOSSY_CONFIG, 0, 0, 0, "Cannot convert from SH None configuration");
+    if (cov == GS_COV3D_SINGLE)
+        return fail(GS_ERR_LOSSY_CONFIG, 0, 0, 0, "Cannot convert from Cov3d Single configuration");
+    if (cov == GS_COV3D_HALF)
+        return fail(GS_ERR_LOSSY_CONFIG, 0, 0, 0, "Cannot convert from Cov3d Half configuration");
+    size_t stride = gs_pod_size(sh, cov);
+    const uint8_t *in = (const uint8_t *)pods;
+    parallel_for(n, [=](size_t a, size_t b) {
+        for (size_t i = a; i < b; i++) {
+            const uint8_t *p = in + i * stride;
+            gs_gaussian &g = out[i];
+            std::memcpy(g.pos, p, 12);
+            std::memcpy(g.color, p + 12, 4);
+            const uint8_t *s = p + 16;
+            for (int k = 0; k < 45; k++) {
+                if (sh == GS_SH_SINGLE) {
+                    std::memcpy(&g.sh[k], s + 4 * k, 4);
+                } else if (sh == GS_SH_HALF) {
+                    uint16_t h;
+                    std::memcpy(&h, s + 2 * k, 2);
+                    g.sh[k] = f16_to_f32_host(h);
+                } else {
+                    float v = (float)(int8_t)s[k] / 127.0f;
+                    g.sh[k] = v < -1.0f ? -1.0f : v;
+                }
+            }
+            const uint8_t *c = s + gs::sh_bytes(sh);
+            std::memcpy(g.rot, c, 16);
+            std::memcpy(g.scale, c + 16, 12);
+        }
+    });
+    return GS_OK;
+}
+
+extern "C" gs_status gs_max_std_dev_encode(float v, uint8_t *out) {
+    if (!out || !(v >= 0.0f && v <= 3.0f))
+        return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "max_std_dev must be in [0, 3]");
+    *out = (uint8_t)(v / 3.0f * 255.0f);
+    return GS_OK;
+}
+
+extern "C" float gs_max_std_dev_decode(uint8_t v) { return (float)v / 255.0f * 3.0f; }
+
+extern "C" gs_status gs_gaussian_transform_pod_new(float size, gs_display_mode mode, uint8_t sh_deg,
+                                                   uint8_t no_sh0, float max_std_dev,
+                                                   gs_gaussian_transform_pod *out) {
+    if (!out || (int)mode < 0 || (int)mode > 2)
+        return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "bad display mode");
+    if (sh_deg > 3) return fail(GS_ERR_INVALID_ARGUMENT, sh_deg, 0, 0, "SH degree must be in [0, 3]");
+    uint8_t sd;
+    GS_TRY(gs_max_std_dev_encode(max_std_dev, &sd));
+    out->size = size;
+    out->flags[0] = (uint8_t)mode;
+    out->flags[1] = sh_deg;
+    out->flags[2] = no_sh0 ? 1 : 0;
+    out->flags[3] = sd;
+    return GS_OK;
+}
+
+extern "C" void gs_gaussian_transform_pod_default(gs_gaussian_transform_pod *out) {
+    gs_gaussian_transform_pod_new(1.0f, GS_DISPLAY_SPLAT, 3, 0, 3.0f, out);
+}
+
+extern "C" void gs_model_transform_pod_new(const float pos[3], const float rot[4],
+                                           const float scale[3], gs_model_transform_pod *out) {
+    std::memset(out, 0, sizeof(*out));
+    std::memcpy(out->pos, pos, 12);
+    std::memcpy(out->rot, rot, 16);
+    std::memcpy(out->scale, scale, 12);
+}
+
+extern "C" void gs_model_transform_pod_default(gs_model_transform_pod *out) {
+    const float p[3] = {0, 0, 0}, r[4] = {0, 0, 0, 1}, s[3] = {1, 1, 1};
+    gs_model_transform_pod_new(p, r, s, out);
+}
+
+// ------------------------------------------------------------------------------------------------
+// device / stream / buffer
+// ------------------------------------------------------------------------------------------------
+
+struct gs_device {
+    int ordinal;
+    gs_limits limits;
+    hipStream_t internal;  // for blocking helper work
+};
+
+struct gs_stream {
+    gs_device *dev;
+    hipStream_t s;
+    bool owned;
+};
+
+struct gs_buffer {
+    gs_device *dev;
+    void *ptr;
+    size_t bytes;
+    bool owned;
+    std::atomic<int> refs;
+};
+
+static gs_status use_device(const gs_device *dev) {
+    if (!dev) return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "null device");
+    GS_HIP(hipSetDevice(dev->ordinal));
+    return GS_OK;
+}
+
+extern "C" gs_status gs_device_create(int32_t ordinal, gs_device **out) {
+    if (!out) return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "null out");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(GS_ERR_NO_DEVICE, (uint64_t)e, 0, 0, "no HIP device available (%s)",
+                    e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+    if (ordinal < 0 || ordinal >= count)
+        return fail(GS_ERR_NO_DEVICE, 0, 0, 0, "device ordinal %d out of range [0, %d)", ordinal, count);
+    GS_HIP(hipSetDevice(ordinal));
+    hipDeviceProp_t props;
+    GS_HIP(hipGetDeviceProperties(&props, ordinal));
+    gs_device *d = new gs_device();
+    d->ordinal = ordinal;
+    std::memset(&d->limits, 0, sizeof(d->limits));
+    d->limits.max_compute_workgroup_size_x = (uint32_t)props.maxThreadsDim[0];
+    d->limits.max_compute_invocations_per_workgroup = (uint32_t)props.maxThreadsPerBlock;
+    d->limits.compute_units = (uint32_t)props.multiProcessorCount;
+    d->limits.wavefront_size = (uint32_t)props.warpSize;
+    d->limits.total_memory_bytes = (uint64_t)props.totalGlobalMem;
+    std::snprintf(d->limits.arch_name, sizeof(d->limits.arch_name), "%s", props.gcnArchName);
+    hipError_t se = hipStreamCreateWithFlags(&d->internal, hipStreamNonBlocking);
+    if (se != hipSuccess) {
+        delete d;
+        return fail(GS_ERR_HIP, (uint64_t)se, 0, 0, "hipStreamCreate failed: %s", hipGetErrorString(se));
+    }
+    *out = d;
+    return GS_OK;
+}
+
+extern "C" void gs_device_destroy(gs_device *dev) {
+    if (!dev) return;
+    (void)hipSetDevice(dev->ordinal);
+    (void)hipStreamDestroy(dev->internal);
+    delete dev;
+}
+
+extern "C" gs_status gs_device_limits(const gs_device *dev, gs_limits *out) {
+    if (!dev || !out) return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "null argument");
+    *out = dev->limits;
+    return GS_OK;
+}
+
+extern "C" gs_status gs_device_synchronize(gs_device *dev) {
+    GS_TRY(use_device(dev));
+    GS_HIP(hipDeviceSynchronize());
+    return GS_OK;
+}
+
+extern "C" gs_status gs_stream_create(gs_device *dev, gs_stream **out) {
+    if (!out) return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "null out");
+    GS_TRY(use_device(dev));
+    hipStream_t s;
+    GS_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *out = new gs_stream{dev, s, true};
+    return GS_OK;
+}
+
+extern "C" gs_status gs_stream_wrap(gs_device *dev, void *hip_stream, gs_stream **out) {
+    if (!dev || !out) return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "null argument");
+    *out = new gs_stream{dev, (hipStream_t)hip_stream, false};
+    return GS_OK;
+}
+
+extern "C" void *gs_stream_native(const gs_stream *s) { return s ? (void *)s->s : nullptr; }
+
+extern "C" gs_status gs_stream_synchronize(gs_stream *s) {
+    if (!s) return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "null stream");
+    GS_TRY(use_device(s->dev));
+    GS_HIP(hipStreamSynchronize(s->s));
+    return GS_OK;
+}
+
+extern "C" void gs_stream_destroy(gs_stream *s) {
+    if (!s) return;
+    if (s->owned) {
+        (void)hipSetDevice(s->dev->ordinal);
+        (void)hipStreamDestroy(s->s);
+    }
+    delete s;
+}
+
+static hipStream_t stream_of(gs_device *dev, gs_stream *s) { return s ? s->s : dev->internal; }
+
+extern "C" gs_status gs_buffer_create(gs_device *dev, size_t bytes, const void *init,
+                                      gs_buffer **out) {
+    if (!out) return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "null out");
+    GS_TRY(use_device(dev));
+    void *p = nullptr;
+    // a zero-sized wgpu buffer is legal; keep a 16-byte allocation so the pointer is valid
+    GS_HIP(hipMalloc(&p, bytes ? bytes : 16));
+    if (init && bytes) {
+        hipError_t e = hipMemcpy(p, init, bytes, hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            (void)hipFree(p);
+            return fail(GS_ERR_HIP, (uint64_t)e, 0, 0, "hipMemcpy failed: %s", hipGetErrorString(e));
+        }
+    } else if (bytes) {
+        // wgpu zero-initialises new buffers
+        hipError_t e = hipMemset(p, 0, bytes);
+        if (e != hipSuccess) {
+            (void)hipFree(p);
+            return fail(GS_ERR_HIP, (uint64_t)e, 0, 0, "hipMemset failed: %s", hipGetErrorString(e));
+        }
+    }
+    gs_buffer *b = new gs_buffer();
+    b->dev = dev;
+    b->ptr = p;
+    b->bytes = bytes;
+    b->owned = true;
+    b->refs.store(1);
+    *out = b;
+    return GS_OK;
+}
+
+extern "C" gs_status gs_buffer_from_raw(gs_device *dev, void *device_ptr, size_t bytes,
+                                        gs_buffer **out) {
+    if (!dev || !out || (!device_ptr && bytes))
+        return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "null argument");
+    gs_buffer *b = new gs_buffer();
+    b->dev = dev;
+    b->ptr = device_ptr;
+    b->bytes = bytes;
+    b->owned = false;
+    b->refs.store(1);
+    *out = b;
+    return GS_OK;
+}
+
+extern "C" gs_buffer *gs_buffer_retain(gs_buffer *b) {
+    if (b) b->refs.fetch_add(1);
+    return b;
+}
+
+extern "C" void gs_buffer_release(gs_buffer *b) {
+    if (!b) return;
+    if (b->refs.fetch_sub(1) == 1) {
+        if (b->owned && b->ptr) {
+            (void)hipSetDevice(b->dev->ordinal);
+            (void)hipFree(b->ptr);
+        }
+        delete b;
+    }
+}
+
+extern "C" size_t gs_buffer_size(const gs_buffer *b) { return b ? b->bytes : 0; }
+extern "C" void *gs_buffer_device_ptr(const gs_buffer *b) { return b ? b->ptr : nullptr; }
+
+extern "C" gs_status gs_buffer_write(gs_buffer *b, gs_stream *s, size_t offset, const void *src,
+                                     size_t bytes) {
+    if (!b || (bytes && !src)) return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "null argument");
+    if (offset > b->bytes || bytes > b->bytes - offset)
+        return fail(GS_ERR_INVALID_ARGUMENT, offset, bytes, b->bytes,
+                    "write of %zu bytes at offset %zu overruns buffer of %zu bytes", bytes, offset,
+                    b->bytes);
+    if (!bytes) return GS_OK;
+    GS_TRY(use_device(b->dev));
+    hipStream_t st = stream_of(b->dev, s);
+    GS_HIP(hipMemcpyAsync((uint8_t *)b->ptr + offset, src, bytes, hipMemcpyHostToDevice, st));
+    // queue.write_buffer captures `src` at call time: do not return while the host memory may
+    // still be read by an in-flight staged copy.
+    GS_HIP(hipStreamSynchronize(st));
+    return GS_OK;
+}
+
+extern "C" gs_status gs_buffer_download(gs_buffer *b, gs_stream *s, void *dst, size_t bytes) {
+    if (!b || (bytes && !dst)) return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "null argument");
+    if (bytes > b->bytes)
+        return fail(GS_ERR_INVALID_ARGUMENT, bytes, b->bytes, 0,
+                    "download of %zu bytes from buffer of %zu bytes", bytes, b->bytes);
+    if (!bytes) return GS_OK;
+    GS_TRY(use_device(b->dev));
+    hipStream_t st = stream_of(b->dev, s);
+    hipError_t e = hipMemcpyAsync(dst, b->ptr, bytes, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess)
+        return fail(GS_ERR_DOWNLOAD, (uint64_t)e, 0, 0, "download failed: %s", hipGetErrorString(e));
+    return GS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// GaussiansBuffer<G>
+// ------------------------------------------------------------------------------------------------
+
+struct gs_gaussians_buffer {
+    gs_buffer *buf;
+    int sh, cov;
+    // chunk-planar mirror read by the preprocess kernel; rebuilt lazily
+    void *planar;
+    size_t planar_stride;  // in 16-byte elements = len rounded up to 64
+    bool dirty;
+};
+
+static size_t pod_stride(const gs_gaussians_buffer *g) { return (size_t)gs::pod_bytes(g->sh, g->cov); }
+
+extern "C" size_t gs_gaussians_buffer_len(const gs_gaussians_buffer *g) {
+    return g ? g->buf->bytes / pod_stride(g) : 0;
+}
+
+extern "C" gs_status gs_gaussians_buffer_from_buffer(gs_buffer *buffer, gs_sh_config sh,
+                                                     gs_cov3d_config cov,
+                                                     gs_gaussians_buffer **out) {
+    if (!buffer || !out || !valid_cfg(sh, cov))
+        return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "bad argument");
+    size_t stride = gs_pod_size(sh, cov);
+    if (buffer->bytes % stride != 0)
+        return fail(GS_ERR_BUFFER_SIZE_NOT_MULTIPLE, buffer->bytes, stride, 0,
+                    "buffer size and expected multiple size mismatch: %zu %% %zu != 0",
+                    buffer->bytes, stride);
+    gs_gaussians_buffer *g = new gs_gaussians_buffer();
+    g->buf = gs_buffer_retain(buffer);
+    g->sh = sh;
+    g->cov = cov;
+    g->planar = nullptr;
+    g->planar_stride = 0;
+    g->dirty = true;
+    *out = g;
+    return GS_OK;
+}
+
+extern "C" gs_status gs_gaussians_buffer_create(gs_device *dev, gs_sh_config sh, gs_cov3d_config cov,
+                                                const void *pods, size_t len,
+                                                gs_gaussians_buffer **out) {
+    if (!out || !valid_cfg(sh, cov)) return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "bad argument");
+    gs_buffer *b = nullptr;
+    GS_TRY(gs_buffer_create(dev, len * gs_pod_size(sh, cov), pods, &b));
+    gs_status st = gs_gaussians_buffer_from_buffer(b, sh, cov, out);
+    gs_buffer_release(b);
+    return st;
+}
+
+extern "C" gs_status gs_gaussians_buffer_create_from_gaussians(gs_device *dev, gs_sh_config sh,
+                                                               gs_cov3d_config cov,
+                                                               const gs_gaussian *gaussians,
+                                                               size_t len,
+                                                               gs_gaussians_buffer **out) {
+    if (!valid_cfg(sh, cov) || (len && !gaussians))
+        return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "bad argument");
+    std::vector<uint8_t> pods(len * gs_pod_size(sh, cov));
+    GS_TRY(gs_pack(sh, cov, gaussians, len, pods.data()));
+    return gs_gaussians_buffer_create(dev, sh, cov, pods.data(), len, out);
+}
+
+extern "C" void gs_gaussians_buffer_destroy(gs_gaussians_buffer *g) {
+    if (!g) return;
+    if (g->planar) {
+        (void)hipSetDevice(g->buf->dev->ordinal);
+        (void)hipFree(g->planar);
+    }
+    gs_buffer_release(g->buf);
+    delete g;
+}
+
+extern "C" gs_buffer *gs_gaussians_buffer_buffer(const gs_gaussians_buffer *g) {
+    return g ? g->buf : nullptr;
+}
+extern "C" gs_sh_config gs_gaussians_buffer_sh(const gs_gaussians_buffer *g) {
+    return (gs_sh_config)(g ? g->sh : 0);
+}
+extern "C" gs_cov3d_config gs_gaussians_buffer_cov3d(const gs_gaussians_buffer *g) {
+    return (gs_cov3d_config)(g ? g->cov : 0);
+}
+
+extern "C" gs_status gs_gaussians_buffer_update(gs_gaussians_buffer *g, gs_stream *s,
+                                                const void *pods, size_t count) {
+    if (!g) return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "null buffer");
+    size_t len = gs_gaussians_buffer_len(g);
+    if (count != len)
+        return fail(GS_ERR_COUNT_MISMATCH, count, len, 0, "Gaussians count mismatch: %zu != %zu",
+                    count, len);
+    g->dirty = true;
+    return gs_buffer_write(g->buf, s, 0, pods, count * pod_stride(g));
+}
+
+extern "C" gs_status gs_gaussians_buffer_update_range(gs_gaussians_buffer *g, gs_stream *s,
+                                                      size_t start, const void *pods,
+                                                      size_t count) {
+    if (!g) return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "null buffer");
+    size_t len = gs_gaussians_buffer_len(g);
+    if (start + count > len)
+        return fail(GS_ERR_RANGE_COUNT_MISMATCH, count, start, len,
+                    "Gaussians count mismatch: %zu + %zu > %zu", count, start, len);
+    g->dirty = true;
+    return gs_buffer_write(g->buf, s, start * pod_stride(g), pods, count * pod_stride(g));
+}
+
+extern "C" gs_status gs_gaussians_buffer_update_gaussians(gs_gaussians_buffer *g, gs_stream *s,
+                                                          const gs_gaussian *gaussians,
+                                                          size_t count) {
+    if (!g) return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "null buffer");
+    size_t len = gs_gaussians_buffer_len(g);
+    if (count != len)
+        return fail(GS_ERR_COUNT_MISMATCH, count, len, 0, "Gaussians count mismatch: %zu != %zu",
+                    count, len);
+    std::vector<uint8_t> pods(count * pod_stride(g));
+    GS_TRY(gs_pack((gs_sh_config)g->sh, (gs_cov3d_config)g->cov, gaussians, count, pods.data()));
+    return gs_gaussians_buffer_update(g, s, pods.data(), count);
+}
+
+extern "C" gs_status gs_gaussians_buffer_update_range_gaussians(gs_gaussians_buffer *g, gs_stream *s,
+                                                                size_t start,
+                                                                const gs_gaussian *gaussians,
+                                                                size_t count) {
+    if (!g) return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "null buffer");
+    size_t len = gs_gaussians_buffer_len(g);
+    if (start + count > len)
+        return fail(GS_ERR_RANGE_COUNT_MISMATCH, count, start, len,
+                    "Gaussians count mismatch: %zu + %zu > %zu", count, start, len);
+    std::vector<uint8_t> pods(count * pod_stride(g));
+    GS_TRY(gs_pack((gs_sh_config)g->sh, (gs_cov3d_config)g->cov, gaussians, count, pods.data()));
+    return gs_gaussians_buffer_update_range(g, s, start, pods.data(), count);
+}
+
+extern "C" gs_status gs_gaussians_buffer_download(gs_gaussians_buffer *g, gs_stream *s,
+                                                  void *pods_out, size_t count) {
+    if (!g) return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "null buffer");
+    if (count > gs_gaussians_buffer_len(g))
+        return fail(GS_ERR_INVALID_ARGUMENT, count, gs_gaussians_buffer_len(g), 0, "count too large");
+    return gs_buffer_download(g->buf, s, pods_out, count * pod_stride(g));
+}
+
+extern "C" gs_status gs_gaussians_buffer_download_gaussians(gs_gaussians_buffer *g, gs_stream *s,
+                                                            gs_gaussian *out, size_t count) {
+    if (!g) return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "null buffer");
+    if (g->sh == GS_SH_NONE || g->cov != GS_COV3D_ROT_SCALE)
+        return gs_unpack_to_gaussian((gs_sh_config)g->sh, (gs_cov3d_config)g->cov, out, 0, out);
+    std::vector<uint8_t> pods(count * pod_stride(g));
+    GS_TRY(gs_gaussians_buffer_download(g, s, pods.data(), count));
+    return gs_unpack_to_gaussian((gs_sh_config)g->sh, (gs_cov3d_config)g->cov, pods.data(), count, out);
+}
+
+extern "C" void gs_gaussians_buffer_mark_dirty(gs_gaussians_buffer *g) {
+    if (g) g->dirty = true;
+}
+
+// (re)build the chunk-planar mirror on `st`
+static gs_status ensure_planar(gs_gaussians_buffer *g, hipStream_t st) {
+    size_t len = gs_gaussians_buffer_len(g);
+    size_t stride = (len + 63) / 64 * 64;
+    uint32_t chunks = (uint32_t)(pod_stride(g) / 16);
+    if (!g->planar || g->planar_stride != stride) {
+        if (g->planar) GS_HIP(hipFree(g->planar));
+        g->planar = nullptr;
+        GS_HIP(hipMalloc(&g->planar, (stride ? stride : 64) * 16 * chunks));
+        g->planar_stride = stride;
+        g->dirty = true;
+    }
+    if (g->dirty && len) {
+        uint64_t total = (uint64_t)len * chunks;
+        uint32_t grid = (uint32_t)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+        hipLaunchKernelGGL(gs::k_repack_planar, dim3(grid), dim3(256), 0, st,
+                           (const uint4 *)g->buf->ptr, (uint4 *)g->planar, (uint64_t)0,
+                           (uint64_t)len, chunks, (uint64_t)stride);
+        GS_HIP(hipGetLastError());
+    }
+    g->dirty = false;
+    return GS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// fixed-size uniform buffers
+// ------------------------------------------------------------------------------------------------
+
+static gs_status fixed_from_buffer(gs_buffer *b, size_t expected) {
+    if (!b) return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "null buffer");
+    if (b->bytes != expected)
+        return fail(GS_ERR_BUFFER_SIZE_MISMATCHED, b->bytes, expected, 0,
+                    "buffer size and expected size mismatch: %zu != %zu", b->bytes, expected);
+    return GS_OK;
+}
+
+extern "C" gs_status gs_gaussian_transform_buffer_create(gs_device *dev, gs_buffer **out) {
+    gs_gaussian_transform_pod pod;
+    gs_gaussian_transform_pod_default(&pod);
+    return gs_buffer_create(dev, sizeof(pod), &pod, out);
+}
+extern "C" gs_status gs_gaussian_transform_buffer_update(gs_buffer *b, gs_stream *s,
+                                                         const gs_gaussian_transform_pod *pod) {
+    GS_TRY(fixed_from_buffer(b, sizeof(*pod)));
+    return gs_buffer_write(b, s, 0, pod, sizeof(*pod));
+}
+extern "C" gs_status gs_gaussian_transform_buffer_from_buffer(gs_buffer *b) {
+    return fixed_from_buffer(b, sizeof(gs_gaussian_transform_pod));
+}
+extern "C" gs_status gs_model_transform_buffer_create(gs_device *dev, gs_buffer **out) {
+    gs_model_transform_pod pod;
+    gs_model_transform_pod_default(&pod);
+    return gs_buffer_create(dev, sizeof(pod), &pod, out);
+}
+extern "C" gs_status gs_model_transform_buffer_update(gs_buffer *b, gs_stream *s,
+                                                      const gs_model_transform_pod *pod) {
+    GS_TRY(fixed_from_buffer(b, sizeof(*pod)));
+    return gs_buffer_write(b, s, 0, pod, sizeof(*pod));
+}
+extern "C" gs_status gs_model_transform_buffer_from_buffer(gs_buffer *b) {
+    return fixed_from_buffer(b, sizeof(gs_model_transform_pod));
+}
+
+// ------------------------------------------------------------------------------------------------
+// ComputeBundle
+// ------------------------------------------------------------------------------------------------
+
+typedef void (*bundle_kernel_fn)(gs::BundleArgs, uint32_t);
+
+#define GS_CFG_TABLE(kernel)                                                                     \
+    {                                                                                            \
+        {kernel<0, 0>, kernel<0, 1>, kernel<0, 2>}, {kernel<1, 0>, kernel<1, 1>, kernel<1, 2>},  \
+        {kernel<2, 0>, kernel<2, 1>, kernel<2, 2>}, {kernel<3, 0>, kernel<3, 1>, kernel<3, 2>},  \
+    }
+
+static bundle_kernel_fn k_tbl_test_gaussian[4][3] = GS_CFG_TABLE(gs::k_test_gaussian);
+static bundle_kernel_fn k_tbl_unpack_soa[4][3] = GS_CFG_TABLE(gs::k_unpack_soa);
+
+struct gs_bundle {
+    gs_device *dev;
+    std::string label;
+    gs_kernel_id kernel;
+    int sh, cov;
+    uint32_t workgroup_size;
+    std::vector<uint32_t> layout;                     // bindings per group
+    std::vector<std::vector<gs_buffer *>> groups;     // managed bind groups (retained)
+    bool managed;
+    bool has_additional_constant;
+    uint32_t additional_constant;
+    uint32_t last_workgroups;
+};
+
+extern "C" gs_status gs_bundle_create(gs_device *dev, const gs_bundle_desc *desc, gs_bundle **out) {
+    if (!dev || !desc || !out) return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "null argument");
+    if ((int)desc->kernel < 0 || desc->kernel >= GS_KERNEL_COUNT_ || !valid_cfg(desc->sh, desc->cov))
+        return fail(GS_ERR_MISSING_MAIN_SHADER, 0, 0, 0, "unknown kernel id %d", (int)desc->kernel);
+    if (desc->bind_group_count == 0 || !desc->bindings_per_group)
+        return fail(GS_ERR_MISSING_BIND_GROUP_LAYOUT, 0, 0, 0,
+                    "missing bind group layout for compute bundle");
+    // compute_bundle.rs:269-281
+    uint32_t limit = dev->limits.max_compute_workgroup_size_x <
+                             dev->limits.max_compute_invocations_per_workgroup
+                         ? dev->limits.max_compute_workgroup_size_x
+                         : dev->limits.max_compute_invocations_per_workgroup;
+    uint32_t wg = desc->workgroup_size ? desc->workgroup_size : limit;
+    if (wg > limit)
+        return fail(GS_ERR_WORKGROUP_SIZE_EXCEEDS_LIMIT, wg, limit, 0,
+                    "workgroup size exceeds device limit: %u > %u", wg, limit);
+    uint32_t total = 0;
+    for (uint32_t i = 0; i < desc->bind_group_count; i++) total += desc->bindings_per_group[i];
+    if (total > (uint32_t)gs::MAX_BINDINGS)
+        return fail(GS_ERR_INVALID_ARGUMENT, total, gs::MAX_BINDINGS, 0, "too many bindings");
+    gs_bundle *b = new gs_bundle();
+    b->dev = dev;
+    b->label = desc->label ? desc->label : "";
+    b->kernel = desc->kernel;
+    b->sh = desc->sh;
+    b->cov = desc->cov;
+    b->workgroup_size = wg;
+    b->layout.assign(desc->bindings_per_group, desc->bindings_per_group + desc->bind_group_count);
+    b->managed = false;
+    b->has_additional_constant = false;
+    b->additional_constant = 0;
+    b->last_workgroups = 0;
+    for (uint32_t i = 0; i < desc->constant_count; i++) {
+        if (desc->constant_names && desc->constant_names[i] &&
+            !std::strcmp(desc->constant_names[i], "additional_constant")) {
+            b->has_additional_constant = true;
+            b->additional_constant = (uint32_t)desc->constant_values[i];
+        }
+    }
+    *out = b;
+    return GS_OK;
+}
+
+static void release_group(std::vector<gs_buffer *> &g) {
+    for (gs_buffer *x : g) gs_buffer_release(x);
+    g.clear();
+}
+
+extern "C" gs_status gs_bundle_set_bind_group(gs_bundle *b, uint32_t index, gs_buffer *const *buffers,
+                                              uint32_t count) {
+    if (!b) return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "null bundle");
+    if (index >= b->groups.size())
+        return fail(GS_ERR_INVALID_ARGUMENT, index, b->groups.size(), 0, "bind group index out of bounds");
+    if (count != b->layout[index])
+        return fail(GS_ERR_INVALID_ARGUMENT, count, b->layout[index], 0,
+                    "bind group %u expects %u bindings, got %u", index, b->layout[index], count);
+    std::vector<gs_buffer *> g;
+    for (uint32_t i = 0; i < count; i++) {
+        if (!buffers[i]) {
+            release_group(g);
+            return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "null binding");
+        }
+        g.push_back(gs_buffer_retain(buffers[i]));
+    }
+    release_group(b->groups[index]);
+    b->groups[index] = g;
+    return GS_OK;
+}
+
+extern "C" gs_status gs_bundle_create_with_bind_groups(gs_device *dev, const gs_bundle_desc *desc,
+                                                       gs_buffer *const *const *resources,
+                                                       const uint32_t *resource_counts,
+                                                       uint32_t resource_group_count,
+                                                       gs_bundle **out) {
+    gs_bundle *b = nullptr;
+    GS_TRY(gs_bundle_create(dev, desc, &b));
+    // compute_bundle.rs:161-168
+    if (resource_group_count != b->layout.size()) {
+        size_t layouts = b->layout.size();
+        gs_bundle_destroy(b);
+        return fail(GS_ERR_RESOURCE_COUNT_MISMATCH, resource_group_count, layouts, 0,
+                    "resource count and bind group layout count mismatch: %u != %zu",
+                    resource_group_count, layouts);
+    }
+    b->managed = true;
+    b->groups.resize(b->layout.size());
+    for (uint32_t i = 0; i < resource_group_count; i++) {
+        gs_status st = gs_bundle_set_bind_group(b, i, resources[i], resource_counts[i]);
+        if (st != GS_OK) {
+            gs_bundle_destroy(b);
+            return st;
+        }
+    }
+    *out = b;
+    return GS_OK;
+}
+
+extern "C" void gs_bundle_destroy(gs_bundle *b) {
+    if (!b) return;
+    for (auto &g : b->groups) release_group(g);
+    delete b;
+}
+
+extern "C" uint32_t gs_bundle_workgroup_size(const gs_bundle *b) { return b ? b->workgroup_size : 0; }
+extern "C" const char *gs_bundle_label(const gs_bundle *b) {
+    return (b && !b->label.empty()) ? b->label.c_str() : nullptr;
+}
+extern "C" uint32_t gs_bundle_bind_group_layout_count(const gs_bundle *b) {
+    return b ? (uint32_t)b->layout.size() : 0;
+}
+extern "C" uint32_t gs_bundle_bind_group_count(const gs_bundle *b) {
+    return b ? (uint32_t)b->groups.size() : 0;
+}
+extern "C" uint32_t gs_bundle_last_workgroup_count(const gs_bundle *b) {
+    return b ? b->last_workgroups : 0;
+}
+
+// minimum byte size each binding must have so that the kernel cannot run out of bounds
+static gs_status validate_bindings(const gs_bundle *b, const gs::BundleArgs &a, uint32_t nbind) {
+    auto need = [&](uint32_t i, uint64_t bytes) -> gs_status {
+        if (i >= nbind || a.size[i] < bytes)
+            return fail(GS_ERR_INVALID_ARGUMENT, i, i < nbind ? a.size[i] : 0, bytes,
+                        "binding %u is smaller than the %llu bytes the kernel accesses", i,
+                        (unsigned long long)bytes);
+        return GS_OK;
+    };
+    uint64_t pod = (uint64_t)gs::pod_bytes(b->sh, b->cov);
+    switch (b->kernel) {
+    case GS_KERNEL_ARRAY_MAP_ADD:
+        GS_TRY(need(0, 0));
+        if (b->layout.size() > 1) GS_TRY(need(1, 4));
+        break;
+    case GS_KERNEL_TEST_GAUSSIAN:
+        GS_TRY(need(0, pod));
+        GS_TRY(need(1, 56 * 4));
+        break;
+    case GS_KERNEL_TEST_GAUSSIAN_TRANSFORM:
+        GS_TRY(need(0, 8));
+        GS_TRY(need(1, 16));
+        break;
+    case GS_KERNEL_TEST_MODEL_TRANSFORM:
+        GS_TRY(need(0, 48));
+        GS_TRY(need(1, 12));
+        GS_TRY(need(2, 44 * 4));
+        break;
+    case GS_KERNEL_UNPACK_SOA:
+        GS_TRY(need(0, 0));
+        GS_TRY(need(1, (a.size[0] / pod) * 55 * 4));
+        break;
+    default: break;
+    }
+    return GS_OK;
+}
+
+static gs_status dispatch_groups(gs_bundle *b, gs_stream *s, uint32_t count,
+                                 const std::vector<std::vector<gs_buffer *>> &groups) {
+    if (!s) return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "null stream");
+    if (groups.size() != b->layout.size())
+        return fail(GS_ERR_INVALID_ARGUMENT, groups.size(), b->layout.size(), 0,
+                    "dispatch needs %zu bind groups, got %zu", b->layout.size(), groups.size());
+    gs::BundleArgs a;
+    std::memset(&a, 0, sizeof(a));
+    uint32_t n = 0;
+    for (size_t gi = 0; gi < groups.size(); gi++) {
+        if (groups[gi].size() != b->layout[gi])
+            return fail(GS_ERR_INVALID_ARGUMENT, groups[gi].size(), b->layout[gi], 0,
+                        "bind group %zu is not set or has the wrong binding count", gi);
+        for (gs_buffer *buf : groups[gi]) {
+            a.ptr[n] = buf->ptr;
+            a.size[n] = buf->bytes;
+            n++;
+        }
+    }
+    a.has_second_group = b->layout.size() > 1 ? 1u : 0u;
+    a.has_additional_constant = b->has_additional_constant ? 1u : 0u;
+    a.additional_constant = b->additional_constant;
+    GS_TRY(validate_bindings(b, a, n));
+    GS_TRY(use_device(b->dev));
+    // compute_bundle.rs:131 — dispatch_workgroups(count.div_ceil(workgroup_size), 1, 1)
+    uint32_t wgs = count / b->workgroup_size + (count % b->workgroup_size != 0);
+    b->last_workgroups = wgs;
+    if (wgs == 0) return GS_OK;
+    bundle_kernel_fn fn = nullptr;
+    switch (b->kernel) {
+    case GS_KERNEL_ARRAY_MAP_ADD: fn = gs::k_array_map_add; break;
+    case GS_KERNEL_TEST_GAUSSIAN: fn = k_tbl_test_gaussian[b->sh][b->cov]; break;
+    case GS_KERNEL_TEST_GAUSSIAN_TRANSFORM: fn = gs::k_test_gaussian_transform; break;
+    case GS_KERNEL_TEST_MODEL_TRANSFORM: fn = gs::k_test_model_transform; break;
+    case GS_KERNEL_UNPACK_SOA: fn = k_tbl_unpack_soa[b->sh][b->cov]; break;
+    default: return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "bad kernel");
+    }
+    hipLaunchKernelGGL(fn, dim3(wgs), dim3(b->workgroup_size), 0, s->s, a, count);
+    GS_HIP(hipGetLastError());
+    return GS_OK;
+}
+
+extern "C" gs_status gs_bundle_dispatch(gs_bundle *b, gs_stream *s, uint32_t count) {
+    if (!b) return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "null bundle");
+    if (!b->managed)
+        return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0,
+                    "bundle was created without bind groups: use gs_bundle_dispatch_with_bind_groups");
+    return dispatch_groups(b, s, count, b->groups);
+}
+
+extern "C" gs_status gs_bundle_dispatch_with_bind_groups(gs_bundle *b, gs_stream *s, uint32_t count,
+                                                         gs_buffer *const *const *groups,
+                                                         const uint32_t *group_counts,
+                                                         uint32_t group_count) {
+    if (!b || (group_count && (!groups || !group_counts)))
+        return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "null argument");
+    std::vector<std::vector<gs_buffer *>> gv(group_count);
+    for (uint32_t i = 0; i < group_count; i++) {
+        for (uint32_t k = 0; k < group_counts[i]; k++) {
+            if (!groups[i][k]) return fail(GS_ERR_INVALID_ARGUMENT, i, k, 0, "null binding");
+            gv[i].push_back(groups[i][k]);
+        }
+    }
+    return dispatch_groups(b, s, count, gv);
+}
+
+// ------------------------------------------------------------------------------------------------
+// renderer
+// ------------------------------------------------------------------------------------------------
+
+extern "C" void gs_camera_look_at(const float eye[3], const float target[3], const float up[3],
+                                  float vfov, uint32_t width, uint32_t height, float near_plane,
+                                  float far_plane, gs_camera *out) {
+    // glam Mat4::look_at_rh; evaluated in double and rounded once
+    double f[3], s[3], u[3], fl = 0, sl = 0;
+    for (int i = 0; i < 3; i++) {
+        f[i] = (double)target[i] - (double)eye[i];
+        fl += f[i] * f[i];
+    }
+    fl = std::sqrt(fl);
+    for (int i = 0; i < 3; i++) f[i] /= fl;
+    s[0] = f[1] * up[2] - f[2] * up[1];
+    s[1] = f[2] * up[0] - f[0] * up[2];
+    s[2] = f[0] * up[1] - f[1] * up[0];
+    for (int i = 0; i < 3; i++) sl += s[i] * s[i];
+    sl = std::sqrt(sl);
+    for (int i = 0; i < 3; i++) s[i] /= sl;
+    u[0] = s[1] * f[2] - s[2] * f[1];
+    u[1] = s[2] * f[0] - s[0] * f[2];
+    u[2] = s[0] * f[1] - s[1] * f[0];
+    double e[3] = {eye[0], eye[1], eye[2]};
+    double ds = s[0] * e[0] + s[1] * e[1] + s[2] * e[2];
+    double du = u[0] * e[0] + u[1] * e[1] + u[2] * e[2];
+    double df = f[0] * e[0] + f[1] * e[1] + f[2] * e[2];
+    float *v = out->view;
+    v[0] = (float)s[0]; v[1] = (float)u[0]; v[2] = (float)-f[0]; v[3] = 0.0f;
+    v[4] = (float)s[1]; v[5] = (float)u[1]; v[6] = (float)-f[1]; v[7] = 0.0f;
+    v[8] = (float)s[2]; v[9] = (float)u[2]; v[10] = (float)-f[2]; v[11] = 0.0f;
+    v[12] = (float)-ds; v[13] = (float)-du; v[14] = (float)df; v[15] = 1.0f;
+    std::memcpy(out->pos, eye, 12);
+    double focal = 0.5 * (double)height / std::tan(0.5 * (double)vfov);
+    out->fx = (float)focal;
+    out->fy = (float)focal;
+    out->cx = 0.5f * (float)width;
+    out->cy = 0.5f * (float)height;
+    out->near_plane = near_plane;
+    out->far_plane = far_plane;
+    out->width = width;
+    out->height = height;
+    out->background[0] = out->background[1] = out->background[2] = 0.0f;
+}
+
+struct DevArray {
+    void *ptr = nullptr;
+    size_t bytes = 0;
+};
+
+static gs_status dev_reserve(DevArray &a, size_t bytes) {
+    if (a.bytes >= bytes && a.ptr) return GS_OK;
+    if (a.ptr) GS_HIP(hipFree(a.ptr));
+    a.ptr = nullptr;
+    a.bytes = 0;
+    size_t want = bytes + bytes / 8 + 256;
+    GS_HIP(hipMalloc(&a.ptr, want));
+    a.bytes = want;
+    return GS_OK;
+}
+
+enum { ST_REPACK = 0, ST_PRE, ST_SCAN, ST_EMIT, ST_SORT, ST_RANGES, ST_BLEND, ST_FRAME, ST_COUNT };
+
+struct gs_renderer {
+    gs_device *dev;
+    DevArray proj, tiles, chunk_sums, chunk_offsets, counters;
+    DevArray keys[2], vals[2], ghist, digit_totals, ranges;
+    uint32_t *host_counters;  // pinned: [0] = D, [1] = visible
+    uint64_t pair_capacity;
+    // last frame
+    uint64_t n, d, visible;
+    uint32_t tiles_x, tiles_y, sort_passes;
+    int sorted_side;
+    hipStream_t last_stream;
+    // timing
+    bool timing;
+    hipEvent_t ev[ST_COUNT + 2];
+    bool ev_valid;
+    bool ev_pending;
+    double stage_ms[ST_COUNT];
+    uint32_t timed_frames;
+};
+
+extern "C" gs_status gs_renderer_create(gs_device *dev, gs_renderer **out) {
+    if (!out) return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "null out");
+    GS_TRY(use_device(dev));
+    gs_renderer *r = new gs_renderer();
+    r->dev = dev;
+    r->host_counters = nullptr;
+    hipError_t e = hipHostMalloc((void **)&r->host_counters, 64, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        delete r;
+        return fail(GS_ERR_HIP, (uint64_t)e, 0, 0, "hipHostMalloc failed: %s", hipGetErrorString(e));
+    }
+    r->pair_capacity = 0;
+    r->n = r->d = r->visible = 0;
+    r->tiles_x = r->tiles_y = r->sort_passes = 0;
+    r->sorted_side = 0;
+    r->last_stream = nullptr;
+    r->timing = false;
+    r->ev_valid = false;
+    r->ev_pending = false;
+    r->timed_frames = 0;
+    for (int i = 0; i < ST_COUNT; i++) r->stage_ms[i] = 0.0;
+    *out = r;
+    return GS_OK;
+}
+
+extern "C" void gs_renderer_destroy(gs_renderer *r) {
+    if (!r) return;
+    (void)hipSetDevice(r->dev->ordinal);
+    DevArray *arrs[] = {&r->proj, &r->tiles, &r->chunk_sums, &r->chunk_offsets, &r->counters,
+                        &r->keys[0], &r->keys[1], &r->vals[0], &r->vals[1], &r->ghist,
+                        &r->digit_totals, &r->ranges};
+    for (DevArray *a : arrs)
+        if (a->ptr) (void)hipFree(a->ptr);
+    if (r->host_counters) (void)hipHostFree(r->host_counters);
+    if (r->ev_valid)
+        for (auto &e : r->ev) (void)hipEventDestroy(e);
+    delete r;
+}
+
+extern "C" gs_status gs_renderer_set_timing(gs_renderer *r, int32_t enabled) {
+    if (!r) return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "null renderer");
+    GS_TRY(use_device(r->dev));
+    if (enabled && !r->ev_valid) {
+        for (auto &e : r->ev) GS_HIP(hipEventCreate(&e));
+        r->ev_valid = true;
+    }
+    r->timing = enabled != 0;
+    return GS_OK;
+}
+
+// fold the events of the previous timed frame into the accumulators
+static gs_status collect_timing(gs_renderer *r) {
+    if (!r->ev_pending) return GS_OK;
+    GS_HIP(hipEventSynchronize(r->ev[ST_COUNT]));
+    for (int i = 0; i < ST_FRAME; i++) {
+        float ms = 0;
+        GS_HIP(hipEventElapsedTime(&ms, r->ev[i], r->ev[i + 1]));
+        r->stage_ms[i] += ms;
+    }
+    float ms = 0;
+    GS_HIP(hipEventElapsedTime(&ms, r->ev[0], r->ev[ST_FRAME]));
+    r->stage_ms[ST_FRAME] += ms;
+    r->timed_frames++;
+    r->ev_pending = false;
+    return GS_OK;
+}
+
+extern "C" gs_status gs_renderer_reset_stats(gs_renderer *r) {
+    if (!r) return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "null renderer");
+    GS_TRY(use_device(r->dev));
+    GS_TRY(collect_timing(r));
+    for (int i = 0; i < ST_COUNT; i++) r->stage_ms[i] = 0.0;
+    r->timed_frames = 0;
+    return GS_OK;
+}
+
+extern "C" gs_status gs_renderer_stats(gs_renderer *r, gs_frame_stats *out) {
+    if (!r || !out) return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "null argument");
+    GS_TRY(use_device(r->dev));
+    if (r->last_stream || r->n) GS_HIP(hipStreamSynchronize(r->last_stream));
+    GS_TRY(collect_timing(r));
+    std::memset(out, 0, sizeof(*out));
+    out->gaussians = r->n;
+    out->visible = r->visible;
+    out->pairs = r->d;
+    out->tiles_x = r->tiles_x;
+    out->tiles_y = r->tiles_y;
+    out->sort_passes = r->sort_passes;
+    out->timed_frames = r->timed_frames;
+    for (int i = 0; i < ST_COUNT; i++) out->stage_ms[i] = r->stage_ms[i];
+    return GS_OK;
+}
+
+typedef void (*preprocess_fn)(const uint4 *, uint64_t, uint32_t, gs::FrameConsts, uint4 *, uint32_t *,
+                              uint32_t *, uint32_t *);
+static preprocess_fn k_tbl_preprocess[4][3] = GS_CFG_TABLE(gs::k_preprocess);
+
+// frame constants from the uniforms
+static void make_frame_consts(const gs_gaussian_transform_pod *gt, const gs_model_transform_pod *mt,
+                              const gs_camera *cam, uint32_t band_ty0, uint32_t band_ty1,
+                              gs::FrameConsts &fc) {
+    gs::ModelTransform m;
+    std::memcpy(&m, mt, sizeof(m));
+    gs::model_transform_mat(m, fc.M);
+    gs::model_transform_inv_sr_mat(m, fc.ISR);
+    float sr[9];
+    gs::model_scale_rot_mat(m, sr);
+    std::memcpy(fc.V, cam->view, 64);
+    for (int r = 0; r < 3; r++) {
+        float sg = r == 0 ? 1.0f : -1.0f;
+        float w0 = sg * cam->view[0 + r], w1 = sg * cam->view[4 + r], w2 = sg * cam->view[8 + r];
+        for (int c = 0; c < 3; c++)
+            fc.WS[3 * r + c] = (w0 * sr[3 * c + 0] + w1 * sr[3 * c + 1]) + w2 * sr[3 * c + 2];
+    }
+    std::memcpy(fc.cam_pos, cam->pos, 12);
+    fc.fx = cam->fx;
+    fc.fy = cam->fy;
+    fc.cx = cam->cx;
+    fc.cy = cam->cy;
+    fc.near_plane = cam->near_plane;
+    fc.far_plane = cam->far_plane;
+    uint32_t flags;
+    std::memcpy(&flags, gt->flags, 4);
+    fc.size2 = gt->size * gt->size;
+    fc.limx = 1.3f * ((0.5f * (float)cam->width) / cam->fx);
+    fc.limy = 1.3f * ((0.5f * (float)cam->height) / cam->fy);
+    fc.max_std_dev = gs::gaussian_transform_max_std_dev(flags);
+    std::memcpy(fc.bg, cam->background, 12);
+    fc.sh_deg = gs::gaussian_transform_sh_deg(flags);
+    fc.no_sh0 = gs::gaussian_transform_no_sh0(flags) ? 1u : 0u;
+    fc.width = cam->width;
+    fc.height = cam->height;
+    fc.tiles_x = (cam->width + 15u) / 16u;
+    fc.tiles_y = (cam->height + 15u) / 16u;
+    fc.band_ty0 = band_ty0 < fc.tiles_y ? band_ty0 : fc.tiles_y;
+    fc.band_ty1 = band_ty1 < fc.tiles_y ? band_ty1 : fc.tiles_y;
+    if (fc.band_ty1 < fc.band_ty0) fc.band_ty1 = fc.band_ty0;
+}
+
+static uint32_t bit_length(uint32_t v) {
+    uint32_t b = 0;
+    while (v) {
+        b++;
+        v >>= 1;
+    }
+    return b;
+}
+
+// Stable LSD radix sort of `count` pairs on key bits [0, end_bit); result side returned.
+struct SortScratch {
+    DevArray *keys[2];
+    DevArray *vals[2];
+    DevArray *ghist;
+    DevArray *digit_totals;
+};
+
+static gs_status sort_pairs_device(SortScratch &sc, uint32_t count, uint32_t end_bit, hipStream_t st,
+                                   int &result_side, uint32_t &passes_out) {
+    uint32_t passes = (end_bit + gs::RADIX_BITS - 1) / gs::RADIX_BITS;
+    passes_out = passes;
+    result_side = 0;
+    if (count == 0 || passes == 0) return GS_OK;
+    uint32_t nb = (count + gs::SORT_TILE - 1) / gs::SORT_TILE;
+    GS_TRY(dev_reserve(*sc.ghist, (size_t)nb * gs::RADIX * 4));
+    GS_TRY(dev_reserve(*sc.digit_totals, gs::RADIX * 4));
+    int side = 0;
+    for (uint32_t p = 0; p < passes; p++) {
+        uint32_t shift = p * gs::RADIX_BITS;
+        const uint64_t *kin = (const uint64_t *)sc.keys[side]->ptr;
+        const uint32_t *vin = (const uint32_t *)sc.vals[side]->ptr;
+        uint64_t *kout = (uint64_t *)sc.keys[side ^ 1]->ptr;
+        uint32_t *vout = (uint32_t *)sc.vals[side ^ 1]->ptr;
+        hipLaunchKernelGGL(gs::k_sort_hist, dim3(nb), dim3(gs::SORT_THREADS), 0, st, kin, count, shift,
+                           (uint32_t *)sc.ghist->ptr, nb);
+        hipLaunchKernelGGL(gs::k_sort_scan_rows, dim3(gs::RADIX), dim3(256), 0, st,
+                           (uint32_t *)sc.ghist->ptr, nb, (uint32_t *)sc.digit_totals->ptr);
+        hipLaunchKernelGGL(gs::k_sort_scatter, dim3(nb), dim3(gs::SORT_THREADS), 0, st, kin, vin, kout,
+                           vout, count, shift, (const uint32_t *)sc.ghist->ptr, nb,
+                           (const uint32_t *)sc.digit_totals->ptr);
+        side ^= 1;
+    }
+    GS_HIP(hipGetLastError());
+    result_side = side;
+    return GS_OK;
+}
+
+static gs_status reserve_pairs(gs_renderer *r, uint64_t pairs) {
+    if (pairs <= r->pair_capacity && r->keys[0].ptr) return GS_OK;
+    uint64_t cap = pairs + pairs / 4 + 4096;
+    for (int i = 0; i < 2; i++) {
+        GS_TRY(dev_reserve(r->keys[i], cap * 8));
+        GS_TRY(dev_reserve(r->vals[i], cap * 4));
+    }
+    r->pair_capacity = cap;
+    return GS_OK;
+}
+
+extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_buffer *g,
+                                     const gs_gaussian_transform_pod *gt,
+                                     const gs_model_transform_pod *mt, const gs_camera *cam,
+                                     uint32_t band_ty0, uint32_t band_ty1, float *rgba) {
+    if (!r || !s || !g || !gt || !mt || !cam || !rgba)
+        return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "null argument");
+    if (g->buf->dev != r->dev || s->dev != r->dev)
+        return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "objects belong to different devices");
+    if (cam->width == 0 || cam->height == 0 || cam->width > 65535u * 16u || cam->height > 65535u * 16u)
+        return fail(GS_ERR_INVALID_ARGUMENT, cam->width, cam->height, 0, "bad image size");
+    uint32_t mode = gt->flags[0];
+    if (mode != GS_DISPLAY_SPLAT)
+        return fail(GS_ERR_INVALID_ARGUMENT, mode, 0, 0, "only GaussianDisplayMode::Splat is implemented");
+    GS_TRY(use_device(r->dev));
+    hipStream_t st = s->s;
+    GS_TRY(collect_timing(r));
+    const bool timing = r->timing && r->ev_valid;
+    auto mark = [&](int i) {
+        if (timing) (void)hipEventRecord(r->ev[i], st);
+    };
+
+    gs::FrameConsts fc;
+    make_frame_consts(gt, mt, cam, band_ty0, band_ty1, fc);
+    size_t n64 = gs_gaussians_buffer_len(g);
+    if (n64 > 0xfffffff0ull) return fail(GS_ERR_INVALID_ARGUMENT, n64, 0, 0, "too many Gaussians");
+    uint32_t n = (uint32_t)n64;
+    uint32_t nchunks = (n + gs::PP_CHUNK - 1) / gs::PP_CHUNK;
+    uint32_t num_tiles = fc.tiles_x * fc.tiles_y;
+
+    mark(ST_REPACK);
+    GS_TRY(ensure_planar(g, st));
+    mark(ST_PRE);
+
+    GS_TRY(dev_reserve(r->proj, (size_t)(n ? n : 1) * 48));
+    GS_TRY(dev_reserve(r->tiles, (size_t)(nchunks ? nchunks : 1) * gs::PP_CHUNK * 4));
+    GS_TRY(dev_reserve(r->chunk_sums, (size_t)(nchunks ? nchunks : 1) * 4));
+    GS_TRY(dev_reserve(r->chunk_offsets, (size_t)(nchunks ? nchunks : 1) * 4));
+    GS_TRY(dev_reserve(r->counters, 64));
+    GS_TRY(dev_reserve(r->ranges, (size_t)num_tiles * 8));
+    GS_HIP(hipMemsetAsync(r->counters.ptr, 0, 64, st));
+
+    uint32_t d = 0, visible = 0;
+    if (n) {
+        hipLaunchKernelGGL(k_tbl_preprocess[g->sh][g->cov], dim3(nchunks), dim3(gs::PP_THREADS), 0, st,
+                           (const uint4 *)g->planar, (uint64_t)g->planar_stride, n, fc,
+                           (uint4 *)r->proj.ptr, (uint32_t *)r->tiles.ptr,
+                           (uint32_t *)r->chunk_sums.ptr, (uint32_t *)r->counters.ptr + 1);
+        mark(ST_SCAN);
+        hipLaunchKernelGGL(gs::k_scan_chunks, dim3(1), dim3(1024), 0, st,
+                           (const uint32_t *)r->chunk_sums.ptr, (uint32_t *)r->chunk_offsets.ptr,
+                           nchunks, (uint32_t *)r->counters.ptr);
+        GS_HIP(hipGetLastError());
+        GS_HIP(hipMemcpyAsync(r->host_counters, r->counters.ptr, 8, hipMemcpyDeviceToHost, st));
+        GS_HIP(hipStreamSynchronize(st));
+        d = r->host_counters[0];
+        visible = r->host_counters[1];
+    } else {
+        mark(ST_SCAN);
+    }
+    mark(ST_EMIT);
+    GS_TRY(reserve_pairs(r, d));
+    if (d) {
+        hipLaunchKernelGGL(gs::k_emit, dim3(nchunks), dim3(gs::PP_THREADS), 0, st,
+                           (const uint32_t *)r->tiles.ptr, (const uint32_t *)r->chunk_offsets.ptr,
+                           (const uint4 *)r->proj.ptr, n, fc.tiles_x, (uint64_t *)r->keys[0].ptr,
+                           (uint32_t *)r->vals[0].ptr, (uint32_t)r->pair_capacity);
+        GS_HIP(hipGetLastError());
+    }
+    mark(ST_SORT);
+    uint32_t end_bit = 32 + bit_length(num_tiles ? num_tiles - 1 : 0);
+    SortScratch sc{{&r->keys[0], &r->keys[1]}, {&r->vals[0], &r->vals[1]}, &r->ghist, &r->digit_totals};
+    int side = 0;
+    uint32_t passes = 0;
+    GS_TRY(sort_pairs_device(sc, d, end_bit, st, side, passes));
+    mark(ST_RANGES);
+    GS_HIP(hipMemsetAsync(r->ranges.ptr, 0, (size_t)num_tiles * 8, st));
+    if (d) {
+        hipLaunchKernelGGL(gs::k_tile_ranges, dim3((d + 255) / 256), dim3(256), 0, st,
+                           (const uint64_t *)r->keys[side].ptr, d, (uint32_t *)r->ranges.ptr);
+        GS_HIP(hipGetLastError());
+    }
+    mark(ST_BLEND);
+    uint32_t band_tiles = (fc.band_ty1 - fc.band_ty0) * fc.tiles_x;
+    if (band_tiles) {
+        hipLaunchKernelGGL(gs::k_blend, dim3(band_tiles), dim3(256), 0, st,
+                           (const uint32_t *)r->ranges.ptr, (const uint32_t *)r->vals[side].ptr,
+                           (const uint4 *)r->proj.ptr, fc, (float4 *)rgba);
+        GS_HIP(hipGetLastError());
+    }
+    mark(ST_FRAME);
+    if (timing) {
+        (void)hipEventRecord(r->ev[ST_COUNT], st);
+        r->ev_pending = true;
+    }
+    r->n = n;
+    r->d = d;
+    r->visible = visible;
+    r->tiles_x = fc.tiles_x;
+    r->tiles_y = fc.tiles_y;
+    r->sort_passes = passes;
+    r->sorted_side = side;
+    r->last_stream = st;
+    return GS_OK;
+}
+
+static gs_status download_sync(gs_renderer *r, void *dst, const void *src, size_t bytes) {
+    if (!bytes) return GS_OK;
+    GS_HIP(hipStreamSynchronize(r->last_stream));
+    hipError_t e = hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost);
+    if (e != hipSuccess)
+        return fail(GS_ERR_DOWNLOAD, (uint64_t)e, 0, 0, "download failed: %s", hipGetErrorString(e));
+    return GS_OK;
+}
+
+extern "C" gs_status gs_renderer_download_projected(gs_renderer *r, gs_projected *proj_out,
+                                                    uint32_t *tiles_out, size_t n) {
+    if (!r) return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "null renderer");
+    if (n > r->n) return fail(GS_ERR_INVALID_ARGUMENT, n, r->n, 0, "n exceeds last frame");
+    GS_TRY(use_device(r->dev));
+    static_assert(sizeof(gs_projected) == 48, "record size");
+    if (proj_out) GS_TRY(download_sync(r, proj_out, r->proj.ptr, n * 48));
+    if (tiles_out) GS_TRY(download_sync(r, tiles_out, r->tiles.ptr, n * 4));
+    return GS_OK;
+}
+
+static gs_status download_pairs(gs_renderer *r, int side, uint64_t *keys_out, uint32_t *idx_out,
+                                uint64_t capacity, uint64_t *pairs_out) {
+    if (!r) return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "null renderer");
+    GS_TRY(use_device(r->dev));
+    if (pairs_out) *pairs_out = r->d;
+    uint64_t m = r->d < capacity ? r->d : capacity;
+    if (keys_out) GS_TRY(download_sync(r, keys_out, r->keys[side].ptr, m * 8));
+    if (idx_out) GS_TRY(download_sync(r, idx_out, r->vals[side].ptr, m * 4));
+    return GS_OK;
+}
+
+extern "C" gs_status gs_renderer_download_sorted(gs_renderer *r, uint64_t *keys_out, uint32_t *idx_out,
+                                                 uint64_t capacity, uint64_t *pairs_out) {
+    return download_pairs(r, r ? r->sorted_side : 0, keys_out, idx_out, capacity, pairs_out);
+}
+
+extern "C" gs_status gs_renderer_download_unsorted(gs_renderer *r, uint64_t *keys_out,
+                                                   uint32_t *idx_out, uint64_t capacity,
+                                                   uint64_t *pairs_out) {
+    // the emitted pairs survive only when the pass count is even (ping-pong) or zero
+    if (r && r->sort_passes % 2 == 1 && r->d)
+        return fail(GS_ERR_INVALID_ARGUMENT, r->sort_passes, 0, 0,
+                    "unsorted pairs were overwritten by an odd number of sort passes");
+    return download_pairs(r, 0, keys_out, idx_out, capacity, pairs_out);
+}
+
+extern "C" gs_status gs_renderer_download_ranges(gs_renderer *r, uint32_t *ranges_out,
+                                                 size_t num_tiles) {
+    if (!r || !ranges_out) return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "null argument");
+    if (num_tiles > (size_t)r->tiles_x * r->tiles_y)
+        return fail(GS_ERR_INVALID_ARGUMENT, num_tiles, 0, 0, "too many tiles");
+    GS_TRY(use_device(r->dev));
+    return download_sync(r, ranges_out, r->ranges.ptr, num_tiles * 8);
+}
+
+// ------------------------------------------------------------------------------------------------
+// stand-alone primitives
+// ------------------------------------------------------------------------------------------------
+
+extern "C" gs_status gs_sort_pairs_u64(gs_device *dev, gs_stream *s, uint64_t *keys, uint32_t *values,
+                                       uint64_t count, uint32_t end_bit) {
+    if (!dev || (count && (!keys || !values)) || end_bit > 64 || count > 0xfffffff0ull)
+        return fail(GS_ERR_INVALID_ARGUMENT, count, end_bit, 0, "bad argument");
+    GS_TRY(use_device(dev));
+    if (!count) return GS_OK;
+    hipStream_t st = stream_of(dev, s);
+    DevArray k[2], v[2], gh, dt;
+    gs_status rc = GS_OK;
+    auto cleanup = [&]() {
+        for (int i = 0; i < 2; i++) {
+            if (k[i].ptr) (void)hipFree(k[i].ptr);
+            if (v[i].ptr) (void)hipFree(v[i].ptr);
+        }
+        if (gh.ptr) (void)hipFree(gh.ptr);
+        if (dt.ptr) (void)hipFree(dt.ptr);
+    };
+    for (int i = 0; i < 2 && rc == GS_OK; i++) {
+        rc = dev_reserve(k[i], count * 8);
+        if (rc == GS_OK) rc = dev_reserve(v[i], count * 4);
+    }
+    if (rc == GS_OK) {
+        hipError_t e = hipMemcpyAsync(k[0].ptr, keys, count * 8, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(v[0].ptr, values, count * 4, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) rc = fail(GS_ERR_HIP, (uint64_t)e, 0, 0, "upload failed: %s", hipGetErrorString(e));
+    }
+    int side = 0;
+    uint32_t passes = 0;
+    if (rc == GS_OK) {
+        SortScratch sc{{&k[0], &k[1]}, {&v[0], &v[1]}, &gh, &dt};
+        rc = sort_pairs_device(sc, (uint32_t)count, end_bit, st, side, passes);
+    }
+    if (rc == GS_OK) {
+        hipError_t e = hipMemcpyAsync(keys, k[side].ptr, count * 8, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(values, v[side].ptr, count * 4, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) rc = fail(GS_ERR_HIP, (uint64_t)e, 0, 0, "download failed: %s", hipGetErrorString(e));
+    }
+    cleanup();
+    return rc;
+}
+
+namespace gs {
+// chunk sums for the stand-alone scan (the frame fuses this into k_preprocess)
+__global__ __launch_bounds__(PP_THREADS) void k_chunk_sums(const uint32_t *__restrict__ in, uint32_t n,
+                                                           uint32_t *__restrict__ sums) {
+    __shared__ uint32_t s_red[4];
+    uint32_t base = blockIdx.x * PP_CHUNK + threadIdx.x * PP_ITEMS;
+    uint32_t v = 0;
+#pragma unroll
+    for (int k = 0; k < PP_ITEMS; k++) v += base + k < n ? in[base + k] : 0u;
+    v = wave_reduce_add(v);
+    if ((threadIdx.x & 63u) == 0) s_red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) sums[blockIdx.x] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+}
+
+// per-chunk exclusive scan written out (the frame fuses this into k_emit)
+__global__ __launch_bounds__(PP_THREADS) void k_chunk_scan_write(const uint32_t *__restrict__ in,
+                                                                 const uint32_t *__restrict__ chunk_offsets,
+                                                                 uint32_t n, uint32_t *__restrict__ out) {
+    __shared__ uint32_t s_scan[4];
+    uint32_t base = blockIdx.x * PP_CHUNK + threadIdx.x * PP_ITEMS;
+    uint32_t c[PP_ITEMS], sum = 0;
+#pragma unroll
+    for (int k = 0; k < PP_ITEMS; k++) {
+        c[k] = base + k < n ? in[base + k] : 0u;
+        sum += c[k];
+    }
+    uint32_t total;
+    uint32_t off = chunk_offsets[blockIdx.x] + block_exclusive_scan_256(sum, s_scan, total);
+#pragma unroll
+    for (int k = 0; k < PP_ITEMS; k++) {
+        if (base + k < n) out[base + k] = off;
+        off += c[k];
+    }
+}
+}  // namespace gs
+
+extern "C" gs_status gs_exclusive_scan_u32(gs_device *dev, gs_stream *s, const uint32_t *in,
+                                           uint32_t *out, uint64_t count, uint64_t *total_out) {
+    if (!dev || (count && (!in || !out)) || count > 0xfffffff0ull)
+        return fail(GS_ERR_INVALID_ARGUMENT, count, 0, 0, "bad argument");
+    GS_TRY(use_device(dev));
+    if (total_out) *total_out = 0;
+    if (!count) return GS_OK;
+    hipStream_t st = stream_of(dev, s);
+    uint32_t n = (uint32_t)count;
+    uint32_t nchunks = (n + gs::PP_CHUNK - 1) / gs::PP_CHUNK;
+    DevArray din, dout, sums, offs, tot;
+    gs_status rc = dev_reserve(din, count * 4);
+    if (rc == GS_OK) rc = dev_reserve(dout, count * 4);
+    if (rc == GS_OK) rc = dev_reserve(sums, (size_t)nchunks * 4);
+    if (rc == GS_OK) rc = dev_reserve(offs, (size_t)nchunks * 4);
+    if (rc == GS_OK) rc = dev_reserve(tot, 16);
+    uint32_t total = 0;
+    if (rc == GS_OK) {
+        hipError_t e = hipMemcpyAsync(din.ptr, in, count * 4, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(gs::k_chunk_sums, dim3(nchunks), dim3(gs::PP_THREADS), 0, st,
+                               (const uint32_t *)din.ptr, n, (uint32_t *)sums.ptr);
+            hipLaunchKernelGGL(gs::k_scan_chunks, dim3(1), dim3(1024), 0, st,
+                               (const uint32_t *)sums.ptr, (uint32_t *)offs.ptr, nchunks,
+                               (uint32_t *)tot.ptr);
+            hipLaunchKernelGGL(gs::k_chunk_scan_write, dim3(nchunks), dim3(gs::PP_THREADS), 0, st,
+                               (const uint32_t *)din.ptr, (const uint32_t *)offs.ptr, n,
+                               (uint32_t *)dout.ptr);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(out, dout.ptr, count * 4, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(&total, tot.ptr, 4, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) rc = fail(GS_ERR_HIP, (uint64_t)e, 0, 0, "scan failed: %s", hipGetErrorString(e));
+    }
+    if (total_out) *total_out = total;
+    for (DevArray *a : {&din, &dout, &sums, &offs, &tot})
+        if (a->ptr) (void)hipFree(a->ptr);
+    return rc;
+}
