@@ -368,8 +368,6 @@ gs_status gs_renderer_download_projected(gs_renderer *r, gs_projected *proj_out,
                                          uint32_t *tiles_touched_out, size_t n);
 gs_status gs_renderer_download_sorted(gs_renderer *r, uint64_t *keys_out, uint32_t *idx_out,
                                       uint64_t capacity, uint64_t *pairs_out);
-gs_status gs_renderer_download_unsorted(gs_renderer *r, uint64_t *keys_out, uint32_t *idx_out,
-                                        uint64_t capacity, uint64_t *pairs_out);
 gs_status gs_renderer_download_ranges(gs_renderer *r, uint32_t *ranges_out, size_t num_tiles);
 
 /* Stand-alone device primitives used by the frame (also exported for tests and callers):

@@ -723,9 +723,6 @@ class Renderer:
     def download_sorted(self):
         return self._pairs(_L.gs_renderer_download_sorted)
 
-    def download_unsorted(self):
-        return self._pairs(_L.gs_renderer_download_unsorted)
-
     def download_ranges(self, num_tiles):
         r = np.zeros((num_tiles, 2), dtype=np.uint32)
         _check(_L.gs_renderer_download_ranges(self._h, _ptr(r), num_tiles))

@@ -122,7 +122,6 @@ SIGNATURES = {
     "gs_render_frame": (i32, [vp, vp, vp, vp, vp, vp, u32, u32, vp]),
     "gs_renderer_download_projected": (i32, [vp, vp, vp, sz]),
     "gs_renderer_download_sorted": (i32, [vp, vp, vp, u64, vp]),
-    "gs_renderer_download_unsorted": (i32, [vp, vp, vp, u64, vp]),
     "gs_renderer_download_ranges": (i32, [vp, vp, sz]),
     "gs_sort_pairs_u64": (i32, [vp, vp, vp, vp, u64, u32]),
     "gs_exclusive_scan_u32": (i32, [vp, vp, vp, vp, u64, vp]),

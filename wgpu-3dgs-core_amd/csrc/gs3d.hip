@@ -1412,16 +1412,6 @@ extern "C" gs_status gs_renderer_download_sorted(gs_renderer *r, uint64_t *keys_
     return download_pairs(r, r ? r->sorted_side : 0, keys_out, idx_out, capacity, pairs_out);
 }
 
-extern "C" gs_status gs_renderer_download_unsorted(gs_renderer *r, uint64_t *keys_out,
-                                                   uint32_t *idx_out, uint64_t capacity,
-                                                   uint64_t *pairs_out) {
-    // the emitted pairs survive only when the pass count is even (ping-pong) or zero
-    if (r && r->sort_passes % 2 == 1 && r->d)
-        return fail(GS_ERR_INVALID_ARGUMENT, r->sort_passes, 0, 0,
-                    "unsorted pairs were overwritten by an odd number of sort passes");
-    return download_pairs(r, 0, keys_out, idx_out, capacity, pairs_out);
-}
-
 extern "C" gs_status gs_renderer_download_ranges(gs_renderer *r, uint32_t *ranges_out,
                                                  size_t num_tiles) {
     if (!r || !ranges_out) return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "null argument");
