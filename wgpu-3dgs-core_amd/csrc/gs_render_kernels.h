@@ -108,7 +108,7 @@ __device__ __forceinline__ float clampf(float v, float lo, float hi) {
     return fminf(fmaxf(v, lo), hi);
 }
 
-// Real SH basis, rest coefficients k = 0..14 (degrees 1..3); same summation order as the oracle.
+// Real SH basis, rest coefficients k = 0..14 (degrees 1..3); summation order per DESIGN.md §3.2.
 template <int SH>
 __device__ __forceinline__ void eval_sh(const uint32_t *w, uint32_t deg, bool no_sh0,
                                         const float d[3], float rgb[3]) {
@@ -522,8 +522,8 @@ __global__ __launch_bounds__(256) void k_tile_ranges(const uint64_t *__restrict_
 // blend (row x5b)
 // ---------------------------------------------------------------------------------------------
 
-// exp for x <= 0, bit-identical to the oracle's gso_exp (explicit fma polynomial, no hardware
-// transcendental): t = x*log2(e); n = rint(t); f = t - n; 2^f by a degree-5 polynomial.
+// exp for x <= 0 exactly as DESIGN.md §3.6 defines it (explicit fma polynomial, no hardware
+// transcendental, so the result is bit-reproducible on any IEEE machine): t = x*log2(e); n = rint(t); f = t - n; 2^f by a degree-5 polynomial.
 __device__ __forceinline__ float gs_exp(float x) {
     float t = x * 1.44269504088896340736f;
     float n = rintf(t);
