@@ -335,8 +335,9 @@ typedef struct gs_frame_stats {
     uint32_t sort_passes;
     uint32_t timed_frames;    /* frames accumulated below since the last reset */
     /* accumulated stage time in ms (only while timing is enabled):
-     * 0 repack, 1 preprocess, 2 scan, 3 emit, 4 sort, 5 ranges, 6 blend, 7 whole frame */
-    double stage_ms[8];
+     * 0 repack, 1 preprocess, 2 scan + compaction of visible Gaussians, 3 depth sort,
+     * 4 pair expansion, 5 tile sort, 6 ranges, 7 blend, 8 whole frame */
+    double stage_ms[12];
 } gs_frame_stats;
 
 typedef struct gs_renderer gs_renderer;
@@ -353,8 +354,8 @@ gs_status gs_renderer_reset_stats(gs_renderer *r);
 /* blocking: synchronises the stream of the last frame first */
 gs_status gs_renderer_stats(gs_renderer *r, gs_frame_stats *out);
 
-/* One frame: repack (if the Gaussians changed) -> preprocess -> scan -> key emit -> radix sort ->
- * tile ranges -> blend.  Renders tile rows [band_ty0, band_ty1) (16-pixel rows; pass 0 and
+/* One frame: repack (if the Gaussians changed) -> preprocess -> scan/compact -> depth sort of the
+ * visible Gaussians -> pair expansion in depth order -> stable tile sort -> tile ranges -> blend.  Renders tile rows [band_ty0, band_ty1) (16-pixel rows; pass 0 and
  * UINT32_MAX for the whole image) into rgba_out_device, a device pointer to the FULL
  * height x width x 4 f32 image; only the band's rows are written. */
 gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_buffer *gaussians,

@@ -677,7 +677,7 @@ class ComputeBundleBuilder:
 # renderer
 # ------------------------------------------------------------------------------------------------
 
-STAGE_NAMES = ["repack", "preprocess", "scan", "emit", "sort", "ranges", "blend", "frame"]
+STAGE_NAMES = ["repack", "preprocess", "scan", "depth_sort", "expand", "tile_sort", "ranges", "blend", "frame"]
 
 
 class Renderer:

@@ -38,7 +38,7 @@ class Camera(C.Structure):
 class FrameStats(C.Structure):
     _fields_ = [("gaussians", u64), ("visible", u64), ("pairs", u64), ("tiles_x", u32),
                 ("tiles_y", u32), ("sort_passes", u32), ("timed_frames", u32),
-                ("stage_ms", C.c_double * 8)]
+                ("stage_ms", C.c_double * 12)]
 
 
 class BundleDesc(C.Structure):

@@ -1052,18 +1052,29 @@ static gs_status dev_reserve(DevArray &a, size_t bytes) {
     return GS_OK;
 }
 
-enum { ST_REPACK = 0, ST_PRE, ST_SCAN, ST_EMIT, ST_SORT, ST_RANGES, ST_BLEND, ST_FRAME, ST_COUNT };
+static void dev_free(DevArray &a) {
+    if (a.ptr) (void)hipFree(a.ptr);
+    a.ptr = nullptr;
+    a.bytes = 0;
+}
+
+// stage indices of gs_frame_stats.stage_ms
+enum { ST_REPACK = 0, ST_PRE, ST_SCAN, ST_DSORT, ST_EXPAND, ST_TSORT, ST_RANGES, ST_BLEND, ST_FRAME, ST_COUNT };
 
 struct gs_renderer {
     gs_device *dev;
-    DevArray proj, tiles, chunk_sums, chunk_offsets, counters;
-    DevArray keys[2], vals[2], ghist, digit_totals, ranges;
-    uint32_t *host_counters;  // pinned: [0] = D, [1] = visible
+    DevArray recs, depth, rect, sorted_rect, chunk_tiles, chunk_vis, chunk_tiles_off, chunk_vis_off, counters;
+    DevArray dkeys[2], dvals[2];          // (depth bits, Gaussian index), capacity N
+    DevArray exp_sums, exp_offsets;
+    DevArray tkeys[2], tvals[2];          // (tile id, Gaussian index), capacity pair_capacity
+    DevArray ghist, digit_totals, ranges;
+    uint32_t *host_counters;  // pinned: [0] = D, [1] = V, [2] = D (depth order; must equal [0])
     uint64_t pair_capacity;
     // last frame
     uint64_t n, d, visible;
     uint32_t tiles_x, tiles_y, sort_passes;
-    int sorted_side;
+    int dsorted_side, tsorted_side;
+    bool wide_tiles;  // tile keys are u32 (more than 65536 tiles) instead of u16
     hipStream_t last_stream;
     // timing
     bool timing;
@@ -1088,7 +1099,8 @@ extern "C" gs_status gs_renderer_create(gs_device *dev, gs_renderer **out) {
     r->pair_capacity = 0;
     r->n = r->d = r->visible = 0;
     r->tiles_x = r->tiles_y = r->sort_passes = 0;
-    r->sorted_side = 0;
+    r->dsorted_side = r->tsorted_side = 0;
+    r->wide_tiles = false;
     r->last_stream = nullptr;
     r->timing = false;
     r->ev_valid = false;
@@ -1102,11 +1114,12 @@ extern "C" gs_status gs_renderer_create(gs_device *dev, gs_renderer **out) {
 extern "C" void gs_renderer_destroy(gs_renderer *r) {
     if (!r) return;
     (void)hipSetDevice(r->dev->ordinal);
-    DevArray *arrs[] = {&r->proj, &r->tiles, &r->chunk_sums, &r->chunk_offsets, &r->counters,
-                        &r->keys[0], &r->keys[1], &r->vals[0], &r->vals[1], &r->ghist,
+    DevArray *arrs[] = {&r->recs, &r->depth, &r->rect, &r->sorted_rect, &r->chunk_tiles, &r->chunk_vis,
+                        &r->chunk_tiles_off, &r->chunk_vis_off, &r->counters, &r->dkeys[0],
+                        &r->dkeys[1], &r->dvals[0], &r->dvals[1], &r->exp_sums, &r->exp_offsets,
+                        &r->tkeys[0], &r->tkeys[1], &r->tvals[0], &r->tvals[1], &r->ghist,
                         &r->digit_totals, &r->ranges};
-    for (DevArray *a : arrs)
-        if (a->ptr) (void)hipFree(a->ptr);
+    for (DevArray *a : arrs) dev_free(*a);
     if (r->host_counters) (void)hipHostFree(r->host_counters);
     if (r->ev_valid)
         for (auto &e : r->ev) (void)hipEventDestroy(e);
@@ -1153,7 +1166,7 @@ extern "C" gs_status gs_renderer_reset_stats(gs_renderer *r) {
 extern "C" gs_status gs_renderer_stats(gs_renderer *r, gs_frame_stats *out) {
     if (!r || !out) return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "null argument");
     GS_TRY(use_device(r->dev));
-    if (r->last_stream || r->n) GS_HIP(hipStreamSynchronize(r->last_stream));
+    GS_HIP(hipStreamSynchronize(r->last_stream));
     GS_TRY(collect_timing(r));
     std::memset(out, 0, sizeof(*out));
     out->gaussians = r->n;
@@ -1163,12 +1176,13 @@ extern "C" gs_status gs_renderer_stats(gs_renderer *r, gs_frame_stats *out) {
     out->tiles_y = r->tiles_y;
     out->sort_passes = r->sort_passes;
     out->timed_frames = r->timed_frames;
+    static_assert(ST_COUNT <= 12, "gs_frame_stats.stage_ms too small");
     for (int i = 0; i < ST_COUNT; i++) out->stage_ms[i] = r->stage_ms[i];
     return GS_OK;
 }
 
-typedef void (*preprocess_fn)(const uint4 *, uint64_t, uint32_t, gs::FrameConsts, uint4 *, uint32_t *,
-                              uint32_t *, uint32_t *);
+typedef void (*preprocess_fn)(const uint4 *, uint64_t, uint32_t, gs::FrameConsts, uint32_t *,
+                              uint32_t *, uint2 *, uint32_t *, uint32_t *);
 static preprocess_fn k_tbl_preprocess[4][3] = GS_CFG_TABLE(gs::k_preprocess);
 
 // frame constants from the uniforms
@@ -1222,37 +1236,34 @@ static uint32_t bit_length(uint32_t v) {
     return b;
 }
 
-// Stable LSD radix sort of `count` pairs on key bits [0, end_bit); result side returned.
-struct SortScratch {
-    DevArray *keys[2];
-    DevArray *vals[2];
-    DevArray *ghist;
-    DevArray *digit_totals;
-};
-
-static gs_status sort_pairs_device(SortScratch &sc, uint32_t count, uint32_t end_bit, hipStream_t st,
-                                   int &result_side, uint32_t &passes_out) {
+// Stable LSD radix sort of `count` (key, u32 value) pairs on key bits [0, end_bit), 8 bits per
+// pass, ping-ponging between side 0 and side 1; the side holding the result is returned.
+template <typename K>
+static gs_status sort_pairs_device(void *const keys[2], void *const vals[2], DevArray &ghist,
+                                   DevArray &digit_totals, uint32_t count, uint32_t end_bit,
+                                   hipStream_t st, int &result_side, uint32_t &passes_out) {
     uint32_t passes = (end_bit + gs::RADIX_BITS - 1) / gs::RADIX_BITS;
     passes_out = passes;
     result_side = 0;
     if (count == 0 || passes == 0) return GS_OK;
-    uint32_t nb = (count + gs::SORT_TILE - 1) / gs::SORT_TILE;
-    GS_TRY(dev_reserve(*sc.ghist, (size_t)nb * gs::RADIX * 4));
-    GS_TRY(dev_reserve(*sc.digit_totals, gs::RADIX * 4));
+    const uint32_t tile = (uint32_t)gs::sort_tile<K>();
+    uint32_t nb = (count + tile - 1) / tile;
+    GS_TRY(dev_reserve(ghist, (size_t)nb * gs::RADIX * 4));
+    GS_TRY(dev_reserve(digit_totals, gs::RADIX * 4));
     int side = 0;
     for (uint32_t p = 0; p < passes; p++) {
         uint32_t shift = p * gs::RADIX_BITS;
-        const uint64_t *kin = (const uint64_t *)sc.keys[side]->ptr;
-        const uint32_t *vin = (const uint32_t *)sc.vals[side]->ptr;
-        uint64_t *kout = (uint64_t *)sc.keys[side ^ 1]->ptr;
-        uint32_t *vout = (uint32_t *)sc.vals[side ^ 1]->ptr;
-        hipLaunchKernelGGL(gs::k_sort_hist, dim3(nb), dim3(gs::SORT_THREADS), 0, st, kin, count, shift,
-                           (uint32_t *)sc.ghist->ptr, nb);
+        const K *kin = (const K *)keys[side];
+        const uint32_t *vin = (const uint32_t *)vals[side];
+        K *kout = (K *)keys[side ^ 1];
+        uint32_t *vout = (uint32_t *)vals[side ^ 1];
+        hipLaunchKernelGGL(gs::k_sort_hist<K>, dim3(nb), dim3(gs::SORT_THREADS), 0, st, kin, count,
+                           shift, (uint32_t *)ghist.ptr, nb);
         hipLaunchKernelGGL(gs::k_sort_scan_rows, dim3(gs::RADIX), dim3(256), 0, st,
-                           (uint32_t *)sc.ghist->ptr, nb, (uint32_t *)sc.digit_totals->ptr);
-        hipLaunchKernelGGL(gs::k_sort_scatter, dim3(nb), dim3(gs::SORT_THREADS), 0, st, kin, vin, kout,
-                           vout, count, shift, (const uint32_t *)sc.ghist->ptr, nb,
-                           (const uint32_t *)sc.digit_totals->ptr);
+                           (uint32_t *)ghist.ptr, nb, (uint32_t *)digit_totals.ptr);
+        hipLaunchKernelGGL(gs::k_sort_scatter<K>, dim3(nb), dim3(gs::SORT_THREADS), 0, st, kin, vin,
+                           kout, vout, count, shift, (const uint32_t *)ghist.ptr, nb,
+                           (const uint32_t *)digit_totals.ptr);
         side ^= 1;
     }
     GS_HIP(hipGetLastError());
@@ -1260,14 +1271,16 @@ static gs_status sort_pairs_device(SortScratch &sc, uint32_t count, uint32_t end
     return GS_OK;
 }
 
-static gs_status reserve_pairs(gs_renderer *r, uint64_t pairs) {
-    if (pairs <= r->pair_capacity && r->keys[0].ptr) return GS_OK;
+static gs_status reserve_pairs(gs_renderer *r, uint64_t pairs, bool wide) {
+    if (pairs <= r->pair_capacity && r->tkeys[0].ptr && wide == r->wide_tiles) return GS_OK;
     uint64_t cap = pairs + pairs / 4 + 4096;
+    if (cap < r->pair_capacity) cap = r->pair_capacity;
     for (int i = 0; i < 2; i++) {
-        GS_TRY(dev_reserve(r->keys[i], cap * 8));
-        GS_TRY(dev_reserve(r->vals[i], cap * 4));
+        GS_TRY(dev_reserve(r->tkeys[i], cap * (wide ? 4 : 2)));
+        GS_TRY(dev_reserve(r->tvals[i], cap * 4));
     }
     r->pair_capacity = cap;
+    r->wide_tiles = wide;
     return GS_OK;
 }
 
@@ -1299,65 +1312,124 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
     uint32_t n = (uint32_t)n64;
     uint32_t nchunks = (n + gs::PP_CHUNK - 1) / gs::PP_CHUNK;
     uint32_t num_tiles = fc.tiles_x * fc.tiles_y;
+    const bool wide = num_tiles > 65536u;
+    const size_t nn = n ? n : 1, nc = nchunks ? nchunks : 1;
 
     mark(ST_REPACK);
     GS_TRY(ensure_planar(g, st));
     mark(ST_PRE);
 
-    GS_TRY(dev_reserve(r->proj, (size_t)(n ? n : 1) * 48));
-    GS_TRY(dev_reserve(r->tiles, (size_t)(nchunks ? nchunks : 1) * gs::PP_CHUNK * 4));
-    GS_TRY(dev_reserve(r->chunk_sums, (size_t)(nchunks ? nchunks : 1) * 4));
-    GS_TRY(dev_reserve(r->chunk_offsets, (size_t)(nchunks ? nchunks : 1) * 4));
+    GS_TRY(dev_reserve(r->recs, nn * 4 * gs::REC_WORDS + 16));
+    GS_TRY(dev_reserve(r->depth, nn * 4));
+    GS_TRY(dev_reserve(r->rect, nn * 8));
+    GS_TRY(dev_reserve(r->sorted_rect, nn * 8));
+    GS_TRY(dev_reserve(r->chunk_tiles, nc * 4));
+    GS_TRY(dev_reserve(r->chunk_vis, nc * 4));
+    GS_TRY(dev_reserve(r->chunk_tiles_off, nc * 4));
+    GS_TRY(dev_reserve(r->chunk_vis_off, nc * 4));
     GS_TRY(dev_reserve(r->counters, 64));
     GS_TRY(dev_reserve(r->ranges, (size_t)num_tiles * 8));
-    GS_HIP(hipMemsetAsync(r->counters.ptr, 0, 64, st));
+    for (int i = 0; i < 2; i++) {
+        GS_TRY(dev_reserve(r->dkeys[i], nn * 4));
+        GS_TRY(dev_reserve(r->dvals[i], nn * 4));
+    }
+    uint32_t *counters = (uint32_t *)r->counters.ptr;
 
     uint32_t d = 0, visible = 0;
     if (n) {
         hipLaunchKernelGGL(k_tbl_preprocess[g->sh][g->cov], dim3(nchunks), dim3(gs::PP_THREADS), 0, st,
                            (const uint4 *)g->planar, (uint64_t)g->planar_stride, n, fc,
-                           (uint4 *)r->proj.ptr, (uint32_t *)r->tiles.ptr,
-                           (uint32_t *)r->chunk_sums.ptr, (uint32_t *)r->counters.ptr + 1);
+                           (uint32_t *)r->recs.ptr, (uint32_t *)r->depth.ptr,
+                           (uint2 *)r->rect.ptr, (uint32_t *)r->chunk_tiles.ptr,
+                           (uint32_t *)r->chunk_vis.ptr);
         mark(ST_SCAN);
-        hipLaunchKernelGGL(gs::k_scan_chunks, dim3(1), dim3(1024), 0, st,
-                           (const uint32_t *)r->chunk_sums.ptr, (uint32_t *)r->chunk_offsets.ptr,
-                           nchunks, (uint32_t *)r->counters.ptr);
+        gs::ScanJob jt{(const uint32_t *)r->chunk_tiles.ptr, (uint32_t *)r->chunk_tiles_off.ptr,
+                       counters + 0, nchunks};
+        gs::ScanJob jv{(const uint32_t *)r->chunk_vis.ptr, (uint32_t *)r->chunk_vis_off.ptr,
+                       counters + 1, nchunks};
+        hipLaunchKernelGGL(gs::k_scan_chunks, dim3(2), dim3(1024), 0, st, jt, jv);
         GS_HIP(hipGetLastError());
-        GS_HIP(hipMemcpyAsync(r->host_counters, r->counters.ptr, 8, hipMemcpyDeviceToHost, st));
+        GS_HIP(hipMemcpyAsync(r->host_counters, counters, 8, hipMemcpyDeviceToHost, st));
+        // compaction does not depend on the counts: enqueue it before waiting for them
+        hipLaunchKernelGGL(gs::k_compact, dim3(nchunks), dim3(gs::PP_THREADS), 0, st,
+                           (const uint32_t *)r->depth.ptr, (const uint32_t *)r->chunk_vis_off.ptr, n,
+                           (uint32_t *)r->dkeys[0].ptr, (uint32_t *)r->dvals[0].ptr);
+        GS_HIP(hipGetLastError());
         GS_HIP(hipStreamSynchronize(st));
         d = r->host_counters[0];
         visible = r->host_counters[1];
     } else {
         mark(ST_SCAN);
     }
-    mark(ST_EMIT);
-    GS_TRY(reserve_pairs(r, d));
-    if (d) {
-        hipLaunchKernelGGL(gs::k_emit, dim3(nchunks), dim3(gs::PP_THREADS), 0, st,
-                           (const uint32_t *)r->tiles.ptr, (const uint32_t *)r->chunk_offsets.ptr,
-                           (const uint4 *)r->proj.ptr, n, fc.tiles_x, (uint64_t *)r->keys[0].ptr,
-                           (uint32_t *)r->vals[0].ptr, (uint32_t)r->pair_capacity);
+    mark(ST_DSORT);
+    // depth sort of the visible Gaussians: u32 keys = bits of the (positive) view depth
+    int dside = 0;
+    uint32_t dpasses = 0;
+    {
+        void *k2[2] = {r->dkeys[0].ptr, r->dkeys[1].ptr};
+        void *v2[2] = {r->dvals[0].ptr, r->dvals[1].ptr};
+        GS_TRY(sort_pairs_device<uint32_t>(k2, v2, r->ghist, r->digit_totals, visible, 32, st, dside,
+                                           dpasses));
+    }
+    mark(ST_EXPAND);
+    GS_TRY(reserve_pairs(r, d, wide));
+    uint32_t vchunks = (visible + gs::PP_CHUNK - 1) / gs::PP_CHUNK;
+    if (visible) {
+        GS_TRY(dev_reserve(r->exp_sums, (size_t)vchunks * 4));
+        GS_TRY(dev_reserve(r->exp_offsets, (size_t)vchunks * 4));
+        const uint32_t *order = (const uint32_t *)r->dvals[dside].ptr;
+        hipLaunchKernelGGL(gs::k_expand_count, dim3(vchunks), dim3(gs::PP_THREADS), 0, st, order,
+                           (const uint2 *)r->rect.ptr, visible, (uint2 *)r->sorted_rect.ptr,
+                           (uint32_t *)r->exp_sums.ptr);
+        gs::ScanJob je{(const uint32_t *)r->exp_sums.ptr, (uint32_t *)r->exp_offsets.ptr, counters + 2,
+                       vchunks};
+        hipLaunchKernelGGL(gs::k_scan_chunks, dim3(1), dim3(1024), 0, st, je, je);
+        if (wide)
+            hipLaunchKernelGGL(gs::k_expand_emit<uint32_t>, dim3(vchunks), dim3(gs::PP_THREADS), 0, st,
+                               order, (const uint2 *)r->sorted_rect.ptr,
+                               (const uint32_t *)r->exp_offsets.ptr, visible, fc.tiles_x,
+                               (uint32_t *)r->tkeys[0].ptr, (uint32_t *)r->tvals[0].ptr,
+                               (uint32_t)r->pair_capacity);
+        else
+            hipLaunchKernelGGL(gs::k_expand_emit<uint16_t>, dim3(vchunks), dim3(gs::PP_THREADS), 0, st,
+                               order, (const uint2 *)r->sorted_rect.ptr,
+                               (const uint32_t *)r->exp_offsets.ptr, visible, fc.tiles_x,
+                               (uint16_t *)r->tkeys[0].ptr, (uint32_t *)r->tvals[0].ptr,
+                               (uint32_t)r->pair_capacity);
         GS_HIP(hipGetLastError());
     }
-    mark(ST_SORT);
-    uint32_t end_bit = 32 + bit_length(num_tiles ? num_tiles - 1 : 0);
-    SortScratch sc{{&r->keys[0], &r->keys[1]}, {&r->vals[0], &r->vals[1]}, &r->ghist, &r->digit_totals};
-    int side = 0;
-    uint32_t passes = 0;
-    GS_TRY(sort_pairs_device(sc, d, end_bit, st, side, passes));
+    mark(ST_TSORT);
+    // stable sort on the tile id alone (pairs are already in depth order)
+    int tside = 0;
+    uint32_t tpasses = 0;
+    {
+        void *k2[2] = {r->tkeys[0].ptr, r->tkeys[1].ptr};
+        void *v2[2] = {r->tvals[0].ptr, r->tvals[1].ptr};
+        uint32_t tile_bits = bit_length(num_tiles ? num_tiles - 1 : 0);
+        if (wide)
+            GS_TRY(sort_pairs_device<uint32_t>(k2, v2, r->ghist, r->digit_totals, d, tile_bits, st,
+                                               tside, tpasses));
+        else
+            GS_TRY(sort_pairs_device<uint16_t>(k2, v2, r->ghist, r->digit_totals, d, tile_bits, st,
+                                               tside, tpasses));
+    }
     mark(ST_RANGES);
     GS_HIP(hipMemsetAsync(r->ranges.ptr, 0, (size_t)num_tiles * 8, st));
     if (d) {
-        hipLaunchKernelGGL(gs::k_tile_ranges, dim3((d + 255) / 256), dim3(256), 0, st,
-                           (const uint64_t *)r->keys[side].ptr, d, (uint32_t *)r->ranges.ptr);
+        if (wide)
+            hipLaunchKernelGGL(gs::k_tile_ranges<uint32_t>, dim3((d + 255) / 256), dim3(256), 0, st,
+                               (const uint32_t *)r->tkeys[tside].ptr, d, (uint32_t *)r->ranges.ptr);
+        else
+            hipLaunchKernelGGL(gs::k_tile_ranges<uint16_t>, dim3((d + 255) / 256), dim3(256), 0, st,
+                               (const uint16_t *)r->tkeys[tside].ptr, d, (uint32_t *)r->ranges.ptr);
         GS_HIP(hipGetLastError());
     }
     mark(ST_BLEND);
     uint32_t band_tiles = (fc.band_ty1 - fc.band_ty0) * fc.tiles_x;
     if (band_tiles) {
-        hipLaunchKernelGGL(gs::k_blend, dim3(band_tiles), dim3(256), 0, st,
-                           (const uint32_t *)r->ranges.ptr, (const uint32_t *)r->vals[side].ptr,
-                           (const uint4 *)r->proj.ptr, fc, (float4 *)rgba);
+        hipLaunchKernelGGL(gs::k_blend, dim3(band_tiles), dim3(gs::BLEND_THREADS), 0, st,
+                           (const uint32_t *)r->ranges.ptr, (const uint32_t *)r->tvals[tside].ptr,
+                           (const uint32_t *)r->recs.ptr, fc, (float4 *)rgba);
         GS_HIP(hipGetLastError());
     }
     mark(ST_FRAME);
@@ -1370,8 +1442,9 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
     r->visible = visible;
     r->tiles_x = fc.tiles_x;
     r->tiles_y = fc.tiles_y;
-    r->sort_passes = passes;
-    r->sorted_side = side;
+    r->sort_passes = dpasses + tpasses;
+    r->dsorted_side = dside;
+    r->tsorted_side = tside;
     r->last_stream = st;
     return GS_OK;
 }
@@ -1385,31 +1458,66 @@ static gs_status download_sync(gs_renderer *r, void *dst, const void *src, size_
     return GS_OK;
 }
 
+// The device keeps the projected data as three dense arrays (36-byte blend record, depth key,
+// tile rect); the 48-byte gs_projected view of DESIGN.md §3.3 is assembled here.
 extern "C" gs_status gs_renderer_download_projected(gs_renderer *r, gs_projected *proj_out,
                                                     uint32_t *tiles_out, size_t n) {
     if (!r) return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "null renderer");
     if (n > r->n) return fail(GS_ERR_INVALID_ARGUMENT, n, r->n, 0, "n exceeds last frame");
     GS_TRY(use_device(r->dev));
     static_assert(sizeof(gs_projected) == 48, "record size");
-    if (proj_out) GS_TRY(download_sync(r, proj_out, r->proj.ptr, n * 48));
-    if (tiles_out) GS_TRY(download_sync(r, tiles_out, r->tiles.ptr, n * 4));
+    if (!n) return GS_OK;
+    std::vector<uint32_t> recs(n * gs::REC_WORDS), depth(n);
+    std::vector<uint2> rect(n);
+    GS_TRY(download_sync(r, recs.data(), r->recs.ptr, n * 4 * gs::REC_WORDS));
+    GS_TRY(download_sync(r, depth.data(), r->depth.ptr, n * 4));
+    GS_TRY(download_sync(r, rect.data(), r->rect.ptr, n * 8));
+    for (size_t i = 0; i < n; i++) {
+        bool vis = depth[i] != 0xffffffffu;
+        uint32_t w = (rect[i].y & 0xffffu) - (rect[i].x & 0xffffu), h = (rect[i].y >> 16) - (rect[i].x >> 16);
+        if (tiles_out) tiles_out[i] = vis ? w * h : 0u;
+        if (proj_out) {
+            gs_projected &p = proj_out[i];
+            std::memset(&p, 0, sizeof(p));
+            if (vis) {
+                std::memcpy(&p, &recs[i * gs::REC_WORDS], 36);
+                std::memcpy(&p.depth, &depth[i], 4);
+                p.tx0 = (uint16_t)(rect[i].x & 0xffffu);
+                p.ty0 = (uint16_t)(rect[i].x >> 16);
+                p.tx1 = (uint16_t)(rect[i].y & 0xffffu);
+                p.ty1 = (uint16_t)(rect[i].y >> 16);
+            }
+        }
+    }
     return GS_OK;
 }
 
-static gs_status download_pairs(gs_renderer *r, int side, uint64_t *keys_out, uint32_t *idx_out,
-                                uint64_t capacity, uint64_t *pairs_out) {
+// The frame sorts (depth) and (tile) separately; the canonical 64-bit key of DESIGN.md §3.4 is
+// rebuilt here as tile << 32 | depth bits of the pair's Gaussian.
+extern "C" gs_status gs_renderer_download_sorted(gs_renderer *r, uint64_t *keys_out, uint32_t *idx_out,
+                                                 uint64_t capacity, uint64_t *pairs_out) {
     if (!r) return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "null renderer");
     GS_TRY(use_device(r->dev));
     if (pairs_out) *pairs_out = r->d;
     uint64_t m = r->d < capacity ? r->d : capacity;
-    if (keys_out) GS_TRY(download_sync(r, keys_out, r->keys[side].ptr, m * 8));
-    if (idx_out) GS_TRY(download_sync(r, idx_out, r->vals[side].ptr, m * 4));
+    if (!m) return GS_OK;
+    std::vector<uint32_t> idx(m);
+    GS_TRY(download_sync(r, idx.data(), r->tvals[r->tsorted_side].ptr, m * 4));
+    if (idx_out) std::memcpy(idx_out, idx.data(), m * 4);
+    if (keys_out) {
+        std::vector<uint32_t> depth(r->n);
+        GS_TRY(download_sync(r, depth.data(), r->depth.ptr, r->n * 4));
+        if (r->wide_tiles) {
+            std::vector<uint32_t> t(m);
+            GS_TRY(download_sync(r, t.data(), r->tkeys[r->tsorted_side].ptr, m * 4));
+            for (uint64_t j = 0; j < m; j++) keys_out[j] = ((uint64_t)t[j] << 32) | depth[idx[j]];
+        } else {
+            std::vector<uint16_t> t(m);
+            GS_TRY(download_sync(r, t.data(), r->tkeys[r->tsorted_side].ptr, m * 2));
+            for (uint64_t j = 0; j < m; j++) keys_out[j] = ((uint64_t)t[j] << 32) | depth[idx[j]];
+        }
+    }
     return GS_OK;
-}
-
-extern "C" gs_status gs_renderer_download_sorted(gs_renderer *r, uint64_t *keys_out, uint32_t *idx_out,
-                                                 uint64_t capacity, uint64_t *pairs_out) {
-    return download_pairs(r, r ? r->sorted_side : 0, keys_out, idx_out, capacity, pairs_out);
 }
 
 extern "C" gs_status gs_renderer_download_ranges(gs_renderer *r, uint32_t *ranges_out,
@@ -1434,14 +1542,6 @@ extern "C" gs_status gs_sort_pairs_u64(gs_device *dev, gs_stream *s, uint64_t *k
     hipStream_t st = stream_of(dev, s);
     DevArray k[2], v[2], gh, dt;
     gs_status rc = GS_OK;
-    auto cleanup = [&]() {
-        for (int i = 0; i < 2; i++) {
-            if (k[i].ptr) (void)hipFree(k[i].ptr);
-            if (v[i].ptr) (void)hipFree(v[i].ptr);
-        }
-        if (gh.ptr) (void)hipFree(gh.ptr);
-        if (dt.ptr) (void)hipFree(dt.ptr);
-    };
     for (int i = 0; i < 2 && rc == GS_OK; i++) {
         rc = dev_reserve(k[i], count * 8);
         if (rc == GS_OK) rc = dev_reserve(v[i], count * 4);
@@ -1455,8 +1555,9 @@ extern "C" gs_status gs_sort_pairs_u64(gs_device *dev, gs_stream *s, uint64_t *k
     int side = 0;
     uint32_t passes = 0;
     if (rc == GS_OK) {
-        SortScratch sc{{&k[0], &k[1]}, {&v[0], &v[1]}, &gh, &dt};
-        rc = sort_pairs_device(sc, (uint32_t)count, end_bit, st, side, passes);
+        void *k2[2] = {k[0].ptr, k[1].ptr};
+        void *v2[2] = {v[0].ptr, v[1].ptr};
+        rc = sort_pairs_device<uint64_t>(k2, v2, gh, dt, (uint32_t)count, end_bit, st, side, passes);
     }
     if (rc == GS_OK) {
         hipError_t e = hipMemcpyAsync(keys, k[side].ptr, count * 8, hipMemcpyDeviceToHost, st);
@@ -1464,7 +1565,12 @@ extern "C" gs_status gs_sort_pairs_u64(gs_device *dev, gs_stream *s, uint64_t *k
         if (e == hipSuccess) e = hipStreamSynchronize(st);
         if (e != hipSuccess) rc = fail(GS_ERR_HIP, (uint64_t)e, 0, 0, "download failed: %s", hipGetErrorString(e));
     }
-    cleanup();
+    for (int i = 0; i < 2; i++) {
+        dev_free(k[i]);
+        dev_free(v[i]);
+    }
+    dev_free(gh);
+    dev_free(dt);
     return rc;
 }
 
@@ -1483,7 +1589,7 @@ __global__ __launch_bounds__(PP_THREADS) void k_chunk_sums(const uint32_t *__res
     if (threadIdx.x == 0) sums[blockIdx.x] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
 }
 
-// per-chunk exclusive scan written out (the frame fuses this into k_emit)
+// per-chunk exclusive scan written out
 __global__ __launch_bounds__(PP_THREADS) void k_chunk_scan_write(const uint32_t *__restrict__ in,
                                                                  const uint32_t *__restrict__ chunk_offsets,
                                                                  uint32_t n, uint32_t *__restrict__ out) {
@@ -1527,9 +1633,8 @@ extern "C" gs_status gs_exclusive_scan_u32(gs_device *dev, gs_stream *s, const u
         if (e == hipSuccess) {
             hipLaunchKernelGGL(gs::k_chunk_sums, dim3(nchunks), dim3(gs::PP_THREADS), 0, st,
                                (const uint32_t *)din.ptr, n, (uint32_t *)sums.ptr);
-            hipLaunchKernelGGL(gs::k_scan_chunks, dim3(1), dim3(1024), 0, st,
-                               (const uint32_t *)sums.ptr, (uint32_t *)offs.ptr, nchunks,
-                               (uint32_t *)tot.ptr);
+            gs::ScanJob job{(const uint32_t *)sums.ptr, (uint32_t *)offs.ptr, (uint32_t *)tot.ptr, nchunks};
+            hipLaunchKernelGGL(gs::k_scan_chunks, dim3(1), dim3(1024), 0, st, job, job);
             hipLaunchKernelGGL(gs::k_chunk_scan_write, dim3(nchunks), dim3(gs::PP_THREADS), 0, st,
                                (const uint32_t *)din.ptr, (const uint32_t *)offs.ptr, n,
                                (uint32_t *)dout.ptr);
@@ -1541,7 +1646,6 @@ extern "C" gs_status gs_exclusive_scan_u32(gs_device *dev, gs_stream *s, const u
         if (e != hipSuccess) rc = fail(GS_ERR_HIP, (uint64_t)e, 0, 0, "scan failed: %s", hipGetErrorString(e));
     }
     if (total_out) *total_out = total;
-    for (DevArray *a : {&din, &dout, &sums, &offs, &tot})
-        if (a->ptr) (void)hipFree(a->ptr);
+    for (DevArray *a : {&din, &dout, &sums, &offs, &tot}) dev_free(*a);
     return rc;
 }

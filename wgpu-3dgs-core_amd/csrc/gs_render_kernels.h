@@ -165,6 +165,9 @@ __device__ __forceinline__ void eval_sh(const uint32_t *w, uint32_t deg, bool no
 }
 
 // One Gaussian: returns the number of tiles touched (0 = culled) and fills the 48-byte record.
+// Written without early exits: every cull test only clears `ok`, so all the record's loads are
+// unconditional and the compiler can issue them back to back at the top (memory-level
+// parallelism is what this HBM-bound kernel needs); arithmetic on culled lanes is discarded.
 template <int SH, int COV>
 __device__ __forceinline__ uint32_t project_one(const uint32_t *w, const FrameConsts &fc,
                                                 uint4 rec[3]) {
@@ -173,7 +176,7 @@ __device__ __forceinline__ uint32_t project_one(const uint32_t *w, const FrameCo
     mat4_mul_point(fc.M, p, pw);
     mat4_mul_point(fc.V, pw, t);
     float xv = t[0], yv = -t[1], zv = -t[2];
-    if (!(zv > fc.near_plane) || !(zv < fc.far_plane)) return 0u;
+    bool ok = (zv > fc.near_plane) && (zv < fc.far_plane);
 
     float S[6];
     gaussian_unpack_cov3d<SH, COV>(w, S);
@@ -199,12 +202,12 @@ __device__ __forceinline__ uint32_t project_one(const uint32_t *w, const FrameCo
     float cb = fc.size2 * ((T0[0] * b0 + T0[1] * b1) + T0[2] * b2);
     float cc = fc.size2 * ((T1[0] * b0 + T1[1] * b1) + T1[2] * b2) + 0.3f;
     float det = ca * cc - cb * cb;
-    if (!(det > 0.0f)) return 0u;
+    ok = ok && (det > 0.0f);
     float inv = 1.0f / det;
     float mid = 0.5f * (ca + cc);
     float lam = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
     float radius = ceilf(fc.max_std_dev * sqrtf(lam));
-    if (!(radius > 0.0f)) return 0u;
+    ok = ok && (radius > 0.0f);
     float mx = fc.fx * txz + fc.cx;
     float my = fc.fy * tyz + fc.cy;
     float lo_y = (float)fc.band_ty0, hi_y = (float)fc.band_ty1;
@@ -212,8 +215,10 @@ __device__ __forceinline__ uint32_t project_one(const uint32_t *w, const FrameCo
     float fx1 = clampf(floorf((mx + radius) * 0.0625f) + 1.0f, 0.0f, (float)fc.tiles_x);
     float fy0 = clampf(floorf((my - radius) * 0.0625f), lo_y, hi_y);
     float fy1 = clampf(floorf((my + radius) * 0.0625f) + 1.0f, lo_y, hi_y);
-    if (!(fx1 > fx0) || !(fy1 > fy0)) return 0u;
-    uint32_t tx0 = (uint32_t)fx0, tx1 = (uint32_t)fx1, ty0 = (uint32_t)fy0, ty1 = (uint32_t)fy1;
+    ok = ok && (fx1 > fx0) && (fy1 > fy0);
+    // NaN-safe conversions: culled lanes may carry garbage; their values are never used
+    uint32_t tx0 = ok ? (uint32_t)fx0 : 0u, tx1 = ok ? (uint32_t)fx1 : 0u;
+    uint32_t ty0 = ok ? (uint32_t)fy0 : 0u, ty1 = ok ? (uint32_t)fy1 : 0u;
 
     float dw[3] = {pw[0] - fc.cam_pos[0], pw[1] - fc.cam_pos[1], pw[2] - fc.cam_pos[2]};
     float dl = sqrtf((dw[0] * dw[0] + dw[1] * dw[1]) + dw[2] * dw[2]);
@@ -234,13 +239,22 @@ __device__ __forceinline__ uint32_t project_one(const uint32_t *w, const FrameCo
     return (tx1 - tx0) * (ty1 - ty0);
 }
 
+// 4-byte aligned 16-byte vector: lets 36-byte records be moved with two dwordx4 + one dword
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+constexpr int REC_WORDS = 9;   // blend record: mx, my, ca, cb, cc, opacity, r, g, b  (36 bytes)
+
 // Grid: one workgroup per PP_CHUNK Gaussians.  Reads the chunk-planar mirror with one
 // global_load_dwordx4 per (lane, chunk): a wave reads 1 KiB contiguous per instruction.
+// Outputs per Gaussian, all written DENSELY (culled lanes store too): the 36-byte blend record,
+// the depth key (0xffffffff when culled) and the 8-byte tile rect (0 when culled).  Masking the
+// stores of culled lanes would leave holes in every 64-byte sector, which turns the writes into
+// read-modify-writes and costs 0.15 ms at 10 M Gaussians (measured); a dense store of a few
+// don't-care bytes is cheaper.  Per workgroup: tile-count sum and visible count (both feed scans).
 template <int SH, int COV>
 __global__ __launch_bounds__(PP_THREADS) void k_preprocess(
     const uint4 *__restrict__ planar, uint64_t plane_stride, uint32_t n, FrameConsts fc,
-    uint4 *__restrict__ proj, uint32_t *__restrict__ tiles, uint32_t *__restrict__ chunk_sums,
-    uint32_t *__restrict__ visible_count) {
+    uint32_t *__restrict__ recs, uint32_t *__restrict__ depth, uint2 *__restrict__ rect,
+    uint32_t *__restrict__ chunk_tiles, uint32_t *__restrict__ chunk_vis) {
     constexpr int NW = pod_words(SH, COV);
     constexpr int NC = NW / 4;
     __shared__ uint32_t s_red[8];
@@ -250,29 +264,34 @@ __global__ __launch_bounds__(PP_THREADS) void k_preprocess(
     for (int k = 0; k < PP_ITEMS; k++) {
         uint32_t i = base + k * PP_THREADS + threadIdx.x;
         if (i < n) {
+            // Issue ALL of the record's loads back to back (NC x 1 KiB per wave in flight), then
+            // pin them with empty asm statements: without this the compiler sinks each load next
+            // to its first use (SH chunks end up behind the projection arithmetic and behind the
+            // uniform sh_deg branches), which serialises 4-5 HBM round trips per Gaussian.
+            uint4 v[NC];
+#pragma unroll
+            for (int c = 0; c < NC; c++) v[c] = planar[(uint64_t)c * plane_stride + i];
             uint32_t w[NW];
 #pragma unroll
             for (int c = 0; c < NC; c++) {
-                uint4 v = planar[(uint64_t)c * plane_stride + i];
-                w[4 * c + 0] = v.x;
-                w[4 * c + 1] = v.y;
-                w[4 * c + 2] = v.z;
-                w[4 * c + 3] = v.w;
+                asm volatile("" : "+v"(v[c].x), "+v"(v[c].y), "+v"(v[c].z), "+v"(v[c].w));
+                w[4 * c + 0] = v[c].x;
+                w[4 * c + 1] = v[c].y;
+                w[4 * c + 2] = v[c].z;
+                w[4 * c + 3] = v[c].w;
             }
             uint4 rec[3];
             uint32_t cnt = project_one<SH, COV>(w, fc, rec);
-            tiles[i] = cnt;
-            if (cnt) {
-                uint4 *o = proj + (uint64_t)i * 3;
-                o[0] = rec[0];
-                o[1] = rec[1];
-                o[2] = rec[2];
-                local += cnt;
-                local_vis += 1u;
-            }
+            uint32_t *o = recs + (uint64_t)i * REC_WORDS;
+            *(u32x4_a4 *)(o) = u32x4_a4{rec[0].x, rec[0].y, rec[0].z, rec[0].w};
+            *(u32x4_a4 *)(o + 4) = u32x4_a4{rec[1].x, rec[1].y, rec[1].z, rec[1].w};
+            o[8] = rec[2].x;
+            depth[i] = cnt ? rec[2].y : 0xffffffffu;
+            rect[i] = cnt ? make_uint2(rec[2].z, rec[2].w) : make_uint2(0u, 0u);
+            local += cnt;
+            local_vis += cnt ? 1u : 0u;
         }
     }
-    // chunk sum (feeds the scan) and visible count
     local = wave_reduce_add(local);
     local_vis = wave_reduce_add(local_vis);
     uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
@@ -282,29 +301,32 @@ __global__ __launch_bounds__(PP_THREADS) void k_preprocess(
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        chunk_sums[blockIdx.x] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
-        uint32_t v = (s_red[4] + s_red[5]) + (s_red[6] + s_red[7]);
-        if (v) atomicAdd(visible_count, v);
+        chunk_tiles[blockIdx.x] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+        chunk_vis[blockIdx.x] = (s_red[4] + s_red[5]) + (s_red[6] + s_red[7]);
     }
 }
 
 // ---------------------------------------------------------------------------------------------
-// scan of chunk sums (single workgroup; <= ~50k chunks for 50 M Gaussians)
+// scan of per-chunk sums: one workgroup per array (blockIdx.x selects it)
 // ---------------------------------------------------------------------------------------------
 
-// counters[0] = total (saturating to 0xffffffff on overflow is not needed: D < 2^32 is checked
-// on the host against capacity)
-__global__ __launch_bounds__(1024) void k_scan_chunks(const uint32_t *__restrict__ sums,
-                                                      uint32_t *__restrict__ offsets,
-                                                      uint32_t num, uint32_t *__restrict__ total_out) {
+struct ScanJob {
+    const uint32_t *sums;
+    uint32_t *offsets;   // exclusive prefix per chunk
+    uint32_t *total;     // grand total
+    uint32_t num;
+};
+
+__global__ __launch_bounds__(1024) void k_scan_chunks(ScanJob j0, ScanJob j1) {
     __shared__ uint32_t s_wave[16];
     __shared__ uint32_t s_carry;
+    const ScanJob job = blockIdx.x == 0 ? j0 : j1;
     uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
     if (threadIdx.x == 0) s_carry = 0;
     __syncthreads();
-    for (uint32_t base = 0; base < num; base += 1024u) {
+    for (uint32_t base = 0; base < job.num; base += 1024u) {
         uint32_t i = base + threadIdx.x;
-        uint32_t v = i < num ? sums[i] : 0u;
+        uint32_t v = i < job.num ? job.sums[i] : 0u;
         uint32_t inc = wave_inclusive_scan(v, lane);
         if (lane == 63u) s_wave[wid] = inc;
         __syncthreads();
@@ -316,77 +338,188 @@ __global__ __launch_bounds__(1024) void k_scan_chunks(const uint32_t *__restrict
             tot += x;
         }
         uint32_t carry = s_carry;
-        if (i < num) offsets[i] = carry + wave_off + inc - v;
+        if (i < job.num) job.offsets[i] = carry + wave_off + inc - v;
         __syncthreads();
         if (threadIdx.x == 0) s_carry = carry + tot;
         __syncthreads();
     }
-    if (threadIdx.x == 0) *total_out = s_carry;
+    if (threadIdx.x == 0) *job.total = s_carry;
 }
 
 // ---------------------------------------------------------------------------------------------
-// emit (row x3): per-chunk exclusive scan + (tile << 32 | depth bits, Gaussian index) pairs
+// compact: visible Gaussians -> (depth bits, index) pairs in index order (input of the depth sort)
 // ---------------------------------------------------------------------------------------------
 
-__global__ __launch_bounds__(PP_THREADS) void k_emit(const uint32_t *__restrict__ tiles,
-                                                     const uint32_t *__restrict__ chunk_offsets,
-                                                     const uint4 *__restrict__ proj, uint32_t n,
-                                                     uint32_t tiles_x, uint64_t *__restrict__ keys,
-                                                     uint32_t *__restrict__ idx, uint32_t capacity) {
+__global__ __launch_bounds__(PP_THREADS) void k_compact(const uint32_t *__restrict__ depth,
+                                                        const uint32_t *__restrict__ vis_offsets,
+                                                        uint32_t n, uint32_t *__restrict__ dkeys,
+                                                        uint32_t *__restrict__ dvals) {
     __shared__ uint32_t s_scan[4];
     uint32_t base = blockIdx.x * PP_CHUNK + threadIdx.x * PP_ITEMS;
-    uint32_t cnt[PP_ITEMS];
-    uint32_t sum = 0;
+    uint32_t dk[PP_ITEMS];
+    uint32_t cnt = 0;
 #pragma unroll
     for (int k = 0; k < PP_ITEMS; k++) {
-        uint32_t i = base + k;
-        cnt[k] = i < n ? tiles[i] : 0u;
-        sum += cnt[k];
+        dk[k] = base + k < n ? depth[base + k] : 0xffffffffu;
+        cnt += dk[k] != 0xffffffffu;
     }
     uint32_t total;
-    uint32_t off = chunk_offsets[blockIdx.x] + block_exclusive_scan_256(sum, s_scan, total);
-#pragma unroll 1
+    uint32_t off = vis_offsets[blockIdx.x] + block_exclusive_scan_256(cnt, s_scan, total);
+#pragma unroll
     for (int k = 0; k < PP_ITEMS; k++) {
-        if (cnt[k]) {
-            uint32_t i = base + k;
-            uint4 r2 = proj[(uint64_t)i * 3 + 2];
-            uint32_t depth_bits = r2.y;
-            uint32_t tx0 = r2.z & 0xffffu, ty0 = r2.z >> 16, tx1 = r2.w & 0xffffu, ty1 = r2.w >> 16;
-            uint32_t o = off;
-            for (uint32_t ty = ty0; ty < ty1; ty++)
-                for (uint32_t tx = tx0; tx < tx1; tx++) {
-                    if (o < capacity) {
-                        keys[o] = ((uint64_t)(ty * tiles_x + tx) << 32) | depth_bits;
-                        idx[o] = i;
-                    }
-                    o++;
-                }
-            off += cnt[k];
+        if (dk[k] != 0xffffffffu) {
+            dkeys[off] = dk[k];
+            dvals[off] = base + k;
+            off++;
         }
     }
 }
 
 // ---------------------------------------------------------------------------------------------
-// radix sort (row x4): stable LSD, 8-bit digits.  Per pass: histogram -> row scan -> scatter.
+// expand (row x3): walk the Gaussians in depth order and emit one (tile id, Gaussian index) pair
+// per overlapped tile.  Within a tile the pairs are therefore already depth-ordered; the
+// following stable sort on the tile id alone yields exactly the order of a stable sort on the
+// 64-bit (tile << 32 | depth) key.
+// ---------------------------------------------------------------------------------------------
+
+// Gather the tile rects into depth order (the only random access of the expansion: 8 bytes per
+// visible Gaussian from a compact array) and produce the per-chunk tile-count sums.
+__global__ __launch_bounds__(PP_THREADS) void k_expand_count(const uint32_t *__restrict__ order,
+                                                             const uint2 *__restrict__ rect,
+                                                             uint32_t v_count,
+                                                             uint2 *__restrict__ sorted_rect,
+                                                             uint32_t *__restrict__ sums) {
+    __shared__ uint32_t s_red[4];
+    uint32_t base = blockIdx.x * PP_CHUNK;
+    uint32_t g[PP_ITEMS];
+#pragma unroll
+    for (int k = 0; k < PP_ITEMS; k++) {
+        uint32_t j = base + k * PP_THREADS + threadIdx.x;
+        g[k] = j < v_count ? order[j] : 0xffffffffu;
+    }
+    uint32_t v = 0;
+#pragma unroll
+    for (int k = 0; k < PP_ITEMS; k++) {
+        uint32_t j = base + k * PP_THREADS + threadIdx.x;
+        if (g[k] != 0xffffffffu) {
+            uint2 r = rect[g[k]];
+            sorted_rect[j] = r;
+            v += ((r.y & 0xffffu) - (r.x & 0xffffu)) * ((r.y >> 16) - (r.x >> 16));
+        }
+    }
+    v = wave_reduce_add(v);
+    if ((threadIdx.x & 63u) == 0) s_red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) sums[blockIdx.x] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+}
+
+// Cooperative, load-balanced expansion at wave granularity.  A wave owns 64 consecutive Gaussians
+// of the depth order; their tile counts are scanned with shuffles, and the wave then produces its
+// output slots 64 at a time: every Gaussian whose first slot falls in the current 64-slot window
+// drops a marker there (LDS), an inclusive max-scan over the lanes turns the markers into "owner
+// of this slot", and each lane fetches its owner's rect with a cross-lane permute.  Consecutive
+// lanes write consecutive slots, so stores are coalesced whatever the splat sizes, and a screen-
+// filling splat costs the same per output as a one-tile splat.
+template <typename TK>
+__global__ __launch_bounds__(PP_THREADS) void k_expand_emit(
+    const uint32_t *__restrict__ order, const uint2 *__restrict__ sorted_rect,
+    const uint32_t *__restrict__ chunk_offsets, uint32_t v_count, uint32_t tiles_x,
+    TK *__restrict__ tkeys, uint32_t *__restrict__ tvals, uint32_t capacity) {
+    __shared__ uint32_t s_scan[PP_ITEMS][4];
+    __shared__ uint32_t s_mark[4][WAVE];
+    const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+    // all loads of the workgroup's PP_CHUNK Gaussians up front (coalesced, independent)
+    uint32_t g_[PP_ITEMS], cnt_[PP_ITEMS], origin_[PP_ITEMS], width_[PP_ITEMS], incl_[PP_ITEMS];
+#pragma unroll
+    for (int round = 0; round < PP_ITEMS; round++) {
+        uint32_t j = blockIdx.x * PP_CHUNK + round * PP_THREADS + threadIdx.x;
+        g_[round] = 0;
+        cnt_[round] = 0;
+        origin_[round] = 0;
+        width_[round] = 1;
+        if (j < v_count) {
+            g_[round] = order[j];
+            uint2 r = sorted_rect[j];
+            uint32_t w = (r.y & 0xffffu) - (r.x & 0xffffu), h = (r.y >> 16) - (r.x >> 16);
+            origin_[round] = r.x;
+            width_[round] = w ? w : 1u;
+            cnt_[round] = w * h;
+        }
+        incl_[round] = wave_inclusive_scan(cnt_[round], lane);
+        if (lane == 63u) s_scan[round][wid] = incl_[round];
+    }
+    __syncthreads();
+    uint32_t out_base = chunk_offsets[blockIdx.x];
+#pragma unroll
+    for (int round = 0; round < PP_ITEMS; round++) {
+        const uint32_t g = g_[round], cnt = cnt_[round], origin = origin_[round], width = width_[round];
+        const uint32_t incl = incl_[round], excl = incl - cnt;
+        const uint32_t wave_total = __shfl(incl, 63, WAVE);
+        uint32_t w0 = s_scan[round][0], w1 = s_scan[round][1], w2 = s_scan[round][2],
+                 w3 = s_scan[round][3];
+        uint32_t wave_off = wid == 0 ? 0u : wid == 1 ? w0 : wid == 2 ? w0 + w1 : w0 + w1 + w2;
+        const uint32_t out0 = out_base + wave_off;
+        uint32_t carry = 0;
+        for (uint32_t win = 0; win < wave_total; win += WAVE) {
+            s_mark[wid][lane] = 0u;
+            __builtin_amdgcn_wave_barrier();
+            if (cnt != 0u && excl >= win && excl < win + WAVE) s_mark[wid][excl - win] = lane + 1u;
+            __builtin_amdgcn_wave_barrier();
+            uint32_t m = s_mark[wid][lane];
+#pragma unroll
+            for (int d = 1; d < WAVE; d <<= 1) {
+                uint32_t t = __shfl_up(m, d, WAVE);
+                if (lane >= (uint32_t)d) m = m > t ? m : t;
+            }
+            uint32_t owner = m ? m - 1u : carry;
+            carry = __shfl(owner, 63, WAVE);
+            uint32_t o_excl = __shfl(excl, owner, WAVE);
+            uint32_t o_g = __shfl(g, owner, WAVE);
+            uint32_t o_org = __shfl(origin, owner, WAVE);
+            uint32_t o_w = __shfl(width, owner, WAVE);
+            uint32_t e = win + lane;
+            uint32_t local = e - o_excl;
+            uint32_t row = local / o_w, col = local - row * o_w;
+            uint32_t tile = ((o_org >> 16) + row) * tiles_x + (o_org & 0xffffu) + col;
+            uint32_t o = out0 + e;
+            if (e < wave_total && o < capacity) {
+                tkeys[o] = (TK)tile;
+                tvals[o] = o_g;
+            }
+        }
+        out_base += (w0 + w1) + (w2 + w3);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// radix sort (row x4): stable LSD, 8-bit digits; per pass: histogram -> row scan -> scatter.
+// Templated on the key type: u32 depth keys (4 passes), u16 / u32 tile keys (2 / 3 passes), and
+// u64 keys for the stand-alone gs_sort_pairs_u64.
 // ---------------------------------------------------------------------------------------------
 
 constexpr int SORT_THREADS = 256;
-constexpr int SORT_ITEMS = 8;
-constexpr int SORT_TILE = SORT_THREADS * SORT_ITEMS;   // 2048 pairs per workgroup
 constexpr int RADIX_BITS = 8;
 constexpr int RADIX = 1 << RADIX_BITS;
 
+template <typename K> struct SortCfg;
+template <> struct SortCfg<uint64_t> { static constexpr int ITEMS = 8; };
+template <> struct SortCfg<uint32_t> { static constexpr int ITEMS = 16; };
+template <> struct SortCfg<uint16_t> { static constexpr int ITEMS = 16; };
+template <typename K> constexpr int sort_tile() { return SORT_THREADS * SortCfg<K>::ITEMS; }
+
 // ghist layout: [digit][block] (digit-major) so that the row scan reads contiguous memory.
-__global__ __launch_bounds__(SORT_THREADS) void k_sort_hist(const uint64_t *__restrict__ keys,
+template <typename K>
+__global__ __launch_bounds__(SORT_THREADS) void k_sort_hist(const K *__restrict__ keys,
                                                             uint32_t count, uint32_t shift,
                                                             uint32_t *__restrict__ ghist,
                                                             uint32_t num_blocks) {
+    constexpr int ITEMS = SortCfg<K>::ITEMS;
     __shared__ uint32_t s_hist[RADIX];
     s_hist[threadIdx.x] = 0;
     __syncthreads();
-    uint32_t base = blockIdx.x * SORT_TILE;
+    uint32_t base = blockIdx.x * (SORT_THREADS * ITEMS);
 #pragma unroll
-    for (int k = 0; k < SORT_ITEMS; k++) {
+    for (int k = 0; k < ITEMS; k++) {
         uint32_t i = base + k * SORT_THREADS + threadIdx.x;
         if (i < count) atomicAdd(&s_hist[(uint32_t)(keys[i] >> shift) & (RADIX - 1)], 1u);
     }
@@ -412,40 +545,43 @@ __global__ __launch_bounds__(256) void k_sort_scan_rows(uint32_t *__restrict__ g
     if (threadIdx.x == 0) digit_totals[blockIdx.x] = carry;
 }
 
-// Stable scatter.  Element order inside a workgroup tile: wave w owns elements
-// [w*512, (w+1)*512) of the tile, round k of the wave covers 64 consecutive elements, lane order
-// inside a round; ranks are assigned in exactly that order, so equal digits keep their order.
+// Stable scatter.  Element order inside a workgroup tile: wave w owns ITEMS*64 consecutive
+// elements, round k of the wave covers 64 consecutive elements, lane order inside a round; ranks
+// are assigned in exactly that order, so equal digits keep their order.
+template <typename K>
 __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
-    const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
-    uint64_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, uint32_t count,
-    uint32_t shift, const uint32_t *__restrict__ ghist, uint32_t num_blocks,
+    const K *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, K *__restrict__ keys_out,
+    uint32_t *__restrict__ vals_out, uint32_t count, uint32_t shift,
+    const uint32_t *__restrict__ ghist, uint32_t num_blocks,
     const uint32_t *__restrict__ digit_totals) {
+    constexpr int ITEMS = SortCfg<K>::ITEMS;
+    constexpr int TILE = SORT_THREADS * ITEMS;
     __shared__ uint32_t s_wave_hist[4][RADIX];   // per-wave digit counters
     __shared__ uint32_t s_bin_start[RADIX];      // exclusive scan of block digit counts
     __shared__ uint32_t s_global[RADIX];         // global offset of this block's digit run
     __shared__ uint32_t s_scan[4];
-    __shared__ uint64_t s_keys[SORT_TILE];
-    __shared__ uint32_t s_vals[SORT_TILE];
+    __shared__ K s_keys[TILE];
+    __shared__ uint32_t s_vals[TILE];
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
 #pragma unroll
     for (int w = 0; w < 4; w++) s_wave_hist[w][tid] = 0;
     __syncthreads();
 
-    const uint32_t tile_base = blockIdx.x * SORT_TILE;
-    const uint32_t wave_base = tile_base + wid * (SORT_ITEMS * WAVE);
-    uint64_t key[SORT_ITEMS];
-    uint32_t val[SORT_ITEMS];
-    uint32_t rank[SORT_ITEMS];
+    const uint32_t tile_base = blockIdx.x * TILE;
+    const uint32_t wave_base = tile_base + wid * (ITEMS * WAVE);
+    K key[ITEMS];
+    uint32_t val[ITEMS];
+    uint32_t rank[ITEMS];
 #pragma unroll
-    for (int k = 0; k < SORT_ITEMS; k++) {
+    for (int k = 0; k < ITEMS; k++) {
         uint32_t i = wave_base + k * WAVE + lane;
         bool ok = i < count;
-        key[k] = ok ? keys_in[i] : ~0ull;
+        key[k] = ok ? keys_in[i] : (K)~(K)0;
         val[k] = ok ? vals_in[i] : 0u;
     }
 #pragma unroll
-    for (int k = 0; k < SORT_ITEMS; k++) {
+    for (int k = 0; k < ITEMS; k++) {
         uint32_t d = (uint32_t)(key[k] >> shift) & (RADIX - 1);
         // wave64 match-any on the digit: peers = lanes holding the same digit
         uint64_t peers = ~0ull;
@@ -484,19 +620,19 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
 
     // local reorder through LDS so that each digit run is written by consecutive lanes
 #pragma unroll
-    for (int k = 0; k < SORT_ITEMS; k++) {
+    for (int k = 0; k < ITEMS; k++) {
         uint32_t d = (uint32_t)(key[k] >> shift) & (RADIX - 1);
         uint32_t pos = s_wave_hist[wid][d] + rank[k];
         s_keys[pos] = key[k];
         s_vals[pos] = val[k];
     }
     __syncthreads();
-    uint32_t valid = count - tile_base < (uint32_t)SORT_TILE ? count - tile_base : (uint32_t)SORT_TILE;
+    uint32_t valid = count - tile_base < (uint32_t)TILE ? count - tile_base : (uint32_t)TILE;
 #pragma unroll
-    for (int k = 0; k < SORT_ITEMS; k++) {
+    for (int k = 0; k < ITEMS; k++) {
         uint32_t pos = k * SORT_THREADS + tid;
         if (pos < valid) {
-            uint64_t kk = s_keys[pos];
+            K kk = s_keys[pos];
             uint32_t d = (uint32_t)(kk >> shift) & (RADIX - 1);
             uint32_t dst = s_global[d] + (pos - s_bin_start[d]);
             keys_out[dst] = kk;
@@ -509,13 +645,14 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
 // tile ranges (row x5a)
 // ---------------------------------------------------------------------------------------------
 
-__global__ __launch_bounds__(256) void k_tile_ranges(const uint64_t *__restrict__ keys,
-                                                     uint32_t count, uint32_t *__restrict__ ranges) {
+template <typename TK>
+__global__ __launch_bounds__(256) void k_tile_ranges(const TK *__restrict__ tkeys, uint32_t count,
+                                                     uint32_t *__restrict__ ranges) {
     uint32_t j = blockIdx.x * 256u + threadIdx.x;
     if (j >= count) return;
-    uint32_t tile = (uint32_t)(keys[j] >> 32);
-    if (j == 0 || (uint32_t)(keys[j - 1] >> 32) != tile) ranges[2 * tile] = j;
-    if (j + 1 == count || (uint32_t)(keys[j + 1] >> 32) != tile) ranges[2 * tile + 1] = j + 1;
+    uint32_t tile = tkeys[j];
+    if (j == 0 || (uint32_t)tkeys[j - 1] != tile) ranges[2 * tile] = j;
+    if (j + 1 == count || (uint32_t)tkeys[j + 1] != tile) ranges[2 * tile + 1] = j + 1;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -537,9 +674,10 @@ __device__ __forceinline__ float gs_exp(float x) {
     return ldexpf(p, (int)n);
 }
 
-// Maximum over t in [lo, hi] of the concave parabola q2*t^2 + q1*t + q0 (q2 < 0).
+// Maximum over t in [lo, hi] of the concave parabola q2*t^2 + q1*t + q0 (q2 < 0).  Used only by
+// the conservative cull below, so the hardware reciprocal (1 ulp) is fine here.
 __device__ __forceinline__ float parabola_max(float q2, float q1, float q0, float lo, float hi) {
-    float t = clampf(-0.5f * q1 / q2, lo, hi);
+    float t = clampf(-0.5f * q1 * __builtin_amdgcn_rcpf(q2), lo, hi);
     return (q2 * t + q1) * t + q0;
 }
 
@@ -549,123 +687,178 @@ __device__ __forceinline__ float parabola_max(float q2, float q1, float q0, floa
 // attained on one of the four edges (a clamped 1-D parabola each).  alpha >= 1/255 needs
 // power >= ln(1/(255*opacity)) >= -5.5413 (opacity <= 1); the threshold -5.7 leaves > 0.15 of
 // slack for rounding in this bound, so a dropped splat is one the pixel loop would skip at
-// every pixel of the tile.
+// every pixel of the rectangle.
 __device__ __forceinline__ bool splat_touches_rect(float mx, float my, float ca, float cb, float cc,
                                                    float rx0, float rx1, float ry0, float ry1) {
     float dx_lo = mx - rx1, dx_hi = mx - rx0, dy_lo = my - ry1, dy_hi = my - ry0;
     bool in_x = dx_lo <= 0.0f && dx_hi >= 0.0f, in_y = dy_lo <= 0.0f && dy_hi >= 0.0f;
-    if (in_x && in_y) return true;
     float m0 = parabola_max(cc, cb * dx_lo, ca * dx_lo * dx_lo, dy_lo, dy_hi);
     float m1 = parabola_max(cc, cb * dx_hi, ca * dx_hi * dx_hi, dy_lo, dy_hi);
     float m2 = parabola_max(ca, cb * dy_lo, cc * dy_lo * dy_lo, dx_lo, dx_hi);
     float m3 = parabola_max(ca, cb * dy_hi, cc * dy_hi * dy_hi, dx_lo, dx_hi);
     float m = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
-    return !(m < -5.7f);
+    return (in_x && in_y) || !(m < -5.7f);
 }
 
-constexpr int BLEND_BATCH = 256;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// One workgroup = one 16x16 tile; wave w covers pixel rows 4w..4w+3.  The tile's sorted splat
-// list is staged through LDS in batches of 256; while staging, each lane tests its splat against
-// the tile rectangle (conservative bound of the 1/255 alpha iso-contour) and the batch is
-// compacted with wave64 ballots + prefix counts, so the pixel loop only walks splats that can
-// contribute.  The compaction never changes results: a removed splat has alpha < 1/255 at every
-// pixel of the tile, which the pixel loop would skip anyway.
-__global__ __launch_bounds__(256) void k_blend(const uint32_t *__restrict__ ranges,
-                                               const uint32_t *__restrict__ idx,
-                                               const uint4 *__restrict__ proj, FrameConsts fc,
-                                               float4 *__restrict__ rgba) {
-    __shared__ float4 s_a[BLEND_BATCH];   // mx, my, ca, cb
-    __shared__ float4 s_b[BLEND_BATCH];   // cc, opacity, r, g
-    __shared__ float s_c[BLEND_BATCH];    // b
-    __shared__ uint32_t s_wave_cnt[4];
-    __shared__ uint32_t s_done;
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) {
+    return __builtin_elementwise_fma(a, b, c);
+}
+
+constexpr int BLEND_THREADS = 128;
+constexpr int BLEND_BATCH = 128;
+
+// One workgroup (2 waves) = one 16x16 tile.  Wave h owns the half-tile of pixel rows 8h..8h+7;
+// each lane owns TWO pixels (x, y) and (x, y+4), so the per-splat arithmetic runs on packed f32
+// (v_pk_mul/fma/add_f32: two IEEE operations per lane per instruction, bit-identical to the scalar
+// form).  The tile's sorted splat list is staged through LDS in batches of 128: each lane fetches
+// one splat, tests it against both half-tiles (exact maximum of the concave exponent over the
+// half-tile rectangle, conservative threshold), and the survivors are compacted per half-tile with
+// wave64 ballots + mbcnt prefix counts (order preserving).  A wave therefore only walks splats
+// that can contribute to its own 16x8 pixels.  The compaction never changes results: a removed
+// splat has alpha < 1/255 at every pixel of the half-tile, which the pixel loop would skip.
+__global__ __launch_bounds__(BLEND_THREADS) void k_blend(const uint32_t *__restrict__ ranges,
+                                                         const uint32_t *__restrict__ idx,
+                                                         const uint32_t *__restrict__ recs,
+                                                         FrameConsts fc, float4 *__restrict__ rgba) {
+    __shared__ float4 s_a[2][BLEND_BATCH];   // mx, my, ca, cb
+    __shared__ float4 s_b[2][BLEND_BATCH];   // cc, opacity, r, g
+    __shared__ float s_c[2][BLEND_BATCH];    // b
+    __shared__ uint32_t s_cnt[2][2];         // [staging wave][half]
+    __shared__ uint32_t s_alive[2];
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
     const uint32_t tile = fc.band_ty0 * fc.tiles_x + blockIdx.x;
     const uint32_t ty = tile / fc.tiles_x, tx = tile % fc.tiles_x;
-    const uint32_t lx = tid & 15u, ly = tid >> 4;
-    const uint32_t px = tx * 16u + lx, py = ty * 16u + ly;
-    const bool inside = px < fc.width && py < fc.height;
-    const float pxf = (float)px + 0.5f, pyf = (float)py + 0.5f;
-    // tile rectangle in pixel-centre coordinates
-    const float rx0 = (float)(tx * 16u) + 0.5f, rx1 = (float)(tx * 16u) + 15.5f;
-    const float ry0 = (float)(ty * 16u) + 0.5f, ry1 = (float)(ty * 16u) + 15.5f;
+    const uint32_t px = tx * 16u + (lane & 15u);
+    const uint32_t py0 = ty * 16u + wid * 8u + (lane >> 4), py1 = py0 + 4u;
+    const float pxf = (float)px + 0.5f;
+    // tile / half-tile rectangles in pixel-centre coordinates
+    const float rx0 = (float)(tx * 16u) + 0.5f, rx1 = rx0 + 15.0f;
+    const float ry0 = (float)(ty * 16u) + 0.5f;
 
     const uint32_t start = ranges[2 * tile], end = ranges[2 * tile + 1];
-    float T = 1.0f, C0 = 0.0f, C1 = 0.0f, C2 = 0.0f;
-    bool done = !inside;
+    f32x2 T = {1.0f, 1.0f}, C0 = {0.0f, 0.0f}, C1 = {0.0f, 0.0f}, C2 = {0.0f, 0.0f};
+    const bool in0 = px < fc.width && py0 < fc.height, in1 = px < fc.width && py1 < fc.height;
+    // A finished (or out-of-image) pixel is parked at y = DEAD: its exponent becomes hugely
+    // negative, so the ordinary "power >= -5.6" test rejects it and the loop carries no per-pixel
+    // "done" masks (those cost scalar-ALU mask arithmetic every iteration).
+    constexpr float DEAD = 1.0e15f;
+    f32x2 pyf = {in0 ? (float)py0 + 0.5f : DEAD, in1 ? (float)py1 + 0.5f : DEAD};
+    // wave-uniform count of unfinished pixels
+    uint32_t remaining = __builtin_amdgcn_readfirstlane(
+        (uint32_t)__popcll(__ballot(in0)) + (uint32_t)__popcll(__ballot(in1)));
 
     for (uint32_t b0 = start; b0 < end; b0 += BLEND_BATCH) {
-        // all pixels of the tile finished -> stop fetching
-        if (tid == 0) s_done = 0;
+        // stop fetching once every pixel of the tile is finished
+        if (lane == 0) s_alive[wid] = remaining;
         __syncthreads();
-        if (!done) s_done = 1;   // benign race: any unfinished lane sets it
-        __syncthreads();
-        if (s_done == 0) break;
+        if ((s_alive[0] | s_alive[1]) == 0u) break;
 
-        // stage + cull + compact (order preserving)
+        // stage + cull + compact per half-tile (order preserving)
         uint32_t j = b0 + tid;
-        bool keep = false;
-        uint4 r0, r1, r2;
+        bool keep0 = false, keep1 = false;
+        u32x4_a4 r0, r1;
+        uint32_t r2x = 0;
         if (j < end) {
-            const uint4 *rec = proj + (uint64_t)idx[j] * 3;
-            r0 = rec[0];
-            r1 = rec[1];
-            r2 = rec[2];
-            keep = splat_touches_rect(u2f(r0.x), u2f(r0.y), u2f(r0.z), u2f(r0.w), u2f(r1.x), rx0,
-                                      rx1, ry0, ry1);
+            const uint32_t *rec = recs + (uint64_t)idx[j] * REC_WORDS;
+            r0 = *(const u32x4_a4 *)(rec);
+            r1 = *(const u32x4_a4 *)(rec + 4);
+            r2x = rec[8];
+            float mx = u2f(r0.x), my = u2f(r0.y), ca = u2f(r0.z), cb = u2f(r0.w), cc = u2f(r1.x);
+            keep0 = splat_touches_rect(mx, my, ca, cb, cc, rx0, rx1, ry0, ry0 + 7.0f);
+            keep1 = splat_touches_rect(mx, my, ca, cb, cc, rx0, rx1, ry0 + 8.0f, ry0 + 15.0f);
         }
-        uint64_t mask = __ballot(keep);
-        uint32_t before = mbcnt(mask);
-        if (lane == 0) s_wave_cnt[wid] = (uint32_t)__popcll(mask);
+        uint64_t m0 = __ballot(keep0), m1 = __ballot(keep1);
+        if (lane == 0) {
+            s_cnt[wid][0] = (uint32_t)__popcll(m0);
+            s_cnt[wid][1] = (uint32_t)__popcll(m1);
+        }
         __syncthreads();
-        uint32_t w0 = s_wave_cnt[0], w1 = s_wave_cnt[1], w2 = s_wave_cnt[2], w3 = s_wave_cnt[3];
-        uint32_t wave_off = wid == 0 ? 0u : wid == 1 ? w0 : wid == 2 ? w0 + w1 : w0 + w1 + w2;
-        uint32_t kept = w0 + w1 + w2 + w3;
-        if (keep) {
-            uint32_t pos = wave_off + before;
-            s_a[pos] = make_float4(u2f(r0.x), u2f(r0.y), u2f(r0.z), u2f(r0.w));
-            s_b[pos] = make_float4(u2f(r1.x), u2f(r1.y), u2f(r1.z), u2f(r1.w));
-            s_c[pos] = u2f(r2.x);
+        const uint32_t base0 = wid ? s_cnt[0][0] : 0u, base1 = wid ? s_cnt[0][1] : 0u;
+        const uint32_t kept =   // list length of MY half-tile (wave-uniform -> scalar loop control)
+            __builtin_amdgcn_readfirstlane(s_cnt[0][wid] + s_cnt[1][wid]);
+        if (keep0) {
+            uint32_t pos = base0 + mbcnt(m0);
+            s_a[0][pos] = make_float4(u2f(r0.x), u2f(r0.y), u2f(r0.z), u2f(r0.w));
+            s_b[0][pos] = make_float4(u2f(r1.x), u2f(r1.y), u2f(r1.z), u2f(r1.w));
+            s_c[0][pos] = u2f(r2x);
+        }
+        if (keep1) {
+            uint32_t pos = base1 + mbcnt(m1);
+            s_a[1][pos] = make_float4(u2f(r0.x), u2f(r0.y), u2f(r0.z), u2f(r0.w));
+            s_b[1][pos] = make_float4(u2f(r1.x), u2f(r1.y), u2f(r1.z), u2f(r1.w));
+            s_c[1][pos] = u2f(r2x);
         }
         __syncthreads();
 
-        // pixel loop over the compacted batch (wave-uniform trip count, LDS broadcast reads)
-        if (!__all(done)) {
+        // pixel loop over this half-tile's compacted list (wave-uniform trip count, LDS
+        // broadcast reads, packed f32 over the lane's two pixels)
+        if (remaining != 0u) {
             for (uint32_t s = 0; s < kept; s++) {
-                float4 a = s_a[s];
-                float dx = a.x - pxf, dy = a.y - pyf;
-                float4 bq = s_b[s];
-                float u = a.z * dx, v = bq.x * dy, wq = a.w * dx;
-                float power = __builtin_fmaf(u, dx, __builtin_fmaf(v, dy, wq * dy));
-                bool act = !done && !(power > 0.0f) && !(power < -5.6f);
-                if (!__any(act)) continue;
-                float alpha = fminf(0.99f, bq.y * gs_exp(fmaxf(power, -6.0f)));
-                act = act && !(alpha < 1.0f / 255.0f);
-                float test_T = T * (1.0f - alpha);
-                if (act && test_T < 0.0001f) {
-                    done = true;
-                    act = false;
+                const float4 a = s_a[wid][s];
+                const float4 bq = s_b[wid][s];
+                const float dx = a.x - pxf;
+                const f32x2 dy = f32x2{a.y, a.y} - pyf;
+                const float u = a.z * dx, wq = a.w * dx;
+                const f32x2 v = f32x2{bq.x, bq.x} * dy;
+                f32x2 t = f32x2{wq, wq} * dy;
+                t = pk_fma(v, dy, t);
+                const f32x2 power = pk_fma(f32x2{u, u}, f32x2{dx, dx}, t);
+                const bool p0 = power.x <= 0.0f && power.x >= -5.6f;
+                const bool p1 = power.y <= 0.0f && power.y >= -5.6f;
+                if (!__any(p0 || p1)) continue;
+                // exp on both pixels
+                const f32x2 tt = power * f32x2{1.44269504088896340736f, 1.44269504088896340736f};
+                const f32x2 n = {rintf(tt.x), rintf(tt.y)};
+                const f32x2 f = tt - n;
+                f32x2 p = {0x1.5f0896p-10f, 0x1.5f0896p-10f};
+                p = pk_fma(p, f, f32x2{0x1.3cbf6cp-7f, 0x1.3cbf6cp-7f});
+                p = pk_fma(p, f, f32x2{0x1.c6af6cp-5f, 0x1.c6af6cp-5f});
+                p = pk_fma(p, f, f32x2{0x1.ebfa4ap-3f, 0x1.ebfa4ap-3f});
+                p = pk_fma(p, f, f32x2{0x1.62e430p-1f, 0x1.62e430p-1f});
+                p = pk_fma(p, f, f32x2{1.0f, 1.0f});
+                const f32x2 e = {ldexpf(p.x, (int)n.x), ldexpf(p.y, (int)n.y)};
+                const f32x2 oe = f32x2{bq.y, bq.y} * e;
+                const f32x2 alpha = {fminf(0.99f, oe.x), fminf(0.99f, oe.y)};
+                const f32x2 test_T = T * (f32x2{1.0f, 1.0f} - alpha);
+                const bool act0 = p0 && alpha.x >= (1.0f / 255.0f);
+                const bool act1 = p1 && alpha.y >= (1.0f / 255.0f);
+                const bool ok0 = act0 && test_T.x >= 0.0001f, ok1 = act1 && test_T.y >= 0.0001f;
+                const f32x2 aT = alpha * T;
+                const f32x2 wgt = {ok0 ? aT.x : 0.0f, ok1 ? aT.y : 0.0f};
+                C0 = pk_fma(f32x2{bq.z, bq.z}, wgt, C0);
+                C1 = pk_fma(f32x2{bq.w, bq.w}, wgt, C1);
+                const float cb_ = s_c[wid][s];
+                C2 = pk_fma(f32x2{cb_, cb_}, wgt, C2);
+                T = f32x2{ok0 ? test_T.x : T.x, ok1 ? test_T.y : T.y};
+                const bool fin0 = act0 && !ok0, fin1 = act1 && !ok1;
+                if (__any(fin0 || fin1)) {   // rare: some pixel reached T < 1e-4
+                    if (fin0) pyf.x = DEAD;
+                    if (fin1) pyf.y = DEAD;
+                    remaining = __builtin_amdgcn_readfirstlane(
+                        remaining - ((uint32_t)__popcll(__ballot(fin0)) + (uint32_t)__popcll(__ballot(fin1))));
+                    if (remaining == 0u) break;
                 }
-                if (act) {
-                    float wgt = alpha * T;
-                    C0 = __builtin_fmaf(bq.z, wgt, C0);
-                    C1 = __builtin_fmaf(bq.w, wgt, C1);
-                    C2 = __builtin_fmaf(s_c[s], wgt, C2);
-                    T = test_T;
-                }
-                if (__all(done)) break;
             }
         }
     }
-    if (inside) {
+    if (in0) {
         float4 o;
-        o.x = __builtin_fmaf(T, fc.bg[0], C0);
-        o.y = __builtin_fmaf(T, fc.bg[1], C1);
-        o.z = __builtin_fmaf(T, fc.bg[2], C2);
-        o.w = 1.0f - T;
-        rgba[(uint64_t)py * fc.width + px] = o;
+        o.x = __builtin_fmaf(T.x, fc.bg[0], C0.x);
+        o.y = __builtin_fmaf(T.x, fc.bg[1], C1.x);
+        o.z = __builtin_fmaf(T.x, fc.bg[2], C2.x);
+        o.w = 1.0f - T.x;
+        rgba[(uint64_t)py0 * fc.width + px] = o;
+    }
+    if (in1) {
+        float4 o;
+        o.x = __builtin_fmaf(T.y, fc.bg[0], C0.y);
+        o.y = __builtin_fmaf(T.y, fc.bg[1], C1.y);
+        o.z = __builtin_fmaf(T.y, fc.bg[2], C2.y);
+        o.w = 1.0f - T.y;
+        rgba[(uint64_t)py1 * fc.width + px] = o;
     }
 }
 
