@@ -1373,25 +1373,25 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
     }
     mark(ST_EXPAND);
     GS_TRY(reserve_pairs(r, d, wide));
-    uint32_t vchunks = (visible + gs::PP_CHUNK - 1) / gs::PP_CHUNK;
+    uint32_t vchunks = (visible + gs::EXP_CHUNK - 1) / gs::EXP_CHUNK;
     if (visible) {
         GS_TRY(dev_reserve(r->exp_sums, (size_t)vchunks * 4));
         GS_TRY(dev_reserve(r->exp_offsets, (size_t)vchunks * 4));
         const uint32_t *order = (const uint32_t *)r->dvals[dside].ptr;
-        hipLaunchKernelGGL(gs::k_expand_count, dim3(vchunks), dim3(gs::PP_THREADS), 0, st, order,
+        hipLaunchKernelGGL(gs::k_expand_count, dim3(vchunks), dim3(gs::EXP_CHUNK), 0, st, order,
                            (const uint2 *)r->rect.ptr, visible, (uint2 *)r->sorted_rect.ptr,
                            (uint32_t *)r->exp_sums.ptr);
         gs::ScanJob je{(const uint32_t *)r->exp_sums.ptr, (uint32_t *)r->exp_offsets.ptr, counters + 2,
                        vchunks};
         hipLaunchKernelGGL(gs::k_scan_chunks, dim3(1), dim3(1024), 0, st, je, je);
         if (wide)
-            hipLaunchKernelGGL(gs::k_expand_emit<uint32_t>, dim3(vchunks), dim3(gs::PP_THREADS), 0, st,
+            hipLaunchKernelGGL(gs::k_expand_emit<uint32_t>, dim3(vchunks), dim3(gs::EXP_CHUNK), 0, st,
                                order, (const uint2 *)r->sorted_rect.ptr,
                                (const uint32_t *)r->exp_offsets.ptr, visible, fc.tiles_x,
                                (uint32_t *)r->tkeys[0].ptr, (uint32_t *)r->tvals[0].ptr,
                                (uint32_t)r->pair_capacity);
         else
-            hipLaunchKernelGGL(gs::k_expand_emit<uint16_t>, dim3(vchunks), dim3(gs::PP_THREADS), 0, st,
+            hipLaunchKernelGGL(gs::k_expand_emit<uint16_t>, dim3(vchunks), dim3(gs::EXP_CHUNK), 0, st,
                                order, (const uint2 *)r->sorted_rect.ptr,
                                (const uint32_t *)r->exp_offsets.ptr, visible, fc.tiles_x,
                                (uint16_t *)r->tkeys[0].ptr, (uint32_t *)r->tvals[0].ptr,

@@ -382,30 +382,22 @@ __global__ __launch_bounds__(PP_THREADS) void k_compact(const uint32_t *__restri
 // 64-bit (tile << 32 | depth) key.
 // ---------------------------------------------------------------------------------------------
 
+constexpr int EXP_CHUNK = 256;   // Gaussians per workgroup in the expansion kernels
+
 // Gather the tile rects into depth order (the only random access of the expansion: 8 bytes per
 // visible Gaussian from a compact array) and produce the per-chunk tile-count sums.
-__global__ __launch_bounds__(PP_THREADS) void k_expand_count(const uint32_t *__restrict__ order,
-                                                             const uint2 *__restrict__ rect,
-                                                             uint32_t v_count,
-                                                             uint2 *__restrict__ sorted_rect,
-                                                             uint32_t *__restrict__ sums) {
+__global__ __launch_bounds__(EXP_CHUNK) void k_expand_count(const uint32_t *__restrict__ order,
+                                                            const uint2 *__restrict__ rect,
+                                                            uint32_t v_count,
+                                                            uint2 *__restrict__ sorted_rect,
+                                                            uint32_t *__restrict__ sums) {
     __shared__ uint32_t s_red[4];
-    uint32_t base = blockIdx.x * PP_CHUNK;
-    uint32_t g[PP_ITEMS];
-#pragma unroll
-    for (int k = 0; k < PP_ITEMS; k++) {
-        uint32_t j = base + k * PP_THREADS + threadIdx.x;
-        g[k] = j < v_count ? order[j] : 0xffffffffu;
-    }
+    uint32_t j = blockIdx.x * EXP_CHUNK + threadIdx.x;
     uint32_t v = 0;
-#pragma unroll
-    for (int k = 0; k < PP_ITEMS; k++) {
-        uint32_t j = base + k * PP_THREADS + threadIdx.x;
-        if (g[k] != 0xffffffffu) {
-            uint2 r = rect[g[k]];
-            sorted_rect[j] = r;
-            v += ((r.y & 0xffffu) - (r.x & 0xffffu)) * ((r.y >> 16) - (r.x >> 16));
-        }
+    if (j < v_count) {
+        uint2 r = rect[order[j]];
+        sorted_rect[j] = r;
+        v = ((r.y & 0xffffu) - (r.x & 0xffffu)) * ((r.y >> 16) - (r.x >> 16));
     }
     v = wave_reduce_add(v);
     if ((threadIdx.x & 63u) == 0) s_red[threadIdx.x >> 6] = v;
@@ -417,53 +409,45 @@ __global__ __launch_bounds__(PP_THREADS) void k_expand_count(const uint32_t *__r
 // of the depth order; their tile counts are scanned with shuffles, and the wave then produces its
 // output slots 64 at a time: every Gaussian whose first slot falls in the current 64-slot window
 // drops a marker there (LDS), an inclusive max-scan over the lanes turns the markers into "owner
-// of this slot", and each lane fetches its owner's rect with a cross-lane permute.  Consecutive
-// lanes write consecutive slots, so stores are coalesced whatever the splat sizes, and a screen-
-// filling splat costs the same per output as a one-tile splat.
+// of this slot", and each lane fetches its owner's rect with a cross-lane permute.  Windows that
+// lie entirely inside one large splat (no marker) skip the scan.  Consecutive lanes write
+// consecutive slots, so stores are coalesced whatever the splat sizes.  (The depth order puts the
+// nearest = largest splats first, so the first workgroups are the heaviest; small workgroups of
+// 256 Gaussians keep that critical path short, and the dispatcher starts them first.)
 template <typename TK>
-__global__ __launch_bounds__(PP_THREADS) void k_expand_emit(
+__global__ __launch_bounds__(EXP_CHUNK) void k_expand_emit(
     const uint32_t *__restrict__ order, const uint2 *__restrict__ sorted_rect,
     const uint32_t *__restrict__ chunk_offsets, uint32_t v_count, uint32_t tiles_x,
     TK *__restrict__ tkeys, uint32_t *__restrict__ tvals, uint32_t capacity) {
-    __shared__ uint32_t s_scan[PP_ITEMS][4];
+    __shared__ uint32_t s_scan[4];
     __shared__ uint32_t s_mark[4][WAVE];
     const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
-    // all loads of the workgroup's PP_CHUNK Gaussians up front (coalesced, independent)
-    uint32_t g_[PP_ITEMS], cnt_[PP_ITEMS], origin_[PP_ITEMS], width_[PP_ITEMS], incl_[PP_ITEMS];
-#pragma unroll
-    for (int round = 0; round < PP_ITEMS; round++) {
-        uint32_t j = blockIdx.x * PP_CHUNK + round * PP_THREADS + threadIdx.x;
-        g_[round] = 0;
-        cnt_[round] = 0;
-        origin_[round] = 0;
-        width_[round] = 1;
-        if (j < v_count) {
-            g_[round] = order[j];
-            uint2 r = sorted_rect[j];
-            uint32_t w = (r.y & 0xffffu) - (r.x & 0xffffu), h = (r.y >> 16) - (r.x >> 16);
-            origin_[round] = r.x;
-            width_[round] = w ? w : 1u;
-            cnt_[round] = w * h;
-        }
-        incl_[round] = wave_inclusive_scan(cnt_[round], lane);
-        if (lane == 63u) s_scan[round][wid] = incl_[round];
+    const uint32_t j = blockIdx.x * EXP_CHUNK + threadIdx.x;
+    uint32_t g = 0, cnt = 0, origin = 0, width = 1;
+    if (j < v_count) {
+        g = order[j];
+        uint2 r = sorted_rect[j];
+        uint32_t w = (r.y & 0xffffu) - (r.x & 0xffffu), h = (r.y >> 16) - (r.x >> 16);
+        origin = r.x;
+        width = w ? w : 1u;
+        cnt = w * h;
     }
+    const uint32_t incl = wave_inclusive_scan(cnt, lane);
+    const uint32_t excl = incl - cnt;
+    const uint32_t wave_total = __shfl(incl, 63, WAVE);
+    if (lane == 63u) s_scan[wid] = incl;
     __syncthreads();
-    uint32_t out_base = chunk_offsets[blockIdx.x];
-#pragma unroll
-    for (int round = 0; round < PP_ITEMS; round++) {
-        const uint32_t g = g_[round], cnt = cnt_[round], origin = origin_[round], width = width_[round];
-        const uint32_t incl = incl_[round], excl = incl - cnt;
-        const uint32_t wave_total = __shfl(incl, 63, WAVE);
-        uint32_t w0 = s_scan[round][0], w1 = s_scan[round][1], w2 = s_scan[round][2],
-                 w3 = s_scan[round][3];
-        uint32_t wave_off = wid == 0 ? 0u : wid == 1 ? w0 : wid == 2 ? w0 + w1 : w0 + w1 + w2;
-        const uint32_t out0 = out_base + wave_off;
-        uint32_t carry = 0;
-        for (uint32_t win = 0; win < wave_total; win += WAVE) {
+    uint32_t w0 = s_scan[0], w1 = s_scan[1], w2 = s_scan[2];
+    uint32_t wave_off = wid == 0 ? 0u : wid == 1 ? w0 : wid == 2 ? w0 + w1 : w0 + w1 + w2;
+    const uint32_t out0 = chunk_offsets[blockIdx.x] + wave_off;
+    uint32_t carry = 0;
+    for (uint32_t win = 0; win < wave_total; win += WAVE) {
+        const bool starts_here = cnt != 0u && excl >= win && excl < win + WAVE;
+        uint32_t owner = carry;
+        if (__any(starts_here)) {
             s_mark[wid][lane] = 0u;
             __builtin_amdgcn_wave_barrier();
-            if (cnt != 0u && excl >= win && excl < win + WAVE) s_mark[wid][excl - win] = lane + 1u;
+            if (starts_here) s_mark[wid][excl - win] = lane + 1u;
             __builtin_amdgcn_wave_barrier();
             uint32_t m = s_mark[wid][lane];
 #pragma unroll
@@ -471,23 +455,22 @@ __global__ __launch_bounds__(PP_THREADS) void k_expand_emit(
                 uint32_t t = __shfl_up(m, d, WAVE);
                 if (lane >= (uint32_t)d) m = m > t ? m : t;
             }
-            uint32_t owner = m ? m - 1u : carry;
+            owner = m ? m - 1u : carry;
             carry = __shfl(owner, 63, WAVE);
-            uint32_t o_excl = __shfl(excl, owner, WAVE);
-            uint32_t o_g = __shfl(g, owner, WAVE);
-            uint32_t o_org = __shfl(origin, owner, WAVE);
-            uint32_t o_w = __shfl(width, owner, WAVE);
-            uint32_t e = win + lane;
-            uint32_t local = e - o_excl;
-            uint32_t row = local / o_w, col = local - row * o_w;
-            uint32_t tile = ((o_org >> 16) + row) * tiles_x + (o_org & 0xffffu) + col;
-            uint32_t o = out0 + e;
-            if (e < wave_total && o < capacity) {
-                tkeys[o] = (TK)tile;
-                tvals[o] = o_g;
-            }
         }
-        out_base += (w0 + w1) + (w2 + w3);
+        uint32_t o_excl = __shfl(excl, owner, WAVE);
+        uint32_t o_g = __shfl(g, owner, WAVE);
+        uint32_t o_org = __shfl(origin, owner, WAVE);
+        uint32_t o_w = __shfl(width, owner, WAVE);
+        uint32_t e = win + lane;
+        uint32_t local = e - o_excl;
+        uint32_t row = local / o_w, col = local - row * o_w;
+        uint32_t tile = ((o_org >> 16) + row) * tiles_x + (o_org & 0xffffu) + col;
+        uint32_t o = out0 + e;
+        if (e < wave_total && o < capacity) {
+            tkeys[o] = (TK)tile;
+            tvals[o] = o_g;
+        }
     }
 }
 
@@ -685,11 +668,12 @@ __device__ __forceinline__ float parabola_max(float q2, float q1, float q0, floa
 // [rx0,rx1] x [ry0,ry1]?".  power(d) = ca*dx^2 + cc*dy^2 + cb*dx*dy is a concave quadratic in
 // d = mean - pixel; its maximum over the rectangle is 0 when the mean lies inside, otherwise it is
 // attained on one of the four edges (a clamped 1-D parabola each).  alpha >= 1/255 needs
-// power >= ln(1/(255*opacity)) >= -5.5413 (opacity <= 1); the threshold -5.7 leaves > 0.15 of
-// slack for rounding in this bound, so a dropped splat is one the pixel loop would skip at
-// every pixel of the rectangle.
+// power >= ln(1/(255*opacity)); the caller passes `thr` = that bound minus 0.1 of slack for the
+// rounding in this test, so a dropped splat is one the pixel loop would skip at every pixel of
+// the rectangle.
 __device__ __forceinline__ bool splat_touches_rect(float mx, float my, float ca, float cb, float cc,
-                                                   float rx0, float rx1, float ry0, float ry1) {
+                                                   float rx0, float rx1, float ry0, float ry1,
+                                                   float thr) {
     float dx_lo = mx - rx1, dx_hi = mx - rx0, dy_lo = my - ry1, dy_hi = my - ry0;
     bool in_x = dx_lo <= 0.0f && dx_hi >= 0.0f, in_y = dy_lo <= 0.0f && dy_hi >= 0.0f;
     float m0 = parabola_max(cc, cb * dx_lo, ca * dx_lo * dx_lo, dy_lo, dy_hi);
@@ -697,7 +681,7 @@ __device__ __forceinline__ bool splat_touches_rect(float mx, float my, float ca,
     float m2 = parabola_max(ca, cb * dy_lo, cc * dy_lo * dy_lo, dx_lo, dx_hi);
     float m3 = parabola_max(ca, cb * dy_hi, cc * dy_hi * dy_hi, dx_lo, dx_hi);
     float m = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
-    return (in_x && in_y) || !(m < -5.7f);
+    return (in_x && in_y) || !(m < thr);
 }
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -724,7 +708,7 @@ __global__ __launch_bounds__(BLEND_THREADS) void k_blend(const uint32_t *__restr
                                                          FrameConsts fc, float4 *__restrict__ rgba) {
     __shared__ float4 s_a[2][BLEND_BATCH];   // mx, my, ca, cb
     __shared__ float4 s_b[2][BLEND_BATCH];   // cc, opacity, r, g
-    __shared__ float s_c[2][BLEND_BATCH];    // b
+    __shared__ float2 s_c[2][BLEND_BATCH];   // b, pmin (see below)
     __shared__ uint32_t s_cnt[2][2];         // [staging wave][half]
     __shared__ uint32_t s_alive[2];
 
@@ -759,6 +743,7 @@ __global__ __launch_bounds__(BLEND_THREADS) void k_blend(const uint32_t *__restr
         // stage + cull + compact per half-tile (order preserving)
         uint32_t j = b0 + tid;
         bool keep0 = false, keep1 = false;
+        float pmin = 0.0f;
         u32x4_a4 r0, r1;
         uint32_t r2x = 0;
         if (j < end) {
@@ -767,8 +752,13 @@ __global__ __launch_bounds__(BLEND_THREADS) void k_blend(const uint32_t *__restr
             r1 = *(const u32x4_a4 *)(rec + 4);
             r2x = rec[8];
             float mx = u2f(r0.x), my = u2f(r0.y), ca = u2f(r0.z), cb = u2f(r0.w), cc = u2f(r1.x);
-            keep0 = splat_touches_rect(mx, my, ca, cb, cc, rx0, rx1, ry0, ry0 + 7.0f);
-            keep1 = splat_touches_rect(mx, my, ca, cb, cc, rx0, rx1, ry0 + 8.0f, ry0 + 15.0f);
+            // alpha = opacity * exp(power) >= 1/255  <=>  power >= -ln(255 * opacity).  pmin is that
+            // bound minus 1e-3 (covers the hardware log's and the exp polynomial's error), so a
+            // pixel with power < pmin is one the exact alpha test would reject anyway: using pmin
+            // in place of the constant -5.6 changes no result, it only skips more work.
+            pmin = fmaxf(-__logf(255.0f * u2f(r1.y)) - 1.0e-3f, -5.6f);
+            keep0 = splat_touches_rect(mx, my, ca, cb, cc, rx0, rx1, ry0, ry0 + 7.0f, pmin - 0.1f);
+            keep1 = splat_touches_rect(mx, my, ca, cb, cc, rx0, rx1, ry0 + 8.0f, ry0 + 15.0f, pmin - 0.1f);
         }
         uint64_t m0 = __ballot(keep0), m1 = __ballot(keep1);
         if (lane == 0) {
@@ -783,13 +773,13 @@ __global__ __launch_bounds__(BLEND_THREADS) void k_blend(const uint32_t *__restr
             uint32_t pos = base0 + mbcnt(m0);
             s_a[0][pos] = make_float4(u2f(r0.x), u2f(r0.y), u2f(r0.z), u2f(r0.w));
             s_b[0][pos] = make_float4(u2f(r1.x), u2f(r1.y), u2f(r1.z), u2f(r1.w));
-            s_c[0][pos] = u2f(r2x);
+            s_c[0][pos] = make_float2(u2f(r2x), pmin);
         }
         if (keep1) {
             uint32_t pos = base1 + mbcnt(m1);
             s_a[1][pos] = make_float4(u2f(r0.x), u2f(r0.y), u2f(r0.z), u2f(r0.w));
             s_b[1][pos] = make_float4(u2f(r1.x), u2f(r1.y), u2f(r1.z), u2f(r1.w));
-            s_c[1][pos] = u2f(r2x);
+            s_c[1][pos] = make_float2(u2f(r2x), pmin);
         }
         __syncthreads();
 
@@ -806,8 +796,9 @@ __global__ __launch_bounds__(BLEND_THREADS) void k_blend(const uint32_t *__restr
                 f32x2 t = f32x2{wq, wq} * dy;
                 t = pk_fma(v, dy, t);
                 const f32x2 power = pk_fma(f32x2{u, u}, f32x2{dx, dx}, t);
-                const bool p0 = power.x <= 0.0f && power.x >= -5.6f;
-                const bool p1 = power.y <= 0.0f && power.y >= -5.6f;
+                const float2 cq = s_c[wid][s];   // b, pmin
+                const bool p0 = power.x <= 0.0f && power.x >= cq.y;
+                const bool p1 = power.y <= 0.0f && power.y >= cq.y;
                 if (!__any(p0 || p1)) continue;
                 // exp on both pixels
                 const f32x2 tt = power * f32x2{1.44269504088896340736f, 1.44269504088896340736f};
@@ -830,8 +821,7 @@ __global__ __launch_bounds__(BLEND_THREADS) void k_blend(const uint32_t *__restr
                 const f32x2 wgt = {ok0 ? aT.x : 0.0f, ok1 ? aT.y : 0.0f};
                 C0 = pk_fma(f32x2{bq.z, bq.z}, wgt, C0);
                 C1 = pk_fma(f32x2{bq.w, bq.w}, wgt, C1);
-                const float cb_ = s_c[wid][s];
-                C2 = pk_fma(f32x2{cb_, cb_}, wgt, C2);
+                C2 = pk_fma(f32x2{cq.x, cq.x}, wgt, C2);
                 T = f32x2{ok0 ? test_T.x : T.x, ok1 ? test_T.y : T.y};
                 const bool fin0 = act0 && !ok0, fin1 = act1 && !ok1;
                 if (__any(fin0 || fin1)) {   // rare: some pixel reached T < 1e-4
