@@ -166,6 +166,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=3)
     ap.add_argument("--timing-steps", type=int, default=20)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
+    ap.add_argument("--force-device", type=int, default=-1, help="rehearsal: put every rank on this GPU")
     args = ap.parse_args()
 
     import torch
@@ -181,10 +183,15 @@ def main():
     if not torch.cuda.is_available():
         sys.stderr.write("bench.py: no GPU visible; the HIP path has no CPU fallback\n")
         sys.exit(3)
+    if args.force_device >= 0:
+        local = args.force_device
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(args.backend)
 
     import synth
     import wgpu_3dgs_core_amd as gs
