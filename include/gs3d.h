@@ -62,7 +62,9 @@ enum {
     /* DownloadBufferError                                                   src/error.rs:55-63  */
     GS_ERR_DOWNLOAD = -22,
     /* the (key,index) pair buffer was too small for this frame; call again (it was grown) */
-    GS_ERR_PAIR_OVERFLOW = -23
+    GS_ERR_PAIR_OVERFLOW = -23,
+    /* std::io::Error (InvalidData / UnexpectedEof) of the PLY reader; message = the Rust message */
+    GS_ERR_PLY = -24
 };
 
 /* Thread-local details of the last failing call on this thread.
@@ -143,6 +145,38 @@ float gs_max_std_dev_decode(uint8_t v);
 void gs_model_transform_pod_new(const float pos[3], const float rot_xyzw[4], const float scale[3],
                                 gs_model_transform_pod *out);
 void gs_model_transform_pod_default(gs_model_transform_pod *out);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Inria PLY source format — src/source_format/ply.rs, src/gaussian.rs:70-125 (host side)      */
+/* ------------------------------------------------------------------------------------------ */
+
+/* PlyGaussianPod — src/source_format/ply.rs:11-21 (62 little-endian f32 = 248 bytes) */
+typedef struct gs_ply_gaussian_pod {
+    float pos[3];
+    float normal[3];
+    float color[3];   /* f_dc_0..2 */
+    float sh[45];     /* f_rest_0..44, channel-planar */
+    float alpha;      /* opacity (logit) */
+    float scale[3];   /* log scale */
+    float rot[4];     /* wxyz */
+} gs_ply_gaussian_pod;
+
+/* PlyGaussians::PLY_PROPERTIES — ply.rs:204-267 */
+const char *gs_ply_property_name(uint32_t index);
+/* Gaussian::from_ply / Gaussian::to_ply — src/gaussian.rs:70-125 */
+void gs_gaussian_from_ply(const gs_ply_gaussian_pod *in, size_t n, gs_gaussian *out);
+void gs_gaussian_to_ply(const gs_gaussian *in, size_t n, gs_ply_gaussian_pod *out);
+/* PlyGaussians::read_from — ply.rs:292-408.  Call with out == NULL to get the vertex count, then
+ * with a buffer.  Handles the Inria fast path (one memcpy) and custom property orders in ascii /
+ * binary little / big endian.  Errors: GS_ERR_PLY with the reference's message, e.g.
+ * "Gaussian vertex element not found in PLY header",
+ * "Gaussian element property invalid or missing in PLY". */
+gs_status gs_ply_read(const void *bytes, size_t len, gs_ply_gaussian_pod *out, size_t capacity,
+                      size_t *count_out, int32_t *is_inria_out);
+/* PlyGaussians::write_to — ply.rs:410-431 (binary_little_endian Inria layout).  Call with
+ * out == NULL to get the size. */
+gs_status gs_ply_write(const gs_ply_gaussian_pod *pods, size_t n, void *out, size_t capacity,
+                       size_t *bytes_out);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Device, streams                                                                             */

@@ -1,0 +1,134 @@
+"""CPU tests of the product's PLY codec, mirroring the reference's
+tests/e2e/ply.rs: conversions, custom property order in ascii / little / big endian, the two
+error messages, write->read round trips, and examples/model.ply through the Inria fast path —
+each checked against the oracle's independent restatement."""
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+EPS = 1e-4  # tests/common/assert.rs:4
+
+
+def _given_plys(gs, ob):
+    return gs.gaussian_to_ply(ob.given_gaussians([42, 123]))       # given::ply_gaussians()
+
+
+def _custom_buffer(gs, plys, enc, drop_last_value=False, element="vertex"):
+    """tests/e2e/ply.rs:10-65: y and z swapped so the layout is NOT the Inria one."""
+    props = list(gs.PLY_PROPERTIES)
+    props[1], props[2] = props[2], props[1]
+    head = "ply\nformat %s 1.0\nelement %s %d\n" % (enc, element, len(plys))
+    head += "".join("property float %s\n" % p for p in props) + "end_header\n"
+    body = b""
+    for p in plys:
+        vals = np.concatenate([p["pos"][[0, 2, 1]], p["normal"], p["color"], p["sh"], [p["alpha"]],
+                               p["scale"], p["rot"]]).astype(np.float32)
+        if enc == "ascii":
+            toks = [repr(float(v)) for v in vals]
+            if drop_last_value:
+                toks = toks[:-1]
+            body += (" ".join(toks) + "\n").encode()
+        elif enc == "binary_little_endian":
+            body += vals.astype("<f4").tobytes()
+        else:
+            body += vals.astype(">f4").tobytes()
+    return head.encode() + body
+
+
+def _assert_ply_close(a, b):
+    for f in ("rot", "pos", "normal", "sh", "scale"):
+        assert np.abs(a[f] - b[f]).max() < EPS, f
+
+
+def test_from_ply_to_ply_match_oracle_and_roundtrip(gs, ob):
+    """ply.rs test 68-78 + bit-equality with the oracle restatement of gaussian.rs:70-125"""
+    g = ob.given_gaussians(list(range(15)) + [42, 123])
+    ply = gs.gaussian_to_ply(g)
+    exp = np.zeros(len(g), dtype=ob.PLY_DTYPE)
+    for i in range(len(g)):
+        ob.lib().gso_gaussian_to_ply(g[i:i + 1].ctypes.data, exp[i:i + 1].ctypes.data)
+    assert ply.tobytes() == exp.tobytes()
+    back = gs.gaussian_from_ply(ply)
+    exp_back = np.zeros(len(g), dtype=ob.GAUSSIAN_DTYPE)
+    for i in range(len(g)):
+        ob.lib().gso_gaussian_from_ply(exp[i:i + 1].ctypes.data, exp_back[i:i + 1].ctypes.data)
+    assert back.tobytes() == exp_back.tobytes()
+    assert np.abs(back["pos"] - g["pos"]).max() < EPS and np.abs(back["rot"] - g["rot"]).max() < EPS
+    assert np.abs(back["scale"] - g["scale"]).max() < 1e-3 * np.abs(g["scale"]).max()
+    assert np.abs(back["color"].astype(int) - g["color"].astype(int)).max() <= 1
+    assert np.array_equal(back["sh"], g["sh"])
+
+
+@pytest.mark.parametrize("enc", ["ascii", "binary_big_endian", "binary_little_endian"])
+def test_read_custom_order(gs, ob, enc):
+    """ply.rs:88-120"""
+    plys = _given_plys(gs, ob)
+    got = gs.PlyGaussians.read_from(_custom_buffer(gs, plys, enc))
+    assert len(got) == 2 and got.inria is False
+    _assert_ply_close(got.pods, plys)
+    if enc != "ascii":
+        assert got.pods.tobytes() == plys.tobytes()
+
+
+def test_missing_vertex_element(gs, ob):
+    """ply.rs:123-160"""
+    with pytest.raises(gs.PlyError) as e:
+        gs.PlyGaussians.read_from(_custom_buffer(gs, _given_plys(gs, ob), "ascii", element="face"))
+    assert str(e.value) == "Gaussian vertex element not found in PLY header"
+
+
+def test_missing_value(gs, ob):
+    """ply.rs:163-201"""
+    with pytest.raises(gs.PlyError) as e:
+        gs.PlyGaussians.read_from(_custom_buffer(gs, _given_plys(gs, ob), "ascii", drop_last_value=True))
+    assert str(e.value) == "Gaussian element property invalid or missing in PLY"
+
+
+def test_write_then_read(gs, ob, tmp_path):
+    """ply.rs:204-231 (file and memory)"""
+    plys = gs.PlyGaussians(_given_plys(gs, ob))
+    data = plys.write_to()
+    assert data.startswith(b"ply\nformat binary_little_endian 1.0\nelement vertex 2\nproperty float x\n")
+    back = gs.PlyGaussians.read_from(data)
+    assert back.inria is True and back.pods.tobytes() == plys.pods.tobytes()
+    path = tmp_path / "g.ply"
+    plys.write_to_file(path)
+    assert gs.PlyGaussians.read_from_file(path).pods.tobytes() == plys.pods.tobytes()
+    empty = gs.PlyGaussians(np.zeros(0, dtype=gs.PLY_GAUSSIAN_DTYPE))
+    assert gs.PlyGaussians.read_from(empty.write_to()).is_empty()
+
+
+def test_model_ply_fast_path_equals_oracle(gs, ob, golden):
+    raw = open(os.path.join(HERE, "golden", "model.ply"), "rb").read()
+    got = gs.PlyGaussians.read_from(raw)
+    assert len(got) == 9 and got.inria is True
+    assert np.array_equal(got.pods.view(np.float32).reshape(9, 62), golden["ply_body"])
+    buf = np.frombuffer(raw, dtype=np.uint8)
+    exp = np.zeros(9, dtype=ob.PLY_DTYPE)
+    assert ob.lib().gso_read_inria_ply(buf.ctypes.data, buf.size, exp.ctypes.data, 9) == 9
+    assert got.pods.tobytes() == exp.tobytes()
+    g = got.iter_gaussian()
+    assert np.abs(g["pos"] - golden["ply_pos"]).max() < EPS
+    assert list(g["color"][:, 3]) == [255] * 9
+    # the writer reproduces the file byte for byte (same header, same body)
+    assert got.write_to() == raw
+
+
+def test_truncated_and_mixed_type_files(gs, ob):
+    plys = _given_plys(gs, ob)
+    data = gs.PlyGaussians(plys).write_to()
+    with pytest.raises(gs.PlyError):
+        gs.PlyGaussians.read_from(data[:-5])
+    with pytest.raises(gs.PlyError):
+        gs.PlyGaussians.read_from(b"plx\n")
+    # extra uchar + double properties and a leading non-vertex element: skipped, not misread
+    head = ("ply\nformat binary_little_endian 1.0\nelement camera 1\nproperty int id\n"
+            "element vertex 2\nproperty uchar flag\n")
+    head += "".join("property float %s\n" % p for p in gs.PLY_PROPERTIES) + "property double extra\nend_header\n"
+    body = np.int32(7).tobytes()
+    for p in plys:
+        body += b"\x01" + p.tobytes() + np.float64(3.5).tobytes()
+    got = gs.PlyGaussians.read_from(head.encode() + body)
+    assert got.inria is False and got.pods.tobytes() == plys.tobytes()

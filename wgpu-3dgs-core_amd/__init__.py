@@ -125,6 +125,9 @@ class KernelResolveError(ComputeBundleBuildError): """ComputeBundleBuildError::W
 
 
 class LossyConfigError(GsError): code = -21
+class PlyError(GsError):
+    """std::io::Error of PlyGaussians::read_from (message = the reference's message)"""
+    code = -24
 class DownloadBufferError(GsError): code = -22
 
 
@@ -132,7 +135,7 @@ _ERRORS = {c.code: c for c in (InvalidArgumentError, NoDeviceError, HipError, Ou
                                GaussiansBufferUpdateError, GaussiansBufferUpdateRangeError,
                                GaussiansBufferTryFromBufferError, FixedSizeBufferWrapperError,
                                ResourceCountMismatch, WorkgroupSizeExceedsDeviceLimit,
-                               LossyConfigError, DownloadBufferError)}
+                               LossyConfigError, DownloadBufferError, PlyError)}
 
 
 def _check(status):
@@ -256,6 +259,82 @@ def camera_look_at(eye, target, up, vfov_radians, width, height, near=0.1, far=1
                          C.byref(cam))
     cam.background[:] = background
     return cam
+
+
+# ------------------------------------------------------------------------------------------------
+# PLY source format — src/source_format/ply.rs
+# ------------------------------------------------------------------------------------------------
+
+#: PlyGaussianPod — src/source_format/ply.rs:11-21
+PLY_GAUSSIAN_DTYPE = np.dtype([("pos", "<f4", 3), ("normal", "<f4", 3), ("color", "<f4", 3),
+                               ("sh", "<f4", 45), ("alpha", "<f4"), ("scale", "<f4", 3), ("rot", "<f4", 4)])
+PLY_PROPERTIES = [_L.gs_ply_property_name(i).decode() for i in range(62)]
+
+
+def gaussian_from_ply(ply):
+    """Gaussian::from_ply over an array of PlyGaussianPod"""
+    p = np.ascontiguousarray(np.atleast_1d(ply), dtype=PLY_GAUSSIAN_DTYPE)
+    out = np.zeros(len(p), dtype=GAUSSIAN_DTYPE)
+    _L.gs_gaussian_from_ply(_ptr(p), len(p), _ptr(out))
+    return out
+
+
+def gaussian_to_ply(gaussians):
+    """Gaussian::to_ply"""
+    g = np.ascontiguousarray(np.atleast_1d(gaussians), dtype=GAUSSIAN_DTYPE)
+    out = np.zeros(len(g), dtype=PLY_GAUSSIAN_DTYPE)
+    _L.gs_gaussian_to_ply(_ptr(g), len(g), _ptr(out))
+    return out
+
+
+class PlyGaussians:
+    """PlyGaussians — src/source_format/ply.rs:200-449 (a Vec<PlyGaussianPod> with I/O)."""
+
+    def __init__(self, pods, inria=None):
+        self.pods = np.ascontiguousarray(pods, dtype=PLY_GAUSSIAN_DTYPE)
+        self.inria = inria
+
+    def __len__(self):
+        return len(self.pods)
+
+    def is_empty(self):
+        return len(self.pods) == 0
+
+    @staticmethod
+    def read_from(data):
+        """ReadIterGaussian::read_from on a bytes-like object"""
+        buf = np.frombuffer(bytes(data), dtype=np.uint8)
+        n, inria = C.c_size_t(), C.c_int32()
+        _check(_L.gs_ply_read(_ptr(buf), buf.size, None, 0, C.byref(n), C.byref(inria)))
+        pods = np.zeros(n.value, dtype=PLY_GAUSSIAN_DTYPE)
+        _check(_L.gs_ply_read(_ptr(buf), buf.size, _ptr(pods), n.value, C.byref(n), C.byref(inria)))
+        return PlyGaussians(pods, bool(inria.value))
+
+    @staticmethod
+    def read_from_file(path):
+        with open(path, "rb") as f:
+            return PlyGaussians.read_from(f.read())
+
+    @staticmethod
+    def from_gaussians(gaussians):
+        """FromIterator<Gaussian>"""
+        return PlyGaussians(gaussian_to_ply(gaussians))
+
+    def write_to(self):
+        """WriteIterGaussian::write_to -> bytes"""
+        n = C.c_size_t()
+        _check(_L.gs_ply_write(_ptr(self.pods), len(self.pods), None, 0, C.byref(n)))
+        out = np.zeros(n.value, dtype=np.uint8)
+        _check(_L.gs_ply_write(_ptr(self.pods), len(self.pods), _ptr(out), out.size, C.byref(n)))
+        return out.tobytes()
+
+    def write_to_file(self, path):
+        with open(path, "wb") as f:
+            f.write(self.write_to())
+
+    def iter_gaussian(self):
+        """IterGaussian: the Gaussians (Gaussian::from_ply of every pod)"""
+        return gaussian_from_ply(self.pods)
 
 
 # ------------------------------------------------------------------------------------------------

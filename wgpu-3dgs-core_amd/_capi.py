@@ -64,6 +64,11 @@ SIGNATURES = {
     "gs_max_std_dev_decode": (f32, [u8]),
     "gs_model_transform_pod_new": (None, [vp, vp, vp, vp]),
     "gs_model_transform_pod_default": (None, [vp]),
+    "gs_ply_property_name": (C.c_char_p, [u32]),
+    "gs_gaussian_from_ply": (None, [vp, sz, vp]),
+    "gs_gaussian_to_ply": (None, [vp, sz, vp]),
+    "gs_ply_read": (i32, [vp, sz, vp, sz, vp, vp]),
+    "gs_ply_write": (i32, [vp, sz, vp, sz, vp]),
     "gs_device_create": (i32, [i32, vp]),
     "gs_device_destroy": (None, [vp]),
     "gs_device_limits": (i32, [vp, vp]),

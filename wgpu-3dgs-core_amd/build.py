@@ -13,9 +13,9 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libgs3d_hip.so")
-SOURCES = [os.path.join(CSRC, "gs3d.hip")]
+SOURCES = [os.path.join(CSRC, "gs3d.hip"), os.path.join(CSRC, "gs_ply.cpp")]
 DEPS = SOURCES + [os.path.join(CSRC, f) for f in
-                  ("gs_kernel_lib.h", "gs_render_kernels.h", "gs_bundle_kernels.h")] + [
+                  ("gs_kernel_lib.h", "gs_render_kernels.h", "gs_bundle_kernels.h", "gs_internal.h")] + [
     os.path.join(ROOT, "include", "gs3d.h")]
 
 # -ffp-contract=off: the render path's results are defined operation by operation;

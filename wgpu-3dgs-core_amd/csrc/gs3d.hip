@@ -1,7 +1,7 @@
 // gs3d.hip — host side of libgs3d_hip.so: the C ABI of include/gs3d.h over the gfx950 kernels.
 // Built by hipcc --offload-arch=gfx950 -ffp-contract=off (see build.py).  No CPU fallback: every
 // compute entry point needs a HIP device.
-#include "../../include/gs3d.h"
+#include "gs_internal.h"
 
 #include <hip/hip_runtime.h>
 
@@ -24,7 +24,7 @@
 
 static thread_local gs_error_info t_err = {0, 0, 0, 0, {0}};
 
-static gs_status fail(gs_status code, uint64_t a, uint64_t b, uint64_t c, const char *fmt, ...) {
+gs_status gs_fail(gs_status code, uint64_t a, uint64_t b, uint64_t c, const char *fmt, ...) {
     t_err.code = code;
     t_err.a = a;
     t_err.b = b;
@@ -49,6 +49,8 @@ static gs_status fail(gs_status code, uint64_t a, uint64_t b, uint64_t c, const 
         gs_status s_ = (expr);        \
         if (s_ != GS_OK) return s_;   \
     } while (0)
+
+#define fail gs_fail
 
 extern "C" void gs_last_error(gs_error_info *out) {
     if (out) *out = t_err;
@@ -77,6 +79,7 @@ extern "C" const char *gs_status_string(gs_status s) {
     case GS_ERR_LOSSY_CONFIG: return "configuration cannot be converted back to a Gaussian";
     case GS_ERR_DOWNLOAD: return "buffer download failed";
     case GS_ERR_PAIR_OVERFLOW: return "pair buffer overflow";
+    case GS_ERR_PLY: return "PLY read error";
     default: return "unknown";
     }
 }
@@ -1417,10 +1420,10 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
     GS_HIP(hipMemsetAsync(r->ranges.ptr, 0, (size_t)num_tiles * 8, st));
     if (d) {
         if (wide)
-            hipLaunchKernelGGL(gs::k_tile_ranges<uint32_t>, dim3((d + 255) / 256), dim3(256), 0, st,
+            hipLaunchKernelGGL(gs::k_tile_ranges<uint32_t>, dim3((d + 2047) / 2048), dim3(256), 0, st,
                                (const uint32_t *)r->tkeys[tside].ptr, d, (uint32_t *)r->ranges.ptr);
         else
-            hipLaunchKernelGGL(gs::k_tile_ranges<uint16_t>, dim3((d + 255) / 256), dim3(256), 0, st,
+            hipLaunchKernelGGL(gs::k_tile_ranges<uint16_t>, dim3((d + 2047) / 2048), dim3(256), 0, st,
                                (const uint16_t *)r->tkeys[tside].ptr, d, (uint32_t *)r->ranges.ptr);
         GS_HIP(hipGetLastError());
     }

@@ -491,23 +491,30 @@ template <> struct SortCfg<uint16_t> { static constexpr int ITEMS = 16; };
 template <typename K> constexpr int sort_tile() { return SORT_THREADS * SortCfg<K>::ITEMS; }
 
 // ghist layout: [digit][block] (digit-major) so that the row scan reads contiguous memory.
+// Tile ids and depth exponents are highly repetitive, so neighbouring lanes often hit the same
+// bin; eight private copies (lane & 7) cut the same-address LDS atomic serialisation 8-fold.
 template <typename K>
 __global__ __launch_bounds__(SORT_THREADS) void k_sort_hist(const K *__restrict__ keys,
                                                             uint32_t count, uint32_t shift,
                                                             uint32_t *__restrict__ ghist,
                                                             uint32_t num_blocks) {
     constexpr int ITEMS = SortCfg<K>::ITEMS;
-    __shared__ uint32_t s_hist[RADIX];
-    s_hist[threadIdx.x] = 0;
+    __shared__ uint32_t s_hist[8][RADIX];
+#pragma unroll
+    for (int c = 0; c < 8; c++) s_hist[c][threadIdx.x] = 0;
     __syncthreads();
     uint32_t base = blockIdx.x * (SORT_THREADS * ITEMS);
+    const uint32_t copy = threadIdx.x & 7u;
 #pragma unroll
     for (int k = 0; k < ITEMS; k++) {
         uint32_t i = base + k * SORT_THREADS + threadIdx.x;
-        if (i < count) atomicAdd(&s_hist[(uint32_t)(keys[i] >> shift) & (RADIX - 1)], 1u);
+        if (i < count) atomicAdd(&s_hist[copy][(uint32_t)(keys[i] >> shift) & (RADIX - 1)], 1u);
     }
     __syncthreads();
-    ghist[(uint64_t)threadIdx.x * num_blocks + blockIdx.x] = s_hist[threadIdx.x];
+    uint32_t sum = 0;
+#pragma unroll
+    for (int c = 0; c < 8; c++) sum += s_hist[c][threadIdx.x];
+    ghist[(uint64_t)threadIdx.x * num_blocks + blockIdx.x] = sum;
 }
 
 // One workgroup per digit: exclusive scan of its row (over blocks) in place; row total out.
@@ -628,14 +635,27 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
 // tile ranges (row x5a)
 // ---------------------------------------------------------------------------------------------
 
+constexpr int RANGE_ITEMS = 8;   // consecutive keys per thread
+
 template <typename TK>
 __global__ __launch_bounds__(256) void k_tile_ranges(const TK *__restrict__ tkeys, uint32_t count,
                                                      uint32_t *__restrict__ ranges) {
-    uint32_t j = blockIdx.x * 256u + threadIdx.x;
-    if (j >= count) return;
-    uint32_t tile = tkeys[j];
-    if (j == 0 || (uint32_t)tkeys[j - 1] != tile) ranges[2 * tile] = j;
-    if (j + 1 == count || (uint32_t)tkeys[j + 1] != tile) ranges[2 * tile + 1] = j + 1;
+    const uint32_t j0 = (blockIdx.x * 256u + threadIdx.x) * RANGE_ITEMS;
+    if (j0 >= count) return;
+    uint32_t prev = j0 ? (uint32_t)tkeys[j0 - 1] : 0xffffffffu;
+#pragma unroll
+    for (int k = 0; k < RANGE_ITEMS; k++) {
+        uint32_t j = j0 + k;
+        if (j < count) {
+            uint32_t tile = tkeys[j];
+            if (tile != prev) {
+                ranges[2 * tile] = j;
+                if (prev != 0xffffffffu) ranges[2 * prev + 1] = j;
+            }
+            if (j + 1 == count) ranges[2 * tile + 1] = j + 1;
+            prev = tile;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
