@@ -1,0 +1,299 @@
+// gs3d.hpp — header-only C++17 mirror of wgpu-3dgs-core's Rust API over the C ABI (gs3d.h).
+//
+// Rust is not available in the build image, so this is the compiled-language host mirror the
+// reference's users would recognise: same type names, same methods, Result<_, E> -> exceptions
+// carrying the variant fields of src/error.rs.  Citations are relative to the reference.
+#pragma once
+
+#include <cstring>
+#include <initializer_list>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "gs3d.h"
+
+namespace gs3d {
+
+// ---- errors (src/error.rs:55-143) --------------------------------------------------------------
+struct Error : std::runtime_error {
+    gs_status status;
+    uint64_t a, b, c;
+    Error(const gs_error_info &i) : std::runtime_error(i.message), status(i.code), a(i.a), b(i.b), c(i.c) {}
+};
+struct GaussiansBufferUpdateError : Error { using Error::Error; uint64_t count() const { return a; } uint64_t expected_count() const { return b; } };
+struct GaussiansBufferUpdateRangeError : Error { using Error::Error; uint64_t count() const { return a; } uint64_t start() const { return b; } uint64_t expected_count() const { return c; } };
+struct GaussiansBufferTryFromBufferError : Error { using Error::Error; uint64_t buffer_size() const { return a; } uint64_t expected_multiple_size() const { return b; } };
+struct FixedSizeBufferWrapperError : Error { using Error::Error; uint64_t buffer_size() const { return a; } uint64_t expected_size() const { return b; } };
+struct ComputeBundleCreateError : Error { using Error::Error; };
+struct ComputeBundleBuildError : std::runtime_error { using std::runtime_error::runtime_error; };
+struct DownloadBufferError : Error { using Error::Error; };
+struct LossyConfigError : Error { using Error::Error; };   // where the reference panics
+struct NoDeviceError : Error { using Error::Error; };
+
+inline void check(gs_status s) {
+    if (s == GS_OK) return;
+    gs_error_info i;
+    gs_last_error(&i);
+    if (i.code != s) { i.code = s; std::strncpy(i.message, gs_status_string(s), sizeof(i.message) - 1); }
+    switch (s) {
+    case GS_ERR_COUNT_MISMATCH: throw GaussiansBufferUpdateError(i);
+    case GS_ERR_RANGE_COUNT_MISMATCH: throw GaussiansBufferUpdateRangeError(i);
+    case GS_ERR_BUFFER_SIZE_NOT_MULTIPLE: throw GaussiansBufferTryFromBufferError(i);
+    case GS_ERR_BUFFER_SIZE_MISMATCHED: throw FixedSizeBufferWrapperError(i);
+    case GS_ERR_RESOURCE_COUNT_MISMATCH:
+    case GS_ERR_WORKGROUP_SIZE_EXCEEDS_LIMIT: throw ComputeBundleCreateError(i);
+    case GS_ERR_DOWNLOAD: throw DownloadBufferError(i);
+    case GS_ERR_LOSSY_CONFIG: throw LossyConfigError(i);
+    case GS_ERR_NO_DEVICE: throw NoDeviceError(i);
+    default: throw Error(i);
+    }
+}
+
+using Gaussian = gs_gaussian;   // src/gaussian.rs:53-60
+
+// ---- GaussianPod family (src/buffer/gaussian.rs:239-384) ---------------------------------------
+template <gs_sh_config SH, gs_cov3d_config COV>
+struct GaussianPod {
+    static constexpr gs_sh_config sh = SH;
+    static constexpr gs_cov3d_config cov3d = COV;
+    static size_t size() { return gs_pod_size(SH, COV); }
+    static std::vector<std::pair<std::string, bool>> features() {
+        uint8_t f[7];
+        check(gs_pod_features(SH, COV, f));
+        std::vector<std::pair<std::string, bool>> out;
+        for (uint32_t i = 0; i < 7; i++) out.emplace_back(gs_feature_name(i), f[i] != 0);
+        return out;
+    }
+    // G::from_gaussian over a slice -> packed bytes
+    static std::vector<uint8_t> from_gaussians(const std::vector<Gaussian> &g) {
+        std::vector<uint8_t> pods(g.size() * size());
+        check(gs_pack(SH, COV, g.data(), g.size(), pods.data()));
+        return pods;
+    }
+    static std::vector<Gaussian> into_gaussians(const std::vector<uint8_t> &pods) {
+        std::vector<Gaussian> g(pods.size() / size());
+        check(gs_unpack_to_gaussian(SH, COV, pods.data(), g.size(), g.data()));
+        return g;
+    }
+};
+#define GS3D_POD(S, C, NAME) using NAME = GaussianPod<S, C>;
+GS3D_POD(GS_SH_SINGLE, GS_COV3D_ROT_SCALE, GaussianPodWithShSingleCov3dRotScaleConfigs)
+GS3D_POD(GS_SH_SINGLE, GS_COV3D_SINGLE, GaussianPodWithShSingleCov3dSingleConfigs)
+GS3D_POD(GS_SH_SINGLE, GS_COV3D_HALF, GaussianPodWithShSingleCov3dHalfConfigs)
+GS3D_POD(GS_SH_HALF, GS_COV3D_ROT_SCALE, GaussianPodWithShHalfCov3dRotScaleConfigs)
+GS3D_POD(GS_SH_HALF, GS_COV3D_SINGLE, GaussianPodWithShHalfCov3dSingleConfigs)
+GS3D_POD(GS_SH_HALF, GS_COV3D_HALF, GaussianPodWithShHalfCov3dHalfConfigs)
+GS3D_POD(GS_SH_NORM8, GS_COV3D_ROT_SCALE, GaussianPodWithShNorm8Cov3dRotScaleConfigs)
+GS3D_POD(GS_SH_NORM8, GS_COV3D_SINGLE, GaussianPodWithShNorm8Cov3dSingleConfigs)
+GS3D_POD(GS_SH_NORM8, GS_COV3D_HALF, GaussianPodWithShNorm8Cov3dHalfConfigs)
+GS3D_POD(GS_SH_NONE, GS_COV3D_ROT_SCALE, GaussianPodWithShNoneCov3dRotScaleConfigs)
+GS3D_POD(GS_SH_NONE, GS_COV3D_SINGLE, GaussianPodWithShNoneCov3dSingleConfigs)
+GS3D_POD(GS_SH_NONE, GS_COV3D_HALF, GaussianPodWithShNoneCov3dHalfConfigs)
+#undef GS3D_POD
+
+// ---- device / stream / buffer --------------------------------------------------------------------
+class Device {
+  public:
+    explicit Device(int ordinal = 0) { check(gs_device_create(ordinal, &h_)); }
+    ~Device() { gs_device_destroy(h_); }
+    Device(const Device &) = delete;
+    Device &operator=(const Device &) = delete;
+    gs_limits limits() const { gs_limits l; check(gs_device_limits(h_, &l)); return l; }
+    gs_device *raw() const { return h_; }
+  private:
+    gs_device *h_ = nullptr;
+};
+
+class Stream {   // CommandEncoder + queue.submit
+  public:
+    explicit Stream(Device &d) { check(gs_stream_create(d.raw(), &h_)); }
+    ~Stream() { gs_stream_destroy(h_); }
+    Stream(const Stream &) = delete;
+    void synchronize() { check(gs_stream_synchronize(h_)); }
+    gs_stream *raw() const { return h_; }
+  private:
+    gs_stream *h_ = nullptr;
+};
+
+class Buffer {   // wgpu::Buffer + BufferWrapper (src/buffer/mod.rs:17-102); Clone = handle copy
+  public:
+    Buffer(Device &d, size_t bytes, const void *init = nullptr) { check(gs_buffer_create(d.raw(), bytes, init, &h_)); }
+    explicit Buffer(gs_buffer *retained) : h_(retained) {}
+    Buffer(const Buffer &o) : h_(gs_buffer_retain(o.h_)) {}
+    Buffer(Buffer &&o) noexcept : h_(o.h_) { o.h_ = nullptr; }
+    Buffer &operator=(Buffer o) { std::swap(h_, o.h_); return *this; }
+    ~Buffer() { gs_buffer_release(h_); }
+    size_t size() const { return gs_buffer_size(h_); }
+    void *device_ptr() const { return gs_buffer_device_ptr(h_); }
+    void write(Stream &s, size_t offset, const void *src, size_t bytes) { check(gs_buffer_write(h_, s.raw(), offset, src, bytes)); }
+    template <class T> std::vector<T> download(Stream &s) const {   // BufferWrapper::download::<T>
+        std::vector<T> out(size() / sizeof(T));
+        check(gs_buffer_download(h_, s.raw(), out.data(), out.size() * sizeof(T)));
+        return out;
+    }
+    gs_buffer *raw() const { return h_; }
+  private:
+    gs_buffer *h_ = nullptr;
+};
+
+template <class G>
+class GaussiansBuffer {   // src/buffer/gaussian.rs:17-229
+  public:
+    GaussiansBuffer(Device &d, const std::vector<Gaussian> &g) { check(gs_gaussians_buffer_create_from_gaussians(d.raw(), G::sh, G::cov3d, g.data(), g.size(), &h_)); }
+    static GaussiansBuffer new_with_pods(Device &d, const std::vector<uint8_t> &pods) { GaussiansBuffer b; check(gs_gaussians_buffer_create(d.raw(), G::sh, G::cov3d, pods.data(), pods.size() / G::size(), &b.h_)); return b; }
+    static GaussiansBuffer new_empty(Device &d, size_t len) { GaussiansBuffer b; check(gs_gaussians_buffer_create(d.raw(), G::sh, G::cov3d, nullptr, len, &b.h_)); return b; }
+    static GaussiansBuffer try_from(const Buffer &buf) { GaussiansBuffer b; check(gs_gaussians_buffer_from_buffer(buf.raw(), G::sh, G::cov3d, &b.h_)); return b; }
+    GaussiansBuffer(GaussiansBuffer &&o) noexcept : h_(o.h_) { o.h_ = nullptr; }
+    GaussiansBuffer(const GaussiansBuffer &) = delete;
+    ~GaussiansBuffer() { gs_gaussians_buffer_destroy(h_); }
+    size_t len() const { return gs_gaussians_buffer_len(h_); }
+    bool is_empty() const { return len() == 0; }
+    Buffer buffer() const { return Buffer(gs_buffer_retain(gs_gaussians_buffer_buffer(h_))); }
+    void update(Stream &s, const std::vector<Gaussian> &g) { check(gs_gaussians_buffer_update_gaussians(h_, s.raw(), g.data(), g.size())); }
+    void update_with_pod(Stream &s, const std::vector<uint8_t> &pods) { check(gs_gaussians_buffer_update(h_, s.raw(), pods.data(), pods.size() / G::size())); }
+    void update_range(Stream &s, size_t start, const std::vector<Gaussian> &g) { check(gs_gaussians_buffer_update_range_gaussians(h_, s.raw(), start, g.data(), g.size())); }
+    void update_range_with_pod(Stream &s, size_t start, const std::vector<uint8_t> &pods) { check(gs_gaussians_buffer_update_range(h_, s.raw(), start, pods.data(), pods.size() / G::size())); }
+    std::vector<uint8_t> download(Stream &s) const { std::vector<uint8_t> out(len() * G::size()); check(gs_gaussians_buffer_download(h_, s.raw(), out.data(), len())); return out; }
+    std::vector<Gaussian> download_gaussians(Stream &s) const { std::vector<Gaussian> out(len()); check(gs_gaussians_buffer_download_gaussians(h_, s.raw(), out.data(), len())); return out; }
+    gs_gaussians_buffer *raw() const { return h_; }
+  private:
+    GaussiansBuffer() = default;
+    gs_gaussians_buffer *h_ = nullptr;
+};
+
+// GaussianTransformPod helpers (src/buffer/gaussian_transform.rs)
+inline std::optional<gs_gaussian_transform_pod> gaussian_transform_pod(float size, gs_display_mode mode, uint8_t sh_deg, bool no_sh0, float max_std_dev) {
+    gs_gaussian_transform_pod p;
+    if (gs_gaussian_transform_pod_new(size, mode, sh_deg, no_sh0, max_std_dev, &p) != GS_OK) return std::nullopt;
+    return p;
+}
+struct GaussianTransformBuffer : Buffer {   // :104-163
+    explicit GaussianTransformBuffer(Device &d) : Buffer(make(d)) {}
+    void update_with_pod(Stream &s, const gs_gaussian_transform_pod &p) { check(gs_gaussian_transform_buffer_update(raw(), s.raw(), &p)); }
+    static GaussianTransformBuffer try_from(const Buffer &b) { check(gs_gaussian_transform_buffer_from_buffer(b.raw())); return GaussianTransformBuffer(b); }
+  private:
+    explicit GaussianTransformBuffer(const Buffer &b) : Buffer(b) {}
+    static gs_buffer *make(Device &d) { gs_buffer *b; check(gs_gaussian_transform_buffer_create(d.raw(), &b)); return b; }
+};
+struct ModelTransformBuffer : Buffer {      // src/buffer/model_transform.rs:10-58
+    explicit ModelTransformBuffer(Device &d) : Buffer(make(d)) {}
+    void update(Stream &s, const float pos[3], const float rot[4], const float scale[3]) { gs_model_transform_pod p; gs_model_transform_pod_new(pos, rot, scale, &p); check(gs_model_transform_buffer_update(raw(), s.raw(), &p)); }
+    static ModelTransformBuffer try_from(const Buffer &b) { check(gs_model_transform_buffer_from_buffer(b.raw())); return ModelTransformBuffer(b); }
+  private:
+    explicit ModelTransformBuffer(const Buffer &b) : Buffer(b) {}
+    static gs_buffer *make(Device &d) { gs_buffer *b; check(gs_model_transform_buffer_create(d.raw(), &b)); return b; }
+};
+
+// ---- ComputeBundle (src/compute_bundle.rs) -------------------------------------------------------
+class ComputeBundle {
+  public:
+    ComputeBundle(gs_bundle *h, bool managed) : h_(h), managed_(managed) {}
+    ComputeBundle(ComputeBundle &&o) noexcept : h_(o.h_), managed_(o.managed_) { o.h_ = nullptr; }
+    ~ComputeBundle() { gs_bundle_destroy(h_); }
+    uint32_t workgroup_size() const { return gs_bundle_workgroup_size(h_); }
+    std::optional<std::string> label() const { const char *l = gs_bundle_label(h_); return l ? std::optional<std::string>(l) : std::nullopt; }
+    void dispatch(Stream &s, uint32_t count) { check(gs_bundle_dispatch(h_, s.raw(), count)); }
+    void dispatch(Stream &s, uint32_t count, const std::vector<std::vector<const Buffer *>> &groups) {
+        std::vector<std::vector<gs_buffer *>> raw(groups.size());
+        std::vector<gs_buffer *const *> ptrs;
+        std::vector<uint32_t> counts;
+        for (size_t i = 0; i < groups.size(); i++) {
+            for (auto *b : groups[i]) raw[i].push_back(b->raw());
+            ptrs.push_back(raw[i].data());
+            counts.push_back((uint32_t)raw[i].size());
+        }
+        check(gs_bundle_dispatch_with_bind_groups(h_, s.raw(), count, ptrs.data(), counts.data(), (uint32_t)groups.size()));
+    }
+    uint32_t last_workgroup_count() const { return gs_bundle_last_workgroup_count(h_); }
+  private:
+    gs_bundle *h_;
+    bool managed_;
+};
+
+class ComputeBundleBuilder {   // :364-593; required fields checked in the reference's order (:505-519)
+  public:
+    ComputeBundleBuilder &label(std::string l) { label_ = std::move(l); return *this; }
+    ComputeBundleBuilder &bind_group_layout(uint32_t bindings) { layouts_.push_back(bindings); return *this; }
+    ComputeBundleBuilder &resolver() { resolver_ = true; return *this; }   // the built-in kernel registry
+    ComputeBundleBuilder &entry_point(std::string e) { entry_ = std::move(e); return *this; }
+    ComputeBundleBuilder &main_shader(gs_kernel_id k) { kernel_ = k; return *this; }
+    template <class G> ComputeBundleBuilder &features() { sh_ = G::sh; cov_ = G::cov3d; return *this; }
+    ComputeBundleBuilder &workgroup_size(uint32_t w) { wg_ = w; return *this; }
+    ComputeBundleBuilder &constant(std::string name, double v) { cnames_.push_back(std::move(name)); cvals_.push_back(v); return *this; }
+    ComputeBundle build(Device &d, const std::vector<std::vector<const Buffer *>> &resources) {
+        validate();
+        gs_bundle_desc desc = make_desc();
+        std::vector<std::vector<gs_buffer *>> raw(resources.size());
+        std::vector<gs_buffer *const *> ptrs;
+        std::vector<uint32_t> counts;
+        for (size_t i = 0; i < resources.size(); i++) {
+            for (auto *b : resources[i]) raw[i].push_back(b->raw());
+            ptrs.push_back(raw[i].data());
+            counts.push_back((uint32_t)raw[i].size());
+        }
+        gs_bundle *h;
+        check(gs_bundle_create_with_bind_groups(d.raw(), &desc, ptrs.data(), counts.data(), (uint32_t)resources.size(), &h));
+        return ComputeBundle(h, true);
+    }
+    ComputeBundle build_without_bind_groups(Device &d) {
+        validate();
+        gs_bundle_desc desc = make_desc();
+        gs_bundle *h;
+        check(gs_bundle_create(d.raw(), &desc, &h));
+        return ComputeBundle(h, false);
+    }
+  private:
+    void validate() const {
+        if (layouts_.empty()) throw ComputeBundleBuildError("missing bind group layout for compute bundle");
+        if (!resolver_) throw ComputeBundleBuildError("missing resolver for compute bundle");
+        if (!entry_) throw ComputeBundleBuildError("missing entry point for compute bundle");
+        if (!kernel_) throw ComputeBundleBuildError("missing main shader for compute bundle");
+    }
+    gs_bundle_desc make_desc() {
+        cptrs_.clear();
+        for (auto &n : cnames_) cptrs_.push_back(n.c_str());
+        gs_bundle_desc d{};
+        d.label = label_ ? label_->c_str() : nullptr;
+        d.kernel = *kernel_;
+        d.sh = sh_;
+        d.cov = cov_;
+        d.bind_group_count = (uint32_t)layouts_.size();
+        d.bindings_per_group = layouts_.data();
+        d.workgroup_size = wg_;
+        d.constant_names = cptrs_.data();
+        d.constant_values = cvals_.data();
+        d.constant_count = (uint32_t)cvals_.size();
+        return d;
+    }
+    std::optional<std::string> label_, entry_;
+    std::vector<uint32_t> layouts_;
+    bool resolver_ = false;
+    std::optional<gs_kernel_id> kernel_;
+    gs_sh_config sh_ = GS_SH_SINGLE;
+    gs_cov3d_config cov_ = GS_COV3D_ROT_SCALE;
+    uint32_t wg_ = 0;
+    std::vector<std::string> cnames_;
+    std::vector<const char *> cptrs_;
+    std::vector<double> cvals_;
+};
+
+// ---- renderer ------------------------------------------------------------------------------------
+class Renderer {
+  public:
+    explicit Renderer(Device &d) { check(gs_renderer_create(d.raw(), &h_)); }
+    ~Renderer() { gs_renderer_destroy(h_); }
+    Renderer(const Renderer &) = delete;
+    template <class G>
+    void render(Stream &s, GaussiansBuffer<G> &g, const gs_gaussian_transform_pod &gt, const gs_model_transform_pod &mt,
+                const gs_camera &cam, float *rgba_device, uint32_t band_ty0 = 0, uint32_t band_ty1 = 0xffffffffu) {
+        check(gs_render_frame(h_, s.raw(), g.raw(), &gt, &mt, &cam, band_ty0, band_ty1, rgba_device));
+    }
+    gs_frame_stats stats() { gs_frame_stats st; check(gs_renderer_stats(h_, &st)); return st; }
+  private:
+    gs_renderer *h_ = nullptr;
+};
+
+}  // namespace gs3d

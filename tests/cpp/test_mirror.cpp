@@ -1,0 +1,81 @@
+// C++ host-mirror test (runs on the GPU box): exercises include/gs3d.hpp the way the reference's
+// Rust tests exercise its API — buffer round trips and error variants (tests/buffer/gaussian.rs),
+// ComputeBundle array_map_add incl. builder errors (tests/e2e/compute_bundle.rs), one frame.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+
+#include "gs3d.hpp"
+
+using namespace gs3d;
+#define REQUIRE(c) do { if (!(c)) { std::printf("FAILED %s:%d: %s\n", __FILE__, __LINE__, #c); return 1; } } while (0)
+
+static Gaussian given_gaussian(uint32_t seed) {   // tests/common/given.rs:48-81
+    Gaussian g{};
+    float b = (float)seed;
+    float q[4] = {b + 0.1f, b + 0.2f, b + 0.3f, b + 0.4f};
+    float l = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    for (int i = 0; i < 4; i++) g.rot[i] = q[i] / l;
+    g.pos[0] = b + 1.1f; g.pos[1] = b + 2.2f; g.pos[2] = b + 3.3f;
+    for (int i = 0; i < 4; i++) g.color[i] = (uint8_t)std::fmod(b + 11.0f * (i + 1), 256.0f);
+    for (int i = 0; i < 15; i++) for (int c = 0; c < 3; c++)
+        g.sh[3 * i + c] = std::fmod(b + i * 0.3f + 0.1f * (c + 1), 2.0f) - 1.0f;
+    g.scale[0] = b + 0.12f; g.scale[1] = b + 0.34f; g.scale[2] = b + 0.56f;
+    return g;
+}
+
+int main() {
+    Device dev(0);
+    Stream s(dev);
+    std::vector<Gaussian> gs;
+    for (uint32_t i = 0; i < 15; i++) gs.push_back(given_gaussian(i));
+
+    // byte-exact upload -> download, all via the typed wrapper
+    using G = GaussianPodWithShHalfCov3dHalfConfigs;
+    REQUIRE(G::size() == 128);
+    GaussiansBuffer<G> buf(dev, gs);
+    REQUIRE(buf.len() == 15 && !buf.is_empty());
+    REQUIRE(buf.download(s) == G::from_gaussians(gs));
+    try { buf.update(s, std::vector<Gaussian>(gs.begin(), gs.begin() + 3)); REQUIRE(false); }
+    catch (const GaussiansBufferUpdateError &e) { REQUIRE(e.count() == 3 && e.expected_count() == 15); }
+    try { buf.update_range(s, 14, std::vector<Gaussian>(gs.begin(), gs.begin() + 3)); REQUIRE(false); }
+    catch (const GaussiansBufferUpdateRangeError &e) { REQUIRE(e.count() == 3 && e.start() == 14 && e.expected_count() == 15); }
+    try { buf.download_gaussians(s); REQUIRE(false); } catch (const LossyConfigError &) {}
+    try { GaussiansBuffer<G>::try_from(Buffer(dev, 130)); REQUIRE(false); }
+    catch (const GaussiansBufferTryFromBufferError &e) { REQUIRE(e.buffer_size() == 130 && e.expected_multiple_size() == 128); }
+    using R = GaussianPodWithShSingleCov3dRotScaleConfigs;
+    GaussiansBuffer<R> rbuf(dev, gs);
+    auto back = rbuf.download_gaussians(s);
+    REQUIRE(std::memcmp(back.data(), gs.data(), gs.size() * sizeof(Gaussian)) == 0);
+    REQUIRE(!gaussian_transform_pod(1.0f, GS_DISPLAY_SPLAT, 4, false, 3.0f).has_value());
+
+    // compute bundle: data [1..5] + 1 (+ uniform 10 + constant 20)
+    uint32_t init[5] = {1, 2, 3, 4, 5}, ten = 10;
+    Buffer data(dev, sizeof(init), init), uni(dev, 4, &ten);
+    auto bundle = ComputeBundleBuilder().label("array map add").bind_group_layout(1).bind_group_layout(1).resolver()
+                      .entry_point("main").main_shader(GS_KERNEL_ARRAY_MAP_ADD).constant("additional_constant", 20.0)
+                      .build(dev, {{&data}, {&uni}});
+    bundle.dispatch(s, 5);
+    auto out = data.download<uint32_t>(s);
+    REQUIRE(out[0] == 32 && out[4] == 36);
+    try { ComputeBundleBuilder().build_without_bind_groups(dev); REQUIRE(false); }
+    catch (const ComputeBundleBuildError &e) { REQUIRE(std::string(e.what()) == "missing bind group layout for compute bundle"); }
+    try { ComputeBundleBuilder().bind_group_layout(1).resolver().entry_point("main").main_shader(GS_KERNEL_ARRAY_MAP_ADD).workgroup_size(1u << 20).build_without_bind_groups(dev); REQUIRE(false); }
+    catch (const ComputeBundleCreateError &e) { REQUIRE(e.status == GS_ERR_WORKGROUP_SIZE_EXCEEDS_LIMIT && e.a == (1u << 20)); }
+
+    // one frame
+    gs_camera cam;
+    const float eye[3] = {0, 0, 30}, target[3] = {8, 8, 8}, up[3] = {0, 1, 0};
+    gs_camera_look_at(eye, target, up, 1.0f, 320, 200, 0.1f, 100.0f, &cam);
+    gs_gaussian_transform_pod gt; gs_gaussian_transform_pod_default(&gt);
+    gs_model_transform_pod mt; gs_model_transform_pod_default(&mt);
+    Buffer img(dev, 320 * 200 * 16);
+    Renderer r(dev);
+    r.render(s, rbuf, gt, mt, cam, (float *)img.device_ptr());
+    auto st = r.stats();
+    auto px = img.download<float>(s);
+    double sum = 0; for (float v : px) sum += v;
+    REQUIRE(st.gaussians == 15 && std::isfinite(sum));
+    std::printf("cpp mirror OK: visible %llu pairs %llu checksum %.6f\n", (unsigned long long)st.visible, (unsigned long long)st.pairs, sum);
+    return 0;
+}
