@@ -319,6 +319,37 @@ gs_status gs_bundle_create_with_bind_groups(gs_device *dev, const gs_bundle_desc
                                             gs_buffer *const *const *resources,
                                             const uint32_t *resource_counts,
                                             uint32_t resource_group_count, gs_bundle **out);
+/* ComputeBundleBuilder::build with a caller-supplied shader — compute_bundle.rs:500-586.
+ * `source` is HIP C++ (the MI355X replacement for the WESL main module).  It is compiled at run
+ * time with hiprtc for the device's gfx arch; `#include <wgpu_3dgs_core.h>` imports the device
+ * library (namespace gs: gaussian_unpack_color / _sh<SH> / _cov3d<SH,COV>, gaussian_transform_*,
+ * model_*; the WESL package of src/shader.rs).  The entry point must be
+ *     extern "C" __global__ void <entry_point>(gs::BundleArgs a, uint32_t count)
+ * Feature flags arrive as macros: GS_SH, GS_COV (config indices) plus one macro per enabled
+ * feature name (sh_single, cov3d_half, ... and every string of `defines`); the reference's
+ * `override workgroup_size` is the macro `workgroup_size`; pipeline constants are macros of their
+ * names.  Compilation errors -> GS_ERR_KERNEL_COMPILE (the ComputeBundleBuildError::Wesl analogue)
+ * with the compiler log in gs_last_error().message. */
+typedef struct gs_bundle_source_desc {
+    const char *label;
+    const char *source;
+    const char *entry_point;
+    gs_sh_config sh;
+    gs_cov3d_config cov;
+    uint32_t bind_group_count;
+    const uint32_t *bindings_per_group;
+    uint32_t workgroup_size;
+    const char *const *constant_names;
+    const double *constant_values;
+    uint32_t constant_count;
+    const char *const *defines;
+    uint32_t define_count;
+} gs_bundle_source_desc;
+gs_status gs_bundle_create_from_source(gs_device *dev, const gs_bundle_source_desc *desc, gs_bundle **out);
+/* create bind groups on a bundle built without them (`build` = `build_without_bind_groups` + this);
+ * GS_ERR_RESOURCE_COUNT_MISMATCH as in compute_bundle.rs:161-168 */
+gs_status gs_bundle_attach_bind_groups(gs_bundle *b, gs_buffer *const *const *resources,
+                                       const uint32_t *resource_counts, uint32_t resource_group_count);
 void gs_bundle_destroy(gs_bundle *b);
 uint32_t gs_bundle_workgroup_size(const gs_bundle *b);
 const char *gs_bundle_label(const gs_bundle *b);

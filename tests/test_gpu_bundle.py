@@ -202,3 +202,104 @@ def test_bindings_too_small_are_rejected_on_the_host(gs, device, stream):
     bundle = gs.ComputeBundle.new(None, device, [2], [[small, out]], gs.KERNEL_TEST_GAUSSIAN, pod)
     with pytest.raises(gs.InvalidArgumentError):
         bundle.dispatch(stream, 1)
+
+
+# ---- custom shaders compiled at run time (the ComputeBundleBuilder + WESL path of the reference) ----
+
+ARRAY_MAP_ADD_SRC = r"""
+// tests/common/shader/array_map_add.wesl restated in HIP C++
+#include <wgpu_3dgs_core.h>
+extern "C" __global__ void main(gs::BundleArgs a, uint32_t count) {
+    uint32_t index = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t *data = (uint32_t *)a.ptr[0];
+    if (index >= (uint32_t)(a.size[0] / 4)) return;
+    data[index] = data[index] + 1;
+#ifdef second_group
+    data[index] = data[index] + *(const uint32_t *)a.ptr[1];
+#endif
+#ifdef additional_constant
+    data[index] = data[index] + additional_constant;
+#endif
+}
+"""
+
+TEST_GAUSSIAN_SRC = r"""
+// tests/shader/gaussian.rs:14-59: a caller's module importing the device library
+#include <wgpu_3dgs_core.h>
+extern "C" __global__ void main(gs::BundleArgs a, uint32_t count) {
+    uint32_t index = blockIdx.x * blockDim.x + threadIdx.x;
+    if (index >= 1) return;
+    const uint32_t *g = (const uint32_t *)a.ptr[0];
+    float *out = (float *)a.ptr[1];
+    gs::vec4 c = gs::gaussian_unpack_color(g);
+    out[0] = c.x; out[1] = c.y; out[2] = c.z; out[3] = c.w;
+    for (uint32_t i = 0; i < 15; i++) {
+        gs::vec3 s = gs::gaussian_unpack_sh<GS_SH>(g, i);
+        out[4 + 3 * i] = s.x; out[5 + 3 * i] = s.y; out[6 + 3 * i] = s.z;
+    }
+    float cov[6];
+    gs::gaussian_unpack_cov3d<GS_SH, GS_COV>(g, cov);
+    for (int k = 0; k < 6; k++) out[49 + k] = cov[k];
+    out[55] = 0.0f;
+}
+"""
+
+
+def test_custom_shader_array_map_add_with_features_and_constant(gs, device, stream):
+    """compute_bundle.rs:113-240 with a runtime-compiled module: WESL features -> macros,
+    override constants -> macros, wg = 1 and wg = device limit"""
+    for wg in (1, None):
+        data = _data(gs, device)
+        uni = gs.Buffer(device, data=np.array([10], dtype=np.uint32))
+        b = (gs.ComputeBundleBuilder().label("custom").bind_group_layouts([1, 1])
+             .resolver(gs.SourceResolver({"array_map_add": ARRAY_MAP_ADD_SRC}))
+             .wesl_compile_options(None, defines=["second_group"])
+             .pipeline_compile_options({"additional_constant": 20})
+             .main_shader("array_map_add").entry_point("main"))
+        if wg:
+            b = b.workgroup_size(wg)
+        bundle = b.build(device, [[data], [uni]])
+        bundle.dispatch(stream, 5)
+        assert list(data.download(stream, np.uint32)) == [32, 33, 34, 35, 36]
+    plain = (gs.ComputeBundleBuilder().bind_group_layout(1)
+             .resolver(gs.SourceResolver({"m": ARRAY_MAP_ADD_SRC})).main_shader("m").entry_point("main")
+             .build_without_bind_groups(device))
+    d2 = _data(gs, device)
+    plain.dispatch(stream, 5, [[d2]])
+    assert list(d2.download(stream, np.uint32)) == [2, 3, 4, 5, 6]
+
+
+@pytest.mark.parametrize("pod_idx", [0, 4, 8, 11])
+def test_custom_shader_imports_device_library(gs, ob, device, stream, pod_idx):
+    """A caller's module importing gaussian_unpack_* (tests/shader/gaussian.rs) is bit-equal to the
+    built-in kernel and to the oracle."""
+    pod = gs.ALL_PODS[pod_idx]
+    g = ob.given_gaussians([42])
+    buf = gs.GaussiansBuffer.new(device, pod, g)
+    out = gs.Buffer(device, size=56 * 4)
+    bundle = (gs.ComputeBundleBuilder().bind_group_layout(2)
+              .resolver(gs.SourceResolver({"test_gaussian": TEST_GAUSSIAN_SRC}))
+              .wesl_compile_options(pod).main_shader("test_gaussian").entry_point("main")
+              .build(device, [[buf.buffer(), out]]))
+    bundle.dispatch(stream, 1)
+    got = out.download(stream, np.float32)
+    assert got.tobytes() == ob.shader_test_gaussian(pod.sh, pod.cov, pod.from_gaussian(g)).tobytes()
+
+
+def test_custom_shader_errors(gs, device):
+    """Wesl compile error analogue, unknown module, missing entry point, resource count mismatch"""
+    B = gs.ComputeBundleBuilder
+    with pytest.raises(gs.KernelResolveError) as e:
+        (B().bind_group_layout(1).resolver(gs.SourceResolver({"bad": "this is not C++"}))
+         .main_shader("bad").entry_point("main").build_without_bind_groups(device))
+    assert "error" in str(e.value)
+    with pytest.raises(gs.KernelResolveError):
+        (B().bind_group_layout(1).resolver(gs.SourceResolver({})).main_shader("nope").entry_point("main")
+         .build_without_bind_groups(device))
+    with pytest.raises(gs.GsError):
+        (B().bind_group_layout(1).resolver(gs.SourceResolver({"m": ARRAY_MAP_ADD_SRC})).main_shader("m")
+         .entry_point("not_there").build_without_bind_groups(device))
+    data = gs.Buffer(device, data=np.zeros(4, np.uint32))
+    with pytest.raises(gs.ResourceCountMismatch):
+        (B().bind_group_layouts([1, 1]).resolver(gs.SourceResolver({"m": ARRAY_MAP_ADD_SRC})).main_shader("m")
+         .entry_point("main").build(device, [[data]]))

@@ -587,6 +587,24 @@ class KernelRegistry:
         return self.MODULES[key]
 
 
+class SourceResolver:
+    """Resolver over caller-supplied HIP C++ modules (the analogue of a wesl::PkgResolver holding
+    the caller's own package next to shader::PACKAGE).  A module's text may
+    `#include <wgpu_3dgs_core.h>` to import the device library."""
+
+    def __init__(self, modules=None):
+        self.modules = dict(modules or {})
+
+    def add_module(self, path, source):
+        self.modules[path] = source
+        return self
+
+    def resolve(self, path):
+        if path not in self.modules:
+            raise KernelResolveError("module not found: %s" % path)
+        return self.modules[path]
+
+
 def _buffer_array(buffers):
     arr = (C.c_void_p * len(buffers))(*[b._h for b in buffers])
     return arr
@@ -637,6 +655,46 @@ class ComputeBundle:
         h = C.c_void_p()
         _check(_L.gs_bundle_create(device._h, C.byref(d), C.byref(h)))
         return ComputeBundle(device, h, False)
+
+    @staticmethod
+    def new_from_source(label, device, layouts, source, entry_point, pod=None, workgroup_size=None,
+                        constants=None, defines=(), resources=None):
+        """Compile `source` (HIP C++) with hiprtc: ComputeBundleBuilder::build for a custom shader."""
+        constants = constants or {}
+        d = _capi.BundleSourceDesc()
+        d.label = label.encode() if label else None
+        d.source = source.encode()
+        d.entry_point = entry_point.encode()
+        d.sh, d.cov = (pod.sh, pod.cov) if pod is not None else (0, 0)
+        layouts = list(layouts)
+        arr = (C.c_uint32 * max(len(layouts), 1))(*layouts)
+        d.bind_group_count, d.bindings_per_group = len(layouts), arr
+        d.workgroup_size = workgroup_size or 0
+        names = (C.c_char_p * max(len(constants), 1))(*[k.encode() for k in constants])
+        vals = (C.c_double * max(len(constants), 1))(*[float(v) for v in constants.values()])
+        d.constant_names, d.constant_values, d.constant_count = names, vals, len(constants)
+        defs = (C.c_char_p * max(len(defines), 1))(*[x.encode() for x in defines])
+        d.defines, d.define_count = defs, len(defines)
+        h = C.c_void_p()
+        status = _L.gs_bundle_create_from_source(device._h, C.byref(d), C.byref(h))
+        if status == -20:
+            info = _capi.ErrorInfo()
+            _L.gs_last_error(C.byref(info))
+            raise KernelResolveError(info.message.decode(errors="replace"))
+        _check(status)
+        bundle = ComputeBundle(device, h, False)
+        if resources is not None:
+            resources = [list(r) for r in resources]
+            groups = [_buffer_array(r) for r in resources]
+            gp = (C.c_void_p * max(len(groups), 1))(*[C.cast(g, C.c_void_p) for g in groups])
+            counts = (C.c_uint32 * max(len(groups), 1))(*[len(r) for r in resources])
+            try:
+                _check(_L.gs_bundle_attach_bind_groups(h, gp, counts, len(groups)))
+            except GsError:
+                bundle.destroy()
+                raise
+            bundle._managed = True
+        return bundle
 
     def workgroup_size(self):
         return _L.gs_bundle_workgroup_size(self._h)
@@ -691,6 +749,7 @@ class ComputeBundleBuilder:
         self._pod = None
         self._resolver = None
         self._workgroup_size = None
+        self._defines = ()
 
     def label(self, label):
         self._label = label
@@ -717,9 +776,11 @@ class ComputeBundleBuilder:
         self._main_shader = module_path
         return self
 
-    def wesl_compile_options(self, features):
-        """`features` = a GaussianPod (its features() select the kernel instantiation)"""
+    def wesl_compile_options(self, features, defines=()):
+        """`features` = a GaussianPod (its features() select the kernel instantiation / the
+        GS_SH, GS_COV and feature-name macros); `defines` = further feature flags"""
         self._pod = features
+        self._defines = tuple(defines)
         return self
 
     def resolver(self, resolver):
@@ -743,11 +804,19 @@ class ComputeBundleBuilder:
 
     def build(self, device, resources):
         kernel = self._resolve()
+        if isinstance(kernel, str):   # a module of a SourceResolver: compile it
+            return ComputeBundle.new_from_source(self._label, device, self._layouts, kernel,
+                                                 self._entry_point, self._pod, self._workgroup_size,
+                                                 self._constants, self._defines, resources)
         return ComputeBundle.new(self._label, device, self._layouts, resources, kernel, self._pod,
                                  self._workgroup_size, self._constants)
 
     def build_without_bind_groups(self, device):
         kernel = self._resolve()
+        if isinstance(kernel, str):
+            return ComputeBundle.new_from_source(self._label, device, self._layouts, kernel,
+                                                 self._entry_point, self._pod, self._workgroup_size,
+                                                 self._constants, self._defines, None)
         return ComputeBundle.new_without_bind_groups(self._label, device, self._layouts, kernel,
                                                      self._pod, self._workgroup_size, self._constants)
 

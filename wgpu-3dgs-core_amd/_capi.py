@@ -48,6 +48,14 @@ class BundleDesc(C.Structure):
                 ("constant_values", C.POINTER(C.c_double)), ("constant_count", u32)]
 
 
+class BundleSourceDesc(C.Structure):
+    _fields_ = [("label", C.c_char_p), ("source", C.c_char_p), ("entry_point", C.c_char_p),
+                ("sh", i32), ("cov", i32), ("bind_group_count", u32),
+                ("bindings_per_group", C.POINTER(u32)), ("workgroup_size", u32),
+                ("constant_names", C.POINTER(C.c_char_p)), ("constant_values", C.POINTER(C.c_double)),
+                ("constant_count", u32), ("defines", C.POINTER(C.c_char_p)), ("define_count", u32)]
+
+
 # name -> (restype, argtypes); must list every function declared in include/gs3d.h
 SIGNATURES = {
     "gs_last_error": (None, [vp]),
@@ -109,6 +117,8 @@ SIGNATURES = {
     "gs_model_transform_buffer_from_buffer": (i32, [vp]),
     "gs_bundle_create": (i32, [vp, vp, vp]),
     "gs_bundle_create_with_bind_groups": (i32, [vp, vp, vp, vp, u32, vp]),
+    "gs_bundle_create_from_source": (i32, [vp, vp, vp]),
+    "gs_bundle_attach_bind_groups": (i32, [vp, vp, vp, u32]),
     "gs_bundle_destroy": (None, [vp]),
     "gs_bundle_workgroup_size": (u32, [vp]),
     "gs_bundle_label": (C.c_char_p, [vp]),

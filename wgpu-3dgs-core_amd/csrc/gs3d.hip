@@ -4,6 +4,7 @@
 #include "gs_internal.h"
 
 #include <hip/hip_runtime.h>
+#include <hip/hiprtc.h>
 
 #include <atomic>
 #include <cmath>
@@ -17,6 +18,7 @@
 
 #include "gs_bundle_kernels.h"
 #include "gs_render_kernels.h"
+#include "_gen_kernel_lib_src.h"
 
 // ------------------------------------------------------------------------------------------------
 // errors
@@ -342,6 +344,9 @@ struct gs_buffer {
 static gs_status use_device(const gs_device *dev) {
     if (!dev) return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "null device");
     GS_HIP(hipSetDevice(dev->ordinal));
+    // HIP's "last error" is sticky per thread: drop whatever an earlier, already reported failure
+    // left behind so that the hipGetLastError() checks after our launches only see our launches
+    (void)hipGetLastError();
     return GS_OK;
 }
 
@@ -771,6 +776,10 @@ struct gs_bundle {
     bool has_additional_constant;
     uint32_t additional_constant;
     uint32_t last_workgroups;
+    // bundles compiled from source (gs_bundle_create_from_source)
+    bool from_source = false;
+    hipModule_t module = nullptr;
+    hipFunction_t func = nullptr;
 };
 
 extern "C" gs_status gs_bundle_create(gs_device *dev, const gs_bundle_desc *desc, gs_bundle **out) {
@@ -873,7 +882,123 @@ extern "C" gs_status gs_bundle_create_with_bind_groups(gs_device *dev, const gs_
 extern "C" void gs_bundle_destroy(gs_bundle *b) {
     if (!b) return;
     for (auto &g : b->groups) release_group(g);
+    if (b->module) {
+        (void)hipSetDevice(b->dev->ordinal);
+        (void)hipModuleUnload(b->module);
+    }
     delete b;
+}
+
+extern "C" gs_status gs_bundle_create_from_source(gs_device *dev, const gs_bundle_source_desc *desc,
+                                                  gs_bundle **out) {
+    if (!dev || !desc || !out) return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "null argument");
+    // same order of checks as ComputeBundleBuilder::build (compute_bundle.rs:505-519)
+    if (desc->bind_group_count == 0 || !desc->bindings_per_group)
+        return fail(GS_ERR_MISSING_BIND_GROUP_LAYOUT, 0, 0, 0, "missing bind group layout for compute bundle");
+    if (!desc->entry_point) return fail(GS_ERR_MISSING_ENTRY_POINT, 0, 0, 0, "missing entry point for compute bundle");
+    if (!desc->source) return fail(GS_ERR_MISSING_MAIN_SHADER, 0, 0, 0, "missing main shader for compute bundle");
+    if (!valid_cfg(desc->sh, desc->cov)) return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "bad config");
+    uint32_t limit = dev->limits.max_compute_workgroup_size_x <
+                             dev->limits.max_compute_invocations_per_workgroup
+                         ? dev->limits.max_compute_workgroup_size_x
+                         : dev->limits.max_compute_invocations_per_workgroup;
+    uint32_t wg = desc->workgroup_size ? desc->workgroup_size : limit;
+    if (wg > limit)
+        return fail(GS_ERR_WORKGROUP_SIZE_EXCEEDS_LIMIT, wg, limit, 0,
+                    "workgroup size exceeds device limit: %u > %u", wg, limit);
+    uint32_t total = 0;
+    for (uint32_t i = 0; i < desc->bind_group_count; i++) total += desc->bindings_per_group[i];
+    if (total > (uint32_t)gs::MAX_BINDINGS)
+        return fail(GS_ERR_INVALID_ARGUMENT, total, gs::MAX_BINDINGS, 0, "too many bindings");
+    GS_TRY(use_device(dev));
+
+    std::vector<std::string> opts;
+    opts.push_back(std::string("--offload-arch=") + dev->limits.arch_name);
+    opts.push_back("-std=c++17");
+    opts.push_back("-ffp-contract=off");
+    opts.push_back("-DGS_SH=" + std::to_string((int)desc->sh));
+    opts.push_back("-DGS_COV=" + std::to_string((int)desc->cov));
+    opts.push_back(std::string("-D") + k_feature_names[desc->sh] + "=1");
+    opts.push_back(std::string("-D") + k_feature_names[4 + desc->cov] + "=1");
+    opts.push_back("-Dworkgroup_size=" + std::to_string(wg));
+    for (uint32_t i = 0; i < desc->define_count; i++)
+        if (desc->defines && desc->defines[i]) opts.push_back(std::string("-D") + desc->defines[i] + "=1");
+    for (uint32_t i = 0; i < desc->constant_count; i++) {
+        if (!desc->constant_names || !desc->constant_names[i]) continue;
+        double v = desc->constant_values[i];
+        char buf[64];
+        if (v == (double)(long long)v) std::snprintf(buf, sizeof(buf), "%lld", (long long)v);
+        else std::snprintf(buf, sizeof(buf), "%.17g", v);
+        opts.push_back(std::string("-D") + desc->constant_names[i] + "=" + buf);
+    }
+    std::string entry = desc->entry_point;
+    opts.push_back("-Dmain=gs_entry_main");   // `main` cannot name a kernel in C++: always renamed
+    if (entry == "main") entry = "gs_entry_main";
+    std::vector<const char *> copts;
+    for (auto &o : opts) copts.push_back(o.c_str());
+
+    hiprtcProgram prog;
+    const char *hdr_src[1] = {k_kernel_lib_src};
+    const char *hdr_names[1] = {"wgpu_3dgs_core.h"};
+    hiprtcResult rr = hiprtcCreateProgram(&prog, desc->source, "main_shader.hip", 1, hdr_src, hdr_names);
+    if (rr != HIPRTC_SUCCESS)
+        return fail(GS_ERR_KERNEL_COMPILE, (uint64_t)rr, 0, 0, "hiprtcCreateProgram: %s", hiprtcGetErrorString(rr));
+    rr = hiprtcCompileProgram(prog, (int)copts.size(), copts.data());
+    if (rr != HIPRTC_SUCCESS) {
+        size_t n = 0;
+        (void)hiprtcGetProgramLogSize(prog, &n);
+        std::string log(n ? n : 1, '\0');
+        if (n) (void)hiprtcGetProgramLog(prog, &log[0]);
+        (void)hiprtcDestroyProgram(&prog);
+        // keep the first error lines
+        size_t e = log.find("error");
+        std::string shown = e == std::string::npos ? log : log.substr(e > 80 ? e - 80 : 0);
+        return fail(GS_ERR_KERNEL_COMPILE, (uint64_t)rr, 0, 0, "kernel compilation failed: %.200s", shown.c_str());
+    }
+    size_t code_size = 0;
+    (void)hiprtcGetCodeSize(prog, &code_size);
+    std::vector<char> code(code_size);
+    (void)hiprtcGetCode(prog, code.data());
+    (void)hiprtcDestroyProgram(&prog);
+
+    gs_bundle *b = new gs_bundle();
+    b->dev = dev;
+    b->label = desc->label ? desc->label : "";
+    b->kernel = GS_KERNEL_COUNT_;
+    b->sh = desc->sh;
+    b->cov = desc->cov;
+    b->workgroup_size = wg;
+    b->layout.assign(desc->bindings_per_group, desc->bindings_per_group + desc->bind_group_count);
+    b->managed = false;
+    b->has_additional_constant = false;
+    b->additional_constant = 0;
+    b->last_workgroups = 0;
+    b->from_source = true;
+    hipError_t he = hipModuleLoadData(&b->module, code.data());
+    if (he == hipSuccess) he = hipModuleGetFunction(&b->func, b->module, entry.c_str());
+    if (he != hipSuccess) {
+        gs_bundle_destroy(b);
+        return fail(GS_ERR_MISSING_ENTRY_POINT, (uint64_t)he, 0, 0, "entry point '%s' not found in the compiled module: %s",
+                    desc->entry_point, hipGetErrorString(he));
+    }
+    *out = b;
+    return GS_OK;
+}
+
+// bind groups for a bundle created without them (gs_bundle_create / _from_source): makes it managed
+extern "C" gs_status gs_bundle_attach_bind_groups(gs_bundle *b, gs_buffer *const *const *resources,
+                                                  const uint32_t *resource_counts,
+                                                  uint32_t resource_group_count) {
+    if (!b) return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "null bundle");
+    if (resource_group_count != b->layout.size())
+        return fail(GS_ERR_RESOURCE_COUNT_MISMATCH, resource_group_count, b->layout.size(), 0,
+                    "resource count and bind group layout count mismatch: %u != %zu",
+                    resource_group_count, b->layout.size());
+    b->managed = true;
+    b->groups.resize(b->layout.size());
+    for (uint32_t i = 0; i < resource_group_count; i++)
+        GS_TRY(gs_bundle_set_bind_group(b, i, resources[i], resource_counts[i]));
+    return GS_OK;
 }
 
 extern "C" uint32_t gs_bundle_workgroup_size(const gs_bundle *b) { return b ? b->workgroup_size : 0; }
@@ -946,15 +1071,23 @@ static gs_status dispatch_groups(gs_bundle *b, gs_stream *s, uint32_t count,
             n++;
         }
     }
-    a.has_second_group = b->layout.size() > 1 ? 1u : 0u;
-    a.has_additional_constant = b->has_additional_constant ? 1u : 0u;
-    a.additional_constant = b->additional_constant;
-    GS_TRY(validate_bindings(b, a, n));
+    a.reg_second_group = b->layout.size() > 1 ? 1u : 0u;
+    a.reg_has_constant = b->has_additional_constant ? 1u : 0u;
+    a.reg_constant = b->additional_constant;
+    if (!b->from_source) GS_TRY(validate_bindings(b, a, n));
     GS_TRY(use_device(b->dev));
     // compute_bundle.rs:131 — dispatch_workgroups(count.div_ceil(workgroup_size), 1, 1)
     uint32_t wgs = count / b->workgroup_size + (count % b->workgroup_size != 0);
     b->last_workgroups = wgs;
     if (wgs == 0) return GS_OK;
+    if (b->from_source) {
+        struct { gs::BundleArgs a; uint32_t count; } params{a, count};
+        size_t psize = sizeof(params);
+        void *config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &params, HIP_LAUNCH_PARAM_BUFFER_SIZE, &psize,
+                          HIP_LAUNCH_PARAM_END};
+        GS_HIP(hipModuleLaunchKernel(b->func, wgs, 1, 1, b->workgroup_size, 1, 1, 0, s->s, nullptr, config));
+        return GS_OK;
+    }
     bundle_kernel_fn fn = nullptr;
     switch (b->kernel) {
     case GS_KERNEL_ARRAY_MAP_ADD: fn = gs::k_array_map_add; break;

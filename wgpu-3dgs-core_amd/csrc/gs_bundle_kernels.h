@@ -8,18 +8,6 @@
 
 namespace gs {
 
-constexpr int MAX_BINDINGS = 8;
-
-// Flattened bind groups (group-major, binding order) + override constants.
-struct BundleArgs {
-    void *ptr[MAX_BINDINGS];
-    uint64_t size[MAX_BINDINGS];
-    uint32_t has_second_group;
-    uint32_t has_additional_constant;
-    uint32_t additional_constant;
-    uint32_t _pad;
-};
-
 // tests/common/shader/array_map_add.wesl:1-28
 __global__ void k_array_map_add(BundleArgs a, uint32_t count) {
     (void)count;
@@ -27,8 +15,8 @@ __global__ void k_array_map_add(BundleArgs a, uint32_t count) {
     uint32_t *data = (uint32_t *)a.ptr[0];
     if (index >= (uint32_t)(a.size[0] / 4u)) return;
     uint32_t v = data[index] + 1u;
-    if (a.has_second_group) v += *(const uint32_t *)a.ptr[1];
-    if (a.has_additional_constant) v += a.additional_constant;
+    if (a.reg_second_group) v += *(const uint32_t *)a.ptr[1];
+    if (a.reg_has_constant) v += a.reg_constant;
     data[index] = v;
 }
 

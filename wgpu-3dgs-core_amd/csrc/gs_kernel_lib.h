@@ -14,8 +14,16 @@
 // -ffp-contract=off, so nothing below fuses unless __builtin_fmaf is written.
 #pragma once
 
+#ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#else   // compiled at run time by hiprtc (gs_bundle_create_from_source): no system headers
+typedef signed char int8_t;
+typedef unsigned char uint8_t;
+typedef unsigned short uint16_t;
+typedef unsigned int uint32_t;
+typedef unsigned long long uint64_t;
+#endif
 
 namespace gs {
 
@@ -232,5 +240,20 @@ __host__ __device__ __forceinline__ void model_to_world(const ModelTransform &m,
     model_transform_mat(m, mat);
     mat4_mul_point(mat, p, out);
 }
+
+// ---- bind groups as seen by a kernel ---------------------------------------------------------------
+// Every ComputeBundle kernel (built-in or compiled from source with gs_bundle_create_from_source)
+// has the signature  __global__ void entry(gs::BundleArgs a, uint32_t count):
+// the bind groups flattened group-major in binding order (buffer pointer + byte size).
+constexpr int MAX_BINDINGS = 8;
+
+struct BundleArgs {
+    void *ptr[MAX_BINDINGS];
+    uint64_t size[MAX_BINDINGS];
+    uint32_t reg_second_group;
+    uint32_t reg_has_constant;
+    uint32_t reg_constant;
+    uint32_t _pad;
+};
 
 }  // namespace gs
