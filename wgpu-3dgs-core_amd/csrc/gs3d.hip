@@ -325,6 +325,7 @@ struct gs_device {
     int ordinal;
     gs_limits limits;
     hipStream_t internal;  // for blocking helper work
+    bool lds_atomic_ordered;   // probe result: returning LDS atomics hand out lane-ordered values
 };
 
 struct gs_stream {
@@ -376,6 +377,23 @@ extern "C" gs_status gs_device_create(int32_t ordinal, gs_device **out) {
     if (se != hipSuccess) {
         delete d;
         return fail(GS_ERR_HIP, (uint64_t)se, 0, 0, "hipStreamCreate failed: %s", hipGetErrorString(se));
+    }
+    // probe the LDS-atomic ordering the fast radix ranking relies on (gs_render_kernels.h)
+    d->lds_atomic_ordered = false;
+    if (!std::getenv("GS3D_DISABLE_FAST_RANK")) {
+        uint32_t *bad = nullptr;
+        if (hipMalloc((void **)&bad, 4) == hipSuccess) {
+            uint32_t h = 1;
+            if (hipMemset(bad, 0, 4) == hipSuccess) {
+                hipLaunchKernelGGL(gs::k_probe_lds_atomic_order, dim3(512), dim3(256), 0, d->internal, 64u,
+                                   0x3D650001u, bad);
+                if (hipStreamSynchronize(d->internal) == hipSuccess &&
+                    hipMemcpy(&h, bad, 4, hipMemcpyDeviceToHost) == hipSuccess)
+                    d->lds_atomic_ordered = (h == 0);
+            }
+            (void)hipFree(bad);
+        }
+        (void)hipGetLastError();
     }
     *out = d;
     return GS_OK;
@@ -1375,9 +1393,10 @@ static uint32_t bit_length(uint32_t v) {
 // Stable LSD radix sort of `count` (key, u32 value) pairs on key bits [0, end_bit), 8 bits per
 // pass, ping-ponging between side 0 and side 1; the side holding the result is returned.
 template <typename K>
-static gs_status sort_pairs_device(void *const keys[2], void *const vals[2], DevArray &ghist,
-                                   DevArray &digit_totals, uint32_t count, uint32_t end_bit,
-                                   hipStream_t st, int &result_side, uint32_t &passes_out) {
+static gs_status sort_pairs_device(const gs_device *dev, void *const keys[2], void *const vals[2],
+                                   DevArray &ghist, DevArray &digit_totals, uint32_t count,
+                                   uint32_t end_bit, hipStream_t st, int &result_side,
+                                   uint32_t &passes_out) {
     uint32_t passes = (end_bit + gs::RADIX_BITS - 1) / gs::RADIX_BITS;
     passes_out = passes;
     result_side = 0;
@@ -1397,9 +1416,14 @@ static gs_status sort_pairs_device(void *const keys[2], void *const vals[2], Dev
                            shift, (uint32_t *)ghist.ptr, nb);
         hipLaunchKernelGGL(gs::k_sort_scan_rows, dim3(gs::RADIX), dim3(256), 0, st,
                            (uint32_t *)ghist.ptr, nb, (uint32_t *)digit_totals.ptr);
-        hipLaunchKernelGGL(gs::k_sort_scatter<K>, dim3(nb), dim3(gs::SORT_THREADS), 0, st, kin, vin,
-                           kout, vout, count, shift, (const uint32_t *)ghist.ptr, nb,
-                           (const uint32_t *)digit_totals.ptr);
+        if (dev->lds_atomic_ordered)
+            hipLaunchKernelGGL((gs::k_sort_scatter<K, true>), dim3(nb), dim3(gs::SORT_THREADS), 0, st, kin,
+                               vin, kout, vout, count, shift, (const uint32_t *)ghist.ptr, nb,
+                               (const uint32_t *)digit_totals.ptr);
+        else
+            hipLaunchKernelGGL((gs::k_sort_scatter<K, false>), dim3(nb), dim3(gs::SORT_THREADS), 0, st, kin,
+                               vin, kout, vout, count, shift, (const uint32_t *)ghist.ptr, nb,
+                               (const uint32_t *)digit_totals.ptr);
         side ^= 1;
     }
     GS_HIP(hipGetLastError());
@@ -1504,7 +1528,7 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
     {
         void *k2[2] = {r->dkeys[0].ptr, r->dkeys[1].ptr};
         void *v2[2] = {r->dvals[0].ptr, r->dvals[1].ptr};
-        GS_TRY(sort_pairs_device<uint32_t>(k2, v2, r->ghist, r->digit_totals, visible, 32, st, dside,
+        GS_TRY(sort_pairs_device<uint32_t>(r->dev, k2, v2, r->ghist, r->digit_totals, visible, 32, st, dside,
                                            dpasses));
     }
     mark(ST_EXPAND);
@@ -1543,17 +1567,17 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
         void *v2[2] = {r->tvals[0].ptr, r->tvals[1].ptr};
         uint32_t tile_bits = bit_length(num_tiles ? num_tiles - 1 : 0);
         if (wide)
-            GS_TRY(sort_pairs_device<uint32_t>(k2, v2, r->ghist, r->digit_totals, d, tile_bits, st,
+            GS_TRY(sort_pairs_device<uint32_t>(r->dev, k2, v2, r->ghist, r->digit_totals, d, tile_bits, st,
                                                tside, tpasses));
         else
-            GS_TRY(sort_pairs_device<uint16_t>(k2, v2, r->ghist, r->digit_totals, d, tile_bits, st,
+            GS_TRY(sort_pairs_device<uint16_t>(r->dev, k2, v2, r->ghist, r->digit_totals, d, tile_bits, st,
                                                tside, tpasses));
     }
     mark(ST_RANGES);
     GS_HIP(hipMemsetAsync(r->ranges.ptr, 0, (size_t)num_tiles * 8, st));
     if (d) {
         if (wide)
-            hipLaunchKernelGGL(gs::k_tile_ranges<uint32_t>, dim3((d + 2047) / 2048), dim3(256), 0, st,
+            hipLaunchKernelGGL(gs::k_tile_ranges<uint32_t>, dim3((d + 1023) / 1024), dim3(256), 0, st,
                                (const uint32_t *)r->tkeys[tside].ptr, d, (uint32_t *)r->ranges.ptr);
         else
             hipLaunchKernelGGL(gs::k_tile_ranges<uint16_t>, dim3((d + 2047) / 2048), dim3(256), 0, st,
@@ -1693,7 +1717,7 @@ extern "C" gs_status gs_sort_pairs_u64(gs_device *dev, gs_stream *s, uint64_t *k
     if (rc == GS_OK) {
         void *k2[2] = {k[0].ptr, k[1].ptr};
         void *v2[2] = {v[0].ptr, v[1].ptr};
-        rc = sort_pairs_device<uint64_t>(k2, v2, gh, dt, (uint32_t)count, end_bit, st, side, passes);
+        rc = sort_pairs_device<uint64_t>(dev, k2, v2, gh, dt, (uint32_t)count, end_bit, st, side, passes);
     }
     if (rc == GS_OK) {
         hipError_t e = hipMemcpyAsync(keys, k[side].ptr, count * 8, hipMemcpyDeviceToHost, st);

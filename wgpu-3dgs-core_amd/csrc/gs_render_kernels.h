@@ -318,16 +318,23 @@ struct ScanJob {
 };
 
 __global__ __launch_bounds__(1024) void k_scan_chunks(ScanJob j0, ScanJob j1) {
+    constexpr uint32_t PER = 8;   // consecutive values per thread -> 8192 per iteration
     __shared__ uint32_t s_wave[16];
     __shared__ uint32_t s_carry;
     const ScanJob job = blockIdx.x == 0 ? j0 : j1;
     uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
     if (threadIdx.x == 0) s_carry = 0;
     __syncthreads();
-    for (uint32_t base = 0; base < job.num; base += 1024u) {
-        uint32_t i = base + threadIdx.x;
-        uint32_t v = i < job.num ? job.sums[i] : 0u;
-        uint32_t inc = wave_inclusive_scan(v, lane);
+    for (uint32_t base = 0; base < job.num; base += 1024u * PER) {
+        uint32_t i0 = base + threadIdx.x * PER;
+        uint32_t v[PER];
+        uint32_t sum = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < PER; k++) {
+            v[k] = i0 + k < job.num ? job.sums[i0 + k] : 0u;
+            sum += v[k];
+        }
+        uint32_t inc = wave_inclusive_scan(sum, lane);
         if (lane == 63u) s_wave[wid] = inc;
         __syncthreads();
         uint32_t wave_off = 0, tot = 0;
@@ -338,7 +345,12 @@ __global__ __launch_bounds__(1024) void k_scan_chunks(ScanJob j0, ScanJob j1) {
             tot += x;
         }
         uint32_t carry = s_carry;
-        if (i < job.num) job.offsets[i] = carry + wave_off + inc - v;
+        uint32_t run = carry + wave_off + inc - sum;
+#pragma unroll
+        for (uint32_t k = 0; k < PER; k++) {
+            if (i0 + k < job.num) job.offsets[i0 + k] = run;
+            run += v[k];
+        }
         __syncthreads();
         if (threadIdx.x == 0) s_carry = carry + tot;
         __syncthreads();
@@ -503,12 +515,33 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_hist(const K *__restrict_
 #pragma unroll
     for (int c = 0; c < 8; c++) s_hist[c][threadIdx.x] = 0;
     __syncthreads();
-    uint32_t base = blockIdx.x * (SORT_THREADS * ITEMS);
+    const uint32_t base = blockIdx.x * (SORT_THREADS * ITEMS);
     const uint32_t copy = threadIdx.x & 7u;
+    // 16-byte loads: the order of the keys does not matter for a histogram
+    constexpr int PER_VEC = 16 / sizeof(K);
+    constexpr int VECS = ITEMS / PER_VEC;
+    static_assert(ITEMS % PER_VEC == 0, "tile must be a whole number of 16-byte vectors per thread");
+    if (base + SORT_THREADS * ITEMS <= count) {
+        const uint4 *src = (const uint4 *)(keys + base);
 #pragma unroll
-    for (int k = 0; k < ITEMS; k++) {
-        uint32_t i = base + k * SORT_THREADS + threadIdx.x;
-        if (i < count) atomicAdd(&s_hist[copy][(uint32_t)(keys[i] >> shift) & (RADIX - 1)], 1u);
+        for (int v = 0; v < VECS; v++) {
+            uint4 q = src[v * SORT_THREADS + threadIdx.x];
+            uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int e = 0; e < PER_VEC; e++) {
+                K k;
+                if constexpr (sizeof(K) == 2) k = (K)(w[e >> 1] >> (16 * (e & 1)));
+                else if constexpr (sizeof(K) == 4) k = (K)w[e];
+                else k = (K)(((uint64_t)w[2 * e + 1] << 32) | w[2 * e]);
+                atomicAdd(&s_hist[copy][(uint32_t)(k >> shift) & (RADIX - 1)], 1u);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < ITEMS; k++) {
+            uint32_t i = base + k * SORT_THREADS + threadIdx.x;
+            if (i < count) atomicAdd(&s_hist[copy][(uint32_t)(keys[i] >> shift) & (RADIX - 1)], 1u);
+        }
     }
     __syncthreads();
     uint32_t sum = 0;
@@ -538,7 +571,13 @@ __global__ __launch_bounds__(256) void k_sort_scan_rows(uint32_t *__restrict__ g
 // Stable scatter.  Element order inside a workgroup tile: wave w owns ITEMS*64 consecutive
 // elements, round k of the wave covers 64 consecutive elements, lane order inside a round; ranks
 // are assigned in exactly that order, so equal digits keep their order.
-template <typename K>
+// FAST_RANK: on gfx950 a returning LDS atomic (ds_add_rtn_u32) issued by one wave instruction
+// hands out its pre-add values in increasing lane order when several lanes hit the same address
+// (measured: tools/mb/mb_ldsatomic.hip, 0 violations in 5e7 operations).  One such atomic per key
+// then IS the stable rank.  This is not an architectural guarantee, so gs_device_create probes it
+// (k_probe_lds_atomic_order) and the host falls back to the ballot-based ranking if the probe
+// ever fails.
+template <typename K, bool FAST_RANK>
 __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
     const K *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, K *__restrict__ keys_out,
     uint32_t *__restrict__ vals_out, uint32_t count, uint32_t shift,
@@ -570,21 +609,29 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
         key[k] = ok ? keys_in[i] : (K)~(K)0;
         val[k] = ok ? vals_in[i] : 0u;
     }
+    if constexpr (FAST_RANK) {
 #pragma unroll
-    for (int k = 0; k < ITEMS; k++) {
-        uint32_t d = (uint32_t)(key[k] >> shift) & (RADIX - 1);
-        // wave64 match-any on the digit: peers = lanes holding the same digit
-        uint64_t peers = ~0ull;
-#pragma unroll
-        for (int b = 0; b < RADIX_BITS; b++) {
-            uint64_t m = __ballot((d >> b) & 1u);
-            peers &= ((d >> b) & 1u) ? m : ~m;
+        for (int k = 0; k < ITEMS; k++) {
+            uint32_t d = (uint32_t)(key[k] >> shift) & (RADIX - 1);
+            rank[k] = atomicAdd(&s_wave_hist[wid][d], 1u);
         }
-        uint32_t before = mbcnt(peers);             // same-digit lanes below me
-        uint32_t old = s_wave_hist[wid][d];
-        rank[k] = old + before;
-        if (before == 0u) s_wave_hist[wid][d] = old + (uint32_t)__popcll(peers);
-        __builtin_amdgcn_wave_barrier();
+    } else {
+#pragma unroll
+        for (int k = 0; k < ITEMS; k++) {
+            uint32_t d = (uint32_t)(key[k] >> shift) & (RADIX - 1);
+            // wave64 match-any on the digit: peers = lanes holding the same digit
+            uint64_t peers = ~0ull;
+#pragma unroll
+            for (int b = 0; b < RADIX_BITS; b++) {
+                uint64_t m = __ballot((d >> b) & 1u);
+                peers &= ((d >> b) & 1u) ? m : ~m;
+            }
+            uint32_t before = mbcnt(peers);             // same-digit lanes below me
+            uint32_t old = s_wave_hist[wid][d];
+            rank[k] = old + before;
+            if (before == 0u) s_wave_hist[wid][d] = old + (uint32_t)__popcll(peers);
+            __builtin_amdgcn_wave_barrier();
+        }
     }
     __syncthreads();
 
@@ -631,29 +678,71 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
     }
 }
 
+// Probe for FAST_RANK: every wave adds 1 to LDS counters chosen by a hash; bad[0] counts lanes whose
+// returned value is not (count before this round) + (lower lanes with the same address).
+__global__ __launch_bounds__(256) void k_probe_lds_atomic_order(uint32_t rounds, uint32_t seed,
+                                                                uint32_t *__restrict__ bad) {
+    __shared__ uint32_t s_cnt[4][RADIX];
+    const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+#pragma unroll
+    for (int w = 0; w < 4; w++) s_cnt[w][threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t errors = 0;
+    for (uint32_t r = 0; r < rounds; r++) {
+        uint32_t x = (blockIdx.x * rounds + r) * 256u + threadIdx.x + seed;
+        x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+        // mix of uniform digits, few digits, runs and all-equal rounds
+        uint32_t mode = r & 3u;
+        uint32_t d = mode == 0 ? (x & 255u) : mode == 1 ? (x & 3u) : mode == 2 ? ((lane >> 3) & 255u) : 7u;
+        uint64_t peers = ~0ull;
+#pragma unroll
+        for (int b = 0; b < RADIX_BITS; b++) {
+            uint64_t m = __ballot((d >> b) & 1u);
+            peers &= ((d >> b) & 1u) ? m : ~m;
+        }
+        uint32_t expect = s_cnt[wid][d] + mbcnt(peers);
+        __builtin_amdgcn_wave_barrier();
+        uint32_t got = atomicAdd(&s_cnt[wid][d], 1u);
+        __builtin_amdgcn_wave_barrier();
+        errors += got != expect;
+    }
+    if (errors) atomicAdd(bad, errors);
+}
+
 // ---------------------------------------------------------------------------------------------
 // tile ranges (row x5a)
 // ---------------------------------------------------------------------------------------------
 
-constexpr int RANGE_ITEMS = 8;   // consecutive keys per thread
+// consecutive keys per thread = one 16-byte load
+template <typename TK> constexpr int range_items() { return 16 / sizeof(TK); }
 
 template <typename TK>
 __global__ __launch_bounds__(256) void k_tile_ranges(const TK *__restrict__ tkeys, uint32_t count,
                                                      uint32_t *__restrict__ ranges) {
-    const uint32_t j0 = (blockIdx.x * 256u + threadIdx.x) * RANGE_ITEMS;
+    constexpr int N = range_items<TK>();
+    const uint32_t j0 = (blockIdx.x * 256u + threadIdx.x) * N;
     if (j0 >= count) return;
+    uint32_t tile[N];
+    if (j0 + N <= count) {
+        uint4 q = *(const uint4 *)(tkeys + j0);
+        uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int e = 0; e < N; e++) tile[e] = sizeof(TK) == 2 ? (w[e >> 1] >> (16 * (e & 1))) & 0xffffu : w[e];
+    } else {
+#pragma unroll
+        for (int e = 0; e < N; e++) tile[e] = j0 + e < count ? (uint32_t)tkeys[j0 + e] : 0u;
+    }
     uint32_t prev = j0 ? (uint32_t)tkeys[j0 - 1] : 0xffffffffu;
 #pragma unroll
-    for (int k = 0; k < RANGE_ITEMS; k++) {
-        uint32_t j = j0 + k;
+    for (int e = 0; e < N; e++) {
+        uint32_t j = j0 + e;
         if (j < count) {
-            uint32_t tile = tkeys[j];
-            if (tile != prev) {
-                ranges[2 * tile] = j;
+            if (tile[e] != prev) {
+                ranges[2 * tile[e]] = j;
                 if (prev != 0xffffffffu) ranges[2 * prev + 1] = j;
             }
-            if (j + 1 == count) ranges[2 * tile + 1] = j + 1;
-            prev = tile;
+            if (j + 1 == count) ranges[2 * tile[e] + 1] = j + 1;
+            prev = tile[e];
         }
     }
 }
