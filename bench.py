@@ -3,8 +3,9 @@
 
     python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
 
-A "step" is one frame (repack-if-dirty -> preprocess -> scan -> key emit -> radix sort -> tile
-ranges -> blend [-> RCCL all-gather of the RGBA rows when N > 1]) of a synthetic random-Gaussian
+A "step" is one frame (repack-if-dirty -> preprocess -> scan/compact -> depth sort -> pair
+expansion -> tile sort -> ranges -> blend [-> RCCL all-gather of the RGBA rows when N > 1]) of a
+synthetic random-Gaussian
 scene at 1920x1080 with the scene already resident in HBM.  The headline `value` is BASELINE.json's
 metric, Msplats/s = Gaussians / frame time, on configs[1] (1 M Gaussians, SH degree 0); the
 `roofline` object is measured on configs[2] (10 M Gaussians, SH degree 3, 224-byte records), the
