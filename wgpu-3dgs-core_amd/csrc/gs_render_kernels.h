@@ -909,9 +909,15 @@ __global__ __launch_bounds__(BLEND_THREADS) void k_blend(const uint32_t *__restr
                 const bool p0 = power.x <= 0.0f && power.x >= cq.y;
                 const bool p1 = power.y <= 0.0f && power.y >= cq.y;
                 if (!__any(p0 || p1)) continue;
-                // exp on both pixels
+                // exp on both pixels.  n = rint(t) is taken with the 1.5*2^23 magic
+                // constant (t + M - M == rint(t) for |t| < 2^22, ties to even like rintf), and the
+                // final ldexp(p, n) is an integer add of n into the exponent field: bits(t + M) =
+                // bits(M) + n and bits(M) has its low 9 bits clear, so (bits(t + M) << 23) is
+                // exactly n << 23 (mod 2^32).  Both equal the spec's rintf / ldexpf bit for bit
+                // wherever the result is used (power in [-5.6, 0] => normal numbers).
                 const f32x2 tt = power * f32x2{1.44269504088896340736f, 1.44269504088896340736f};
-                const f32x2 n = {rintf(tt.x), rintf(tt.y)};
+                const f32x2 tm = tt + f32x2{12582912.0f, 12582912.0f};
+                const f32x2 n = tm - f32x2{12582912.0f, 12582912.0f};
                 const f32x2 f = tt - n;
                 f32x2 p = {0x1.5f0896p-10f, 0x1.5f0896p-10f};
                 p = pk_fma(p, f, f32x2{0x1.3cbf6cp-7f, 0x1.3cbf6cp-7f});
@@ -919,27 +925,28 @@ __global__ __launch_bounds__(BLEND_THREADS) void k_blend(const uint32_t *__restr
                 p = pk_fma(p, f, f32x2{0x1.ebfa4ap-3f, 0x1.ebfa4ap-3f});
                 p = pk_fma(p, f, f32x2{0x1.62e430p-1f, 0x1.62e430p-1f});
                 p = pk_fma(p, f, f32x2{1.0f, 1.0f});
-                const f32x2 e = {ldexpf(p.x, (int)n.x), ldexpf(p.y, (int)n.y)};
+                const f32x2 e = {u2f(f2u(p.x) + (f2u(tm.x) << 23)), u2f(f2u(p.y) + (f2u(tm.y) << 23))};
                 const f32x2 oe = f32x2{bq.y, bq.y} * e;
                 const f32x2 alpha = {fminf(0.99f, oe.x), fminf(0.99f, oe.y)};
-                const f32x2 test_T = T * (f32x2{1.0f, 1.0f} - alpha);
                 const bool act0 = p0 && alpha.x >= (1.0f / 255.0f);
                 const bool act1 = p1 && alpha.y >= (1.0f / 255.0f);
-                const bool ok0 = act0 && test_T.x >= 0.0001f, ok1 = act1 && test_T.y >= 0.0001f;
-                const f32x2 aT = alpha * T;
-                const f32x2 wgt = {ok0 ? aT.x : 0.0f, ok1 ? aT.y : 0.0f};
+                // a pixel that skips this splat blends it with alpha 0: T * (1 - 0) == T and
+                // fma(rgb, 0 * T, C) == C exactly, so no selects are needed on T and C
+                f32x2 alpha_eff = {act0 ? alpha.x : 0.0f, act1 ? alpha.y : 0.0f};
+                f32x2 test_T = T * (f32x2{1.0f, 1.0f} - alpha_eff);
+                const bool fin0 = act0 && test_T.x < 0.0001f, fin1 = act1 && test_T.y < 0.0001f;
+                if (__any(fin0 || fin1)) {   // rare: some pixel reached T < 1e-4 -> it stops here
+                    if (fin0) { pyf.x = DEAD; alpha_eff.x = 0.0f; test_T.x = T.x; }
+                    if (fin1) { pyf.y = DEAD; alpha_eff.y = 0.0f; test_T.y = T.y; }
+                    remaining = __builtin_amdgcn_readfirstlane(
+                        remaining - ((uint32_t)__popcll(__ballot(fin0)) + (uint32_t)__popcll(__ballot(fin1))));
+                }
+                const f32x2 wgt = alpha_eff * T;
                 C0 = pk_fma(f32x2{bq.z, bq.z}, wgt, C0);
                 C1 = pk_fma(f32x2{bq.w, bq.w}, wgt, C1);
                 C2 = pk_fma(f32x2{cq.x, cq.x}, wgt, C2);
-                T = f32x2{ok0 ? test_T.x : T.x, ok1 ? test_T.y : T.y};
-                const bool fin0 = act0 && !ok0, fin1 = act1 && !ok1;
-                if (__any(fin0 || fin1)) {   // rare: some pixel reached T < 1e-4
-                    if (fin0) pyf.x = DEAD;
-                    if (fin1) pyf.y = DEAD;
-                    remaining = __builtin_amdgcn_readfirstlane(
-                        remaining - ((uint32_t)__popcll(__ballot(fin0)) + (uint32_t)__popcll(__ballot(fin1))));
-                    if (remaining == 0u) break;
-                }
+                T = test_T;
+                if (remaining == 0u) break;
             }
         }
     }
