@@ -1406,24 +1406,28 @@ static gs_status sort_pairs_device(const gs_device *dev, void *const keys[2], vo
     GS_TRY(dev_reserve(ghist, (size_t)nb * gs::RADIX * 4));
     GS_TRY(dev_reserve(digit_totals, gs::RADIX * 4));
     int side = 0;
+    uint32_t shift = 0;
     for (uint32_t p = 0; p < passes; p++) {
-        uint32_t shift = p * gs::RADIX_BITS;
+        // balanced digit widths: e.g. 13 bits -> 7 + 6, 15 -> 8 + 7, 32 -> 8 + 8 + 8 + 8
+        const uint32_t bits = (end_bit - shift + (passes - p) - 1) / (passes - p);
+        const uint32_t digit_mask = (1u << bits) - 1u;
         const K *kin = (const K *)keys[side];
         const uint32_t *vin = (const uint32_t *)vals[side];
         K *kout = (K *)keys[side ^ 1];
         uint32_t *vout = (uint32_t *)vals[side ^ 1];
         hipLaunchKernelGGL(gs::k_sort_hist<K>, dim3(nb), dim3(gs::SORT_THREADS), 0, st, kin, count,
-                           shift, (uint32_t *)ghist.ptr, nb);
+                           shift, digit_mask, (uint32_t *)ghist.ptr, nb);
         hipLaunchKernelGGL(gs::k_sort_scan_rows, dim3(gs::RADIX), dim3(256), 0, st,
                            (uint32_t *)ghist.ptr, nb, (uint32_t *)digit_totals.ptr);
         if (dev->lds_atomic_ordered)
             hipLaunchKernelGGL((gs::k_sort_scatter<K, true>), dim3(nb), dim3(gs::SORT_THREADS), 0, st, kin,
-                               vin, kout, vout, count, shift, (const uint32_t *)ghist.ptr, nb,
+                               vin, kout, vout, count, shift, digit_mask, (const uint32_t *)ghist.ptr, nb,
                                (const uint32_t *)digit_totals.ptr);
         else
             hipLaunchKernelGGL((gs::k_sort_scatter<K, false>), dim3(nb), dim3(gs::SORT_THREADS), 0, st, kin,
-                               vin, kout, vout, count, shift, (const uint32_t *)ghist.ptr, nb,
+                               vin, kout, vout, count, shift, digit_mask, (const uint32_t *)ghist.ptr, nb,
                                (const uint32_t *)digit_totals.ptr);
+        shift += bits;
         side ^= 1;
     }
     GS_HIP(hipGetLastError());

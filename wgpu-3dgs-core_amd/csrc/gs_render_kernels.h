@@ -487,7 +487,10 @@ __global__ __launch_bounds__(EXP_CHUNK) void k_expand_emit(
 }
 
 // ---------------------------------------------------------------------------------------------
-// radix sort (row x4): stable LSD, 8-bit digits; per pass: histogram -> row scan -> scatter.
+// radix sort (row x4): stable LSD, up to 8 bits per pass (the host balances the digit widths over
+// the passes: 13 tile bits -> 7 + 6, which doubles / quadruples the length of the digit runs a
+// workgroup writes and so the share of whole 64-byte sectors); per pass: histogram -> row scan ->
+// scatter.
 // Templated on the key type: u32 depth keys (4 passes), u16 / u32 tile keys (2 / 3 passes), and
 // u64 keys for the stand-alone gs_sort_pairs_u64.
 // ---------------------------------------------------------------------------------------------
@@ -499,7 +502,7 @@ constexpr int RADIX = 1 << RADIX_BITS;
 template <typename K> struct SortCfg;
 template <> struct SortCfg<uint64_t> { static constexpr int ITEMS = 8; };
 template <> struct SortCfg<uint32_t> { static constexpr int ITEMS = 16; };
-template <> struct SortCfg<uint16_t> { static constexpr int ITEMS = 16; };
+template <> struct SortCfg<uint16_t> { static constexpr int ITEMS = 32; };
 template <typename K> constexpr int sort_tile() { return SORT_THREADS * SortCfg<K>::ITEMS; }
 
 // ghist layout: [digit][block] (digit-major) so that the row scan reads contiguous memory.
@@ -508,6 +511,7 @@ template <typename K> constexpr int sort_tile() { return SORT_THREADS * SortCfg<
 template <typename K>
 __global__ __launch_bounds__(SORT_THREADS) void k_sort_hist(const K *__restrict__ keys,
                                                             uint32_t count, uint32_t shift,
+                                                            uint32_t digit_mask,
                                                             uint32_t *__restrict__ ghist,
                                                             uint32_t num_blocks) {
     constexpr int ITEMS = SortCfg<K>::ITEMS;
@@ -533,14 +537,14 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_hist(const K *__restrict_
                 if constexpr (sizeof(K) == 2) k = (K)(w[e >> 1] >> (16 * (e & 1)));
                 else if constexpr (sizeof(K) == 4) k = (K)w[e];
                 else k = (K)(((uint64_t)w[2 * e + 1] << 32) | w[2 * e]);
-                atomicAdd(&s_hist[copy][(uint32_t)(k >> shift) & (RADIX - 1)], 1u);
+                atomicAdd(&s_hist[copy][(uint32_t)(k >> shift) & digit_mask], 1u);
             }
         }
     } else {
 #pragma unroll
         for (int k = 0; k < ITEMS; k++) {
             uint32_t i = base + k * SORT_THREADS + threadIdx.x;
-            if (i < count) atomicAdd(&s_hist[copy][(uint32_t)(keys[i] >> shift) & (RADIX - 1)], 1u);
+            if (i < count) atomicAdd(&s_hist[copy][(uint32_t)(keys[i] >> shift) & digit_mask], 1u);
         }
     }
     __syncthreads();
@@ -580,7 +584,7 @@ __global__ __launch_bounds__(256) void k_sort_scan_rows(uint32_t *__restrict__ g
 template <typename K, bool FAST_RANK>
 __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
     const K *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, K *__restrict__ keys_out,
-    uint32_t *__restrict__ vals_out, uint32_t count, uint32_t shift,
+    uint32_t *__restrict__ vals_out, uint32_t count, uint32_t shift, uint32_t digit_mask,
     const uint32_t *__restrict__ ghist, uint32_t num_blocks,
     const uint32_t *__restrict__ digit_totals) {
     constexpr int ITEMS = SortCfg<K>::ITEMS;
@@ -612,13 +616,13 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
     if constexpr (FAST_RANK) {
 #pragma unroll
         for (int k = 0; k < ITEMS; k++) {
-            uint32_t d = (uint32_t)(key[k] >> shift) & (RADIX - 1);
+            uint32_t d = (uint32_t)(key[k] >> shift) & digit_mask;
             rank[k] = atomicAdd(&s_wave_hist[wid][d], 1u);
         }
     } else {
 #pragma unroll
         for (int k = 0; k < ITEMS; k++) {
-            uint32_t d = (uint32_t)(key[k] >> shift) & (RADIX - 1);
+            uint32_t d = (uint32_t)(key[k] >> shift) & digit_mask;
             // wave64 match-any on the digit: peers = lanes holding the same digit
             uint64_t peers = ~0ull;
 #pragma unroll
@@ -658,7 +662,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
     // local reorder through LDS so that each digit run is written by consecutive lanes
 #pragma unroll
     for (int k = 0; k < ITEMS; k++) {
-        uint32_t d = (uint32_t)(key[k] >> shift) & (RADIX - 1);
+        uint32_t d = (uint32_t)(key[k] >> shift) & digit_mask;
         uint32_t pos = s_wave_hist[wid][d] + rank[k];
         s_keys[pos] = key[k];
         s_vals[pos] = val[k];
@@ -670,7 +674,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
         uint32_t pos = k * SORT_THREADS + tid;
         if (pos < valid) {
             K kk = s_keys[pos];
-            uint32_t d = (uint32_t)(kk >> shift) & (RADIX - 1);
+            uint32_t d = (uint32_t)(kk >> shift) & digit_mask;
             uint32_t dst = s_global[d] + (pos - s_bin_start[d]);
             keys_out[dst] = kk;
             vals_out[dst] = s_vals[pos];
