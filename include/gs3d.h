@@ -64,7 +64,9 @@ enum {
     /* the (key,index) pair buffer was too small for this frame; call again (it was grown) */
     GS_ERR_PAIR_OVERFLOW = -23,
     /* std::io::Error (InvalidData / UnexpectedEof) of the PLY reader; message = the Rust message */
-    GS_ERR_PLY = -24
+    GS_ERR_PLY = -24,
+    /* std::io::Error of the SPZ reader / header validation; message = the Rust message */
+    GS_ERR_SPZ = -25
 };
 
 /* Thread-local details of the last failing call on this thread.
@@ -177,6 +179,47 @@ gs_status gs_ply_read(const void *bytes, size_t len, gs_ply_gaussian_pod *out, s
  * out == NULL to get the size. */
 gs_status gs_ply_write(const gs_ply_gaussian_pod *pods, size_t n, void *out, size_t capacity,
                        size_t *bytes_out);
+
+/* ------------------------------------------------------------------------------------------ */
+/* SPZ source format — src/source_format/spz.rs, src/gaussian.rs:126-352 (host side)           */
+/* ------------------------------------------------------------------------------------------ */
+
+/* SpzGaussiansHeaderPod — spz.rs:436-446 (16 bytes; magic 0x5053474e, versions 1..=3) */
+typedef struct gs_spz_header {
+    uint32_t magic;
+    uint32_t version;
+    uint32_t num_points;
+    uint8_t sh_degree;
+    uint8_t fractional_bits;
+    uint8_t flags;      /* bit 0 = antialiased */
+    uint8_t reserved;
+} gs_spz_header;
+
+/* SpzGaussiansFromGaussianSliceOptions — spz.rs:962-999 (default: version 3, sh 3, 12 fractional
+ * bits, not antialiased, sh_quantize_bits [5,4,4]) */
+typedef struct gs_spz_options {
+    uint32_t version;
+    uint8_t sh_degree;
+    uint8_t fractional_bits;
+    uint8_t antialiased;
+    uint8_t _pad;
+    uint32_t sh_quantize_bits[3];
+} gs_spz_options;
+
+void gs_spz_options_default(gs_spz_options *out);
+/* SpzGaussians::read_from + iter_gaussian (gzip -> columns -> Gaussian::from_spz).  Call with
+ * out == NULL for the count / header.  Errors: GS_ERR_SPZ with the reference's message, e.g.
+ * "Invalid SPZ magic number: 0, expected 5053474E", "Unsupported SPZ version: 999, expected one of 1..=3" */
+gs_status gs_spz_decode(const void *bytes, size_t len, gs_spz_header *header_out, gs_gaussian *out,
+                        size_t capacity, size_t *count_out);
+gs_status gs_spz_decode_decompressed(const void *bytes, size_t len, gs_spz_header *header_out,
+                                     gs_gaussian *out, size_t capacity, size_t *count_out);
+/* SpzGaussians::from_gaussians_with_options + write_to (Gaussian::to_spz -> columns -> gzip).
+ * Call with out == NULL for the size. */
+gs_status gs_spz_encode(const gs_gaussian *in, size_t n, const gs_spz_options *options, void *out,
+                        size_t capacity, size_t *bytes_out);
+gs_status gs_spz_encode_decompressed(const gs_gaussian *in, size_t n, const gs_spz_options *options,
+                                     void *out, size_t capacity, size_t *bytes_out);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Device, streams                                                                             */

@@ -5,6 +5,7 @@
 // carrying the variant fields of src/error.rs.  Citations are relative to the reference.
 #pragma once
 
+#include <cstdint>
 #include <cstring>
 #include <initializer_list>
 #include <optional>
@@ -32,6 +33,8 @@ struct ComputeBundleBuildError : std::runtime_error { using std::runtime_error::
 struct DownloadBufferError : Error { using Error::Error; };
 struct LossyConfigError : Error { using Error::Error; };   // where the reference panics
 struct NoDeviceError : Error { using Error::Error; };
+struct PlyError : Error { using Error::Error; };   // std::io::Error of the PLY reader
+struct SpzError : Error { using Error::Error; };   // std::io::Error of the SPZ reader
 
 inline void check(gs_status s) {
     if (s == GS_OK) return;
@@ -48,6 +51,8 @@ inline void check(gs_status s) {
     case GS_ERR_DOWNLOAD: throw DownloadBufferError(i);
     case GS_ERR_LOSSY_CONFIG: throw LossyConfigError(i);
     case GS_ERR_NO_DEVICE: throw NoDeviceError(i);
+    case GS_ERR_PLY: throw PlyError(i);
+    case GS_ERR_SPZ: throw SpzError(i);
     default: throw Error(i);
     }
 }
@@ -93,6 +98,82 @@ GS3D_POD(GS_SH_NONE, GS_COV3D_ROT_SCALE, GaussianPodWithShNoneCov3dRotScaleConfi
 GS3D_POD(GS_SH_NONE, GS_COV3D_SINGLE, GaussianPodWithShNoneCov3dSingleConfigs)
 GS3D_POD(GS_SH_NONE, GS_COV3D_HALF, GaussianPodWithShNoneCov3dHalfConfigs)
 #undef GS3D_POD
+
+// ---- source formats (src/source_format/{ply,spz}.rs) --------------------------------------------
+using PlyGaussianPod = gs_ply_gaussian_pod;   // ply.rs:11-21
+
+class PlyGaussians {   // ply.rs:204-431 (both the Inria and Custom variants decode to pods here)
+public:
+    std::vector<PlyGaussianPod> pods;
+    bool inria = true;
+    static PlyGaussians read_from(const void *bytes, size_t len) {
+        PlyGaussians p;
+        size_t n = 0;
+        int32_t is_inria = 0;
+        check(gs_ply_read(bytes, len, nullptr, 0, &n, &is_inria));
+        p.pods.resize(n);
+        check(gs_ply_read(bytes, len, p.pods.data(), n, &n, &is_inria));
+        p.inria = is_inria != 0;
+        return p;
+    }
+    static PlyGaussians from_gaussians(const std::vector<Gaussian> &g) {   // FromIterator<Gaussian>
+        PlyGaussians p;
+        p.pods.resize(g.size());
+        gs_gaussian_to_ply(g.data(), g.size(), p.pods.data());
+        return p;
+    }
+    std::vector<uint8_t> write_to() const {
+        size_t n = 0;
+        check(gs_ply_write(pods.data(), pods.size(), nullptr, 0, &n));
+        std::vector<uint8_t> out(n);
+        check(gs_ply_write(pods.data(), pods.size(), out.data(), out.size(), &n));
+        return out;
+    }
+    std::vector<Gaussian> iter_gaussian() const {   // IterGaussian
+        std::vector<Gaussian> g(pods.size());
+        gs_gaussian_from_ply(pods.data(), pods.size(), g.data());
+        return g;
+    }
+    size_t len() const { return pods.size(); }
+    bool is_empty() const { return pods.empty(); }
+};
+
+struct SpzGaussiansFromGaussianSliceOptions : gs_spz_options {   // spz.rs:962-999
+    SpzGaussiansFromGaussianSliceOptions() { gs_spz_options_default(this); }
+};
+
+class SpzGaussians {   // spz.rs:514-959, decoded view (header + Gaussian::from_spz of every point)
+public:
+    gs_spz_header header{};
+    std::vector<Gaussian> gaussians;
+    static SpzGaussians read_from(const void *bytes, size_t len) { return decode(gs_spz_decode, bytes, len); }
+    static SpzGaussians read_decompressed(const void *bytes, size_t len) { return decode(gs_spz_decode_decompressed, bytes, len); }
+    static std::vector<uint8_t> write_gaussians(const std::vector<Gaussian> &g, const gs_spz_options &o = SpzGaussiansFromGaussianSliceOptions()) { return encode(gs_spz_encode, g, o); }
+    static std::vector<uint8_t> write_gaussians_decompressed(const std::vector<Gaussian> &g, const gs_spz_options &o = SpzGaussiansFromGaussianSliceOptions()) { return encode(gs_spz_encode_decompressed, g, o); }
+    const std::vector<Gaussian> &iter_gaussian() const { return gaussians; }
+    size_t len() const { return gaussians.size(); }
+    bool is_empty() const { return gaussians.empty(); }
+
+private:
+    template <class F>
+    static SpzGaussians decode(F fn, const void *bytes, size_t len) {
+        SpzGaussians s;
+        size_t n = 0;
+        check(fn(bytes, len, &s.header, nullptr, 0, &n));
+        s.gaussians.resize(n);
+        check(fn(bytes, len, &s.header, s.gaussians.data(), n, &n));
+        return s;
+    }
+    template <class F>
+    static std::vector<uint8_t> encode(F fn, const std::vector<Gaussian> &g, const gs_spz_options &o) {
+        size_t n = 0;
+        check(fn(g.data(), g.size(), &o, nullptr, 0, &n));
+        std::vector<uint8_t> out(n);
+        check(fn(g.data(), g.size(), &o, out.data(), out.size(), &n));
+        out.resize(n);
+        return out;
+    }
+};
 
 // ---- device / stream / buffer --------------------------------------------------------------------
 class Device {

@@ -97,6 +97,10 @@ def lib():
     L.gso_gaussian_to_ply.argtypes = [vp, vp]
     L.gso_read_inria_ply.restype = C.c_long
     L.gso_read_inria_ply.argtypes = [vp, sz, vp, sz]
+    L.gso_spz_decode_raw.restype = C.c_long
+    L.gso_spz_decode_raw.argtypes = [vp, sz, vp, sz]
+    L.gso_spz_encode_raw.restype = C.c_long
+    L.gso_spz_encode_raw.argtypes = [vp, sz, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, vp, vp, sz]
     L.gso_dispatch_workgroups.restype = u32
     L.gso_dispatch_workgroups.argtypes = [u32, u32]
     L.gso_exp.restype = f32
@@ -233,3 +237,32 @@ def render(sh, cov, pods, gt, mt, cam, band=None, want_image=True):
     st = (C.c_double * 5)()
     lib().gso_last_stage_seconds(st)
     return rgba, int(d), int(vis.value), list(st)
+
+
+def spz_decode_raw(data):
+    """decompressed SPZ payload -> Gaussians (negative return codes raise ValueError)"""
+    buf = np.frombuffer(bytes(data), dtype=np.uint8)
+    n = lib().gso_spz_decode_raw(_p(buf), buf.size, None, 0)
+    if n < 0:
+        raise ValueError(n)
+    out = np.zeros(n, dtype=GAUSSIAN_DTYPE)
+    rc = lib().gso_spz_decode_raw(_p(buf), buf.size, _p(out), n)
+    if rc < 0:
+        raise ValueError(rc)
+    return out
+
+
+def spz_encode_raw(gaussians, version=3, sh_degree=3, fractional_bits=12, antialiased=False,
+                   sh_quantize_bits=(5, 4, 4)):
+    g = np.ascontiguousarray(gaussians, dtype=GAUSSIAN_DTYPE)
+    bits = np.array(sh_quantize_bits, dtype=np.uint32)
+    n = lib().gso_spz_encode_raw(_p(g), len(g), version, sh_degree, fractional_bits, int(antialiased),
+                                 _p(bits), None, 0)
+    if n < 0:
+        raise ValueError(n)
+    out = np.zeros(n, dtype=np.uint8)
+    rc = lib().gso_spz_encode_raw(_p(g), len(g), version, sh_degree, fractional_bits, int(antialiased),
+                                  _p(bits), _p(out), n)
+    if rc < 0:
+        raise ValueError(rc)
+    return out.tobytes()

@@ -1024,3 +1024,197 @@ int gso_get_max_threads(void) {
     return 1;
 #endif
 }
+
+
+/* ==================================================================================================
+ * SPZ — src/source_format/spz.rs (header :436-512, column order :739-794) and
+ * src/gaussian.rs:126-352 (from_spz / to_spz).  Works on the decompressed payload; tests wrap it
+ * with Python's gzip.  Written column by column (the product walks Gaussian by Gaussian).
+ * PARITY UNPINNED beyond tests/golden/model.spz: the reference's tests only hold tolerance checks.
+ * Reference quirks kept on purpose: quantize_sh buckets only when bucket_size < 8
+ * (gaussian.rs:317-324); smallest-three unpack walks components ascending (gaussian.rs:171-190).
+ * ================================================================================================== */
+static uint32_t spz_rd32(const uint8_t *p) {
+    return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+}
+static int spz_ncoef(uint32_t deg) {
+    static const int t[4] = {0, 3, 8, 15};
+    return t[deg];
+}
+static float spz_clamp255(float v) { return v < 0.0f ? 0.0f : (v > 255.0f ? 255.0f : v); }
+/* Rust `as u8` / `as u32` / `as i32` on f32: truncate toward zero, saturate, NaN -> 0 */
+static uint32_t spz_as_u32(float v) {
+    if (!(v >= 1.0f)) return 0u;
+    if (v >= 4294967296.0f) return 0xffffffffu;
+    return (uint32_t)v;
+}
+static int32_t spz_as_i32(float v) {
+    if (v != v) return 0;
+    if (v >= 2147483648.0f) return INT32_MAX;
+    if (v <= -2147483648.0f) return INT32_MIN;
+    return (int32_t)v;
+}
+
+long gso_spz_decode_raw(const uint8_t *bytes, size_t len, gso_gaussian *out, size_t cap) {
+    if (len < 16) return -4;
+    uint32_t magic = spz_rd32(bytes), version = spz_rd32(bytes + 4), n = spz_rd32(bytes + 8);
+    uint32_t deg = bytes[12], frac = bytes[13];
+    if (magic != 0x5053474eu) return -1;
+    if (version < 1 || version > 3) return -2;
+    if (deg > 3) return -3;
+    if (!out) return (long)n;
+    const size_t pb = version == 1 ? 6 : 9, rb = version >= 3 ? 4 : 3;
+    const int nc = spz_ncoef(deg);
+    if (len < 16 + (size_t)n * (pb + 7 + rb + 3 * (size_t)nc)) return -4;
+    const size_t m = n < cap ? n : cap;
+    const uint8_t *positions = bytes + 16;
+    const uint8_t *alphas = positions + pb * n;
+    const uint8_t *colors = alphas + n;
+    const uint8_t *scales = colors + 3u * (size_t)n;
+    const uint8_t *rotations = scales + 3u * (size_t)n;
+    const uint8_t *shs = rotations + rb * n;
+    const float A_B = 0.2820948f / 0.15f;
+    const float C0 = (1.0f - A_B) * (0.5f * 255.0f);
+
+    /* positions — gaussian.rs:135-158 */
+    if (version == 1) {
+        for (size_t i = 0; i < m; i++)
+            for (int a = 0; a < 3; a++)
+                out[i].pos[a] = f16_to_f32((uint16_t)(positions[6 * i + 2 * a] | (positions[6 * i + 2 * a + 1] << 8)));
+    } else {
+        float inv = 1.0f / (float)(1 << frac);
+        for (size_t i = 0; i < m; i++)
+            for (int a = 0; a < 3; a++) {
+                const uint8_t *p = positions + 9 * i + 3 * a;
+                uint32_t u = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
+                if (u & 0x800000u) u |= 0xff000000u;
+                out[i].pos[a] = (float)(int32_t)u * inv;
+            }
+    }
+    /* scales — gaussian.rs:160 */
+    for (size_t i = 0; i < m; i++)
+        for (int a = 0; a < 3; a++) out[i].scale[a] = expf((float)scales[3 * i + a] / 16.0f - 10.0f);
+    /* rotations — gaussian.rs:162-197 */
+    if (version < 3) {
+        for (size_t i = 0; i < m; i++) {
+            float v[3];
+            for (int a = 0; a < 3; a++) v[a] = (float)rotations[3 * i + a] / 127.5f - 1.0f;
+            float w2 = 1.0f - ((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]);
+            out[i].rot[0] = v[0];
+            out[i].rot[1] = v[1];
+            out[i].rot[2] = v[2];
+            out[i].rot[3] = sqrtf(w2 > 0.0f ? w2 : 0.0f);
+        }
+    } else {
+        for (size_t i = 0; i < m; i++) {
+            uint32_t word = spz_rd32(rotations + 4 * i);
+            int big = (int)(word >> 30);
+            float acc = 0.0f;
+            for (int a = 0; a < 4; a++) {
+                if (a == big) continue;
+                uint32_t field = word & 0x3ffu;
+                word >>= 10;
+                float val = 0.70710678118654752440f * ((float)(field & 0x1ffu) / 511.0f) *
+                            ((field & 0x200u) ? -1.0f : 1.0f);
+                acc += val * val;
+                out[i].rot[a] = val;
+            }
+            float r = 1.0f - acc;
+            out[i].rot[big] = sqrtf(r > 0.0f ? r : 0.0f);
+        }
+    }
+    /* colors + alpha — gaussian.rs:199-203 */
+    for (size_t i = 0; i < m; i++) {
+        for (int a = 0; a < 3; a++)
+            out[i].color[a] = (uint8_t)spz_as_u32(spz_clamp255((float)colors[3 * i + a] * A_B + C0));
+        out[i].color[3] = alphas[i];
+    }
+    /* sh — gaussian.rs:205-208 */
+    for (size_t i = 0; i < m; i++) {
+        for (int k = 0; k < 45; k++)
+            out[i].sh[k] = k < 3 * nc ? ((float)shs[i * 3 * (size_t)nc + (size_t)k] - 128.0f) / 128.0f : 0.0f;
+    }
+    return (long)n;
+}
+
+long gso_spz_encode_raw(const gso_gaussian *in, size_t n, uint32_t version, uint32_t sh_degree,
+                        uint32_t fractional_bits, int antialiased, const uint32_t sh_bits[3],
+                        uint8_t *out, size_t cap) {
+    if (version < 1 || version > 3) return -2;
+    if (sh_degree > 3) return -3;
+    const size_t pb = version == 1 ? 6 : 9, rb = version >= 3 ? 4 : 3;
+    const int nc = spz_ncoef(sh_degree);
+    const size_t total = 16 + n * (pb + 7 + rb + 3 * (size_t)nc);
+    if (!out) return (long)total;
+    if (cap < total) return -4;
+    uint32_t words[3] = {0x5053474eu, version, (uint32_t)n};
+    memcpy(out, words, 12);
+    out[12] = (uint8_t)sh_degree;
+    out[13] = (uint8_t)fractional_bits;
+    out[14] = antialiased ? 1 : 0;
+    out[15] = 0;
+    uint8_t *positions = out + 16;
+    uint8_t *alphas = positions + pb * n;
+    uint8_t *colors = alphas + n;
+    uint8_t *scales = colors + 3 * n;
+    uint8_t *rotations = scales + 3 * n;
+    uint8_t *shs = rotations + rb * n;
+    const float A_B = 0.2820948f / 0.15f;
+    const float C0 = (1.0f - A_B) * (0.5f * 255.0f);
+
+    for (size_t i = 0; i < n; i++) {   /* gaussian.rs:245-264 */
+        for (int a = 0; a < 3; a++) {
+            if (version == 1) {
+                uint16_t hbits = f32_to_f16(in[i].pos[a]);
+                positions[6 * i + 2 * a] = (uint8_t)(hbits & 0xff);
+                positions[6 * i + 2 * a + 1] = (uint8_t)(hbits >> 8);
+            } else {
+                int32_t fx = spz_as_i32(roundf(in[i].pos[a] * (float)(1 << fractional_bits)));
+                for (int b = 0; b < 3; b++) positions[9 * i + 3 * a + b] = (uint8_t)((fx >> (8 * b)) & 0xff);
+            }
+        }
+    }
+    for (size_t i = 0; i < n; i++) alphas[i] = in[i].color[3];   /* :299 */
+    for (size_t i = 0; i < 3 * n; i++)                            /* :301-308 */
+        colors[i] = (uint8_t)spz_as_u32(spz_clamp255(((float)in[i / 3].color[i % 3] - C0) / A_B));
+    for (size_t i = 0; i < 3 * n; i++)                            /* :266-269 */
+        scales[i] = (uint8_t)spz_as_u32(spz_clamp255(roundf((logf(in[i / 3].scale[i % 3]) + 10.0f) * 16.0f)));
+    for (size_t i = 0; i < n; i++) {                              /* :271-297 */
+        const float *r = in[i].rot;
+        float len = sqrtf(((r[0] * r[0] + r[1] * r[1]) + r[2] * r[2]) + r[3] * r[3]);
+        float q[4] = {r[0] / len, r[1] / len, r[2] / len, r[3] / len};
+        if (version >= 3) {
+            int big = 0;
+            float best = fabsf(q[0]);
+            for (int a = 1; a < 4; a++)
+                if (!(fabsf(q[a]) < best)) {   /* Iterator::max_by returns the last maximum */
+                    best = fabsf(q[a]);
+                    big = a;
+                }
+            uint32_t flip = q[big] < 0.0f;
+            uint32_t word = (uint32_t)big;
+            for (int a = 0; a < 4; a++) {
+                if (a == big) continue;
+                float mf = 511.0f * (fabsf(q[a]) * 1.41421356237309504880f) + 0.5f;
+                mf = mf < 0.0f ? 0.0f : (mf > 510.0f ? 510.0f : mf);
+                word = (word << 10) | ((((uint32_t)(q[a] < 0.0f)) ^ flip) << 9) | spz_as_u32(mf);
+            }
+            for (int b = 0; b < 4; b++) rotations[4 * i + b] = (uint8_t)((word >> (8 * b)) & 0xff);
+        } else {
+            float s = q[3] < 0.0f ? -1.0f : 1.0f;
+            for (int a = 0; a < 3; a++)
+                rotations[3 * i + a] = (uint8_t)spz_as_u32(spz_clamp255(roundf((s * q[a] + 1.0f) * 127.5f)));
+        }
+    }
+    if (nc) {                                                     /* :310-337 */
+        uint32_t bits = sh_bits[sh_degree - 1];
+        uint32_t bucket = bits <= 8 ? 1u << (8 - bits) : 0;
+        for (size_t i = 0; i < n; i++)
+            for (int k = 0; k < 3 * nc; k++) {
+                uint32_t qv = spz_as_u32(roundf(in[i].sh[k] * 128.0f + 128.0f));
+                if (bucket < 8) qv = (qv + bucket / 2) / bucket * bucket;
+                shs[i * 3 * (size_t)nc + (size_t)k] = (uint8_t)(qv > 255u ? 255u : qv);
+            }
+    }
+    return (long)total;
+}

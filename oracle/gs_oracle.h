@@ -15,6 +15,7 @@
  *   - model matrices .......................... src/shader/model_transform.wesl:6-143,
  *                                               src/buffer/model_transform.rs:61-84
  *   - test fixture given::gaussian_with_seed .. tests/common/given.rs:48-81
+ *   - SPZ columns + from_spz / to_spz ......... src/source_format/spz.rs:436-794, src/gaussian.rs:126-352
  *   - Inria PLY record + from_ply ............. src/source_format/ply.rs:11-21,204-267,
  *                                               src/gaussian.rs:70-92
  *
@@ -137,6 +138,15 @@ void gso_gaussian_from_ply(const gso_ply_pod *ply, gso_gaussian *out);
 void gso_gaussian_to_ply(const gso_gaussian *g, gso_ply_pod *out);
 /* Inria fast-path reader: returns count (>=0) or negative error; out may be NULL to query count */
 long gso_read_inria_ply(const uint8_t *bytes, size_t len, gso_ply_pod *out, size_t cap);
+
+/* ---- SPZ (decompressed payload), src/source_format/spz.rs:436-512,739-794 + src/gaussian.rs:126-352.
+ * header = 16 bytes {magic u32, version u32, num_points u32, sh_degree u8, fractional_bits u8,
+ * flags u8, reserved u8}.  Return: count / byte size (>= 0), -1 bad magic, -2 bad version,
+ * -3 bad sh degree, -4 truncated. out may be NULL to query. */
+long gso_spz_decode_raw(const uint8_t *bytes, size_t len, gso_gaussian *out, size_t cap);
+long gso_spz_encode_raw(const gso_gaussian *in, size_t n, uint32_t version, uint32_t sh_degree,
+                        uint32_t fractional_bits, int antialiased, const uint32_t sh_bits[3],
+                        uint8_t *out, size_t cap);
 
 /* ---- launch arithmetic, src/compute_bundle.rs:131 ---- */
 uint32_t gso_dispatch_workgroups(uint32_t count, uint32_t workgroup_size);

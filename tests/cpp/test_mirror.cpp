@@ -24,7 +24,43 @@ static Gaussian given_gaussian(uint32_t seed) {   // tests/common/given.rs:48-81
     return g;
 }
 
+// host-only source formats: tests/e2e/ply.rs:68-86 and tests/e2e/spz.rs:82-93,277-293
+static int host_codecs() {
+    std::vector<Gaussian> gs = {given_gaussian(42), given_gaussian(123)};
+    auto ply = PlyGaussians::from_gaussians(gs);
+    auto bytes = ply.write_to();
+    auto ply2 = PlyGaussians::read_from(bytes.data(), bytes.size());
+    REQUIRE(ply2.inria && ply2.len() == 2);
+    REQUIRE(std::memcmp(ply2.pods.data(), ply.pods.data(), 2 * sizeof(PlyGaussianPod)) == 0);
+    const char *bad = "ply\nformat ascii 1.0\nelement face 0\nend_header\n";
+    try { PlyGaussians::read_from(bad, std::strlen(bad)); REQUIRE(false); }
+    catch (const PlyError &e) { REQUIRE(std::string(e.what()) == "Gaussian vertex element not found in PLY header"); }
+
+    for (uint32_t version = 1; version <= 3; version++) {
+        SpzGaussiansFromGaussianSliceOptions o;
+        REQUIRE(o.version == 3 && o.sh_degree == 3 && o.fractional_bits == 12 && o.sh_quantize_bits[0] == 5);
+        o.version = version;
+        auto z = SpzGaussians::write_gaussians(gs, o);
+        auto spz = SpzGaussians::read_from(z.data(), z.size());
+        REQUIRE(spz.len() == 2 && spz.header.version == version && spz.header.sh_degree == 3);
+        for (size_t i = 0; i < 2; i++) {
+            for (int c = 0; c < 3; c++) REQUIRE(std::fabs(spz.gaussians[i].pos[c] - gs[i].pos[c]) <= 1.0f);
+            for (int c = 0; c < 4; c++) REQUIRE(std::fabs(spz.gaussians[i].rot[c] - gs[i].rot[c]) <= 0.1f);
+            for (int c = 0; c < 45; c++) REQUIRE(std::fabs(spz.gaussians[i].sh[c] - gs[i].sh[c]) <= 0.1f);
+            for (int c = 0; c < 4; c++) REQUIRE(std::abs((int)spz.gaussians[i].color[c] - (int)gs[i].color[c]) <= 2);
+        }
+    }
+    SpzGaussiansFromGaussianSliceOptions o;
+    o.version = 999;
+    try { SpzGaussians::write_gaussians(gs, o); REQUIRE(false); }
+    catch (const SpzError &e) { REQUIRE(std::string(e.what()) == "Unsupported SPZ version: 999, expected one of 1..=3"); }
+    std::printf("host codecs OK\n");
+    return 0;
+}
+
 int main() {
+    if (host_codecs()) return 1;
+    std::fflush(stdout);
     Device dev(0);
     Stream s(dev);
     std::vector<Gaussian> gs;

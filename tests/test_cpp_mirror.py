@@ -22,6 +22,7 @@ def test_cpp_mirror_compiles_and_fails_loudly_without_gpu():
     if torch.cuda.is_available():
         pytest.skip("a GPU is present")
     res = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert "host codecs OK" in res.stdout, res.stdout
     assert res.returncode != 0 and "no HIP device" in res.stdout
 
 

@@ -28,7 +28,7 @@ __global__ void k_gen(uint4* planar, uint64_t stride, uint32_t n) {
 
 int main(int argc, char** argv) {
     const uint32_t n = 10000000;
-    uint64_t stride = (n + 63) / 64 * 64;
+    uint64_t stride = (n + 63) / 64 * 64 + (argc > 2 ? atoi(argv[2]) : 0);
     uint4 *planar; uint32_t *proj, *depth, *ct, *cv; uint2* rect;
     uint32_t nchunks = (n + gs::PP_CHUNK - 1) / gs::PP_CHUNK;
     CK(hipMalloc(&planar, stride * 16 * 14)); CK(hipMalloc(&proj, (size_t)n * 36 + 16));
@@ -52,6 +52,6 @@ int main(int argc, char** argv) {
     float ms; CK(hipEventElapsedTime(&ms, a, b)); ms /= 10;
     std::vector<uint32_t> h(nchunks); CK(hipMemcpy(h.data(), cv, nchunks * 4ull, hipMemcpyDeviceToHost));
     uint64_t vis = 0; for (auto x : h) vis += x;
-    printf("k_preprocess<0,0> sh_deg=%u: %.3f ms  read %.2f TB/s  visible %llu\n", fc.sh_deg, ms, n * 224.0 / ms / 1e9, (unsigned long long)vis);
+    printf("stride+%d k_preprocess<0,0> sh_deg=%u: %.3f ms  read %.2f TB/s  visible %llu\n", (int)(stride - (n + 63) / 64 * 64), fc.sh_deg, ms, n * 224.0 / ms / 1e9, (unsigned long long)vis);
     return 0;
 }

@@ -125,6 +125,11 @@ class KernelResolveError(ComputeBundleBuildError): """ComputeBundleBuildError::W
 
 
 class LossyConfigError(GsError): code = -21
+class SpzError(GsError):
+    """std::io::Error of the SPZ reader / header validation"""
+    code = -25
+
+
 class PlyError(GsError):
     """std::io::Error of PlyGaussians::read_from (message = the reference's message)"""
     code = -24
@@ -135,7 +140,7 @@ _ERRORS = {c.code: c for c in (InvalidArgumentError, NoDeviceError, HipError, Ou
                                GaussiansBufferUpdateError, GaussiansBufferUpdateRangeError,
                                GaussiansBufferTryFromBufferError, FixedSizeBufferWrapperError,
                                ResourceCountMismatch, WorkgroupSizeExceedsDeviceLimit,
-                               LossyConfigError, DownloadBufferError, PlyError)}
+                               LossyConfigError, DownloadBufferError, PlyError, SpzError)}
 
 
 def _check(status):
@@ -335,6 +340,75 @@ class PlyGaussians:
     def iter_gaussian(self):
         """IterGaussian: the Gaussians (Gaussian::from_ply of every pod)"""
         return gaussian_from_ply(self.pods)
+
+
+# ------------------------------------------------------------------------------------------------
+# SPZ source format — src/source_format/spz.rs
+# ------------------------------------------------------------------------------------------------
+
+def spz_options(version=3, sh_degree=3, fractional_bits=12, antialiased=False, sh_quantize_bits=(5, 4, 4)):
+    """SpzGaussiansFromGaussianSliceOptions (defaults as the reference's)"""
+    o = _capi.SpzOptions()
+    _L.gs_spz_options_default(C.byref(o))
+    o.version, o.sh_degree, o.fractional_bits = version, sh_degree, fractional_bits
+    o.antialiased = int(bool(antialiased))
+    o.sh_quantize_bits[:] = list(sh_quantize_bits)
+    return o
+
+
+class SpzGaussians:
+    """SpzGaussians — decoded view: header + the Gaussians (Gaussian::from_spz of every point)."""
+
+    def __init__(self, header, gaussians):
+        self.header, self.gaussians = header, gaussians
+
+    def __len__(self):
+        return len(self.gaussians)
+
+    @staticmethod
+    def _decode(fn, data):
+        buf = np.frombuffer(bytes(data), dtype=np.uint8)
+        hdr, n = _capi.SpzHeader(), C.c_size_t()
+        _check(fn(_ptr(buf), buf.size, C.byref(hdr), None, 0, C.byref(n)))
+        out = np.zeros(n.value, dtype=GAUSSIAN_DTYPE)
+        _check(fn(_ptr(buf), buf.size, C.byref(hdr), _ptr(out), n.value, C.byref(n)))
+        return SpzGaussians(hdr, out)
+
+    @staticmethod
+    def read_from(data):
+        """ReadIterGaussian::read_from (gzip'd .spz bytes)"""
+        return SpzGaussians._decode(_L.gs_spz_decode, data)
+
+    @staticmethod
+    def read_decompressed(data):
+        return SpzGaussians._decode(_L.gs_spz_decode_decompressed, data)
+
+    @staticmethod
+    def read_from_file(path):
+        with open(path, "rb") as f:
+            return SpzGaussians.read_from(f.read())
+
+    def iter_gaussian(self):
+        return self.gaussians
+
+    @staticmethod
+    def _encode(fn, gaussians, options):
+        g = np.ascontiguousarray(np.atleast_1d(gaussians), dtype=GAUSSIAN_DTYPE)
+        options = options or spz_options()
+        n = C.c_size_t()
+        _check(fn(_ptr(g), len(g), C.byref(options), None, 0, C.byref(n)))
+        out = np.zeros(n.value, dtype=np.uint8)
+        _check(fn(_ptr(g), len(g), C.byref(options), _ptr(out), out.size, C.byref(n)))
+        return out[:n.value].tobytes()
+
+    @staticmethod
+    def write_gaussians(gaussians, options=None):
+        """from_gaussians_with_options + write_to -> gzip'd bytes"""
+        return SpzGaussians._encode(_L.gs_spz_encode, gaussians, options)
+
+    @staticmethod
+    def write_gaussians_decompressed(gaussians, options=None):
+        return SpzGaussians._encode(_L.gs_spz_encode_decompressed, gaussians, options)
 
 
 # ------------------------------------------------------------------------------------------------

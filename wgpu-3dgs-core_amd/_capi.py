@@ -48,6 +48,16 @@ class BundleDesc(C.Structure):
                 ("constant_values", C.POINTER(C.c_double)), ("constant_count", u32)]
 
 
+class SpzHeader(C.Structure):
+    _fields_ = [("magic", u32), ("version", u32), ("num_points", u32), ("sh_degree", u8),
+                ("fractional_bits", u8), ("flags", u8), ("reserved", u8)]
+
+
+class SpzOptions(C.Structure):
+    _fields_ = [("version", u32), ("sh_degree", u8), ("fractional_bits", u8), ("antialiased", u8),
+                ("_pad", u8), ("sh_quantize_bits", u32 * 3)]
+
+
 class BundleSourceDesc(C.Structure):
     _fields_ = [("label", C.c_char_p), ("source", C.c_char_p), ("entry_point", C.c_char_p),
                 ("sh", i32), ("cov", i32), ("bind_group_count", u32),
@@ -77,6 +87,11 @@ SIGNATURES = {
     "gs_gaussian_to_ply": (None, [vp, sz, vp]),
     "gs_ply_read": (i32, [vp, sz, vp, sz, vp, vp]),
     "gs_ply_write": (i32, [vp, sz, vp, sz, vp]),
+    "gs_spz_options_default": (None, [vp]),
+    "gs_spz_decode": (i32, [vp, sz, vp, vp, sz, vp]),
+    "gs_spz_decode_decompressed": (i32, [vp, sz, vp, vp, sz, vp]),
+    "gs_spz_encode": (i32, [vp, sz, vp, vp, sz, vp]),
+    "gs_spz_encode_decompressed": (i32, [vp, sz, vp, vp, sz, vp]),
     "gs_device_create": (i32, [i32, vp]),
     "gs_device_destroy": (None, [vp]),
     "gs_device_limits": (i32, [vp, vp]),

@@ -82,6 +82,7 @@ extern "C" const char *gs_status_string(gs_status s) {
     case GS_ERR_DOWNLOAD: return "buffer download failed";
     case GS_ERR_PAIR_OVERFLOW: return "pair buffer overflow";
     case GS_ERR_PLY: return "PLY read error";
+    case GS_ERR_SPZ: return "SPZ read error";
     default: return "unknown";
     }
 }

@@ -1,0 +1,317 @@
+// gs_spz.cpp — SPZ (Niantic) source format: gzip'd column-major quantised Gaussians, versions 1-3.
+// Restates src/source_format/spz.rs:436-959 (header, column order, gzip framing) and
+// src/gaussian.rs:126-352 (Gaussian::from_spz / to_spz, GaussianToSpzOptions).  Host side only.
+// The reference's arithmetic is mirrored operation by operation, including two quirks that a
+// drop-in must keep: quantize_sh only buckets when bucket_size < 8 (gaussian.rs:317-324, so the
+// default [5,4,4] bits do not bucket at all), and the smallest-three quaternion is unpacked in
+// ascending component order (gaussian.rs:171-190; Niantic's own decoder walks it descending).
+#include <zlib.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "gs_internal.h"
+
+static_assert(sizeof(gs_spz_header) == 16, "SpzGaussiansHeaderPod is 16 bytes");
+
+static const uint32_t k_magic = 0x5053474eu;   // "NGSP", spz.rs:458
+static const float k_ab = 0.2820948f / 0.15f;  // SPZ_COLOR_TO_LINEAR_FRAC_A_B, gaussian.rs:127-128
+static const float k_c = (1.0f - k_ab) * (0.5f * 255.0f);   // SPZ_COLOR_TO_LINEAR_C, :130-131
+
+static uint32_t num_coefficients(uint32_t deg) { return deg == 0 ? 0 : deg == 1 ? 3 : deg == 2 ? 8 : 15; }
+
+extern "C" void gs_spz_options_default(gs_spz_options *o) {   // spz.rs:985-999
+    o->version = 3;
+    o->sh_degree = 3;
+    o->fractional_bits = 12;
+    o->antialiased = 0;
+    o->sh_quantize_bits[0] = 5;
+    o->sh_quantize_bits[1] = 4;
+    o->sh_quantize_bits[2] = 4;
+}
+
+// SpzGaussiansHeader::try_from_pod, spz.rs:487-512
+static gs_status validate_header(const gs_spz_header &h) {
+    if (h.magic != k_magic)
+        return gs_fail(GS_ERR_SPZ, h.magic, k_magic, 0, "Invalid SPZ magic number: %X, expected %X", h.magic, k_magic);
+    if (h.version < 1 || h.version > 3)
+        return gs_fail(GS_ERR_SPZ, h.version, 0, 0, "Unsupported SPZ version: %u, expected one of 1..=3", h.version);
+    if (h.sh_degree > 3)
+        return gs_fail(GS_ERR_SPZ, h.sh_degree, 0, 0, "Unsupported SPZ SH degree: %u, expected one of 0..=3", h.sh_degree);
+    return GS_OK;
+}
+
+// ---- f16 (half crate const conversions == IEEE RNE) ---------------------------------------------
+static uint16_t f32_to_f16(float value) {
+    union { uint32_t u; float f; } f, magic;
+    f.f = value;
+    const uint32_t f32infty = 255u << 23, f16max = (127u + 16u) << 23;
+    magic.u = ((127u - 15u) + (23u - 10u) + 1u) << 23;
+    uint32_t sign = f.u & 0x80000000u;
+    f.u ^= sign;
+    uint16_t o;
+    if (f.u >= f16max) o = (f.u > f32infty) ? (uint16_t)0x7e00u : (uint16_t)0x7c00u;
+    else if (f.u < (113u << 23)) { f.f += magic.f; o = (uint16_t)(f.u - magic.u); }
+    else { uint32_t odd = (f.u >> 13) & 1u; f.u += ((uint32_t)(15 - 127) << 23) + 0xfffu; f.u += odd; o = (uint16_t)(f.u >> 13); }
+    return (uint16_t)(o | (sign >> 16));
+}
+static float f16_to_f32(uint16_t h) {
+    union { uint32_t u; float f; } o;
+    uint32_t sign = ((uint32_t)h & 0x8000u) << 16, e = (h >> 10) & 0x1fu, m = h & 0x3ffu;
+    if (e == 0) { o.f = std::ldexp((float)m, -24); o.u |= sign; }
+    else if (e == 31) o.u = sign | 0x7f800000u | (m << 13);
+    else o.u = sign | ((e + 112u) << 23) | (m << 13);
+    return o.f;
+}
+static uint8_t sat_u8(float v) { return !(v > 0.0f) ? 0 : v >= 255.0f ? 255 : (uint8_t)v; }
+static uint32_t sat_u32(float v) { return !(v > 0.0f) ? 0u : v >= 4294967295.0f ? 0xffffffffu : (uint32_t)v; }
+static int32_t sat_i32(float v) { return v != v ? 0 : v >= 2147483647.0f ? 2147483647 : v <= -2147483648.0f ? (int32_t)0x80000000 : (int32_t)v; }
+
+// column sizes (bytes per Gaussian)
+static size_t pos_bytes(uint32_t version) { return version == 1 ? 6 : 9; }
+static size_t rot_bytes(uint32_t version) { return version >= 3 ? 4 : 3; }
+
+static size_t payload_bytes(const gs_spz_header &h) {
+    return 16 + (size_t)h.num_points * (pos_bytes(h.version) + 1 + 3 + 3 + rot_bytes(h.version) + 3 * num_coefficients(h.sh_degree));
+}
+
+// ---- Gaussian::from_spz over a decompressed buffer (gaussian.rs:134-229, spz.rs:739-771) --------
+extern "C" gs_status gs_spz_decode_decompressed(const void *bytes, size_t len, gs_spz_header *header_out,
+                                                gs_gaussian *out, size_t capacity, size_t *count_out) {
+    if (!bytes || !count_out) return gs_fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "null argument");
+    if (len < 16) return gs_fail(GS_ERR_SPZ, len, 0, 0, "failed to fill whole buffer");
+    gs_spz_header h;
+    std::memcpy(&h, bytes, 16);
+    gs_status rc = validate_header(h);
+    if (rc != GS_OK) return rc;
+    if (header_out) *header_out = h;
+    *count_out = h.num_points;
+    if (!out) return GS_OK;
+    if (len < payload_bytes(h)) return gs_fail(GS_ERR_SPZ, len, payload_bytes(h), 0, "failed to fill whole buffer");
+    const size_t n = h.num_points, m = n < capacity ? n : capacity;
+    const uint8_t *b = (const uint8_t *)bytes + 16;
+    const uint8_t *pos = b;
+    const uint8_t *alpha = pos + n * pos_bytes(h.version);
+    const uint8_t *color = alpha + n;
+    const uint8_t *scale = color + 3 * n;
+    const uint8_t *rot = scale + 3 * n;
+    const uint8_t *sh = rot + n * rot_bytes(h.version);
+    const uint32_t ncoef = num_coefficients(h.sh_degree);
+    for (size_t i = 0; i < m; i++) {
+        gs_gaussian &g = out[i];
+        if (h.version == 1) {
+            for (int c = 0; c < 3; c++) {
+                uint16_t v;
+                std::memcpy(&v, pos + 6 * i + 2 * c, 2);
+                g.pos[c] = f16_to_f32(v);
+            }
+        } else {
+            const float s = 1.0f / (float)(1 << h.fractional_bits);
+            for (int c = 0; c < 3; c++) {
+                const uint8_t *p = pos + 9 * i + 3 * c;
+                int32_t fixed = (int32_t)p[0] | ((int32_t)p[1] << 8) | ((int32_t)p[2] << 16);
+                if (fixed & 0x800000) fixed |= (int32_t)0xff000000u;
+                g.pos[c] = (float)fixed * s;
+            }
+        }
+        for (int c = 0; c < 3; c++) g.scale[c] = std::exp((float)scale[3 * i + c] / 16.0f - 10.0f);
+        if (h.version < 3) {
+            float x = (float)rot[3 * i] / 127.5f - 1.0f, y = (float)rot[3 * i + 1] / 127.5f - 1.0f,
+                  z = (float)rot[3 * i + 2] / 127.5f - 1.0f;
+            float l2 = (x * x + y * y) + z * z;
+            g.rot[0] = x; g.rot[1] = y; g.rot[2] = z;
+            g.rot[3] = std::sqrt(std::fmax(1.0f - l2, 0.0f));
+        } else {
+            const uint8_t *q = rot + 4 * i;
+            uint32_t comp = (uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16) | ((uint32_t)q[3] << 24);
+            const uint32_t mask = (1u << 9) - 1u;
+            uint32_t largest = comp >> 30;
+            float sum = 0.0f, comps[4];
+            for (uint32_t k = 0; k < 4; k++) {   // ascending, as the reference's array::from_fn
+                if (k == largest) { comps[k] = 0.0f; continue; }
+                uint32_t mag = comp & mask, neg = (comp >> 9) & 1u;
+                comp >>= 10;
+                float v = 0.70710678118654752440f * ((float)mag / (float)mask) * (neg ? -1.0f : 1.0f);
+                sum += v * v;
+                comps[k] = v;
+            }
+            comps[largest] = std::sqrt(std::fmax(1.0f - sum, 0.0f));
+            std::memcpy(g.rot, comps, 16);
+        }
+        for (int c = 0; c < 3; c++) {
+            float v = (float)color[3 * i + c] * k_ab + k_c;
+            g.color[c] = sat_u8(std::fmin(std::fmax(v, 0.0f), 255.0f));
+        }
+        g.color[3] = alpha[i];
+        for (int k = 0; k < 45; k++) g.sh[k] = 0.0f;
+        for (uint32_t k = 0; k < ncoef; k++)
+            for (int c = 0; c < 3; c++) g.sh[3 * k + c] = ((float)sh[(i * ncoef + k) * 3 + c] - 128.0f) / 128.0f;
+    }
+    return GS_OK;
+}
+
+// ---- Gaussian::to_spz (gaussian.rs:240-352) + write_decompressed (spz.rs:776-794) --------------
+static uint8_t quantize_sh(float x, uint32_t bucket) {   // gaussian.rs:317-324
+    uint32_t q = sat_u32(std::round(x * 128.0f + 128.0f));
+    if (!(bucket >= 8)) q = (q + bucket / 2) / bucket * bucket;
+    return (uint8_t)(q > 255u ? 255u : q);
+}
+
+extern "C" gs_status gs_spz_encode_decompressed(const gs_gaussian *in, size_t n, const gs_spz_options *opt,
+                                                void *out, size_t capacity, size_t *bytes_out) {
+    if (!opt || !bytes_out || (n && !in)) return gs_fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "null argument");
+    gs_spz_header h;
+    h.magic = k_magic;
+    h.version = opt->version;
+    h.num_points = (uint32_t)n;
+    h.sh_degree = opt->sh_degree;
+    h.fractional_bits = opt->fractional_bits;
+    h.flags = opt->antialiased ? 1 : 0;
+    h.reserved = 0;
+    gs_status rc = validate_header(h);
+    if (rc != GS_OK) return rc;
+    if (h.sh_degree && opt->sh_quantize_bits[h.sh_degree - 1] > 8)
+        return gs_fail(GS_ERR_INVALID_ARGUMENT, opt->sh_quantize_bits[h.sh_degree - 1], 8, 0,
+                       "sh_quantize_bits must be in 0..=8");
+    if (h.version > 1 && h.fractional_bits > 30)
+        return gs_fail(GS_ERR_INVALID_ARGUMENT, h.fractional_bits, 30, 0, "fractional_bits must be below 31");
+    const size_t total = payload_bytes(h);
+    *bytes_out = total;
+    if (!out) return GS_OK;
+    if (capacity < total) return gs_fail(GS_ERR_INVALID_ARGUMENT, capacity, total, 0, "output buffer too small");
+    uint8_t *b = (uint8_t *)out;
+    std::memcpy(b, &h, 16);
+    uint8_t *pos = b + 16;
+    uint8_t *alpha = pos + n * pos_bytes(h.version);
+    uint8_t *color = alpha + n;
+    uint8_t *scale = color + 3 * n;
+    uint8_t *rot = scale + 3 * n;
+    uint8_t *sh = rot + n * rot_bytes(h.version);
+    const uint32_t ncoef = num_coefficients(h.sh_degree);
+    const uint32_t bits = h.sh_degree ? opt->sh_quantize_bits[h.sh_degree - 1] : 8;
+    const uint32_t bucket = 1u << (8 - bits);
+    for (size_t i = 0; i < n; i++) {
+        const gs_gaussian &g = in[i];
+        if (h.version == 1) {
+            for (int c = 0; c < 3; c++) {
+                uint16_t v = f32_to_f16(g.pos[c]);
+                std::memcpy(pos + 6 * i + 2 * c, &v, 2);
+            }
+        } else {
+            const float s = (float)(1 << h.fractional_bits);
+            for (int c = 0; c < 3; c++) {
+                int32_t fixed = sat_i32(std::round(g.pos[c] * s));
+                uint8_t *p = pos + 9 * i + 3 * c;
+                p[0] = (uint8_t)(fixed & 0xff);
+                p[1] = (uint8_t)((fixed >> 8) & 0xff);
+                p[2] = (uint8_t)((fixed >> 16) & 0xff);
+            }
+        }
+        for (int c = 0; c < 3; c++) {
+            float v = std::round((std::log(g.scale[c]) + 10.0f) * 16.0f);
+            scale[3 * i + c] = sat_u8(std::fmin(std::fmax(v, 0.0f), 255.0f));
+        }
+        // Quat::normalize
+        float q[4];
+        {
+            float len = std::sqrt(((g.rot[0] * g.rot[0] + g.rot[1] * g.rot[1]) + g.rot[2] * g.rot[2]) + g.rot[3] * g.rot[3]);
+            for (int c = 0; c < 4; c++) q[c] = g.rot[c] / len;
+        }
+        if (h.version >= 3) {
+            uint32_t largest = 0;
+            for (uint32_t k = 1; k < 4; k++)
+                if (std::fabs(q[k]) >= std::fabs(q[largest])) largest = k;   // max_by keeps the LAST maximum
+            const uint32_t mask = (1u << 9) - 1u;
+            uint32_t negate = q[largest] < 0.0f ? 1u : 0u;
+            uint32_t comp = largest;
+            for (uint32_t k = 0; k < 4; k++) {
+                if (k == largest) continue;
+                uint32_t neg = (q[k] < 0.0f ? 1u : 0u) ^ negate;
+                float mv = (float)mask * (std::fabs(q[k]) * 1.41421356237309504880f) + 0.5f;
+                uint32_t mag = sat_u32(std::fmin(std::fmax(mv, 0.0f), (float)mask - 1.0f));
+                comp = (comp << 10) | (neg << 9) | mag;
+            }
+            uint8_t *r = rot + 4 * i;
+            r[0] = (uint8_t)(comp & 0xff);
+            r[1] = (uint8_t)((comp >> 8) & 0xff);
+            r[2] = (uint8_t)((comp >> 16) & 0xff);
+            r[3] = (uint8_t)((comp >> 24) & 0xff);
+        } else {
+            float sgn = q[3] < 0.0f ? -1.0f : 1.0f;
+            for (int c = 0; c < 3; c++) {
+                float v = std::round(((sgn < 0.0f ? -q[c] : q[c]) + 1.0f) * 127.5f);
+                rot[3 * i + c] = sat_u8(std::fmin(std::fmax(v, 0.0f), 255.0f));
+            }
+        }
+        alpha[i] = g.color[3];
+        for (int c = 0; c < 3; c++) {
+            float v = ((float)g.color[c] - k_c) / k_ab;
+            color[3 * i + c] = sat_u8(std::fmin(std::fmax(v, 0.0f), 255.0f));
+        }
+        for (uint32_t k = 0; k < ncoef; k++)
+            for (int c = 0; c < 3; c++) sh[(i * ncoef + k) * 3 + c] = quantize_sh(g.sh[3 * k + c], bucket);
+    }
+    return GS_OK;
+}
+
+// ---- gzip framing (flate2 GzDecoder / GzEncoder, spz.rs:945-959) ---------------------------------
+static gs_status gunzip(const void *bytes, size_t len, std::vector<uint8_t> &out) {
+    z_stream zs;
+    std::memset(&zs, 0, sizeof(zs));
+    if (inflateInit2(&zs, 16 + MAX_WBITS) != Z_OK) return gs_fail(GS_ERR_SPZ, 0, 0, 0, "zlib init failed");
+    zs.next_in = (Bytef *)bytes;
+    zs.avail_in = (uInt)len;
+    out.resize(len * 4 + 1024);
+    int rc;
+    do {
+        if (zs.total_out == out.size()) out.resize(out.size() * 2);
+        zs.next_out = out.data() + zs.total_out;
+        zs.avail_out = (uInt)(out.size() - zs.total_out);
+        rc = inflate(&zs, Z_NO_FLUSH);
+    } while (rc == Z_OK);
+    size_t total = zs.total_out;
+    inflateEnd(&zs);
+    if (rc != Z_STREAM_END) return gs_fail(GS_ERR_SPZ, (uint64_t)rc, 0, 0, "invalid gzip header");
+    out.resize(total);
+    return GS_OK;
+}
+
+extern "C" gs_status gs_spz_decode(const void *bytes, size_t len, gs_spz_header *header_out, gs_gaussian *out,
+                                   size_t capacity, size_t *count_out) {
+    if (!bytes || !count_out) return gs_fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "null argument");
+    std::vector<uint8_t> raw;
+    gs_status rc = gunzip(bytes, len, raw);
+    if (rc != GS_OK) return rc;
+    return gs_spz_decode_decompressed(raw.data(), raw.size(), header_out, out, capacity, count_out);
+}
+
+extern "C" gs_status gs_spz_encode(const gs_gaussian *in, size_t n, const gs_spz_options *opt, void *out,
+                                   size_t capacity, size_t *bytes_out) {
+    if (!bytes_out) return gs_fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "null argument");
+    size_t raw_size = 0;
+    gs_status rc = gs_spz_encode_decompressed(in, n, opt, nullptr, 0, &raw_size);
+    if (rc != GS_OK) return rc;
+    std::vector<uint8_t> raw(raw_size);
+    rc = gs_spz_encode_decompressed(in, n, opt, raw.data(), raw.size(), &raw_size);
+    if (rc != GS_OK) return rc;
+    z_stream zs;
+    std::memset(&zs, 0, sizeof(zs));
+    if (deflateInit2(&zs, Z_DEFAULT_COMPRESSION, Z_DEFLATED, 16 + MAX_WBITS, 8, Z_DEFAULT_STRATEGY) != Z_OK)
+        return gs_fail(GS_ERR_SPZ, 0, 0, 0, "zlib init failed");
+    std::vector<uint8_t> z(deflateBound(&zs, (uLong)raw.size()) + 64);
+    zs.next_in = raw.data();
+    zs.avail_in = (uInt)raw.size();
+    zs.next_out = z.data();
+    zs.avail_out = (uInt)z.size();
+    int zr = deflate(&zs, Z_FINISH);
+    size_t total = zs.total_out;
+    deflateEnd(&zs);
+    if (zr != Z_STREAM_END) return gs_fail(GS_ERR_SPZ, (uint64_t)zr, 0, 0, "gzip compression failed");
+    *bytes_out = total;
+    if (!out) return GS_OK;
+    if (capacity < total) return gs_fail(GS_ERR_INVALID_ARGUMENT, capacity, total, 0, "output buffer too small");
+    std::memcpy(out, z.data(), total);
+    return GS_OK;
+}
