@@ -220,6 +220,10 @@ gs_status gs_spz_encode(const gs_gaussian *in, size_t n, const gs_spz_options *o
                         size_t capacity, size_t *bytes_out);
 gs_status gs_spz_encode_decompressed(const gs_gaussian *in, size_t n, const gs_spz_options *options,
                                      void *out, size_t capacity, size_t *bytes_out);
+/* the gzip member around the payload on its own (flate2 GzDecoder / GzEncoder, spz.rs:945-959), so a
+ * host mirror can keep the payload it read and write the identical columns back.  out == NULL: size */
+gs_status gs_spz_decompress(const void *bytes, size_t len, void *out, size_t capacity, size_t *bytes_out);
+gs_status gs_spz_compress(const void *bytes, size_t len, void *out, size_t capacity, size_t *bytes_out);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Device, streams                                                                             */

@@ -175,6 +175,30 @@ def test_edge_cases(gs, ob, device, stream):
     assert st.pairs >= 40 * 30
 
 
+def test_pair_overflow_is_reported_not_wrapped(gs, ob, device, stream):
+    """150k screen-filling splats at 4K need 150k x 32400 > 2^32 pairs: the frame must fail with
+    GS_ERR_PAIR_OVERFLOW instead of wrapping the 32-bit pair count (and must stay usable after)."""
+    n = 150_000
+    g = np.zeros(n, dtype=gs.GAUSSIAN_DTYPE)
+    g["rot"] = [0, 0, 0, 1]
+    g["pos"] = [0, 0, -5]
+    g["scale"] = [50, 50, 50]
+    g["color"] = [255, 255, 255, 255]
+    pod = gs.GaussianPod(gs.SH_NONE, gs.COV3D_ROT_SCALE)
+    buf = gs.GaussiansBuffer.new_with_pods(device, pod, pod.from_gaussian(g))
+    cam = helpers.default_camera(gs, 3840, 2160)
+    img = gs.Buffer(device, size=cam.height * cam.width * 16)
+    r = gs.Renderer(device)
+    gt, mt = gs.gaussian_transform_pod(sh_deg=0), gs.model_transform_pod()
+    with pytest.raises(gs.PairOverflowError):
+        r.render(stream, buf, gt, mt, cam, img.device_ptr())
+    small = helpers.default_camera(gs, 64, 64)      # 16 tiles x 150k pairs fits
+    r.render(stream, buf, gt, mt, small, img.device_ptr())
+    stream.synchronize()
+    assert r.stats().pairs == 16 * n
+    buf.destroy(); img.release(); r.destroy()
+
+
 def test_deep_tiles_early_termination(gs, ob, device, stream):
     """Many opaque splats stacked in few tiles: exercises multi-batch staging and the per-pixel /
     per-tile early-out (T < 1e-4)."""

@@ -134,13 +134,16 @@ class PlyError(GsError):
     """std::io::Error of PlyGaussians::read_from (message = the reference's message)"""
     code = -24
 class DownloadBufferError(GsError): code = -22
+class PairOverflowError(GsError):
+    """a frame needs more (tile, Gaussian) pairs than 32-bit pair indices can address"""
+    code = -23
 
 
 _ERRORS = {c.code: c for c in (InvalidArgumentError, NoDeviceError, HipError, OutOfMemoryError,
                                GaussiansBufferUpdateError, GaussiansBufferUpdateRangeError,
                                GaussiansBufferTryFromBufferError, FixedSizeBufferWrapperError,
                                ResourceCountMismatch, WorkgroupSizeExceedsDeviceLimit,
-                               LossyConfigError, DownloadBufferError, PlyError, SpzError)}
+                               LossyConfigError, DownloadBufferError, PlyError, SpzError, PairOverflowError)}
 
 
 def _check(status):
@@ -341,6 +344,9 @@ class PlyGaussians:
         """IterGaussian: the Gaussians (Gaussian::from_ply of every pod)"""
         return gaussian_from_ply(self.pods)
 
+    def __eq__(self, o):
+        return isinstance(o, PlyGaussians) and self.pods.tobytes() == o.pods.tobytes()
+
 
 # ------------------------------------------------------------------------------------------------
 # SPZ source format — src/source_format/spz.rs
@@ -356,59 +362,179 @@ def spz_options(version=3, sh_degree=3, fractional_bits=12, antialiased=False, s
     return o
 
 
-class SpzGaussians:
-    """SpzGaussians — decoded view: header + the Gaussians (Gaussian::from_spz of every point)."""
+def _sized_call(fn, *head):
+    """two-call pattern of the C ABI: size query with out == NULL, then fill"""
+    n = C.c_size_t()
+    _check(fn(*head, None, 0, C.byref(n)))
+    out = np.zeros(max(n.value, 1), dtype=np.uint8)
+    _check(fn(*head, _ptr(out), n.value, C.byref(n)))
+    return out[:n.value].tobytes()
 
-    def __init__(self, header, gaussians):
-        self.header, self.gaussians = header, gaussians
+
+class SpzGaussians:
+    """SpzGaussians — spz.rs:514-959.  Holds the decompressed payload (header + columns) exactly as
+    read or encoded, so write_to reproduces the same columns; `gaussians` is Gaussian::from_spz of
+    every point (what iter_gaussian yields)."""
+
+    def __init__(self, payload):
+        self.payload = bytes(payload)
+        buf = np.frombuffer(self.payload, dtype=np.uint8)
+        hdr, n = _capi.SpzHeader(), C.c_size_t()
+        _check(_L.gs_spz_decode_decompressed(_ptr(buf), buf.size, C.byref(hdr), None, 0, C.byref(n)))
+        out = np.zeros(n.value, dtype=GAUSSIAN_DTYPE)
+        _check(_L.gs_spz_decode_decompressed(_ptr(buf), buf.size, C.byref(hdr), _ptr(out), n.value, C.byref(n)))
+        self.header, self.gaussians = hdr, out
 
     def __len__(self):
         return len(self.gaussians)
 
-    @staticmethod
-    def _decode(fn, data):
-        buf = np.frombuffer(bytes(data), dtype=np.uint8)
-        hdr, n = _capi.SpzHeader(), C.c_size_t()
-        _check(fn(_ptr(buf), buf.size, C.byref(hdr), None, 0, C.byref(n)))
-        out = np.zeros(n.value, dtype=GAUSSIAN_DTYPE)
-        _check(fn(_ptr(buf), buf.size, C.byref(hdr), _ptr(out), n.value, C.byref(n)))
-        return SpzGaussians(hdr, out)
+    def is_empty(self):
+        return len(self.gaussians) == 0
 
+    def __eq__(self, o):
+        return isinstance(o, SpzGaussians) and self.payload == o.payload
+
+    # ---- reading
     @staticmethod
     def read_from(data):
         """ReadIterGaussian::read_from (gzip'd .spz bytes)"""
-        return SpzGaussians._decode(_L.gs_spz_decode, data)
+        buf = np.frombuffer(bytes(data), dtype=np.uint8)
+        return SpzGaussians(_sized_call(_L.gs_spz_decompress, _ptr(buf), buf.size))
 
     @staticmethod
     def read_decompressed(data):
-        return SpzGaussians._decode(_L.gs_spz_decode_decompressed, data)
+        return SpzGaussians(data)
 
     @staticmethod
     def read_from_file(path):
         with open(path, "rb") as f:
             return SpzGaussians.read_from(f.read())
 
+    # ---- from Gaussians
+    @staticmethod
+    def from_gaussians_with_options(gaussians, options=None):
+        """from_gaussians_with_options (spz.rs:806-835); from_gaussians / FromIterator use the defaults"""
+        return SpzGaussians(SpzGaussians.write_gaussians_decompressed(gaussians, options))
+
+    from_gaussians = from_gaussians_with_options
+
     def iter_gaussian(self):
         return self.gaussians
 
+    # ---- writing
+    def write_decompressed(self):
+        return self.payload
+
+    def write_to(self):
+        """WriteIterGaussian::write_to -> gzip'd bytes"""
+        buf = np.frombuffer(self.payload, dtype=np.uint8)
+        return _sized_call(_L.gs_spz_compress, _ptr(buf), buf.size)
+
+    def write_to_file(self, path):
+        with open(path, "wb") as f:
+            f.write(self.write_to())
+
+    # ---- one-shot helpers over the C ABI's fused entry points
     @staticmethod
     def _encode(fn, gaussians, options):
         g = np.ascontiguousarray(np.atleast_1d(gaussians), dtype=GAUSSIAN_DTYPE)
         options = options or spz_options()
-        n = C.c_size_t()
-        _check(fn(_ptr(g), len(g), C.byref(options), None, 0, C.byref(n)))
-        out = np.zeros(n.value, dtype=np.uint8)
-        _check(fn(_ptr(g), len(g), C.byref(options), _ptr(out), out.size, C.byref(n)))
-        return out[:n.value].tobytes()
+        return _sized_call(fn, _ptr(g), len(g), C.byref(options))
 
     @staticmethod
     def write_gaussians(gaussians, options=None):
-        """from_gaussians_with_options + write_to -> gzip'd bytes"""
+        """from_gaussians_with_options + write_to -> gzip'd bytes (gs_spz_encode)"""
         return SpzGaussians._encode(_L.gs_spz_encode, gaussians, options)
 
     @staticmethod
     def write_gaussians_decompressed(gaussians, options=None):
         return SpzGaussians._encode(_L.gs_spz_encode_decompressed, gaussians, options)
+
+    @staticmethod
+    def decode(data):
+        """gs_spz_decode: gzip'd bytes -> (header, Gaussians) in one call"""
+        buf = np.frombuffer(bytes(data), dtype=np.uint8)
+        hdr, n = _capi.SpzHeader(), C.c_size_t()
+        _check(_L.gs_spz_decode(_ptr(buf), buf.size, C.byref(hdr), None, 0, C.byref(n)))
+        out = np.zeros(n.value, dtype=GAUSSIAN_DTYPE)
+        _check(_L.gs_spz_decode(_ptr(buf), buf.size, C.byref(hdr), _ptr(out), n.value, C.byref(n)))
+        return hdr, out
+
+
+class GaussiansSource:
+    """GaussiansSource — src/gaussian.rs:394-416"""
+    Internal, Ply, Spz = "Internal", "Ply", "Spz"
+
+
+class Gaussians:
+    """Gaussians — the unified representation (src/gaussian.rs:412-548): Internal holds an array of
+    Gaussian, Ply a PlyGaussians, Spz a SpzGaussians."""
+
+    def __init__(self, inner):
+        if isinstance(inner, Gaussians):
+            inner = inner.inner
+        if not isinstance(inner, (PlyGaussians, SpzGaussians)):
+            inner = np.ascontiguousarray(np.atleast_1d(inner), dtype=GAUSSIAN_DTYPE)   # From<Vec<Gaussian>>
+        self.inner = inner
+
+    @staticmethod
+    def from_gaussians_iter(gaussians, source):
+        g = np.ascontiguousarray(np.atleast_1d(gaussians), dtype=GAUSSIAN_DTYPE)
+        if source == GaussiansSource.Internal:
+            return Gaussians(g)
+        if source == GaussiansSource.Ply:
+            return Gaussians(PlyGaussians.from_gaussians(g))
+        if source == GaussiansSource.Spz:
+            return Gaussians(SpzGaussians.from_gaussians(g))
+        raise ValueError("unknown GaussiansSource %r" % (source,))
+
+    def source(self):
+        if isinstance(self.inner, PlyGaussians):
+            return GaussiansSource.Ply
+        if isinstance(self.inner, SpzGaussians):
+            return GaussiansSource.Spz
+        return GaussiansSource.Internal
+
+    def __len__(self):
+        return len(self.inner)
+
+    def is_empty(self):
+        return len(self.inner) == 0
+
+    @staticmethod
+    def read_from(data, source):
+        if source == GaussiansSource.Internal:
+            raise ValueError("cannot read Internal Gaussians from buffer")      # gaussian.rs:480-483
+        cls = PlyGaussians if source == GaussiansSource.Ply else SpzGaussians
+        return Gaussians(cls.read_from(data))
+
+    @staticmethod
+    def read_from_file(path, source):
+        if source == GaussiansSource.Internal:
+            raise ValueError("cannot read Internal Gaussians from file")        # gaussian.rs:461-464
+        cls = PlyGaussians if source == GaussiansSource.Ply else SpzGaussians
+        return Gaussians(cls.read_from_file(path))
+
+    def write_to(self):
+        if self.source() == GaussiansSource.Internal:
+            raise ValueError("cannot write Internal Gaussians to buffer")       # gaussian.rs:510-513
+        return self.inner.write_to()
+
+    def write_to_file(self, path):
+        if self.source() == GaussiansSource.Internal:
+            raise ValueError("cannot write Internal Gaussians to file")         # gaussian.rs:498-501
+        self.inner.write_to_file(path)
+
+    def iter_gaussian(self):
+        """IterGaussian — the Gaussians in the internal format, whatever the source"""
+        return self.inner if self.source() == GaussiansSource.Internal else self.inner.iter_gaussian()
+
+    def __eq__(self, o):
+        if not isinstance(o, Gaussians) or self.source() != o.source():
+            return False
+        if self.source() == GaussiansSource.Internal:
+            return self.inner.tobytes() == o.inner.tobytes()
+        return self.inner == o.inner
 
 
 # ------------------------------------------------------------------------------------------------

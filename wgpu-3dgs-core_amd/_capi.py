@@ -92,6 +92,8 @@ SIGNATURES = {
     "gs_spz_decode_decompressed": (i32, [vp, sz, vp, vp, sz, vp]),
     "gs_spz_encode": (i32, [vp, sz, vp, vp, sz, vp]),
     "gs_spz_encode_decompressed": (i32, [vp, sz, vp, vp, sz, vp]),
+    "gs_spz_decompress": (i32, [vp, sz, vp, sz, vp]),
+    "gs_spz_compress": (i32, [vp, sz, vp, sz, vp]),
     "gs_device_create": (i32, [i32, vp]),
     "gs_device_destroy": (None, [vp]),
     "gs_device_limits": (i32, [vp, vp]),

@@ -1403,7 +1403,7 @@ static gs_status sort_pairs_device(const gs_device *dev, void *const keys[2], vo
     result_side = 0;
     if (count == 0 || passes == 0) return GS_OK;
     const uint32_t tile = (uint32_t)gs::sort_tile<K>();
-    uint32_t nb = (count + tile - 1) / tile;
+    uint32_t nb = (uint32_t)(((uint64_t)count + tile - 1) / tile);
     GS_TRY(dev_reserve(ghist, (size_t)nb * gs::RADIX * 4));
     GS_TRY(dev_reserve(digit_totals, gs::RADIX * 4));
     int side = 0;
@@ -1477,6 +1477,9 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
     uint32_t n = (uint32_t)n64;
     uint32_t nchunks = (n + gs::PP_CHUNK - 1) / gs::PP_CHUNK;
     uint32_t num_tiles = fc.tiles_x * fc.tiles_y;
+    // one 1024-Gaussian chunk may touch at most chunk * num_tiles pairs: keep that inside 32 bits
+    if ((uint64_t)fc.tiles_x * fc.tiles_y > (1ull << 22))
+        return fail(GS_ERR_INVALID_ARGUMENT, cam->width, cam->height, 0, "more than 2^22 tiles");
     const bool wide = num_tiles > 65536u;
     const size_t nn = n ? n : 1, nc = nchunks ? nchunks : 1;
 
@@ -1523,6 +1526,9 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
         GS_HIP(hipStreamSynchronize(st));
         d = r->host_counters[0];
         visible = r->host_counters[1];
+        if (d == 0xffffffffu)
+            return fail(GS_ERR_PAIR_OVERFLOW, n, 0, 0,
+                        "the frame needs more than 2^32 (tile, Gaussian) pairs; pair indices are 32-bit");
     } else {
         mark(ST_SCAN);
     }
@@ -1554,13 +1560,13 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
                                order, (const uint2 *)r->sorted_rect.ptr,
                                (const uint32_t *)r->exp_offsets.ptr, visible, fc.tiles_x,
                                (uint32_t *)r->tkeys[0].ptr, (uint32_t *)r->tvals[0].ptr,
-                               (uint32_t)r->pair_capacity);
+                               (uint32_t)(r->pair_capacity > 0xffffffffull ? 0xffffffffull : r->pair_capacity));
         else
             hipLaunchKernelGGL(gs::k_expand_emit<uint16_t>, dim3(vchunks), dim3(gs::EXP_CHUNK), 0, st,
                                order, (const uint2 *)r->sorted_rect.ptr,
                                (const uint32_t *)r->exp_offsets.ptr, visible, fc.tiles_x,
                                (uint16_t *)r->tkeys[0].ptr, (uint32_t *)r->tvals[0].ptr,
-                               (uint32_t)r->pair_capacity);
+                               (uint32_t)(r->pair_capacity > 0xffffffffull ? 0xffffffffull : r->pair_capacity));
         GS_HIP(hipGetLastError());
     }
     mark(ST_TSORT);
@@ -1582,10 +1588,10 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
     GS_HIP(hipMemsetAsync(r->ranges.ptr, 0, (size_t)num_tiles * 8, st));
     if (d) {
         if (wide)
-            hipLaunchKernelGGL(gs::k_tile_ranges<uint32_t>, dim3((d + 1023) / 1024), dim3(256), 0, st,
+            hipLaunchKernelGGL(gs::k_tile_ranges<uint32_t>, dim3((uint32_t)(((uint64_t)d + 1023) / 1024)), dim3(256), 0, st,
                                (const uint32_t *)r->tkeys[tside].ptr, d, (uint32_t *)r->ranges.ptr);
         else
-            hipLaunchKernelGGL(gs::k_tile_ranges<uint16_t>, dim3((d + 2047) / 2048), dim3(256), 0, st,
+            hipLaunchKernelGGL(gs::k_tile_ranges<uint16_t>, dim3((uint32_t)(((uint64_t)d + 2047) / 2048)), dim3(256), 0, st,
                                (const uint16_t *)r->tkeys[tside].ptr, d, (uint32_t *)r->ranges.ptr);
         GS_HIP(hipGetLastError());
     }

@@ -321,9 +321,13 @@ __global__ __launch_bounds__(1024) void k_scan_chunks(ScanJob j0, ScanJob j1) {
     constexpr uint32_t PER = 8;   // consecutive values per thread -> 8192 per iteration
     __shared__ uint32_t s_wave[16];
     __shared__ uint32_t s_carry;
+    __shared__ uint32_t s_overflow;   // the running total left 32 bits: reported as 0xffffffff
     const ScanJob job = blockIdx.x == 0 ? j0 : j1;
     uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
-    if (threadIdx.x == 0) s_carry = 0;
+    if (threadIdx.x == 0) {
+        s_carry = 0;
+        s_overflow = 0;
+    }
     __syncthreads();
     for (uint32_t base = 0; base < job.num; base += 1024u * PER) {
         uint32_t i0 = base + threadIdx.x * PER;
@@ -352,10 +356,16 @@ __global__ __launch_bounds__(1024) void k_scan_chunks(ScanJob j0, ScanJob j1) {
             run += v[k];
         }
         __syncthreads();
-        if (threadIdx.x == 0) s_carry = carry + tot;
+        if (threadIdx.x == 0) {
+            // every addend of this iteration is a partial sum of `tot`, so one wrap test covers them
+            uint64_t wide_tot = 0;
+            for (uint32_t k = 0; k < 16; k++) wide_tot += s_wave[k];
+            if ((uint64_t)carry + wide_tot > 0xfffffff0ull) s_overflow = 1;
+            s_carry = carry + tot;
+        }
         __syncthreads();
     }
-    if (threadIdx.x == 0) *job.total = s_carry;
+    if (threadIdx.x == 0) *job.total = s_overflow ? 0xffffffffu : s_carry;
 }
 
 // ---------------------------------------------------------------------------------------------

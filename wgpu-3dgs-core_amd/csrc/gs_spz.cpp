@@ -267,8 +267,9 @@ static gs_status gunzip(const void *bytes, size_t len, std::vector<uint8_t> &out
     int rc;
     do {
         if (zs.total_out == out.size()) out.resize(out.size() * 2);
+        size_t room = out.size() - zs.total_out;
         zs.next_out = out.data() + zs.total_out;
-        zs.avail_out = (uInt)(out.size() - zs.total_out);
+        zs.avail_out = (uInt)(room > 0x40000000u ? 0x40000000u : room);
         rc = inflate(&zs, Z_NO_FLUSH);
     } while (rc == Z_OK);
     size_t total = zs.total_out;
@@ -276,6 +277,52 @@ static gs_status gunzip(const void *bytes, size_t len, std::vector<uint8_t> &out
     if (rc != Z_STREAM_END) return gs_fail(GS_ERR_SPZ, (uint64_t)rc, 0, 0, "invalid gzip header");
     out.resize(total);
     return GS_OK;
+}
+
+static gs_status gzip_member(const void *bytes, size_t len, std::vector<uint8_t> &z) {
+    z_stream zs;
+    std::memset(&zs, 0, sizeof(zs));
+    if (deflateInit2(&zs, Z_DEFAULT_COMPRESSION, Z_DEFLATED, 16 + MAX_WBITS, 8, Z_DEFAULT_STRATEGY) != Z_OK)
+        return gs_fail(GS_ERR_SPZ, 0, 0, 0, "zlib init failed");
+    z.resize(deflateBound(&zs, (uLong)len) + 64);
+    zs.next_in = (Bytef *)bytes;
+    zs.avail_in = (uInt)len;
+    zs.next_out = z.data();
+    zs.avail_out = (uInt)z.size();
+    int zr = deflate(&zs, Z_FINISH);
+    size_t total = zs.total_out;
+    deflateEnd(&zs);
+    if (zr != Z_STREAM_END) return gs_fail(GS_ERR_SPZ, (uint64_t)zr, 0, 0, "gzip compression failed");
+    z.resize(total);
+    return GS_OK;
+}
+
+static gs_status copy_out(const std::vector<uint8_t> &v, void *out, size_t capacity, size_t *bytes_out) {
+    *bytes_out = v.size();
+    if (!out) return GS_OK;
+    if (capacity < v.size()) return gs_fail(GS_ERR_INVALID_ARGUMENT, capacity, v.size(), 0, "output buffer too small");
+    if (!v.empty()) std::memcpy(out, v.data(), v.size());
+    return GS_OK;
+}
+
+// the gzip framing on its own: SpzGaussians::read_from = decompress + read_decompressed,
+// write_to = write_decompressed + compress (spz.rs:945-959)
+extern "C" gs_status gs_spz_decompress(const void *bytes, size_t len, void *out, size_t capacity, size_t *bytes_out) {
+    if (!bytes || !bytes_out) return gs_fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "null argument");
+    if (len > 0xffffffffull) return gs_fail(GS_ERR_INVALID_ARGUMENT, len, 0, 0, "input larger than 4 GiB");
+    std::vector<uint8_t> raw;
+    gs_status rc = gunzip(bytes, len, raw);
+    if (rc != GS_OK) return rc;
+    return copy_out(raw, out, capacity, bytes_out);
+}
+
+extern "C" gs_status gs_spz_compress(const void *bytes, size_t len, void *out, size_t capacity, size_t *bytes_out) {
+    if ((len && !bytes) || !bytes_out) return gs_fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "null argument");
+    if (len > 0xffffffffull) return gs_fail(GS_ERR_INVALID_ARGUMENT, len, 0, 0, "input larger than 4 GiB");
+    std::vector<uint8_t> z;
+    gs_status rc = gzip_member(bytes, len, z);
+    if (rc != GS_OK) return rc;
+    return copy_out(z, out, capacity, bytes_out);
 }
 
 extern "C" gs_status gs_spz_decode(const void *bytes, size_t len, gs_spz_header *header_out, gs_gaussian *out,
@@ -296,22 +343,8 @@ extern "C" gs_status gs_spz_encode(const gs_gaussian *in, size_t n, const gs_spz
     std::vector<uint8_t> raw(raw_size);
     rc = gs_spz_encode_decompressed(in, n, opt, raw.data(), raw.size(), &raw_size);
     if (rc != GS_OK) return rc;
-    z_stream zs;
-    std::memset(&zs, 0, sizeof(zs));
-    if (deflateInit2(&zs, Z_DEFAULT_COMPRESSION, Z_DEFLATED, 16 + MAX_WBITS, 8, Z_DEFAULT_STRATEGY) != Z_OK)
-        return gs_fail(GS_ERR_SPZ, 0, 0, 0, "zlib init failed");
-    std::vector<uint8_t> z(deflateBound(&zs, (uLong)raw.size()) + 64);
-    zs.next_in = raw.data();
-    zs.avail_in = (uInt)raw.size();
-    zs.next_out = z.data();
-    zs.avail_out = (uInt)z.size();
-    int zr = deflate(&zs, Z_FINISH);
-    size_t total = zs.total_out;
-    deflateEnd(&zs);
-    if (zr != Z_STREAM_END) return gs_fail(GS_ERR_SPZ, (uint64_t)zr, 0, 0, "gzip compression failed");
-    *bytes_out = total;
-    if (!out) return GS_OK;
-    if (capacity < total) return gs_fail(GS_ERR_INVALID_ARGUMENT, capacity, total, 0, "output buffer too small");
-    std::memcpy(out, z.data(), total);
-    return GS_OK;
+    std::vector<uint8_t> z;
+    rc = gzip_member(raw.data(), raw.size(), z);
+    if (rc != GS_OK) return rc;
+    return copy_out(z, out, capacity, bytes_out);
 }
