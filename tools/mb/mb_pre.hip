@@ -23,12 +23,12 @@ __global__ void k_gen(uint4* planar, uint64_t stride, uint32_t n) {
     float l = sqrtf(q[0]*q[0]+q[1]*q[1]+q[2]*q[2]+q[3]*q[3]) + 1e-9f;
     for (int k = 0; k < 4; k++) w[49 + k] = __float_as_uint(q[k] / l);
     for (int k = 0; k < 3; k++) w[53 + k] = __float_as_uint(expf(-3.6f + (u01(i, 7 + k) - 0.5f) * 1.7f));
-    for (int c = 0; c < 14; c++) planar[(uint64_t)c * stride + i] = make_uint4(w[4*c], w[4*c+1], w[4*c+2], w[4*c+3]);
+    for (int c = 0; c < 14; c++) planar[gs::planar_at(c, i, 14)] = make_uint4(w[4*c], w[4*c+1], w[4*c+2], w[4*c+3]);
 }
 
 int main(int argc, char** argv) {
     const uint32_t n = 10000000;
-    uint64_t stride = (n + 63) / 64 * 64 + (argc > 2 ? atoi(argv[2]) : 0);
+    uint64_t stride = (n + 1023) / 1024 * 1024;
     uint4 *planar; uint32_t *proj, *depth, *ct, *cv; uint2* rect;
     uint32_t nchunks = (n + gs::PP_CHUNK - 1) / gs::PP_CHUNK;
     CK(hipMalloc(&planar, stride * 16 * 14)); CK(hipMalloc(&proj, (size_t)n * 36 + 16));
@@ -44,7 +44,7 @@ int main(int argc, char** argv) {
     fc.sh_deg = argc > 1 ? atoi(argv[1]) : 3; fc.width = 1920; fc.height = 1080; fc.tiles_x = 120; fc.tiles_y = 68; fc.band_ty1 = 68;
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     auto launch = [&]() { hipLaunchKernelGGL((gs::k_preprocess<0, 0>), dim3(nchunks), dim3(gs::PP_THREADS), 0, 0,
-        (const uint4*)planar, stride, n, fc, proj, depth, rect, ct, cv); };
+        (const uint4*)planar, n, fc, proj, depth, rect, ct, cv); };
     for (int w = 0; w < 3; w++) launch();
     CK(hipEventRecord(a));
     for (int r = 0; r < 10; r++) launch();
@@ -52,6 +52,6 @@ int main(int argc, char** argv) {
     float ms; CK(hipEventElapsedTime(&ms, a, b)); ms /= 10;
     std::vector<uint32_t> h(nchunks); CK(hipMemcpy(h.data(), cv, nchunks * 4ull, hipMemcpyDeviceToHost));
     uint64_t vis = 0; for (auto x : h) vis += x;
-    printf("stride+%d k_preprocess<0,0> sh_deg=%u: %.3f ms  read %.2f TB/s  visible %llu\n", (int)(stride - (n + 63) / 64 * 64), fc.sh_deg, ms, n * 224.0 / ms / 1e9, (unsigned long long)vis);
+    printf("k_preprocess<0,0> sh_deg=%u: %.3f ms  read %.2f TB/s  visible %llu\n", fc.sh_deg, ms, n * 224.0 / ms / 1e9, (unsigned long long)vis);
     return 0;
 }

@@ -557,9 +557,9 @@ extern "C" gs_status gs_buffer_download(gs_buffer *b, gs_stream *s, void *dst, s
 struct gs_gaussians_buffer {
     gs_buffer *buf;
     int sh, cov;
-    // chunk-planar mirror read by the preprocess kernel; rebuilt lazily
+    // block-planar mirror read by the preprocess kernel; rebuilt lazily
     void *planar;
-    size_t planar_stride;  // in 16-byte elements = len rounded up to 64
+    size_t planar_stride;  // capacity in Gaussians = len rounded up to whole 1024-blocks
     bool dirty;
 };
 
@@ -705,15 +705,15 @@ extern "C" void gs_gaussians_buffer_mark_dirty(gs_gaussians_buffer *g) {
     if (g) g->dirty = true;
 }
 
-// (re)build the chunk-planar mirror on `st`
+// (re)build the block-planar mirror on `st`
 static gs_status ensure_planar(gs_gaussians_buffer *g, hipStream_t st) {
     size_t len = gs_gaussians_buffer_len(g);
-    size_t stride = (len + 63) / 64 * 64;
+    size_t stride = (len + gs::PLANAR_BLOCK - 1) / gs::PLANAR_BLOCK * gs::PLANAR_BLOCK;   // whole blocks
     uint32_t chunks = (uint32_t)(pod_stride(g) / 16);
     if (!g->planar || g->planar_stride != stride) {
         if (g->planar) GS_HIP(hipFree(g->planar));
         g->planar = nullptr;
-        GS_HIP(hipMalloc(&g->planar, (stride ? stride : 64) * 16 * chunks));
+        GS_HIP(hipMalloc(&g->planar, (stride ? stride : gs::PLANAR_BLOCK) * 16 * chunks));
         g->planar_stride = stride;
         g->dirty = true;
     }
@@ -722,7 +722,7 @@ static gs_status ensure_planar(gs_gaussians_buffer *g, hipStream_t st) {
         uint32_t grid = (uint32_t)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
         hipLaunchKernelGGL(gs::k_repack_planar, dim3(grid), dim3(256), 0, st,
                            (const uint4 *)g->buf->ptr, (uint4 *)g->planar, (uint64_t)0,
-                           (uint64_t)len, chunks, (uint64_t)stride);
+                           (uint64_t)len, chunks);
         GS_HIP(hipGetLastError());
     }
     g->dirty = false;
@@ -1336,7 +1336,7 @@ extern "C" gs_status gs_renderer_stats(gs_renderer *r, gs_frame_stats *out) {
     return GS_OK;
 }
 
-typedef void (*preprocess_fn)(const uint4 *, uint64_t, uint32_t, gs::FrameConsts, uint32_t *,
+typedef void (*preprocess_fn)(const uint4 *, uint32_t, gs::FrameConsts, uint32_t *,
                               uint32_t *, uint2 *, uint32_t *, uint32_t *);
 static preprocess_fn k_tbl_preprocess[4][3] = GS_CFG_TABLE(gs::k_preprocess);
 
@@ -1506,7 +1506,7 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
     uint32_t d = 0, visible = 0;
     if (n) {
         hipLaunchKernelGGL(k_tbl_preprocess[g->sh][g->cov], dim3(nchunks), dim3(gs::PP_THREADS), 0, st,
-                           (const uint4 *)g->planar, (uint64_t)g->planar_stride, n, fc,
+                           (const uint4 *)g->planar, n, fc,
                            (uint32_t *)r->recs.ptr, (uint32_t *)r->depth.ptr,
                            (uint2 *)r->rect.ptr, (uint32_t *)r->chunk_tiles.ptr,
                            (uint32_t *)r->chunk_vis.ptr);

@@ -84,19 +84,28 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_256(uint32_t v, uint32_
 }
 
 // ---------------------------------------------------------------------------------------------
-// repack: AoS (N x pod_bytes) -> chunk-planar (pod_bytes/16 planes of plane_stride x 16 B)
+// repack: AoS (N x pod_bytes) -> block-planar mirror
 // ---------------------------------------------------------------------------------------------
+
+// Mirror layout ("block-planar"): Gaussians are grouped in blocks of PLANAR_BLOCK = 1024; inside a
+// block the nc = pod_bytes/16 chunk planes follow each other, each PLANAR_BLOCK x 16 B.  A
+// preprocess workgroup (one block) therefore streams one contiguous nc x 16 KiB span, and a wave
+// still reads 1 KiB contiguous per load instruction.  (Whole-array planes — plane stride N x 16 B —
+// measured 2 % slower at 10 M: 14 streams 160 MB apart instead of one 224 KiB span per workgroup.)
+constexpr uint32_t PLANAR_BLOCK = 1024;
+__device__ __forceinline__ uint64_t planar_at(uint32_t c, uint64_t i, uint32_t nc) {
+    return (((i / PLANAR_BLOCK) * nc + c) * PLANAR_BLOCK) | (i % PLANAR_BLOCK);
+}
 
 __global__ __launch_bounds__(256) void k_repack_planar(const uint4 *__restrict__ aos,
                                                        uint4 *__restrict__ planar, uint64_t first,
-                                                       uint64_t count, uint32_t chunks,
-                                                       uint64_t plane_stride) {
+                                                       uint64_t count, uint32_t chunks) {
     uint64_t total = count * chunks;
     for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total;
          q += (uint64_t)gridDim.x * blockDim.x) {
         uint64_t i = first + q / chunks;
         uint32_t c = (uint32_t)(q % chunks);
-        planar[(uint64_t)c * plane_stride + i] = aos[first * chunks + q];
+        planar[planar_at(c, i, chunks)] = aos[first * chunks + q];
     }
 }
 
@@ -243,16 +252,24 @@ __device__ __forceinline__ uint32_t project_one(const uint32_t *w, const FrameCo
 typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 constexpr int REC_WORDS = 9;   // blend record: mx, my, ca, cb, cc, opacity, r, g, b  (36 bytes)
 
-// Grid: one workgroup per PP_CHUNK Gaussians.  Reads the chunk-planar mirror with one
+// Grid: one workgroup per PP_CHUNK Gaussians (= one block of the block-planar mirror).  One
 // global_load_dwordx4 per (lane, chunk): a wave reads 1 KiB contiguous per instruction.
 // Outputs per Gaussian, all written DENSELY (culled lanes store too): the 36-byte blend record,
 // the depth key (0xffffffff when culled) and the 8-byte tile rect (0 when culled).  Masking the
 // stores of culled lanes would leave holes in every 64-byte sector, which turns the writes into
 // read-modify-writes and costs 0.15 ms at 10 M Gaussians (measured); a dense store of a few
 // don't-care bytes is cheaper.  Per workgroup: tile-count sum and visible count (both feed scans).
+//
+// What bounds it (tools/mb/mb_rw.hip, 10 M x 224 B on MI355X): the read pattern alone streams at
+// 6.3 TB/s (0.354 ms); every written byte costs about three read bytes, whatever the store
+// pattern — 4 B/Gaussian +0.035 ms, 12 B +0.083 ms, 48 B +0.165 ms as whole-array planes, as one
+// contiguous span per workgroup, staged through LDS and burst out, or as these 36+4+8-byte
+// streams.  This kernel runs within 2 % of that read+write floor; the order of loads and stores
+// in the loop, non-temporal hints and compacting away the culled records (-24 % written bytes)
+// were each measured and change nothing.
 template <int SH, int COV>
 __global__ __launch_bounds__(PP_THREADS) void k_preprocess(
-    const uint4 *__restrict__ planar, uint64_t plane_stride, uint32_t n, FrameConsts fc,
+    const uint4 *__restrict__ planar, uint32_t n, FrameConsts fc,
     uint32_t *__restrict__ recs, uint32_t *__restrict__ depth, uint2 *__restrict__ rect,
     uint32_t *__restrict__ chunk_tiles, uint32_t *__restrict__ chunk_vis) {
     constexpr int NW = pod_words(SH, COV);
@@ -270,7 +287,7 @@ __global__ __launch_bounds__(PP_THREADS) void k_preprocess(
             // uniform sh_deg branches), which serialises 4-5 HBM round trips per Gaussian.
             uint4 v[NC];
 #pragma unroll
-            for (int c = 0; c < NC; c++) v[c] = planar[(uint64_t)c * plane_stride + i];
+            for (int c = 0; c < NC; c++) v[c] = planar[planar_at(c, i, NC)];
             uint32_t w[NW];
 #pragma unroll
             for (int c = 0; c < NC; c++) {
@@ -321,12 +338,12 @@ __global__ __launch_bounds__(1024) void k_scan_chunks(ScanJob j0, ScanJob j1) {
     constexpr uint32_t PER = 8;   // consecutive values per thread -> 8192 per iteration
     __shared__ uint32_t s_wave[16];
     __shared__ uint32_t s_carry;
-    __shared__ uint32_t s_overflow;   // the running total left 32 bits: reported as 0xffffffff
+    __shared__ unsigned long long s_total64;   // exact grand total: past 32 bits it is reported as 0xffffffff
     const ScanJob job = blockIdx.x == 0 ? j0 : j1;
     uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
     if (threadIdx.x == 0) {
         s_carry = 0;
-        s_overflow = 0;
+        s_total64 = 0;
     }
     __syncthreads();
     for (uint32_t base = 0; base < job.num; base += 1024u * PER) {
@@ -337,6 +354,12 @@ __global__ __launch_bounds__(1024) void k_scan_chunks(ScanJob j0, ScanJob j1) {
         for (uint32_t k = 0; k < PER; k++) {
             v[k] = i0 + k < job.num ? job.sums[i0 + k] : 0u;
             sum += v[k];
+        }
+        {   // 8 values of < 2^32 cannot wrap 64 bits; one LDS atomic per thread and iteration
+            unsigned long long wide = 0;
+#pragma unroll
+            for (uint32_t k = 0; k < PER; k++) wide += v[k];
+            if (wide) atomicAdd(&s_total64, wide);
         }
         uint32_t inc = wave_inclusive_scan(sum, lane);
         if (lane == 63u) s_wave[wid] = inc;
@@ -356,16 +379,10 @@ __global__ __launch_bounds__(1024) void k_scan_chunks(ScanJob j0, ScanJob j1) {
             run += v[k];
         }
         __syncthreads();
-        if (threadIdx.x == 0) {
-            // every addend of this iteration is a partial sum of `tot`, so one wrap test covers them
-            uint64_t wide_tot = 0;
-            for (uint32_t k = 0; k < 16; k++) wide_tot += s_wave[k];
-            if ((uint64_t)carry + wide_tot > 0xfffffff0ull) s_overflow = 1;
-            s_carry = carry + tot;
-        }
+        if (threadIdx.x == 0) s_carry = carry + tot;
         __syncthreads();
     }
-    if (threadIdx.x == 0) *job.total = s_overflow ? 0xffffffffu : s_carry;
+    if (threadIdx.x == 0) *job.total = s_total64 > 0xfffffff0ull ? 0xffffffffu : s_carry;
 }
 
 // ---------------------------------------------------------------------------------------------
