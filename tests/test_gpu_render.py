@@ -276,6 +276,33 @@ def test_update_then_rerender_uses_new_data(gs, ob, device, stream):
     assert np.array_equal(b.view(np.uint32).reshape(-1), o.view(np.uint32).reshape(-1))
 
 
+@pytest.mark.parametrize("sh,cov", [(0, 0), (1, 2), (2, 1), (3, 0)])
+def test_partial_updates_remirror_only_their_range_correctly(gs, ob, device, stream, sh, cov):
+    """Several update_range calls with awkward starts / counts (crossing 128-Gaussian repack groups
+    and 1024-Gaussian mirror blocks, a single Gaussian, the tail) between frames: every frame must
+    equal the oracle's frame of the current scene bit for bit."""
+    import synth
+    pod = gs.GaussianPod(sh, cov)
+    g = synth.scene(4500, first=77)
+    cam = helpers.default_camera(gs, 400, 304)
+    gt, mt = gs.gaussian_transform_pod(sh_deg=3), gs.model_transform_pod()
+    ocam = helpers.copy_camera(cam, ob.Camera)
+    buf = gs.GaussiansBuffer.new(device, pod, g)
+    img = gs.Buffer(device, size=cam.height * cam.width * 16)
+    r = gs.Renderer(device)
+    rng = np.random.default_rng(5)
+    for start, count in [(0, 0), (1000, 300), (127, 2), (4499, 1), (1023, 1026), (0, 4500), (3000, 1500)]:
+        if count:
+            g[start:start + count]["pos"][:, :2] += rng.normal(0, 0.3, (count, 2)).astype(np.float32)
+            g["color"][start:start + count, :3] = 255 - g["color"][start:start + count, :3]
+            buf.update_range(stream, start, g[start:start + count])
+        r.render(stream, buf, gt, mt, cam, img.device_ptr())
+        got = img.download(stream, np.float32)
+        exp = ob.render(sh, cov, ob.pack(sh, cov, g), ob.gaussian_transform(sh_deg=3), ob.model_transform(), ocam)[0]
+        assert np.array_equal(got.view(np.uint32).reshape(-1), exp.view(np.uint32).reshape(-1)), (start, count)
+    buf.destroy(); img.release(); r.destroy()
+
+
 # ---- stand-alone primitives -------------------------------------------------------------------
 
 @pytest.mark.parametrize("n", [0, 1, 63, 64, 65, 1023, 1024, 1025, 2047, 2048, 2049, 100000, 1 << 20])

@@ -560,7 +560,17 @@ struct gs_gaussians_buffer {
     // block-planar mirror read by the preprocess kernel; rebuilt lazily
     void *planar;
     size_t planar_stride;  // capacity in Gaussians = len rounded up to whole 1024-blocks
-    bool dirty;
+    // Gaussians [dirty_lo, dirty_hi) of the AoS buffer are newer than the mirror (empty when lo >= hi).
+    // update_range dirties only its own range, so an editor's per-edit update re-mirrors a few
+    // Gaussians instead of the whole scene.
+    size_t dirty_lo, dirty_hi;
+    void mark(size_t lo, size_t hi) {
+        if (lo >= hi) return;
+        if (dirty_lo >= dirty_hi) { dirty_lo = lo; dirty_hi = hi; return; }
+        if (lo < dirty_lo) dirty_lo = lo;
+        if (hi > dirty_hi) dirty_hi = hi;
+    }
+    void mark_all() { dirty_lo = 0; dirty_hi = (size_t)-1; }
 };
 
 static size_t pod_stride(const gs_gaussians_buffer *g) { return (size_t)gs::pod_bytes(g->sh, g->cov); }
@@ -585,7 +595,7 @@ extern "C" gs_status gs_gaussians_buffer_from_buffer(gs_buffer *buffer, gs_sh_co
     g->cov = cov;
     g->planar = nullptr;
     g->planar_stride = 0;
-    g->dirty = true;
+    g->mark_all();
     *out = g;
     return GS_OK;
 }
@@ -640,7 +650,7 @@ extern "C" gs_status gs_gaussians_buffer_update(gs_gaussians_buffer *g, gs_strea
     if (count != len)
         return fail(GS_ERR_COUNT_MISMATCH, count, len, 0, "Gaussians count mismatch: %zu != %zu",
                     count, len);
-    g->dirty = true;
+    g->mark_all();
     return gs_buffer_write(g->buf, s, 0, pods, count * pod_stride(g));
 }
 
@@ -652,7 +662,7 @@ extern "C" gs_status gs_gaussians_buffer_update_range(gs_gaussians_buffer *g, gs
     if (start + count > len)
         return fail(GS_ERR_RANGE_COUNT_MISMATCH, count, start, len,
                     "Gaussians count mismatch: %zu + %zu > %zu", count, start, len);
-    g->dirty = true;
+    g->mark(start, start + count);
     return gs_buffer_write(g->buf, s, start * pod_stride(g), pods, count * pod_stride(g));
 }
 
@@ -702,7 +712,7 @@ extern "C" gs_status gs_gaussians_buffer_download_gaussians(gs_gaussians_buffer 
 }
 
 extern "C" void gs_gaussians_buffer_mark_dirty(gs_gaussians_buffer *g) {
-    if (g) g->dirty = true;
+    if (g) g->mark_all();
 }
 
 // (re)build the block-planar mirror on `st`
@@ -715,17 +725,17 @@ static gs_status ensure_planar(gs_gaussians_buffer *g, hipStream_t st) {
         g->planar = nullptr;
         GS_HIP(hipMalloc(&g->planar, (stride ? stride : gs::PLANAR_BLOCK) * 16 * chunks));
         g->planar_stride = stride;
-        g->dirty = true;
+        g->mark_all();
     }
-    if (g->dirty && len) {
-        uint64_t total = (uint64_t)len * chunks;
-        uint32_t grid = (uint32_t)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    size_t lo = g->dirty_lo, hi = g->dirty_hi < len ? g->dirty_hi : len;
+    if (lo < hi) {
+        uint64_t count = hi - lo;
+        uint32_t grid = (uint32_t)((count + gs::REPACK_GROUP - 1) / gs::REPACK_GROUP);
         hipLaunchKernelGGL(gs::k_repack_planar, dim3(grid), dim3(256), 0, st,
-                           (const uint4 *)g->buf->ptr, (uint4 *)g->planar, (uint64_t)0,
-                           (uint64_t)len, chunks);
+                           (const uint4 *)g->buf->ptr, (uint4 *)g->planar, (uint64_t)lo, count, chunks);
         GS_HIP(hipGetLastError());
     }
-    g->dirty = false;
+    g->dirty_lo = g->dirty_hi = 0;
     return GS_OK;
 }
 

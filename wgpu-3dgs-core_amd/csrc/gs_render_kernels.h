@@ -97,15 +97,25 @@ __device__ __forceinline__ uint64_t planar_at(uint32_t c, uint64_t i, uint32_t n
     return (((i / PLANAR_BLOCK) * nc + c) * PLANAR_BLOCK) | (i % PLANAR_BLOCK);
 }
 
+// One workgroup transposes REPACK_GROUP Gaussians through LDS: the AoS side is read as one
+// contiguous span (REPACK_GROUP x pod_bytes), the mirror side is written 1 KiB contiguous per wave
+// and plane; both directions are fully coalesced.  (A direct per-chunk copy scatters 16-byte
+// writes over the planes: measured 1.66 ms vs the transposed kernel for 10 M x 224 B.)
+constexpr uint32_t REPACK_GROUP = 128;
+constexpr uint32_t REPACK_MAX_CHUNKS = 14;   // pod_bytes / 16 <= 224 / 16
 __global__ __launch_bounds__(256) void k_repack_planar(const uint4 *__restrict__ aos,
                                                        uint4 *__restrict__ planar, uint64_t first,
                                                        uint64_t count, uint32_t chunks) {
-    uint64_t total = count * chunks;
-    for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total;
-         q += (uint64_t)gridDim.x * blockDim.x) {
-        uint64_t i = first + q / chunks;
-        uint32_t c = (uint32_t)(q % chunks);
-        planar[planar_at(c, i, chunks)] = aos[first * chunks + q];
+    __shared__ uint4 s_t[REPACK_GROUP * REPACK_MAX_CHUNKS];   // 28 KiB
+    const uint64_t g0 = (uint64_t)blockIdx.x * REPACK_GROUP;   // first Gaussian of this group, relative to `first`
+    const uint32_t ng = (uint32_t)(count - g0 < REPACK_GROUP ? count - g0 : REPACK_GROUP);
+    const uint32_t total = ng * chunks;
+    const uint4 *src = aos + (first + g0) * chunks;
+    for (uint32_t q = threadIdx.x; q < total; q += 256) s_t[q] = src[q];
+    __syncthreads();
+    for (uint32_t e = threadIdx.x; e < total; e += 256) {
+        const uint32_t c = e / ng, t = e - c * ng;   // consecutive threads -> consecutive Gaussians of one plane
+        planar[planar_at(c, first + g0 + t, chunks)] = s_t[t * chunks + c];
     }
 }
 
