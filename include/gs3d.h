@@ -308,7 +308,7 @@ gs_status gs_gaussians_buffer_download(gs_gaussians_buffer *g, gs_stream *s, voi
 gs_status gs_gaussians_buffer_download_gaussians(gs_gaussians_buffer *g, gs_stream *s,
                                                  gs_gaussian *out, size_t count);
 /* tell the wrapper that device code wrote the underlying buffer (e.g. a compute bundle bound it
- * read-write), so the renderer's chunk-planar mirror must be rebuilt on the next frame */
+ * read-write), so the renderer's block-planar mirror must be rebuilt on the next frame */
 void gs_gaussians_buffer_mark_dirty(gs_gaussians_buffer *g);
 
 /* GaussianTransformBuffer — src/buffer/gaussian_transform.rs:104-163 (8-byte uniform) */
