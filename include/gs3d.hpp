@@ -142,34 +142,43 @@ struct SpzGaussiansFromGaussianSliceOptions : gs_spz_options {   // spz.rs:962-9
     SpzGaussiansFromGaussianSliceOptions() { gs_spz_options_default(this); }
 };
 
-class SpzGaussians {   // spz.rs:514-959, decoded view (header + Gaussian::from_spz of every point)
+class SpzGaussians {   // spz.rs:514-959: keeps the decompressed payload (header + columns) as read / encoded
 public:
     gs_spz_header header{};
-    std::vector<Gaussian> gaussians;
-    static SpzGaussians read_from(const void *bytes, size_t len) { return decode(gs_spz_decode, bytes, len); }
-    static SpzGaussians read_decompressed(const void *bytes, size_t len) { return decode(gs_spz_decode_decompressed, bytes, len); }
-    static std::vector<uint8_t> write_gaussians(const std::vector<Gaussian> &g, const gs_spz_options &o = SpzGaussiansFromGaussianSliceOptions()) { return encode(gs_spz_encode, g, o); }
-    static std::vector<uint8_t> write_gaussians_decompressed(const std::vector<Gaussian> &g, const gs_spz_options &o = SpzGaussiansFromGaussianSliceOptions()) { return encode(gs_spz_encode_decompressed, g, o); }
+    std::vector<uint8_t> payload;       // what write_decompressed emits: reading then writing keeps the columns
+    std::vector<Gaussian> gaussians;    // Gaussian::from_spz of every point (what iter_gaussian yields)
+
+    explicit SpzGaussians(std::vector<uint8_t> decompressed) : payload(std::move(decompressed)) {
+        size_t n = 0;
+        check(gs_spz_decode_decompressed(payload.data(), payload.size(), &header, nullptr, 0, &n));
+        gaussians.resize(n);
+        check(gs_spz_decode_decompressed(payload.data(), payload.size(), &header, gaussians.data(), n, &n));
+    }
+    static SpzGaussians read_from(const void *bytes, size_t len) { return SpzGaussians(sized(gs_spz_decompress, bytes, len)); }
+    static SpzGaussians read_decompressed(const void *bytes, size_t len) {
+        return SpzGaussians(std::vector<uint8_t>((const uint8_t *)bytes, (const uint8_t *)bytes + len));
+    }
+    static SpzGaussians from_gaussians_with_options(const std::vector<Gaussian> &g, const gs_spz_options &o = SpzGaussiansFromGaussianSliceOptions()) {
+        return SpzGaussians(write_gaussians_decompressed(g, o));
+    }
+    static SpzGaussians from_gaussians(const std::vector<Gaussian> &g) { return from_gaussians_with_options(g); }
+    std::vector<uint8_t> write_to() const { return sized(gs_spz_compress, payload.data(), payload.size()); }
+    const std::vector<uint8_t> &write_decompressed() const { return payload; }
+    // one-shot helpers over the fused entry points
+    static std::vector<uint8_t> write_gaussians(const std::vector<Gaussian> &g, const gs_spz_options &o = SpzGaussiansFromGaussianSliceOptions()) { return sized(gs_spz_encode, g.data(), g.size(), &o); }
+    static std::vector<uint8_t> write_gaussians_decompressed(const std::vector<Gaussian> &g, const gs_spz_options &o = SpzGaussiansFromGaussianSliceOptions()) { return sized(gs_spz_encode_decompressed, g.data(), g.size(), &o); }
     const std::vector<Gaussian> &iter_gaussian() const { return gaussians; }
     size_t len() const { return gaussians.size(); }
     bool is_empty() const { return gaussians.empty(); }
+    bool operator==(const SpzGaussians &o) const { return payload == o.payload; }
 
 private:
-    template <class F>
-    static SpzGaussians decode(F fn, const void *bytes, size_t len) {
-        SpzGaussians s;
+    template <class F, class... A>
+    static std::vector<uint8_t> sized(F fn, A... head) {   // the ABI's two-call pattern: size query, then fill
         size_t n = 0;
-        check(fn(bytes, len, &s.header, nullptr, 0, &n));
-        s.gaussians.resize(n);
-        check(fn(bytes, len, &s.header, s.gaussians.data(), n, &n));
-        return s;
-    }
-    template <class F>
-    static std::vector<uint8_t> encode(F fn, const std::vector<Gaussian> &g, const gs_spz_options &o) {
-        size_t n = 0;
-        check(fn(g.data(), g.size(), &o, nullptr, 0, &n));
+        check(fn(head..., nullptr, 0, &n));
         std::vector<uint8_t> out(n);
-        check(fn(g.data(), g.size(), &o, out.data(), out.size(), &n));
+        check(fn(head..., out.data(), out.size(), &n));
         out.resize(n);
         return out;
     }

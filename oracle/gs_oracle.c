@@ -1082,7 +1082,7 @@ long gso_spz_decode_raw(const uint8_t *bytes, size_t len, gso_gaussian *out, siz
             for (int a = 0; a < 3; a++)
                 out[i].pos[a] = f16_to_f32((uint16_t)(positions[6 * i + 2 * a] | (positions[6 * i + 2 * a + 1] << 8)));
     } else {
-        float inv = 1.0f / (float)(1 << frac);
+        float inv = 1.0f / (float)(int32_t)(1u << (frac & 31u));   /* Rust release-mode i32 shift */
         for (size_t i = 0; i < m; i++)
             for (int a = 0; a < 3; a++) {
                 const uint8_t *p = positions + 9 * i + 3 * a;

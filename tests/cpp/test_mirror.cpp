@@ -43,6 +43,9 @@ static int host_codecs() {
         auto z = SpzGaussians::write_gaussians(gs, o);
         auto spz = SpzGaussians::read_from(z.data(), z.size());
         REQUIRE(spz.len() == 2 && spz.header.version == version && spz.header.sh_degree == 3);
+        auto again = spz.write_to();   // writing what was read keeps the columns
+        REQUIRE(SpzGaussians::read_from(again.data(), again.size()) == spz);
+        REQUIRE(SpzGaussians::from_gaussians_with_options(gs, o) == spz);
         for (size_t i = 0; i < 2; i++) {
             for (int c = 0; c < 3; c++) REQUIRE(std::fabs(spz.gaussians[i].pos[c] - gs[i].pos[c]) <= 1.0f);
             for (int c = 0; c < 4; c++) REQUIRE(std::fabs(spz.gaussians[i].rot[c] - gs[i].rot[c]) <= 0.1f);

@@ -108,7 +108,9 @@ extern "C" gs_status gs_spz_decode_decompressed(const void *bytes, size_t len, g
                 g.pos[c] = f16_to_f32(v);
             }
         } else {
-            const float s = 1.0f / (float)(1 << h.fractional_bits);
+            // `1 << fractional_bits` on i32 as Rust evaluates it in release builds (shift count masked to
+            // 5 bits); the header byte is untrusted, so the plain C shift would be undefined behaviour
+            const float s = 1.0f / (float)(int32_t)(1u << (h.fractional_bits & 31u));
             for (int c = 0; c < 3; c++) {
                 const uint8_t *p = pos + 9 * i + 3 * c;
                 int32_t fixed = (int32_t)p[0] | ((int32_t)p[1] << 8) | ((int32_t)p[2] << 16);
