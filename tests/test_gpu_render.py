@@ -149,6 +149,30 @@ def test_odd_image_size_and_background(gs, ob, device, stream):
     assert np.array_equal(rgba.view(np.uint32), o_rgba.view(np.uint32))
 
 
+def test_more_than_65536_tiles_uses_wide_tile_keys(gs, ob, device, stream):
+    """4112 x 4100 px = 257 x 257 = 66049 tiles: tile ids no longer fit u16, the pair arrays switch
+    to u32 tile keys (17 key bits -> 3 tile-sort passes).  Whole frame, all stages, bit-exact; then
+    a normal-sized frame on the same renderer (switching back to u16 keys)."""
+    import synth
+    g = synth.scene(6000, first=4242)
+    g["scale"] *= 3.0   # cover more tiles
+    st = _compare_frame(gs, ob, device, stream, gs.SH_HALF, gs.COV3D_SINGLE, g, 4112, 4100, gt_kw=dict(sh_deg=2))
+    assert st.tiles_x * st.tiles_y == 257 * 257 and st.pairs > 0
+    pod = gs.GaussianPod(gs.SH_HALF, gs.COV3D_SINGLE)
+    pods = pod.from_gaussian(g)
+    r = gs.Renderer(device)
+    gt, mt = gs.gaussian_transform_pod(sh_deg=2), gs.model_transform_pod()
+    frames = []
+    for (w, h) in ((4112, 4100), (640, 480), (4112, 4100)):
+        cam = helpers.default_camera(gs, w, h)
+        _, buf, img, rgba = _render_gpu(gs, device, stream, pod, pods, gt, mt, cam, renderer=r)
+        ocam = helpers.copy_camera(cam, ob.Camera)
+        o = ob.render(pod.sh, pod.cov, pods, ob.gaussian_transform(sh_deg=2), ob.model_transform(), ocam)[0]
+        assert np.array_equal(rgba.view(np.uint32), o.view(np.uint32)), (w, h)
+        buf.destroy(); img.release()
+    r.destroy()
+
+
 def test_edge_cases(gs, ob, device, stream):
     """empty buffer, single Gaussian, everything culled, one splat covering the whole screen."""
     import synth
