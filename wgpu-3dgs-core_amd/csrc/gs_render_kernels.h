@@ -53,19 +53,43 @@ __device__ __forceinline__ uint32_t mbcnt(uint64_t mask) {
                                      __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
+// Wave64 inclusive scans on the DPP cross-lane path (no LDS traffic, one VALU instruction per step):
+// row_shr 1/2/4/8 scan each 16-lane row, row_bcast15 carries the row totals into the odd rows
+// (row mask 0xa) and row_bcast31 carries the lower half's total into the upper half (row mask 0xc).
+// Lanes without a source keep `identity`.  (A __shfl_up ladder costs a ds_bpermute round trip per
+// step: ~6 dependent LDS operations per scan.)
+#define GS_DPP_STEP(OP, CTRL, ROWMASK)                                                             \
+    v = OP(v, (uint32_t)__builtin_amdgcn_update_dpp((int)identity, (int)v, CTRL, ROWMASK, 0xf, false))
+__device__ __forceinline__ uint32_t dpp_op_add(uint32_t a, uint32_t b) { return a + b; }
+__device__ __forceinline__ uint32_t dpp_op_max(uint32_t a, uint32_t b) { return a > b ? a : b; }
+
 __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, uint32_t lane) {
-#pragma unroll
-    for (int d = 1; d < WAVE; d <<= 1) {
-        uint32_t t = __shfl_up(v, d, WAVE);
-        if (lane >= (uint32_t)d) v += t;
-    }
+    (void)lane;
+    const uint32_t identity = 0u;
+    GS_DPP_STEP(dpp_op_add, 0x111, 0xf);   // row_shr:1
+    GS_DPP_STEP(dpp_op_add, 0x112, 0xf);   // row_shr:2
+    GS_DPP_STEP(dpp_op_add, 0x114, 0xf);   // row_shr:4
+    GS_DPP_STEP(dpp_op_add, 0x118, 0xf);   // row_shr:8
+    GS_DPP_STEP(dpp_op_add, 0x142, 0xa);   // row_bcast:15
+    GS_DPP_STEP(dpp_op_add, 0x143, 0xc);   // row_bcast:31
     return v;
 }
 
-__device__ __forceinline__ uint32_t wave_reduce_add(uint32_t v) {
-#pragma unroll
-    for (int d = WAVE / 2; d > 0; d >>= 1) v += __shfl_xor(v, d, WAVE);
+__device__ __forceinline__ uint32_t wave_inclusive_max(uint32_t v) {
+    const uint32_t identity = 0u;
+    GS_DPP_STEP(dpp_op_max, 0x111, 0xf);
+    GS_DPP_STEP(dpp_op_max, 0x112, 0xf);
+    GS_DPP_STEP(dpp_op_max, 0x114, 0xf);
+    GS_DPP_STEP(dpp_op_max, 0x118, 0xf);
+    GS_DPP_STEP(dpp_op_max, 0x142, 0xa);
+    GS_DPP_STEP(dpp_op_max, 0x143, 0xc);
     return v;
+}
+#undef GS_DPP_STEP
+
+// wave total, uniform in every lane (all 64 lanes must be active)
+__device__ __forceinline__ uint32_t wave_reduce_add(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan(v, 0u), 63);
 }
 
 // Exclusive scan over a 256-thread block; `smem` holds >= 4 words; returns exclusive prefix and
@@ -498,12 +522,7 @@ __global__ __launch_bounds__(EXP_CHUNK) void k_expand_emit(
             __builtin_amdgcn_wave_barrier();
             if (starts_here) s_mark[wid][excl - win] = lane + 1u;
             __builtin_amdgcn_wave_barrier();
-            uint32_t m = s_mark[wid][lane];
-#pragma unroll
-            for (int d = 1; d < WAVE; d <<= 1) {
-                uint32_t t = __shfl_up(m, d, WAVE);
-                if (lane >= (uint32_t)d) m = m > t ? m : t;
-            }
+            uint32_t m = wave_inclusive_max(s_mark[wid][lane]);
             owner = m ? m - 1u : carry;
             carry = __shfl(owner, 63, WAVE);
         }
@@ -513,7 +532,17 @@ __global__ __launch_bounds__(EXP_CHUNK) void k_expand_emit(
         uint32_t o_w = __shfl(width, owner, WAVE);
         uint32_t e = win + lane;
         uint32_t local = e - o_excl;
-        uint32_t row = local / o_w, col = local - row * o_w;
+        // local / o_w without the 35-instruction integer division: local < 2^22 (<= 2^22 tiles) and
+        // o_w < 2^16 are exact in f32, the reciprocal estimate is off by at most one, fixed up exactly
+        uint32_t row = (uint32_t)((float)local * __builtin_amdgcn_rcpf((float)o_w));
+        uint32_t col = local - row * o_w;
+        if ((int32_t)col < 0) {
+            row--;
+            col += o_w;
+        } else if (col >= o_w) {
+            row++;
+            col -= o_w;
+        }
         uint32_t tile = ((o_org >> 16) + row) * tiles_x + (o_org & 0xffffu) + col;
         uint32_t o = out0 + e;
         if (e < wave_total && o < capacity) {
