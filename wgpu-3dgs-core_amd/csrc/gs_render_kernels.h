@@ -494,6 +494,7 @@ __global__ __launch_bounds__(EXP_CHUNK) void k_expand_emit(
     TK *__restrict__ tkeys, uint32_t *__restrict__ tvals, uint32_t capacity) {
     __shared__ uint32_t s_scan[4];
     __shared__ uint32_t s_mark[4][WAVE];
+    __shared__ uint4 s_tab[4][WAVE];   // per lane: first slot, Gaussian id, rect origin, rect width
     const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
     const uint32_t j = blockIdx.x * EXP_CHUNK + threadIdx.x;
     uint32_t g = 0, cnt = 0, origin = 0, width = 1;
@@ -509,6 +510,7 @@ __global__ __launch_bounds__(EXP_CHUNK) void k_expand_emit(
     const uint32_t excl = incl - cnt;
     const uint32_t wave_total = __shfl(incl, 63, WAVE);
     if (lane == 63u) s_scan[wid] = incl;
+    s_tab[wid][lane] = make_uint4(excl, g, origin, width);
     __syncthreads();
     uint32_t w0 = s_scan[0], w1 = s_scan[1], w2 = s_scan[2];
     uint32_t wave_off = wid == 0 ? 0u : wid == 1 ? w0 : wid == 2 ? w0 + w1 : w0 + w1 + w2;
@@ -526,10 +528,8 @@ __global__ __launch_bounds__(EXP_CHUNK) void k_expand_emit(
             owner = m ? m - 1u : carry;
             carry = __shfl(owner, 63, WAVE);
         }
-        uint32_t o_excl = __shfl(excl, owner, WAVE);
-        uint32_t o_g = __shfl(g, owner, WAVE);
-        uint32_t o_org = __shfl(origin, owner, WAVE);
-        uint32_t o_w = __shfl(width, owner, WAVE);
+        const uint4 ot = s_tab[wid][owner];   // one 16-byte LDS read instead of four cross-lane permutes
+        const uint32_t o_excl = ot.x, o_g = ot.y, o_org = ot.z, o_w = ot.w;
         uint32_t e = win + lane;
         uint32_t local = e - o_excl;
         // local / o_w without the 35-instruction integer division: local < 2^22 (<= 2^22 tiles) and
