@@ -1256,7 +1256,7 @@ extern "C" gs_status gs_renderer_create(gs_device *dev, gs_renderer **out) {
     gs_renderer *r = new gs_renderer();
     r->dev = dev;
     r->host_counters = nullptr;
-    hipError_t e = hipHostMalloc((void **)&r->host_counters, 64, hipHostMallocDefault);
+    hipError_t e = hipHostMalloc((void **)&r->host_counters, 64, hipHostMallocMapped | hipHostMallocCoherent);
     if (e != hipSuccess) {
         delete r;
         return fail(GS_ERR_HIP, (uint64_t)e, 0, 0, "hipHostMalloc failed: %s", hipGetErrorString(e));
@@ -1521,17 +1521,19 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
                            (uint2 *)r->rect.ptr, (uint32_t *)r->chunk_tiles.ptr,
                            (uint32_t *)r->chunk_vis.ptr);
         mark(ST_SCAN);
+        // the two grand totals (D, V) go straight into pinned host memory (device-visible through
+        // the unified address space): no separate copy launch, one stream wait below
         gs::ScanJob jt{(const uint32_t *)r->chunk_tiles.ptr, (uint32_t *)r->chunk_tiles_off.ptr,
-                       counters + 0, nchunks};
+                       r->host_counters + 0, nchunks};
         gs::ScanJob jv{(const uint32_t *)r->chunk_vis.ptr, (uint32_t *)r->chunk_vis_off.ptr,
-                       counters + 1, nchunks};
+                       r->host_counters + 1, nchunks};
         hipLaunchKernelGGL(gs::k_scan_chunks, dim3(2), dim3(1024), 0, st, jt, jv);
         GS_HIP(hipGetLastError());
-        GS_HIP(hipMemcpyAsync(r->host_counters, counters, 8, hipMemcpyDeviceToHost, st));
         // compaction does not depend on the counts: enqueue it before waiting for them
         hipLaunchKernelGGL(gs::k_compact, dim3(nchunks), dim3(gs::PP_THREADS), 0, st,
                            (const uint32_t *)r->depth.ptr, (const uint32_t *)r->chunk_vis_off.ptr, n,
-                           (uint32_t *)r->dkeys[0].ptr, (uint32_t *)r->dvals[0].ptr);
+                           (uint32_t *)r->dkeys[0].ptr, (uint32_t *)r->dvals[0].ptr,
+                           (uint2 *)r->ranges.ptr, num_tiles);
         GS_HIP(hipGetLastError());
         GS_HIP(hipStreamSynchronize(st));
         d = r->host_counters[0];
@@ -1595,7 +1597,7 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
                                                tside, tpasses));
     }
     mark(ST_RANGES);
-    GS_HIP(hipMemsetAsync(r->ranges.ptr, 0, (size_t)num_tiles * 8, st));
+    if (!n) GS_HIP(hipMemsetAsync(r->ranges.ptr, 0, (size_t)num_tiles * 8, st));   // otherwise k_compact cleared them
     if (d) {
         if (wide)
             hipLaunchKernelGGL(gs::k_tile_ranges<uint32_t>, dim3((uint32_t)(((uint64_t)d + 1023) / 1024)), dim3(256), 0, st,

@@ -426,8 +426,14 @@ __global__ __launch_bounds__(1024) void k_scan_chunks(ScanJob j0, ScanJob j1) {
 __global__ __launch_bounds__(PP_THREADS) void k_compact(const uint32_t *__restrict__ depth,
                                                         const uint32_t *__restrict__ vis_offsets,
                                                         uint32_t n, uint32_t *__restrict__ dkeys,
-                                                        uint32_t *__restrict__ dvals) {
+                                                        uint32_t *__restrict__ dvals,
+                                                        uint2 *__restrict__ ranges_to_clear,
+                                                        uint32_t num_tiles) {
     __shared__ uint32_t s_scan[4];
+    // side job: clear the per-tile ranges for this frame (saves a separate fill launch; every
+    // dependent kernel boundary costs ~4-5 us on this part, which matters for a 0.5 ms frame)
+    for (uint32_t t = blockIdx.x * PP_THREADS + threadIdx.x; t < num_tiles; t += gridDim.x * PP_THREADS)
+        ranges_to_clear[t] = make_uint2(0u, 0u);
     uint32_t base = blockIdx.x * PP_CHUNK + threadIdx.x * PP_ITEMS;
     uint32_t dk[PP_ITEMS];
     uint32_t cnt = 0;
