@@ -33,7 +33,7 @@ int main(int argc, char** argv) {
     uint32_t nchunks = (n + gs::PP_CHUNK - 1) / gs::PP_CHUNK;
     CK(hipMalloc(&planar, stride * 16 * 14)); CK(hipMalloc(&proj, (size_t)n * 36 + 16));
     CK(hipMalloc(&depth, n * 4ull)); CK(hipMalloc(&rect, n * 8ull));
-    CK(hipMalloc(&ct, nchunks * 4ull)); CK(hipMalloc(&cv, nchunks * 4ull));
+    CK(hipMalloc(&ct, nchunks * 4ull)); CK(hipMalloc(&cv, nchunks * 4ull)); uint2* cr; CK(hipMalloc(&cr, nchunks * 8ull));
     hipLaunchKernelGGL(k_gen, dim3((n + 255) / 256), dim3(256), 0, 0, planar, stride, n);
     gs::FrameConsts fc; memset(&fc, 0, sizeof(fc));
     for (int i = 0; i < 4; i++) { fc.M[5*i] = 1.f; fc.V[5*i] = 1.f; }
@@ -44,7 +44,7 @@ int main(int argc, char** argv) {
     fc.sh_deg = argc > 1 ? atoi(argv[1]) : 3; fc.width = 1920; fc.height = 1080; fc.tiles_x = 120; fc.tiles_y = 68; fc.band_ty1 = 68;
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     auto launch = [&]() { hipLaunchKernelGGL((gs::k_preprocess<0, 0>), dim3(nchunks), dim3(gs::PP_THREADS), 0, 0,
-        (const uint4*)planar, n, fc, proj, depth, rect, ct, cv); };
+        (const uint4*)planar, n, fc, proj, depth, rect, ct, cv, cr); };
     for (int w = 0; w < 3; w++) launch();
     CK(hipEventRecord(a));
     for (int r = 0; r < 10; r++) launch();

@@ -1228,7 +1228,7 @@ enum { ST_REPACK = 0, ST_PRE, ST_SCAN, ST_DSORT, ST_EXPAND, ST_TSORT, ST_RANGES,
 
 struct gs_renderer {
     gs_device *dev;
-    DevArray recs, depth, rect, sorted_rect, chunk_tiles, chunk_vis, chunk_tiles_off, chunk_vis_off, counters;
+    DevArray recs, depth, rect, sorted_rect, chunk_tiles, chunk_vis, chunk_range, chunk_tiles_off, chunk_vis_off, counters;
     DevArray dkeys[2], dvals[2];          // (depth bits, Gaussian index), capacity N
     DevArray exp_sums, exp_offsets;
     DevArray tkeys[2], tvals[2];          // (tile id, Gaussian index), capacity pair_capacity
@@ -1279,7 +1279,7 @@ extern "C" gs_status gs_renderer_create(gs_device *dev, gs_renderer **out) {
 extern "C" void gs_renderer_destroy(gs_renderer *r) {
     if (!r) return;
     (void)hipSetDevice(r->dev->ordinal);
-    DevArray *arrs[] = {&r->recs, &r->depth, &r->rect, &r->sorted_rect, &r->chunk_tiles, &r->chunk_vis,
+    DevArray *arrs[] = {&r->recs, &r->depth, &r->rect, &r->sorted_rect, &r->chunk_tiles, &r->chunk_vis, &r->chunk_range,
                         &r->chunk_tiles_off, &r->chunk_vis_off, &r->counters, &r->dkeys[0],
                         &r->dkeys[1], &r->dvals[0], &r->dvals[1], &r->exp_sums, &r->exp_offsets,
                         &r->tkeys[0], &r->tkeys[1], &r->tvals[0], &r->tvals[1], &r->ghist,
@@ -1347,7 +1347,7 @@ extern "C" gs_status gs_renderer_stats(gs_renderer *r, gs_frame_stats *out) {
 }
 
 typedef void (*preprocess_fn)(const uint4 *, uint32_t, gs::FrameConsts, uint32_t *,
-                              uint32_t *, uint2 *, uint32_t *, uint32_t *);
+                              uint32_t *, uint2 *, uint32_t *, uint32_t *, uint2 *);
 static preprocess_fn k_tbl_preprocess[4][3] = GS_CFG_TABLE(gs::k_preprocess);
 
 // frame constants from the uniforms
@@ -1401,41 +1401,43 @@ static uint32_t bit_length(uint32_t v) {
     return b;
 }
 
-// Stable LSD radix sort of `count` (key, u32 value) pairs on key bits [0, end_bit), 8 bits per
-// pass, ping-ponging between side 0 and side 1; the side holding the result is returned.
-template <typename K>
-static gs_status sort_pairs_device(const gs_device *dev, void *const keys[2], void *const vals[2],
-                                   DevArray &ghist, DevArray &digit_totals, uint32_t count,
-                                   uint32_t end_bit, hipStream_t st, int &result_side,
-                                   uint32_t &passes_out) {
-    uint32_t passes = (end_bit + gs::RADIX_BITS - 1) / gs::RADIX_BITS;
+// Stable LSD radix sort of `count` (key, u32 value) pairs on key bits [0, end_bit), RB bits per
+// pass at most (digit widths balanced over the passes), ping-ponging between side 0 and side 1;
+// the side holding the result is returned.
+template <typename K, int RB>
+static gs_status sort_pairs_device_rb(const gs_device *dev, void *const keys[2], void *const vals[2],
+                                      DevArray &ghist, DevArray &digit_totals, uint32_t count,
+                                      uint32_t end_bit, hipStream_t st, int &result_side,
+                                      uint32_t &passes_out) {
+    constexpr uint32_t R = 1u << RB;
+    uint32_t passes = (end_bit + RB - 1) / RB;
     passes_out = passes;
     result_side = 0;
     if (count == 0 || passes == 0) return GS_OK;
     const uint32_t tile = (uint32_t)gs::sort_tile<K>();
     uint32_t nb = (uint32_t)(((uint64_t)count + tile - 1) / tile);
-    GS_TRY(dev_reserve(ghist, (size_t)nb * gs::RADIX * 4));
-    GS_TRY(dev_reserve(digit_totals, gs::RADIX * 4));
+    GS_TRY(dev_reserve(ghist, (size_t)nb * R * 4));
+    GS_TRY(dev_reserve(digit_totals, R * 4));
     int side = 0;
     uint32_t shift = 0;
     for (uint32_t p = 0; p < passes; p++) {
-        // balanced digit widths: e.g. 13 bits -> 7 + 6, 15 -> 8 + 7, 32 -> 8 + 8 + 8 + 8
+        // balanced digit widths: e.g. 13 bits -> 7 + 6, 15 -> 8 + 7, 25 -> 9 + 8 + 8, 32 -> 8 + 8 + 8 + 8
         const uint32_t bits = (end_bit - shift + (passes - p) - 1) / (passes - p);
         const uint32_t digit_mask = (1u << bits) - 1u;
         const K *kin = (const K *)keys[side];
         const uint32_t *vin = (const uint32_t *)vals[side];
         K *kout = (K *)keys[side ^ 1];
         uint32_t *vout = (uint32_t *)vals[side ^ 1];
-        hipLaunchKernelGGL(gs::k_sort_hist<K>, dim3(nb), dim3(gs::SORT_THREADS), 0, st, kin, count,
+        hipLaunchKernelGGL((gs::k_sort_hist<K, RB>), dim3(nb), dim3(gs::SORT_THREADS), 0, st, kin, count,
                            shift, digit_mask, (uint32_t *)ghist.ptr, nb);
-        hipLaunchKernelGGL(gs::k_sort_scan_rows, dim3(gs::RADIX), dim3(256), 0, st,
+        hipLaunchKernelGGL(gs::k_sort_scan_rows, dim3(R), dim3(256), 0, st,
                            (uint32_t *)ghist.ptr, nb, (uint32_t *)digit_totals.ptr);
         if (dev->lds_atomic_ordered)
-            hipLaunchKernelGGL((gs::k_sort_scatter<K, true>), dim3(nb), dim3(gs::SORT_THREADS), 0, st, kin,
+            hipLaunchKernelGGL((gs::k_sort_scatter<K, true, RB>), dim3(nb), dim3(gs::SORT_THREADS), 0, st, kin,
                                vin, kout, vout, count, shift, digit_mask, (const uint32_t *)ghist.ptr, nb,
                                (const uint32_t *)digit_totals.ptr);
         else
-            hipLaunchKernelGGL((gs::k_sort_scatter<K, false>), dim3(nb), dim3(gs::SORT_THREADS), 0, st, kin,
+            hipLaunchKernelGGL((gs::k_sort_scatter<K, false, RB>), dim3(nb), dim3(gs::SORT_THREADS), 0, st, kin,
                                vin, kout, vout, count, shift, digit_mask, (const uint32_t *)ghist.ptr, nb,
                                (const uint32_t *)digit_totals.ptr);
         shift += bits;
@@ -1444,6 +1446,29 @@ static gs_status sort_pairs_device(const gs_device *dev, void *const keys[2], vo
     GS_HIP(hipGetLastError());
     result_side = side;
     return GS_OK;
+}
+
+template <typename K>
+static gs_status sort_pairs_device(const gs_device *dev, void *const keys[2], void *const vals[2],
+                                   DevArray &ghist, DevArray &digit_totals, uint32_t count,
+                                   uint32_t end_bit, hipStream_t st, int &result_side,
+                                   uint32_t &passes_out) {
+    return sort_pairs_device_rb<K, gs::RADIX_BITS>(dev, keys, vals, ghist, digit_totals, count, end_bit, st,
+                                                   result_side, passes_out);
+}
+
+// Depth keys: 9-bit digits when that saves a pass (e.g. 25 significant bits: 3 passes instead of
+// 4); otherwise 8-bit digits, whose 256-bin tiles write longer runs and fit more workgroups per CU.
+static gs_status sort_depth_keys(const gs_device *dev, void *const keys[2], void *const vals[2],
+                                 DevArray &ghist, DevArray &digit_totals, uint32_t count,
+                                 uint32_t key_bits, hipStream_t st, int &result_side,
+                                 uint32_t &passes_out) {
+    const uint32_t p8 = (key_bits + 7) / 8, p9 = (key_bits + 8) / 9;
+    if (p9 < p8)
+        return sort_pairs_device_rb<uint32_t, gs::RADIX_BITS_MAX>(dev, keys, vals, ghist, digit_totals, count,
+                                                                  key_bits, st, result_side, passes_out);
+    return sort_pairs_device_rb<uint32_t, gs::RADIX_BITS>(dev, keys, vals, ghist, digit_totals, count, key_bits,
+                                                          st, result_side, passes_out);
 }
 
 static gs_status reserve_pairs(gs_renderer *r, uint64_t pairs, bool wide) {
@@ -1503,6 +1528,7 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
     GS_TRY(dev_reserve(r->sorted_rect, nn * 8));
     GS_TRY(dev_reserve(r->chunk_tiles, nc * 4));
     GS_TRY(dev_reserve(r->chunk_vis, nc * 4));
+    GS_TRY(dev_reserve(r->chunk_range, nc * 8));
     GS_TRY(dev_reserve(r->chunk_tiles_off, nc * 4));
     GS_TRY(dev_reserve(r->chunk_vis_off, nc * 4));
     GS_TRY(dev_reserve(r->counters, 64));
@@ -1519,21 +1545,22 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
                            (const uint4 *)g->planar, n, fc,
                            (uint32_t *)r->recs.ptr, (uint32_t *)r->depth.ptr,
                            (uint2 *)r->rect.ptr, (uint32_t *)r->chunk_tiles.ptr,
-                           (uint32_t *)r->chunk_vis.ptr);
+                           (uint32_t *)r->chunk_vis.ptr, (uint2 *)r->chunk_range.ptr);
         mark(ST_SCAN);
         // the two grand totals (D, V) go straight into pinned host memory (device-visible through
         // the unified address space): no separate copy launch, one stream wait below
         gs::ScanJob jt{(const uint32_t *)r->chunk_tiles.ptr, (uint32_t *)r->chunk_tiles_off.ptr,
                        r->host_counters + 0, nchunks};
         gs::ScanJob jv{(const uint32_t *)r->chunk_vis.ptr, (uint32_t *)r->chunk_vis_off.ptr,
-                       r->host_counters + 1, nchunks};
+                       r->host_counters + 1, nchunks, (const uint2 *)r->chunk_range.ptr,
+                       counters + 4, r->host_counters + 2};   // + (min, max) of the visible depth keys
         hipLaunchKernelGGL(gs::k_scan_chunks, dim3(2), dim3(1024), 0, st, jt, jv);
         GS_HIP(hipGetLastError());
         // compaction does not depend on the counts: enqueue it before waiting for them
         hipLaunchKernelGGL(gs::k_compact, dim3(nchunks), dim3(gs::PP_THREADS), 0, st,
                            (const uint32_t *)r->depth.ptr, (const uint32_t *)r->chunk_vis_off.ptr, n,
                            (uint32_t *)r->dkeys[0].ptr, (uint32_t *)r->dvals[0].ptr,
-                           (uint2 *)r->ranges.ptr, num_tiles);
+                           (uint2 *)r->ranges.ptr, num_tiles, (const uint32_t *)(counters + 4));
         GS_HIP(hipGetLastError());
         GS_HIP(hipStreamSynchronize(st));
         d = r->host_counters[0];
@@ -1545,14 +1572,16 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
         mark(ST_SCAN);
     }
     mark(ST_DSORT);
-    // depth sort of the visible Gaussians: u32 keys = bits of the (positive) view depth
+    // depth sort of the visible Gaussians: u32 keys = bits of the (positive) view depth minus the
+    // smallest visible key, so only bit_length(max - min) bits need sorting
     int dside = 0;
     uint32_t dpasses = 0;
-    {
+    if (visible) {
         void *k2[2] = {r->dkeys[0].ptr, r->dkeys[1].ptr};
         void *v2[2] = {r->dvals[0].ptr, r->dvals[1].ptr};
-        GS_TRY(sort_pairs_device<uint32_t>(r->dev, k2, v2, r->ghist, r->digit_totals, visible, 32, st, dside,
-                                           dpasses));
+        const uint32_t dmin = r->host_counters[2], dmax = r->host_counters[3];
+        const uint32_t key_bits = dmax >= dmin ? bit_length(dmax - dmin) : 32u;
+        GS_TRY(sort_depth_keys(r->dev, k2, v2, r->ghist, r->digit_totals, visible, key_bits, st, dside, dpasses));
     }
     mark(ST_EXPAND);
     GS_TRY(reserve_pairs(r, d, wide));

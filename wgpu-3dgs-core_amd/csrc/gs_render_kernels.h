@@ -87,6 +87,21 @@ __device__ __forceinline__ uint32_t wave_inclusive_max(uint32_t v) {
 }
 #undef GS_DPP_STEP
 
+__device__ __forceinline__ uint32_t dpp_op_min(uint32_t a, uint32_t b) { return a < b ? a : b; }
+// wave minimum / maximum, uniform in every lane (all 64 lanes must be active)
+__device__ __forceinline__ uint32_t wave_reduce_min(uint32_t v) {
+    const uint32_t identity = 0xffffffffu;
+#define GS_DPP_MIN(CTRL, ROWMASK) \
+    v = dpp_op_min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)identity, (int)v, CTRL, ROWMASK, 0xf, false))
+    GS_DPP_MIN(0x111, 0xf); GS_DPP_MIN(0x112, 0xf); GS_DPP_MIN(0x114, 0xf); GS_DPP_MIN(0x118, 0xf);
+    GS_DPP_MIN(0x142, 0xa); GS_DPP_MIN(0x143, 0xc);
+#undef GS_DPP_MIN
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ uint32_t wave_reduce_max(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_max(v), 63);
+}
+
 // wave total, uniform in every lane (all 64 lanes must be active)
 __device__ __forceinline__ uint32_t wave_reduce_add(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan(v, 0u), 63);
@@ -305,12 +320,13 @@ template <int SH, int COV>
 __global__ __launch_bounds__(PP_THREADS) void k_preprocess(
     const uint4 *__restrict__ planar, uint32_t n, FrameConsts fc,
     uint32_t *__restrict__ recs, uint32_t *__restrict__ depth, uint2 *__restrict__ rect,
-    uint32_t *__restrict__ chunk_tiles, uint32_t *__restrict__ chunk_vis) {
+    uint32_t *__restrict__ chunk_tiles, uint32_t *__restrict__ chunk_vis,
+    uint2 *__restrict__ chunk_depth_range) {
     constexpr int NW = pod_words(SH, COV);
     constexpr int NC = NW / 4;
-    __shared__ uint32_t s_red[8];
+    __shared__ uint32_t s_red[16];
     uint32_t base = blockIdx.x * PP_CHUNK;
-    uint32_t local = 0, local_vis = 0;
+    uint32_t local = 0, local_vis = 0, dmin = 0xffffffffu, dmax = 0u;
 #pragma unroll 1
     for (int k = 0; k < PP_ITEMS; k++) {
         uint32_t i = base + k * PP_THREADS + threadIdx.x;
@@ -341,19 +357,32 @@ __global__ __launch_bounds__(PP_THREADS) void k_preprocess(
             rect[i] = cnt ? make_uint2(rec[2].z, rec[2].w) : make_uint2(0u, 0u);
             local += cnt;
             local_vis += cnt ? 1u : 0u;
+            if (cnt) {
+                dmin = dmin < rec[2].y ? dmin : rec[2].y;
+                dmax = dmax > rec[2].y ? dmax : rec[2].y;
+            }
         }
     }
     local = wave_reduce_add(local);
     local_vis = wave_reduce_add(local_vis);
+    dmin = wave_reduce_min(dmin);
+    dmax = wave_reduce_max(dmax);
     uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
     if (lane == 0) {
         s_red[wid] = local;
         s_red[4 + wid] = local_vis;
+        s_red[8 + wid] = dmin;
+        s_red[12 + wid] = dmax;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         chunk_tiles[blockIdx.x] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
         chunk_vis[blockIdx.x] = (s_red[4] + s_red[5]) + (s_red[6] + s_red[7]);
+        // range of the visible depth keys: the depth sort only has to order (key - min), which for
+        // real scenes has 24-27 significant bits instead of 32 (fewer radix passes)
+        uint32_t lo = min(min(s_red[8], s_red[9]), min(s_red[10], s_red[11]));
+        uint32_t hi = max(max(s_red[12], s_red[13]), max(s_red[14], s_red[15]));
+        chunk_depth_range[blockIdx.x] = make_uint2(lo, hi);
     }
 }
 
@@ -364,8 +393,13 @@ __global__ __launch_bounds__(PP_THREADS) void k_preprocess(
 struct ScanJob {
     const uint32_t *sums;
     uint32_t *offsets;   // exclusive prefix per chunk
-    uint32_t *total;     // grand total
+    uint32_t *total;     // grand total (may point into pinned host memory)
     uint32_t num;
+    // optional: (min, max) pairs per chunk reduced to one pair, written to range_out[0..1] (device)
+    // and range_host[0..1] (pinned host); null = no range job
+    const uint2 *ranges;
+    uint32_t *range_out;
+    uint32_t *range_host;
 };
 
 __global__ __launch_bounds__(1024) void k_scan_chunks(ScanJob j0, ScanJob j1) {
@@ -375,11 +409,28 @@ __global__ __launch_bounds__(1024) void k_scan_chunks(ScanJob j0, ScanJob j1) {
     __shared__ unsigned long long s_total64;   // exact grand total: past 32 bits it is reported as 0xffffffff
     const ScanJob job = blockIdx.x == 0 ? j0 : j1;
     uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+    __shared__ uint32_t s_lo, s_hi;
     if (threadIdx.x == 0) {
         s_carry = 0;
         s_total64 = 0;
+        s_lo = 0xffffffffu;
+        s_hi = 0u;
     }
     __syncthreads();
+    if (job.ranges) {
+        uint32_t lo = 0xffffffffu, hi = 0u;
+        for (uint32_t i = threadIdx.x; i < job.num; i += 1024u) {
+            uint2 r = job.ranges[i];
+            lo = lo < r.x ? lo : r.x;
+            hi = hi > r.y ? hi : r.y;
+        }
+        lo = wave_reduce_min(lo);
+        hi = wave_reduce_max(hi);
+        if (lane == 0) {
+            atomicMin(&s_lo, lo);
+            atomicMax(&s_hi, hi);
+        }
+    }
     for (uint32_t base = 0; base < job.num; base += 1024u * PER) {
         uint32_t i0 = base + threadIdx.x * PER;
         uint32_t v[PER];
@@ -416,7 +467,15 @@ __global__ __launch_bounds__(1024) void k_scan_chunks(ScanJob j0, ScanJob j1) {
         if (threadIdx.x == 0) s_carry = carry + tot;
         __syncthreads();
     }
-    if (threadIdx.x == 0) *job.total = s_total64 > 0xfffffff0ull ? 0xffffffffu : s_carry;
+    if (threadIdx.x == 0) {
+        *job.total = s_total64 > 0xfffffff0ull ? 0xffffffffu : s_carry;
+        if (job.ranges) {   // (all barriers of the loop above lie between the atomics and this read)
+            job.range_out[0] = s_lo;
+            job.range_out[1] = s_hi;
+            job.range_host[0] = s_lo;
+            job.range_host[1] = s_hi;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -428,8 +487,10 @@ __global__ __launch_bounds__(PP_THREADS) void k_compact(const uint32_t *__restri
                                                         uint32_t n, uint32_t *__restrict__ dkeys,
                                                         uint32_t *__restrict__ dvals,
                                                         uint2 *__restrict__ ranges_to_clear,
-                                                        uint32_t num_tiles) {
+                                                        uint32_t num_tiles,
+                                                        const uint32_t *__restrict__ depth_range) {
     __shared__ uint32_t s_scan[4];
+    const uint32_t key_bias = depth_range[0];   // minimum visible depth key (k_scan_chunks)
     // side job: clear the per-tile ranges for this frame (saves a separate fill launch; every
     // dependent kernel boundary costs ~4-5 us on this part, which matters for a 0.5 ms frame)
     for (uint32_t t = blockIdx.x * PP_THREADS + threadIdx.x; t < num_tiles; t += gridDim.x * PP_THREADS)
@@ -447,7 +508,7 @@ __global__ __launch_bounds__(PP_THREADS) void k_compact(const uint32_t *__restri
 #pragma unroll
     for (int k = 0; k < PP_ITEMS; k++) {
         if (dk[k] != 0xffffffffu) {
-            dkeys[off] = dk[k];
+            dkeys[off] = dk[k] - key_bias;
             dvals[off] = base + k;
             off++;
         }
@@ -568,8 +629,9 @@ __global__ __launch_bounds__(EXP_CHUNK) void k_expand_emit(
 // ---------------------------------------------------------------------------------------------
 
 constexpr int SORT_THREADS = 256;
-constexpr int RADIX_BITS = 8;
+constexpr int RADIX_BITS = 8;          // default digit width; the depth sort may use 9 (see sort_pairs_device)
 constexpr int RADIX = 1 << RADIX_BITS;
+constexpr int RADIX_BITS_MAX = 9;
 
 template <typename K> struct SortCfg;
 template <> struct SortCfg<uint64_t> { static constexpr int ITEMS = 8; };
@@ -580,19 +642,24 @@ template <typename K> constexpr int sort_tile() { return SORT_THREADS * SortCfg<
 // ghist layout: [digit][block] (digit-major) so that the row scan reads contiguous memory.
 // Tile ids and depth exponents are highly repetitive, so neighbouring lanes often hit the same
 // bin; eight private copies (lane & 7) cut the same-address LDS atomic serialisation 8-fold.
-template <typename K>
+template <typename K, int RB>
 __global__ __launch_bounds__(SORT_THREADS) void k_sort_hist(const K *__restrict__ keys,
                                                             uint32_t count, uint32_t shift,
                                                             uint32_t digit_mask,
                                                             uint32_t *__restrict__ ghist,
                                                             uint32_t num_blocks) {
     constexpr int ITEMS = SortCfg<K>::ITEMS;
-    __shared__ uint32_t s_hist[8][RADIX];
+    constexpr int R = 1 << RB;
+    constexpr int COPIES = 2048 / R;   // 8 KiB of private copies: 8 x 256 or 4 x 512 bins
+    constexpr int DPT = R / SORT_THREADS;
+    __shared__ uint32_t s_hist[COPIES][R];
 #pragma unroll
-    for (int c = 0; c < 8; c++) s_hist[c][threadIdx.x] = 0;
+    for (int c = 0; c < COPIES; c++)
+#pragma unroll
+        for (int q = 0; q < DPT; q++) s_hist[c][threadIdx.x + q * SORT_THREADS] = 0;
     __syncthreads();
     const uint32_t base = blockIdx.x * (SORT_THREADS * ITEMS);
-    const uint32_t copy = threadIdx.x & 7u;
+    const uint32_t copy = threadIdx.x & (uint32_t)(COPIES - 1);
     // 16-byte loads: the order of the keys does not matter for a histogram
     constexpr int PER_VEC = 16 / sizeof(K);
     constexpr int VECS = ITEMS / PER_VEC;
@@ -620,10 +687,14 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_hist(const K *__restrict_
         }
     }
     __syncthreads();
-    uint32_t sum = 0;
 #pragma unroll
-    for (int c = 0; c < 8; c++) sum += s_hist[c][threadIdx.x];
-    ghist[(uint64_t)threadIdx.x * num_blocks + blockIdx.x] = sum;
+    for (int q = 0; q < DPT; q++) {
+        const uint32_t digit = threadIdx.x + q * SORT_THREADS;
+        uint32_t sum = 0;
+#pragma unroll
+        for (int c = 0; c < COPIES; c++) sum += s_hist[c][digit];
+        ghist[(uint64_t)digit * num_blocks + blockIdx.x] = sum;
+    }
 }
 
 // One workgroup per digit: exclusive scan of its row (over blocks) in place; row total out.
@@ -653,7 +724,7 @@ __global__ __launch_bounds__(256) void k_sort_scan_rows(uint32_t *__restrict__ g
 // then IS the stable rank.  This is not an architectural guarantee, so gs_device_create probes it
 // (k_probe_lds_atomic_order) and the host falls back to the ballot-based ranking if the probe
 // ever fails.
-template <typename K, bool FAST_RANK>
+template <typename K, bool FAST_RANK, int RB>
 __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
     const K *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, K *__restrict__ keys_out,
     uint32_t *__restrict__ vals_out, uint32_t count, uint32_t shift, uint32_t digit_mask,
@@ -661,16 +732,20 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
     const uint32_t *__restrict__ digit_totals) {
     constexpr int ITEMS = SortCfg<K>::ITEMS;
     constexpr int TILE = SORT_THREADS * ITEMS;
-    __shared__ uint32_t s_wave_hist[4][RADIX];   // per-wave digit counters
-    __shared__ uint32_t s_bin_start[RADIX];      // exclusive scan of block digit counts
-    __shared__ uint32_t s_global[RADIX];         // global offset of this block's digit run
+    constexpr int R = 1 << RB;
+    constexpr int DPT = R / SORT_THREADS;        // digits per thread: thread t owns digits [t*DPT, t*DPT+DPT)
+    __shared__ uint32_t s_wave_hist[4][R];       // per-wave digit counters
+    __shared__ uint32_t s_bin_start[R];          // exclusive scan of block digit counts
+    __shared__ uint32_t s_global[R];             // global offset of this block's digit run
     __shared__ uint32_t s_scan[4];
     __shared__ K s_keys[TILE];
     __shared__ uint32_t s_vals[TILE];
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
 #pragma unroll
-    for (int w = 0; w < 4; w++) s_wave_hist[w][tid] = 0;
+    for (int w = 0; w < 4; w++)
+#pragma unroll
+        for (int q = 0; q < DPT; q++) s_wave_hist[w][tid + q * SORT_THREADS] = 0;
     __syncthreads();
 
     const uint32_t tile_base = blockIdx.x * TILE;
@@ -698,7 +773,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
             // wave64 match-any on the digit: peers = lanes holding the same digit
             uint64_t peers = ~0ull;
 #pragma unroll
-            for (int b = 0; b < RADIX_BITS; b++) {
+            for (int b = 0; b < RB; b++) {
                 uint64_t m = __ballot((d >> b) & 1u);
                 peers &= ((d >> b) & 1u) ? m : ~m;
             }
@@ -711,23 +786,46 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
     }
     __syncthreads();
 
-    // per-digit: offsets of each wave inside the digit run, block digit count
-    uint32_t c0 = s_wave_hist[0][tid], c1 = s_wave_hist[1][tid], c2 = s_wave_hist[2][tid],
-             c3 = s_wave_hist[3][tid];
-    uint32_t digit_count = (c0 + c1) + (c2 + c3);
-    uint32_t total;
-    uint32_t bin_start = block_exclusive_scan_256(digit_count, s_scan, total);
-    s_bin_start[tid] = bin_start;
-    s_wave_hist[0][tid] = bin_start;
-    s_wave_hist[1][tid] = bin_start + c0;
-    s_wave_hist[2][tid] = bin_start + c0 + c1;
-    s_wave_hist[3][tid] = bin_start + c0 + c1 + c2;
-    // global base of digit `tid`: sum of totals of smaller digits + this block's row prefix
+    // per digit: offsets of each wave inside the digit run, block digit count
     {
-        uint32_t tot = digit_totals[tid];
+        uint32_t c[DPT][4], dc[DPT], mine = 0;
+#pragma unroll
+        for (int q = 0; q < DPT; q++) {
+            const uint32_t digit = tid * DPT + q;
+#pragma unroll
+            for (int w = 0; w < 4; w++) c[q][w] = s_wave_hist[w][digit];
+            dc[q] = (c[q][0] + c[q][1]) + (c[q][2] + c[q][3]);
+            mine += dc[q];
+        }
+        uint32_t total;
+        uint32_t bin_start = block_exclusive_scan_256(mine, s_scan, total);
+#pragma unroll
+        for (int q = 0; q < DPT; q++) {
+            const uint32_t digit = tid * DPT + q;
+            s_bin_start[digit] = bin_start;
+            s_wave_hist[0][digit] = bin_start;
+            s_wave_hist[1][digit] = bin_start + c[q][0];
+            s_wave_hist[2][digit] = bin_start + c[q][0] + c[q][1];
+            s_wave_hist[3][digit] = bin_start + c[q][0] + c[q][1] + c[q][2];
+            bin_start += dc[q];
+        }
+    }
+    // global base of every digit: sum of totals of smaller digits + this block's row prefix
+    {
+        uint32_t tot[DPT], mine = 0;
+#pragma unroll
+        for (int q = 0; q < DPT; q++) {
+            tot[q] = digit_totals[tid * DPT + q];
+            mine += tot[q];
+        }
         uint32_t t2;
-        uint32_t digit_base = block_exclusive_scan_256(tot, s_scan, t2);
-        s_global[tid] = digit_base + ghist[(uint64_t)tid * num_blocks + blockIdx.x];
+        uint32_t digit_base = block_exclusive_scan_256(mine, s_scan, t2);
+#pragma unroll
+        for (int q = 0; q < DPT; q++) {
+            const uint32_t digit = tid * DPT + q;
+            s_global[digit] = digit_base + ghist[(uint64_t)digit * num_blocks + blockIdx.x];
+            digit_base += tot[q];
+        }
     }
     __syncthreads();
 
