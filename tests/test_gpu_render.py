@@ -173,6 +173,31 @@ def test_more_than_65536_tiles_uses_wide_tile_keys(gs, ob, device, stream):
     r.destroy()
 
 
+@pytest.mark.parametrize("case", ["same_depth", "two_depths", "wide_range", "narrow_range"])
+def test_depth_key_ranges(gs, ob, device, stream, case):
+    """The depth sort orders (key - min key) with as few radix passes as the range needs: 0 passes
+    when every visible Gaussian has the same depth (order = index order), 9-bit digits for 19-27
+    significant bits, the 8-bit four-pass path for a near..far span of 1e5."""
+    import synth
+    g = synth.scene(3000, first=999)
+    rng = np.random.default_rng(11)
+    if case == "same_depth":
+        g["pos"][:, 2] = -7.25
+    elif case == "two_depths":
+        g["pos"][:, 2] = np.where(rng.random(len(g)) < 0.5, -3.0, -3.0000002).astype(np.float32)
+    elif case == "wide_range":
+        g["pos"][:, 2] = -np.exp(rng.uniform(np.log(0.00102), np.log(95.0), len(g))).astype(np.float32)
+        g["pos"][:, :2] *= (-g["pos"][:, 2:3] / 14.0)
+    else:
+        g["pos"][:, 2] = (-10.0 - rng.random(len(g)) * 1e-3).astype(np.float32)
+    st = _compare_frame(gs, ob, device, stream, gs.SH_NONE, gs.COV3D_ROT_SCALE, g, 640, 360,
+                        gt_kw=dict(sh_deg=0), cam_kw=dict(near=0.001, far=100.0))
+    assert st.visible > 100
+    tile_passes = 2   # 40 x 23 = 920 tiles -> 10 bits -> 5 + 5
+    depth_passes = st.sort_passes - tile_passes
+    assert depth_passes == {"same_depth": 0, "two_depths": 1, "wide_range": 4, "narrow_range": 2}[case], st.sort_passes
+
+
 def test_edge_cases(gs, ob, device, stream):
     """empty buffer, single Gaussian, everything culled, one splat covering the whole screen."""
     import synth
