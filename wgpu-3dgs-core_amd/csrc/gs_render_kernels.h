@@ -410,9 +410,12 @@ __global__ __launch_bounds__(1024) void k_scan_chunks(ScanJob j0, ScanJob j1) {
     const ScanJob job = blockIdx.x == 0 ? j0 : j1;
     uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
     __shared__ uint32_t s_lo, s_hi;
+    __shared__ uint32_t s_half[2];
     if (threadIdx.x == 0) {
         s_carry = 0;
         s_total64 = 0;
+        s_half[0] = 0;
+        s_half[1] = 0;
         s_lo = 0xffffffffu;
         s_hi = 0u;
     }
@@ -440,11 +443,20 @@ __global__ __launch_bounds__(1024) void k_scan_chunks(ScanJob j0, ScanJob j1) {
             v[k] = i0 + k < job.num ? job.sums[i0 + k] : 0u;
             sum += v[k];
         }
-        {   // 8 values of < 2^32 cannot wrap 64 bits; one LDS atomic per thread and iteration
-            unsigned long long wide = 0;
+        // exact (non-wrapping) total for the overflow check: the low and high 16-bit halves of the
+        // values are summed separately (8192 halves of < 2^16 stay below 2^29), reduced per wave on
+        // the DPP path, and only lane 0 of each wave touches the two LDS accumulators
+        uint32_t half_lo = 0, half_hi = 0;
 #pragma unroll
-            for (uint32_t k = 0; k < PER; k++) wide += v[k];
-            if (wide) atomicAdd(&s_total64, wide);
+        for (uint32_t k = 0; k < PER; k++) {
+            half_lo += v[k] & 0xffffu;
+            half_hi += v[k] >> 16;
+        }
+        half_lo = wave_reduce_add(half_lo);
+        half_hi = wave_reduce_add(half_hi);
+        if (lane == 0) {
+            atomicAdd(&s_half[0], half_lo);
+            atomicAdd(&s_half[1], half_hi);
         }
         uint32_t inc = wave_inclusive_scan(sum, lane);
         if (lane == 63u) s_wave[wid] = inc;
@@ -464,7 +476,12 @@ __global__ __launch_bounds__(1024) void k_scan_chunks(ScanJob j0, ScanJob j1) {
             run += v[k];
         }
         __syncthreads();
-        if (threadIdx.x == 0) s_carry = carry + tot;
+        if (threadIdx.x == 0) {
+            s_carry = carry + tot;
+            s_total64 += (unsigned long long)s_half[0] + ((unsigned long long)s_half[1] << 16);
+            s_half[0] = 0;
+            s_half[1] = 0;
+        }
         __syncthreads();
     }
     if (threadIdx.x == 0) {
