@@ -135,3 +135,22 @@ def test_large_upload_roundtrip_property(gs, device, stream):
     buf = gs.GaussiansBuffer.new_with_pods(device, pod, pods)
     assert buf.len() == 1_000_000
     assert np.array_equal(buf.download(stream), pods)
+
+
+def test_misaligned_device_pointers_are_rejected(gs, device, stream):
+    """Adopted raw pointers and the frame pointer are moved with 16-byte vector accesses: a
+    misaligned one must be refused up front instead of faulting on the device."""
+    import helpers
+    pod = gs.GaussianPodWithShNoneCov3dHalfConfigs     # 32-byte records
+    big = gs.Buffer(device, size=32 * 8 + 16)
+    raw = gs.Buffer.from_raw(device, big.device_ptr() + 4, 32 * 8)
+    with pytest.raises(gs.InvalidArgumentError):
+        gs.GaussiansBuffer.try_from(raw, pod)
+    ok = gs.GaussiansBuffer.try_from(gs.Buffer.from_raw(device, big.device_ptr() + 16, 32 * 8), pod)
+    assert len(ok) == 8
+    img = gs.Buffer(device, size=64 * 64 * 16 + 16)
+    r = gs.Renderer(device)
+    cam = helpers.default_camera(gs, 64, 64)
+    with pytest.raises(gs.InvalidArgumentError):
+        r.render(stream, ok, gs.gaussian_transform_pod(sh_deg=0), gs.model_transform_pod(), cam, img.device_ptr() + 4)
+    r.destroy()

@@ -585,6 +585,11 @@ extern "C" gs_status gs_gaussians_buffer_from_buffer(gs_buffer *buffer, gs_sh_co
     if (!buffer || !out || !valid_cfg(sh, cov))
         return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "bad argument");
     size_t stride = gs_pod_size(sh, cov);
+    // the kernels move records as 16-byte vectors: an adopted raw pointer (gs_buffer_from_raw) must
+    // be 16-byte aligned, as every hipMalloc allocation is
+    if ((uintptr_t)buffer->ptr & 15u)
+        return fail(GS_ERR_INVALID_ARGUMENT, (uint64_t)(uintptr_t)buffer->ptr, 16, 0,
+                    "Gaussian buffer device pointer must be 16-byte aligned");
     if (buffer->bytes % stride != 0)
         return fail(GS_ERR_BUFFER_SIZE_NOT_MULTIPLE, buffer->bytes, stride, 0,
                     "buffer size and expected multiple size mismatch: %zu %% %zu != 0",
@@ -1494,6 +1499,9 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
         return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "objects belong to different devices");
     if (cam->width == 0 || cam->height == 0 || cam->width > 65535u * 16u || cam->height > 65535u * 16u)
         return fail(GS_ERR_INVALID_ARGUMENT, cam->width, cam->height, 0, "bad image size");
+    if ((uintptr_t)rgba & 15u)
+        return fail(GS_ERR_INVALID_ARGUMENT, (uint64_t)(uintptr_t)rgba, 16, 0,
+                    "the RGBA frame must be 16-byte aligned (pixels are stored as float4)");
     uint32_t mode = gt->flags[0];
     if (mode != GS_DISPLAY_SPLAT)
         return fail(GS_ERR_INVALID_ARGUMENT, mode, 0, 0, "only GaussianDisplayMode::Splat is implemented");
