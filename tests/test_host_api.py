@@ -122,3 +122,19 @@ def test_builder_errors_need_no_device(gs):
         B().bind_group_layout(1).resolver(gs.KernelRegistry()).build(None, [])
     with pytest.raises(gs.MissingMainShader):
         B().bind_group_layout(1).resolver(gs.KernelRegistry()).entry_point("main").build(None, [])
+
+
+def test_generated_rust_ffi_is_in_sync_with_the_header():
+    """bindings/rust/gs3d_sys.rs is generated from include/gs3d.h: it must be regenerated whenever the
+    header changes, and declare exactly the functions the ctypes table binds."""
+    import re
+    import subprocess
+    import sys
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_rust_sys.py"), "--check"],
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert res.returncode == 0, res.stdout
+    rs = open(os.path.join(ROOT, "bindings", "rust", "gs3d_sys.rs")).read()
+    from wgpu_3dgs_core_amd import _capi
+    assert sorted(re.findall(r"pub fn (gs_\w+)\(", rs)) == sorted(_capi.SIGNATURES)
+    for struct, size in (("gs_gaussian", 236), ("gs_camera", 116), ("gs_projected", 48), ("gs_spz_header", 16)):
+        assert "pub struct %s {" % struct in rs
