@@ -50,12 +50,22 @@ class Camera(C.Structure):
                 ("height", C.c_uint32), ("background", C.c_float * 3)]
 
 
+def _stale():
+    return not os.path.exists(_LIB_PATH) or (
+        os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(os.path.join(_HERE, f))
+                                          for f in ("gs_oracle.c", "gs_oracle.h")))
+
+
 def build(force=False):
-    if force or not os.path.exists(_LIB_PATH) or (
-            os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(os.path.join(_HERE, f))
-                                              for f in ("gs_oracle.c", "gs_oracle.h"))):
-        subprocess.run(["make", "-C", _HERE, "-B" if force else "-s"], check=True,
-                       stdout=subprocess.DEVNULL)
+    """make the oracle library if needed (serialised across processes with a file lock)"""
+    if force or _stale():
+        import fcntl
+        os.makedirs(os.path.dirname(_LIB_PATH), exist_ok=True)
+        with open(os.path.join(os.path.dirname(_LIB_PATH), ".build.lock"), "w") as lock:
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            if force or _stale():
+                subprocess.run(["make", "-C", _HERE, "-B" if force else "-s"], check=True,
+                               stdout=subprocess.DEVNULL)
     return _LIB_PATH
 
 

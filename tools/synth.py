@@ -14,9 +14,19 @@ GAUSSIAN_DTYPE = np.dtype([("rot", "<f4", 4), ("pos", "<f4", 3), ("color", "u1",
 
 
 def build(force=False):
+    """make the generator library if needed (serialised across processes with a file lock)"""
     src = os.path.join(_HERE, "gs_synth.c")
-    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(src):
-        subprocess.run(["make", "-C", _HERE, "-s"] + (["-B"] if force else []), check=True)
+
+    def stale():
+        return not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(src)
+
+    if force or stale():
+        import fcntl
+        os.makedirs(os.path.dirname(_LIB), exist_ok=True)
+        with open(os.path.join(os.path.dirname(_LIB), ".build.lock"), "w") as lock:
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            if force or stale():
+                subprocess.run(["make", "-C", _HERE, "-s"] + (["-B"] if force else []), check=True)
     return _LIB
 
 
