@@ -1354,6 +1354,7 @@ extern "C" gs_status gs_renderer_stats(gs_renderer *r, gs_frame_stats *out) {
 typedef void (*preprocess_fn)(const uint4 *, uint32_t, gs::FrameConsts, uint32_t *,
                               uint32_t *, uint2 *, uint32_t *, uint32_t *, uint2 *);
 static preprocess_fn k_tbl_preprocess[4][3] = GS_CFG_TABLE(gs::k_preprocess);
+static preprocess_fn k_tbl_preprocess_banded[4][3] = GS_CFG_TABLE(gs::k_preprocess_banded);
 
 // frame constants from the uniforms
 static void make_frame_consts(const gs_gaussian_transform_pod *gt, const gs_model_transform_pod *mt,
@@ -1549,7 +1550,12 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
 
     uint32_t d = 0, visible = 0;
     if (n) {
-        hipLaunchKernelGGL(k_tbl_preprocess[g->sh][g->cov], dim3(nchunks), dim3(gs::PP_THREADS), 0, st,
+        // narrow band (one rank of >= 4) and SH to skip: two-phase loads (see k_preprocess_banded)
+        static const int force_banded = std::getenv("GS3D_FORCE_BANDED") ? std::atoi(std::getenv("GS3D_FORCE_BANDED")) : -1;
+        const bool narrow = 4u * (fc.band_ty1 - fc.band_ty0) <= fc.tiles_y;
+        const bool banded = g->sh != GS_SH_NONE && (force_banded >= 0 ? force_banded != 0 : narrow);
+        hipLaunchKernelGGL((banded ? k_tbl_preprocess_banded : k_tbl_preprocess)[g->sh][g->cov], dim3(nchunks),
+                           dim3(gs::PP_THREADS), 0, st,
                            (const uint4 *)g->planar, n, fc,
                            (uint32_t *)r->recs.ptr, (uint32_t *)r->depth.ptr,
                            (uint2 *)r->rect.ptr, (uint32_t *)r->chunk_tiles.ptr,

@@ -226,9 +226,11 @@ __device__ __forceinline__ void eval_sh(const uint32_t *w, uint32_t deg, bool no
 // Written without early exits: every cull test only clears `ok`, so all the record's loads are
 // unconditional and the compiler can issue them back to back at the top (memory-level
 // parallelism is what this HBM-bound kernel needs); arithmetic on culled lanes is discarded.
+// The geometry half reads only the position / colour chunk and the covariance words; the colour
+// half (shade_one) reads the SH words.  project_one = both, in the order the spec gives.
 template <int SH, int COV>
-__device__ __forceinline__ uint32_t project_one(const uint32_t *w, const FrameConsts &fc,
-                                                uint4 rec[3]) {
+__device__ __forceinline__ uint32_t project_geom(const uint32_t *w, const FrameConsts &fc,
+                                                 uint4 rec[3], float d[3]) {
     float p[3] = {u2f(w[0]), u2f(w[1]), u2f(w[2])};
     float pw[4], t[4];
     mat4_mul_point(fc.M, p, pw);
@@ -286,15 +288,34 @@ __device__ __forceinline__ uint32_t project_one(const uint32_t *w, const FrameCo
     for (int r = 0; r < 3; r++)
         dm[r] = (fc.ISR[r] * dn[0] + fc.ISR[3 + r] * dn[1]) + fc.ISR[6 + r] * dn[2];
     float ml = sqrtf((dm[0] * dm[0] + dm[1] * dm[1]) + dm[2] * dm[2]);
-    float d[3] = {dm[0] / ml, dm[1] / ml, dm[2] / ml};
-    float rgb[3];
-    eval_sh<SH>(w, fc.sh_deg, fc.no_sh0 != 0u, d, rgb);
+    d[0] = dm[0] / ml;
+    d[1] = dm[1] / ml;
+    d[2] = dm[2] / ml;
     float opacity = unorm8(w[3], 3);
 
     rec[0] = make_uint4(f2u(mx), f2u(my), f2u(-0.5f * (cc * inv)), f2u(cb * inv));
-    rec[1] = make_uint4(f2u(-0.5f * (ca * inv)), f2u(opacity), f2u(rgb[0]), f2u(rgb[1]));
-    rec[2] = make_uint4(f2u(rgb[2]), f2u(zv), tx0 | (ty0 << 16), tx1 | (ty1 << 16));
+    rec[1] = make_uint4(f2u(-0.5f * (ca * inv)), f2u(opacity), 0u, 0u);
+    rec[2] = make_uint4(0u, f2u(zv), tx0 | (ty0 << 16), tx1 | (ty1 << 16));
     return (tx1 - tx0) * (ty1 - ty0);
+}
+
+template <int SH>
+__device__ __forceinline__ void shade_one(const uint32_t *w, const FrameConsts &fc, const float d[3],
+                                          uint4 rec[3]) {
+    float rgb[3];
+    eval_sh<SH>(w, fc.sh_deg, fc.no_sh0 != 0u, d, rgb);
+    rec[1].z = f2u(rgb[0]);
+    rec[1].w = f2u(rgb[1]);
+    rec[2].x = f2u(rgb[2]);
+}
+
+template <int SH, int COV>
+__device__ __forceinline__ uint32_t project_one(const uint32_t *w, const FrameConsts &fc,
+                                                uint4 rec[3]) {
+    float d[3];
+    uint32_t cnt = project_geom<SH, COV>(w, fc, rec, d);
+    shade_one<SH>(w, fc, d, rec);
+    return cnt;
 }
 
 // 4-byte aligned 16-byte vector: lets 36-byte records be moved with two dwordx4 + one dword
@@ -380,6 +401,100 @@ __global__ __launch_bounds__(PP_THREADS) void k_preprocess(
         chunk_vis[blockIdx.x] = (s_red[4] + s_red[5]) + (s_red[6] + s_red[7]);
         // range of the visible depth keys: the depth sort only has to order (key - min), which for
         // real scenes has 24-27 significant bits instead of 32 (fewer radix passes)
+        uint32_t lo = min(min(s_red[8], s_red[9]), min(s_red[10], s_red[11]));
+        uint32_t hi = max(max(s_red[12], s_red[13]), max(s_red[14], s_red[15]));
+        chunk_depth_range[blockIdx.x] = make_uint2(lo, hi);
+    }
+}
+
+// Two-phase variant for narrow tile-row bands (one rank of a multi-GPU frame): phase 1
+// loads only the chunks that hold position, colour and covariance, projects and band-culls; only
+// the surviving lanes then load their SH chunks (EXEC-masked loads: a 128-byte line none of whose
+// lanes survived is not fetched).  With Gaussians in user order a line of an SH plane holds 8
+// unrelated Gaussians, so at 8 bands about half of the SH lines are skipped (at 2 bands almost
+// none, and the second dependent round trip costs latency: the host uses this kernel only when the
+// band covers at most a quarter of the tile rows).  Same arithmetic, same outputs as k_preprocess.
+template <int SH, int COV>
+__global__ __launch_bounds__(PP_THREADS) void k_preprocess_banded(
+    const uint4 *__restrict__ planar, uint32_t n, FrameConsts fc,
+    uint32_t *__restrict__ recs, uint32_t *__restrict__ depth, uint2 *__restrict__ rect,
+    uint32_t *__restrict__ chunk_tiles, uint32_t *__restrict__ chunk_vis,
+    uint2 *__restrict__ chunk_depth_range) {
+    constexpr int NW = pod_words(SH, COV);
+    constexpr int NC = NW / 4;
+    constexpr int G0 = cov_word0(SH) / 4;                              // first chunk holding covariance words
+    constexpr int G1 = (cov_word0(SH) + cov_bytes(COV) / 4 - 1) / 4;   // last one
+    __shared__ uint32_t s_red[16];
+    uint32_t base = blockIdx.x * PP_CHUNK;
+    uint32_t local = 0, local_vis = 0, dmin = 0xffffffffu, dmax = 0u;
+#pragma unroll 1
+    for (int k = 0; k < PP_ITEMS; k++) {
+        uint32_t i = base + k * PP_THREADS + threadIdx.x;
+        if (i < n) {
+            uint32_t w[NW];
+            uint4 v0 = planar[planar_at(0, i, NC)];
+            uint4 vg[G1 - G0 + 1];
+#pragma unroll
+            for (int c = G0; c <= G1; c++)
+                if (c != 0) vg[c - G0] = planar[planar_at(c, i, NC)];
+            asm volatile("" : "+v"(v0.x), "+v"(v0.y), "+v"(v0.z), "+v"(v0.w));
+            w[0] = v0.x; w[1] = v0.y; w[2] = v0.z; w[3] = v0.w;
+#pragma unroll
+            for (int c = G0; c <= G1; c++) {
+                if (c == 0) continue;
+                asm volatile("" : "+v"(vg[c - G0].x), "+v"(vg[c - G0].y), "+v"(vg[c - G0].z), "+v"(vg[c - G0].w));
+                w[4 * c + 0] = vg[c - G0].x;
+                w[4 * c + 1] = vg[c - G0].y;
+                w[4 * c + 2] = vg[c - G0].z;
+                w[4 * c + 3] = vg[c - G0].w;
+            }
+            uint4 rec[3];
+            float d[3];
+            uint32_t cnt = project_geom<SH, COV>(w, fc, rec, d);
+            if (cnt) {
+                constexpr int S0 = 1, S1 = G0 - 1;   // SH-only chunks (G0.. were loaded above)
+                if constexpr (S1 >= S0) {
+                    uint4 vs[S1 - S0 + 1];
+#pragma unroll
+                    for (int c = S0; c <= S1; c++) vs[c - S0] = planar[planar_at(c, i, NC)];
+#pragma unroll
+                    for (int c = S0; c <= S1; c++) {
+                        asm volatile("" : "+v"(vs[c - S0].x), "+v"(vs[c - S0].y), "+v"(vs[c - S0].z), "+v"(vs[c - S0].w));
+                        w[4 * c + 0] = vs[c - S0].x;
+                        w[4 * c + 1] = vs[c - S0].y;
+                        w[4 * c + 2] = vs[c - S0].z;
+                        w[4 * c + 3] = vs[c - S0].w;
+                    }
+                }
+                shade_one<SH>(w, fc, d, rec);
+                dmin = dmin < rec[2].y ? dmin : rec[2].y;
+                dmax = dmax > rec[2].y ? dmax : rec[2].y;
+            }
+            uint32_t *o = recs + (uint64_t)i * REC_WORDS;
+            *(u32x4_a4 *)(o) = u32x4_a4{rec[0].x, rec[0].y, rec[0].z, rec[0].w};
+            *(u32x4_a4 *)(o + 4) = u32x4_a4{rec[1].x, rec[1].y, rec[1].z, rec[1].w};
+            o[8] = rec[2].x;
+            depth[i] = cnt ? rec[2].y : 0xffffffffu;
+            rect[i] = cnt ? make_uint2(rec[2].z, rec[2].w) : make_uint2(0u, 0u);
+            local += cnt;
+            local_vis += cnt ? 1u : 0u;
+        }
+    }
+    local = wave_reduce_add(local);
+    local_vis = wave_reduce_add(local_vis);
+    dmin = wave_reduce_min(dmin);
+    dmax = wave_reduce_max(dmax);
+    uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+    if (lane == 0) {
+        s_red[wid] = local;
+        s_red[4 + wid] = local_vis;
+        s_red[8 + wid] = dmin;
+        s_red[12 + wid] = dmax;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        chunk_tiles[blockIdx.x] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+        chunk_vis[blockIdx.x] = (s_red[4] + s_red[5]) + (s_red[6] + s_red[7]);
         uint32_t lo = min(min(s_red[8], s_red[9]), min(s_red[10], s_red[11]));
         uint32_t hi = max(max(s_red[12], s_red[13]), max(s_red[14], s_red[15]));
         chunk_depth_range[blockIdx.x] = make_uint2(lo, hi);
