@@ -243,7 +243,7 @@ def main():
                 except Exception:
                     traffic = None
             line["roofline"] = {
-                "bound": "hbm", "kernel": "k_preprocess<ShSingle,RotScale>",
+                "bound": "hbm", "kernel": "k_preprocess_banded<ShSingle,RotScale>",
                 "workload": roof_wl["label"],
                 "achieved": pre["achieved_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": pre["frac"], "traffic": traffic,

@@ -282,6 +282,9 @@ extern "C" {
     pub fn gs_gaussians_buffer_download(g: *mut gs_gaussians_buffer, s: *mut gs_stream, pods_out: *mut c_void, count: usize) -> gs_status;
     pub fn gs_gaussians_buffer_download_gaussians(g: *mut gs_gaussians_buffer, s: *mut gs_stream, out: *mut gs_gaussian, count: usize) -> gs_status;
     pub fn gs_gaussians_buffer_mark_dirty(g: *mut gs_gaussians_buffer);
+    pub fn gs_gaussians_buffer_set_spatial_order(g: *mut gs_gaussians_buffer, enabled: i32) -> gs_status;
+    pub fn gs_gaussians_buffer_spatial_order(g: *const gs_gaussians_buffer) -> i32;
+    pub fn gs_gaussians_buffer_download_order(g: *mut gs_gaussians_buffer, s: *mut gs_stream, order_out: *mut u32, count: usize) -> gs_status;
     pub fn gs_gaussian_transform_buffer_create(dev: *mut gs_device, out: *mut *mut gs_buffer) -> gs_status;
     pub fn gs_gaussian_transform_buffer_update(b: *mut gs_buffer, s: *mut gs_stream, pod: *const gs_gaussian_transform_pod) -> gs_status;
     pub fn gs_gaussian_transform_buffer_from_buffer(b: *mut gs_buffer) -> gs_status;

@@ -310,6 +310,18 @@ gs_status gs_gaussians_buffer_download_gaussians(gs_gaussians_buffer *g, gs_stre
 /* tell the wrapper that device code wrote the underlying buffer (e.g. a compute bundle bound it
  * read-write), so the renderer's block-planar mirror must be rebuilt on the next frame */
 void gs_gaussians_buffer_mark_dirty(gs_gaussians_buffer *g);
+/* The renderer reads a mirror of the buffer whose slots are, by default, in SPATIAL order: ids
+ * sorted by the 30-bit Morton code of the position (10 bits per axis over the bounding box of all
+ * positions; ties by index) — DESIGN.md §3.4a.  The order is computed whenever the whole buffer
+ * is (re)mirrored (creation, gs_gaussians_buffer_update, mark_dirty); update_range keeps it.  It is
+ * observable in exactly one way: (tile, Gaussian) pairs with bit-identical depth in one tile are
+ * blended in mirror order.  Disable (index order) per buffer here or globally with
+ * GS3D_SPATIAL_ORDER=0.  download_order writes order[slot] = Gaussian index (the identity when
+ * disabled); count must equal the buffer length. */
+gs_status gs_gaussians_buffer_set_spatial_order(gs_gaussians_buffer *g, int32_t enabled);
+int32_t gs_gaussians_buffer_spatial_order(const gs_gaussians_buffer *g);
+gs_status gs_gaussians_buffer_download_order(gs_gaussians_buffer *g, gs_stream *s, uint32_t *order_out,
+                                             size_t count);
 
 /* GaussianTransformBuffer — src/buffer/gaussian_transform.rs:104-163 (8-byte uniform) */
 gs_status gs_gaussian_transform_buffer_create(gs_device *dev, gs_buffer **out);

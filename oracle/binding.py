@@ -203,11 +203,28 @@ def preprocess(sh, cov, pods, gt, mt, cam, band=None):
     return proj, tiles
 
 
-def build_keys(proj, tiles, tiles_x):
+def spatial_order(sh, cov, pods):
+    """slot -> Gaussian index of the spatially ordered mirror"""
+    pods = np.ascontiguousarray(pods, dtype=np.uint8)
+    n = len(pods.reshape(-1)) // pod_size(sh, cov)
+    order = np.zeros(n, dtype=np.uint32)
+    lib().gso_spatial_order.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]
+    lib().gso_spatial_order.restype = None
+    lib().gso_spatial_order(_p(pods), n, pod_size(sh, cov), _p(order))
+    return order
+
+
+def build_keys(proj, tiles, tiles_x, order=None):
     d = int(tiles.astype(np.uint64).sum())
     keys = np.zeros(max(d, 1), dtype=np.uint64)
     idx = np.zeros(max(d, 1), dtype=np.uint32)
-    d2 = lib().gso_build_keys(_p(proj), _p(tiles), len(proj), tiles_x, _p(keys), _p(idx))
+    fn = lib().gso_build_keys_ordered
+    fn.restype = C.c_uint64
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+    if order is not None:
+        order = np.ascontiguousarray(order, dtype=np.uint32)
+        assert len(order) == len(proj)
+    d2 = fn(_p(proj), _p(tiles), len(proj), tiles_x, _p(keys), _p(idx), _p(order) if order is not None else None)
     assert d2 == d
     return keys[:d], idx[:d]
 
@@ -235,15 +252,22 @@ def blend(proj, idx, ranges, cam, band=None):
     return rgba
 
 
-def render(sh, cov, pods, gt, mt, cam, band=None, want_image=True):
+def render(sh, cov, pods, gt, mt, cam, band=None, want_image=True, order=None):
     pods = np.ascontiguousarray(pods, dtype=np.uint8)
     n = len(pods) // pod_size(sh, cov)
     tiles_y = (cam.height + 15) // 16
     b0, b1 = band if band is not None else (0, tiles_y)
     rgba = np.zeros((cam.height, cam.width, 4), dtype=np.float32) if want_image else None
     vis = C.c_uint64(0)
-    d = lib().gso_render(sh, cov, _p(pods), n, C.byref(gt), C.byref(mt), C.byref(cam), b0, b1,
-                         _p(rgba) if want_image else None, C.byref(vis))
+    fn = lib().gso_render_ordered
+    fn.restype = C.c_uint64
+    fn.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
+                   C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+    if order is not None:
+        order = np.ascontiguousarray(order, dtype=np.uint32)
+        assert len(order) == n
+    d = fn(sh, cov, _p(pods), n, C.byref(gt), C.byref(mt), C.byref(cam), b0, b1,
+           _p(rgba) if want_image else None, C.byref(vis), _p(order) if order is not None else None)
     st = (C.c_double * 5)()
     lib().gso_last_stage_seconds(st)
     return rgba, int(d), int(vis.value), list(st)

@@ -850,10 +850,14 @@ void gso_preprocess(int sh, int cov, const void *pods, size_t n, const gso_gauss
 }
 
 /* pairs ordered by Gaussian index, then tile row, then tile column. */
-uint64_t gso_build_keys(const gso_projected *proj, const uint32_t *tiles_touched, size_t n,
-                        uint32_t tiles_x, uint64_t *keys, uint32_t *idx) {
+/* pairs are emitted in the buffer's mirror order (`order[slot]` = Gaussian index;
+ * NULL = index order), and the sort is stable, so pairs with exactly equal (tile, depth) keys keep
+ * that order. */
+uint64_t gso_build_keys_ordered(const gso_projected *proj, const uint32_t *tiles_touched, size_t n,
+                                uint32_t tiles_x, uint64_t *keys, uint32_t *idx, const uint32_t *order) {
     uint64_t d = 0;
-    for (size_t i = 0; i < n; i++) {
+    for (size_t slot = 0; slot < n; slot++) {
+        size_t i = order ? order[slot] : slot;
         if (!tiles_touched[i]) continue;
         const gso_projected *p = &proj[i];
         uint32_t depth_bits = f2u(p->depth);
@@ -869,7 +873,54 @@ uint64_t gso_build_keys(const gso_projected *proj, const uint32_t *tiles_touched
     return d;
 }
 
-/* Stable LSD radix sort on the 64-bit key (ties keep emission order = Gaussian index). */
+uint64_t gso_build_keys(const gso_projected *proj, const uint32_t *tiles_touched, size_t n,
+                        uint32_t tiles_x, uint64_t *keys, uint32_t *idx) {
+    return gso_build_keys_ordered(proj, tiles_touched, n, tiles_x, keys, idx, NULL);
+}
+
+/* DESIGN.md §3.4a — the spatial mirror order: 30-bit Morton code of the position quantised to 10
+ * bits per axis over the bounding box of all positions, ids sorted by (code, id).  `pods` is any of
+ * the 12 layouts (the position is the first 12 bytes of every record). */
+void gso_spatial_order(const void *pods, size_t n, size_t pod_bytes, uint32_t *order) {
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    const uint8_t *b = (const uint8_t *)pods;
+    for (size_t i = 0; i < n; i++) {
+        float p[3];
+        memcpy(p, b + i * pod_bytes, 12);
+        for (int a = 0; a < 3; a++) {
+            lo[a] = fminf(lo[a], p[a]);   /* fminf / fmaxf ignore NaNs */
+            hi[a] = fmaxf(hi[a], p[a]);
+        }
+    }
+    uint32_t *code = (uint32_t *)malloc((n ? n : 1) * sizeof(uint32_t));
+    for (size_t i = 0; i < n; i++) {
+        float p[3];
+        memcpy(p, b + i * pod_bytes, 12);
+        uint32_t c = 0;
+        for (int a = 0; a < 3; a++) {
+            float s = ((p[a] - lo[a]) / (hi[a] - lo[a])) * 1024.0f;
+            uint32_t q = s >= 1023.0f ? 1023u : (s > 0.0f ? (uint32_t)s : 0u);   /* NaN -> 0 */
+            for (int bit = 0; bit < 10; bit++) c |= ((q >> bit) & 1u) << (3 * bit + a);
+        }
+        code[i] = c;
+    }
+    /* stable counting sort, three 10-bit passes over the 30-bit code */
+    uint32_t *tmp = (uint32_t *)malloc((n ? n : 1) * sizeof(uint32_t));
+    for (size_t i = 0; i < n; i++) order[i] = (uint32_t)i;
+    uint32_t *src = order, *dst = tmp;
+    for (int pass = 0; pass < 3; pass++) {
+        size_t hist[1025] = {0};
+        for (size_t i = 0; i < n; i++) hist[((code[src[i]] >> (10 * pass)) & 1023u) + 1]++;
+        for (int k = 0; k < 1024; k++) hist[k + 1] += hist[k];
+        for (size_t i = 0; i < n; i++) dst[hist[(code[src[i]] >> (10 * pass)) & 1023u]++] = src[i];
+        uint32_t *t = src; src = dst; dst = t;
+    }
+    if (src != order) memcpy(order, src, n * sizeof(uint32_t));
+    free(code);
+    free(tmp);
+}
+
+/* Stable LSD radix sort on the 64-bit key (ties keep emission order). */
 void gso_sort_pairs(uint64_t *keys, uint32_t *idx, uint64_t d) {
     if (d < 2) return;
     uint64_t *k2 = (uint64_t *)malloc(d * sizeof(uint64_t));
@@ -973,18 +1024,25 @@ static double now_s(void) {
 uint64_t gso_render(int sh, int cov, const void *pods, size_t n, const gso_gaussian_transform *gt,
                     const gso_model_transform *mt, const gso_camera *cam, uint32_t band_ty0,
                     uint32_t band_ty1, float *rgba, uint64_t *visible_out) {
+    return gso_render_ordered(sh, cov, pods, n, gt, mt, cam, band_ty0, band_ty1, rgba, visible_out, NULL);
+}
+
+uint64_t gso_render_ordered(int sh, int cov, const void *pods, size_t n, const gso_gaussian_transform *gt,
+                            const gso_model_transform *mt, const gso_camera *cam, uint32_t band_ty0,
+                            uint32_t band_ty1, float *rgba, uint64_t *visible_out,
+                            const uint32_t *order) {
     uint32_t tiles_x = (cam->width + 15u) / 16u, tiles_y = (cam->height + 15u) / 16u;
     gso_projected *proj = (gso_projected *)malloc((n ? n : 1) * sizeof(gso_projected));
     uint32_t *tt = (uint32_t *)malloc((n ? n : 1) * sizeof(uint32_t));
     double t0 = now_s();
     gso_preprocess(sh, cov, pods, n, gt, mt, cam, band_ty0, band_ty1, proj, tt);
     double t1 = now_s();
-    uint64_t d = gso_build_keys(proj, tt, n, tiles_x, NULL, NULL);
+    uint64_t d = gso_build_keys_ordered(proj, tt, n, tiles_x, NULL, NULL, order);
     uint64_t vis = 0;
     for (size_t i = 0; i < n; i++) vis += tt[i] != 0;
     uint64_t *keys = (uint64_t *)malloc((d ? d : 1) * sizeof(uint64_t));
     uint32_t *idx = (uint32_t *)malloc((d ? d : 1) * sizeof(uint32_t));
-    gso_build_keys(proj, tt, n, tiles_x, keys, idx);
+    gso_build_keys_ordered(proj, tt, n, tiles_x, keys, idx, order);
     double t2 = now_s();
     gso_sort_pairs(keys, idx, d);
     double t3 = now_s();

@@ -163,6 +163,11 @@ void gso_preprocess(int sh, int cov, const void *pods, size_t n, const gso_gauss
 /* keys/idx must hold sum(tiles_touched) entries; returns that sum */
 uint64_t gso_build_keys(const gso_projected *proj, const uint32_t *tiles_touched, size_t n,
                         uint32_t tiles_x, uint64_t *keys, uint32_t *idx);
+/* same, emitting in mirror order: order[slot] = Gaussian index (NULL = index order); DESIGN.md §3.4 */
+uint64_t gso_build_keys_ordered(const gso_projected *proj, const uint32_t *tiles_touched, size_t n,
+                                uint32_t tiles_x, uint64_t *keys, uint32_t *idx, const uint32_t *order);
+/* the spatial mirror order of DESIGN.md §3.4a (30-bit Morton code of the position, ties by index) */
+void gso_spatial_order(const void *pods, size_t n, size_t pod_bytes, uint32_t *order);
 void gso_sort_pairs(uint64_t *keys, uint32_t *idx, uint64_t d);
 /* ranges: 2 u32 per tile [start,end) over tiles_x*tiles_y tiles */
 void gso_tile_ranges(const uint64_t *keys, uint64_t d, uint32_t num_tiles, uint32_t *ranges);
@@ -173,6 +178,10 @@ void gso_blend(const gso_projected *proj, const uint32_t *idx, const uint32_t *r
 uint64_t gso_render(int sh, int cov, const void *pods, size_t n, const gso_gaussian_transform *gt,
                     const gso_model_transform *mt, const gso_camera *cam, uint32_t band_ty0,
                     uint32_t band_ty1, float *rgba, uint64_t *visible_out);
+uint64_t gso_render_ordered(int sh, int cov, const void *pods, size_t n, const gso_gaussian_transform *gt,
+                            const gso_model_transform *mt, const gso_camera *cam, uint32_t band_ty0,
+                            uint32_t band_ty1, float *rgba, uint64_t *visible_out,
+                            const uint32_t *order);
 /* per-stage wall time of the last gso_render on this thread, seconds:
  * preprocess, keys, sort, ranges, blend */
 void gso_last_stage_seconds(double out[5]);

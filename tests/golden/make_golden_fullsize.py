@@ -2,8 +2,9 @@
 """Full-size golden results: the CPU oracle (oracle/gs_oracle.c) run once, offline, on the
 BASELINE.json configurations — the synthetic scenes of SURVEY §8(d) at their full N and resolution.
 Per workload it records N, the visible count V, the pair count D, the sha256 of the packed scene
-(so a differing generator is told apart from a differing renderer) and the sha256 of the f32 RGBA
-frame.  The HIP path is bit-exact against the oracle, so tests/test_gpu_fullsize.py compares hashes.
+(so a differing generator is told apart from a differing renderer), of the spatial mirror order and
+of the f32 RGBA frame (in that order, and in plain index order for buffers with the spatial order
+switched off).  The HIP path is bit-exact against the oracle, so tests/test_gpu_fullsize.py compares hashes.
 Output: tests/golden/fullsize_v1.json.   Run:  python tests/golden/make_golden_fullsize.py [workload ...]
 (1m takes seconds, 10m a few minutes on 8 cores, 50m needs ~25 GB of RAM.)"""
 import hashlib
@@ -38,12 +39,18 @@ def run(name):
                             0.1, 100.0)
     gt, mt = ob.gaussian_transform(sh_deg=wl["sh_deg"]), ob.model_transform()
     t0 = time.time()
-    rgba, d, v, _ = ob.render(wl["sh"], wl["cov"], pods, gt, mt, cam, want_image=True)
+    # the buffer's default mirror order: pairs of bit-identical depth follow it
+    order = ob.spatial_order(wl["sh"], wl["cov"], pods)
+    rgba, d, v, _ = ob.render(wl["sh"], wl["cov"], pods, gt, mt, cam, want_image=True, order=order)
     dt = time.time() - t0
+    rgba_index_order = ob.render(wl["sh"], wl["cov"], pods, gt, mt, cam, want_image=True)[0]
     alpha = rgba[..., 3]
     return dict(n=wl["n"], sh=wl["sh"], cov=wl["cov"], sh_deg=wl["sh_deg"], width=wl["width"], height=wl["height"],
                 visible=v, pairs=d, scene_sha256=pods_hash.hexdigest(),
                 frame_sha256=hashlib.sha256(rgba.tobytes()).hexdigest(),
+                order_sha256=hashlib.sha256(order.tobytes()).hexdigest(),
+                frame_sha256_index_order=hashlib.sha256(rgba_index_order.tobytes()).hexdigest(),
+                pixels_differing_from_index_order=int((rgba.view(np.uint32) != rgba_index_order.view(np.uint32)).any(axis=2).sum()),
                 frame_sum=float(rgba.astype(np.float64).sum()), alpha_max=float(alpha.max()),
                 covered_pixels=int((alpha > 0).sum()), oracle_seconds=round(dt, 2))
 

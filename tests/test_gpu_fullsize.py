@@ -2,7 +2,7 @@
 at 10 M Gaussians, so these tests use (1) frame / scene hashes the oracle produced offline
 (tests/golden/fullsize_v1.json, generator: tests/golden/make_golden_fullsize.py) — the HIP path is
 specified bit-exact, so equal sha256 == equal frames — and (2) size-independent properties of the
-intermediate results: sortedness and stability of the (tile, depth) pairs, the pair multiset being
+intermediate results: sortedness and stability (in mirror order) of the (tile, depth) pairs, the pair multiset being
 exactly the rect expansion of the projected records, tile ranges partitioning [0, D), idempotence,
 band stitching, and the background identity out(bg) = out(0) + (1 - alpha) * bg."""
 import hashlib
@@ -43,7 +43,7 @@ def _frame(gs, device, stream, r, buf, gt, mt, cam, band=None):
     return rgba
 
 
-def _check_intermediates(gs, r, g, cam):
+def _check_intermediates(gs, r, g, cam, order):
     """properties of the sorted pairs / ranges / projected records that hold at any size"""
     n = g["n"]
     tiles_x, tiles_y = (cam.width + 15) // 16, (cam.height + 15) // 16
@@ -55,7 +55,9 @@ def _check_intermediates(gs, r, g, cam):
     # sortedness: keys non-decreasing; stability: equal keys keep ascending Gaussian index
     assert D < 2 or bool((keys[1:] >= keys[:-1]).all()), "keys not sorted"
     same = keys[1:] == keys[:-1]
-    assert bool((idx[1:][same] > idx[:-1][same]).all()), "equal keys not in stable (index) order"
+    rank = np.empty(n, dtype=np.int64)
+    rank[order] = np.arange(n)      # mirror slot of every Gaussian
+    assert bool((rank[idx[1:][same]] > rank[idx[:-1][same]]).all()), "equal keys not in stable (mirror) order"
     proj, tiles = r.download_projected(n)
     assert int((tiles > 0).sum()) == st.visible == g["visible"]
     assert int(tiles.sum(dtype=np.int64)) == D
@@ -87,6 +89,8 @@ def test_fullsize_frame_matches_oracle_hash(gs, device, stream, name):
     g = GOLD[name]
     pod, buf, scene_hash = _upload(gs, device, stream, g)
     assert scene_hash == g["scene_sha256"], "synthetic scene generator differs from the golden run (not a renderer issue)"
+    assert hashlib.sha256(buf.download_order(stream).tobytes()).hexdigest() == g["order_sha256"], \
+        "spatial mirror order differs from the oracle's"
     cam = helpers.default_camera(gs, g["width"], g["height"])
     gt, mt = gs.gaussian_transform_pod(sh_deg=g["sh_deg"]), gs.model_transform_pod()
     r = gs.Renderer(device)
@@ -97,7 +101,7 @@ def test_fullsize_frame_matches_oracle_hash(gs, device, stream, name):
     assert int((rgba[..., 3] > 0).sum()) == g["covered_pixels"]
     assert abs(float(rgba.astype(np.float64).sum()) - g["frame_sum"]) <= 1e-6 * g["frame_sum"]
     assert hashlib.sha256(rgba.tobytes()).hexdigest() == g["frame_sha256"], "frame differs from the oracle's"
-    _check_intermediates(gs, r, g, cam)
+    _check_intermediates(gs, r, g, cam, buf.download_order(stream))
     # idempotence: same inputs, same bits (the pipeline has no order-dependent atomics in its results)
     again = _frame(gs, device, stream, r, buf, gt, mt, cam)
     assert np.array_equal(again.view(np.uint32), rgba.view(np.uint32))
@@ -112,6 +116,11 @@ def test_fullsize_frame_matches_oracle_hash(gs, device, stream, name):
         vis_sum += r.stats().pairs
     assert hashlib.sha256(stitched.tobytes()).hexdigest() == g["frame_sha256"]
     assert vis_sum == g["pairs"], "bands must emit each (tile, Gaussian) pair exactly once"
+    # the same buffer with the spatial order switched off: plain index order, the oracle's other hash
+    buf.set_spatial_order(False)
+    plain = _frame(gs, device, stream, r, buf, gt, mt, cam)
+    assert np.array_equal(buf.download_order(stream), np.arange(g["n"], dtype=np.uint32))
+    assert hashlib.sha256(plain.tobytes()).hexdigest() == g["frame_sha256_index_order"]
     r.destroy()
     buf.destroy()
 

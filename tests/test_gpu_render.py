@@ -27,11 +27,23 @@ def _render_gpu(gs, device, stream, pod, pods, gt, mt, cam, band=None, renderer=
     return r, buf, img, rgba
 
 
-def _oracle_frame(ob, sh, cov, pods, ogt, omt, ocam, band=None):
+def _mirror_order(ob, buf, stream, sh, cov, pods, fresh=True):
+    """The buffer's mirror order, which the oracle needs for exact-depth ties.  For
+    a freshly created buffer it must equal the oracle's own restatement of the spatial order."""
+    order = buf.download_order(stream)
+    assert np.array_equal(np.sort(order), np.arange(len(order), dtype=np.uint32)), "order is not a permutation"
+    if fresh:
+        exp = ob.spatial_order(sh, cov, pods) if buf.spatial_order() and len(order) > 1 else np.arange(
+            len(order), dtype=np.uint32)
+        assert np.array_equal(order, exp), "mirror order differs from the oracle's spatial order"
+    return order
+
+
+def _oracle_frame(ob, sh, cov, pods, ogt, omt, ocam, band=None, order=None):
     proj, tiles = ob.preprocess(sh, cov, pods, ogt, omt, ocam, band=band)
     tiles_x = (ocam.width + 15) // 16
     tiles_y = (ocam.height + 15) // 16
-    keys, idx = ob.build_keys(proj, tiles, tiles_x)
+    keys, idx = ob.build_keys(proj, tiles, tiles_x, order=order)
     skeys, sidx = ob.sort_pairs(keys, idx)
     ranges = ob.tile_ranges(skeys, tiles_x * tiles_y)
     rgba = ob.blend(proj, sidx, ranges, ocam, band=band)
@@ -54,9 +66,10 @@ def _compare_frame(gs, ob, device, stream, sh, cov, gaussians, W, H, gt_kw=None,
     cam = helpers.copy_camera(ocam, gs.Camera)
     assert bytes(gt) == bytes(ogt) and bytes(mt) == bytes(omt)
 
-    o_proj, o_tiles, o_keys, o_idx, o_skeys, o_sidx, o_ranges, o_rgba = _oracle_frame(
-        ob, sh, cov, pods, ogt, omt, ocam, band)
     r, buf, img, rgba = _render_gpu(gs, device, stream, pod, pods, gt, mt, cam, band)
+    order = _mirror_order(ob, buf, stream, sh, cov, pods)
+    o_proj, o_tiles, o_keys, o_idx, o_skeys, o_sidx, o_ranges, o_rgba = _oracle_frame(
+        ob, sh, cov, pods, ogt, omt, ocam, band, order=order)
     n = len(gaussians)
     st = r.stats()
     g_proj, g_tiles = r.download_projected(n)
@@ -143,9 +156,10 @@ def test_odd_image_size_and_background(gs, ob, device, stream):
     ocam = helpers.default_camera(ob, 333, 211)
     ocam.background[:] = [0.25, 0.5, 0.75]
     cam = helpers.copy_camera(ocam, gs.Camera)
-    _, _, _, _, _, _, _, o_rgba = _oracle_frame(ob, pod.sh, pod.cov, pods, ogt, omt, ocam)
     r, buf, img, rgba = _render_gpu(gs, device, stream, pod, pods, gs.gaussian_transform_pod(sh_deg=1),
                                     gs.model_transform_pod(), cam)
+    _, _, _, _, _, _, _, o_rgba = _oracle_frame(ob, pod.sh, pod.cov, pods, ogt, omt, ocam,
+                                                order=_mirror_order(ob, buf, stream, pod.sh, pod.cov, pods))
     assert np.array_equal(rgba.view(np.uint32), o_rgba.view(np.uint32))
 
 
@@ -167,7 +181,8 @@ def test_more_than_65536_tiles_uses_wide_tile_keys(gs, ob, device, stream):
         cam = helpers.default_camera(gs, w, h)
         _, buf, img, rgba = _render_gpu(gs, device, stream, pod, pods, gt, mt, cam, renderer=r)
         ocam = helpers.copy_camera(cam, ob.Camera)
-        o = ob.render(pod.sh, pod.cov, pods, ob.gaussian_transform(sh_deg=2), ob.model_transform(), ocam)[0]
+        o = ob.render(pod.sh, pod.cov, pods, ob.gaussian_transform(sh_deg=2), ob.model_transform(), ocam,
+                      order=_mirror_order(ob, buf, stream, pod.sh, pod.cov, pods))[0]
         assert np.array_equal(rgba.view(np.uint32), o.view(np.uint32)), (w, h)
         buf.destroy(); img.release()
     r.destroy()
@@ -295,7 +310,8 @@ def test_tile_row_bands_stitch_bit_exact(gs, ob, device, stream):
         # per-band parity against the oracle too
         ocam = helpers.copy_camera(cam, ob.Camera)
         o = _oracle_frame(ob, pod.sh, pod.cov, pods, ob.gaussian_transform(sh_deg=3),
-                          ob.model_transform(), ocam, band=b)
+                          ob.model_transform(), ocam, band=b,
+                          order=_mirror_order(ob, buf2, stream, pod.sh, pod.cov, pods))
         assert np.array_equal(part[y0:y1].view(np.uint32), o[-1][y0:y1].view(np.uint32))
         buf2.destroy(); img2.release(); r2.destroy()
     assert np.array_equal(stitched.view(np.uint32), full.view(np.uint32))
@@ -320,8 +336,10 @@ def test_update_then_rerender_uses_new_data(gs, ob, device, stream):
     b = img.download(stream, np.float32).copy()
     assert not np.array_equal(a, b)
     ocam = helpers.copy_camera(cam, ob.Camera)
+    # update_range keeps the order computed at creation (from the OLD positions, which are unchanged here)
     o = ob.render(pod.sh, pod.cov, ob.pack(pod.sh, pod.cov, g2), ob.gaussian_transform(sh_deg=0),
-                  ob.model_transform(), ocam)[0]
+                  ob.model_transform(), ocam, order=_mirror_order(ob, buf, stream, pod.sh, pod.cov,
+                                                                  ob.pack(pod.sh, pod.cov, g)))[0]
     assert np.array_equal(b.view(np.uint32).reshape(-1), o.view(np.uint32).reshape(-1))
 
 
@@ -347,7 +365,12 @@ def test_partial_updates_remirror_only_their_range_correctly(gs, ob, device, str
             buf.update_range(stream, start, g[start:start + count])
         r.render(stream, buf, gt, mt, cam, img.device_ptr())
         got = img.download(stream, np.float32)
-        exp = ob.render(sh, cov, ob.pack(sh, cov, g), ob.gaussian_transform(sh_deg=3), ob.model_transform(), ocam)[0]
+        # positions move between updates: a whole-buffer update re-sorts, a partial one keeps the slots
+        order = _mirror_order(ob, buf, stream, sh, cov, None, fresh=False)
+        if (start, count) == (0, 4500):
+            assert np.array_equal(order, ob.spatial_order(sh, cov, ob.pack(sh, cov, g)))
+        exp = ob.render(sh, cov, ob.pack(sh, cov, g), ob.gaussian_transform(sh_deg=3), ob.model_transform(), ocam,
+                        order=order)[0]
         assert np.array_equal(got.view(np.uint32).reshape(-1), exp.view(np.uint32).reshape(-1)), (start, count)
     buf.destroy(); img.release(); r.destroy()
 

@@ -18,7 +18,7 @@ out = sys.argv[1]
 line = [l for l in open(out + "/bench.json") if l.startswith("{")][-1]
 b = json.loads(line)
 rows = list(csv.DictReader(open(out + "/kernel_stats.csv")))
-pre = [r for r in rows if "k_preprocess<0, 0>" in r["Name"] or "k_preprocessILi0ELi0" in r["Name"]]
+pre = [r for r in rows if "k_preprocess" in r["Name"] and "<0, 0>" in r["Name"]]
 print("bench roofline.avg_launch_ms = %.4f ms" % b["roofline"]["avg_launch_ms"])
 for r in pre:
     print("rocprofv3 %s: calls %s avg %.4f ms" % (r["Name"][:60], r["Calls"], float(r["AverageNs"]) / 1e6))

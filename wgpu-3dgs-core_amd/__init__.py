@@ -721,6 +721,20 @@ class GaussiansBuffer:
     def mark_dirty(self):
         _L.gs_gaussians_buffer_mark_dirty(self._h)
 
+    def set_spatial_order(self, enabled):
+        """mirror slots in spatial (Morton) order (default) or in index order — DESIGN.md §3.4a"""
+        _check(_L.gs_gaussians_buffer_set_spatial_order(self._h, int(bool(enabled))))
+
+    def spatial_order(self):
+        return bool(_L.gs_gaussians_buffer_spatial_order(self._h))
+
+    def download_order(self, stream=None):
+        """order[slot] = Gaussian index of the renderer's mirror (the identity in index order)"""
+        out = np.zeros(self.len(), dtype=np.uint32)
+        _check(_L.gs_gaussians_buffer_download_order(self._h, stream._h if stream is not None else None,
+                                                      _ptr(out), self.len()))
+        return out
+
     def destroy(self):
         if self._h:
             _L.gs_gaussians_buffer_destroy(self._h)

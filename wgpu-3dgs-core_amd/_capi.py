@@ -126,6 +126,9 @@ SIGNATURES = {
     "gs_gaussians_buffer_download": (i32, [vp, vp, vp, sz]),
     "gs_gaussians_buffer_download_gaussians": (i32, [vp, vp, vp, sz]),
     "gs_gaussians_buffer_mark_dirty": (None, [vp]),
+    "gs_gaussians_buffer_set_spatial_order": (i32, [vp, i32]),
+    "gs_gaussians_buffer_spatial_order": (i32, [vp]),
+    "gs_gaussians_buffer_download_order": (i32, [vp, vp, vp, sz]),
     "gs_gaussian_transform_buffer_create": (i32, [vp, vp]),
     "gs_gaussian_transform_buffer_update": (i32, [vp, vp, vp]),
     "gs_gaussian_transform_buffer_from_buffer": (i32, [vp]),

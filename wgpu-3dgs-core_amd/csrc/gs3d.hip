@@ -564,6 +564,12 @@ struct gs_gaussians_buffer {
     // update_range dirties only its own range, so an editor's per-edit update re-mirrors a few
     // Gaussians instead of the whole scene.
     size_t dirty_lo, dirty_hi;
+    // spatial mirror order: order[slot] = Gaussian index, inv[index] = slot; both
+    // null while the mirror is in index order.  `order` is a ref-counted gs_buffer so that the
+    // renderer's parity taps can keep the order of the frame they describe.
+    bool spatial;
+    gs_buffer *order;
+    void *inv;
     void mark(size_t lo, size_t hi) {
         if (lo >= hi) return;
         if (dirty_lo >= dirty_hi) { dirty_lo = lo; dirty_hi = hi; return; }
@@ -600,6 +606,12 @@ extern "C" gs_status gs_gaussians_buffer_from_buffer(gs_buffer *buffer, gs_sh_co
     g->cov = cov;
     g->planar = nullptr;
     g->planar_stride = 0;
+    {   // default: spatial order on; GS3D_SPATIAL_ORDER=0 keeps the mirror in index order
+        const char *e = std::getenv("GS3D_SPATIAL_ORDER");
+        g->spatial = !(e && e[0] == '0');
+    }
+    g->order = nullptr;
+    g->inv = nullptr;
     g->mark_all();
     *out = g;
     return GS_OK;
@@ -630,10 +642,10 @@ extern "C" gs_status gs_gaussians_buffer_create_from_gaussians(gs_device *dev, g
 
 extern "C" void gs_gaussians_buffer_destroy(gs_gaussians_buffer *g) {
     if (!g) return;
-    if (g->planar) {
-        (void)hipSetDevice(g->buf->dev->ordinal);
-        (void)hipFree(g->planar);
-    }
+    (void)hipSetDevice(g->buf->dev->ordinal);
+    if (g->planar) (void)hipFree(g->planar);
+    if (g->inv) (void)hipFree(g->inv);
+    if (g->order) gs_buffer_release(g->order);
     gs_buffer_release(g->buf);
     delete g;
 }
@@ -718,30 +730,6 @@ extern "C" gs_status gs_gaussians_buffer_download_gaussians(gs_gaussians_buffer 
 
 extern "C" void gs_gaussians_buffer_mark_dirty(gs_gaussians_buffer *g) {
     if (g) g->mark_all();
-}
-
-// (re)build the block-planar mirror on `st`
-static gs_status ensure_planar(gs_gaussians_buffer *g, hipStream_t st) {
-    size_t len = gs_gaussians_buffer_len(g);
-    size_t stride = (len + gs::PLANAR_BLOCK - 1) / gs::PLANAR_BLOCK * gs::PLANAR_BLOCK;   // whole blocks
-    uint32_t chunks = (uint32_t)(pod_stride(g) / 16);
-    if (!g->planar || g->planar_stride != stride) {
-        if (g->planar) GS_HIP(hipFree(g->planar));
-        g->planar = nullptr;
-        GS_HIP(hipMalloc(&g->planar, (stride ? stride : gs::PLANAR_BLOCK) * 16 * chunks));
-        g->planar_stride = stride;
-        g->mark_all();
-    }
-    size_t lo = g->dirty_lo, hi = g->dirty_hi < len ? g->dirty_hi : len;
-    if (lo < hi) {
-        uint64_t count = hi - lo;
-        uint32_t grid = (uint32_t)((count + gs::REPACK_GROUP - 1) / gs::REPACK_GROUP);
-        hipLaunchKernelGGL(gs::k_repack_planar, dim3(grid), dim3(256), 0, st,
-                           (const uint4 *)g->buf->ptr, (uint4 *)g->planar, (uint64_t)lo, count, chunks);
-        GS_HIP(hipGetLastError());
-    }
-    g->dirty_lo = g->dirty_hi = 0;
-    return GS_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1246,6 +1234,7 @@ struct gs_renderer {
     int dsorted_side, tsorted_side;
     bool wide_tiles;  // tile keys are u32 (more than 65536 tiles) instead of u16
     hipStream_t last_stream;
+    gs_buffer *last_order;   // mirror order of the last frame's buffer (null = index order), for the taps
     // timing
     bool timing;
     hipEvent_t ev[ST_COUNT + 2];
@@ -1272,6 +1261,7 @@ extern "C" gs_status gs_renderer_create(gs_device *dev, gs_renderer **out) {
     r->dsorted_side = r->tsorted_side = 0;
     r->wide_tiles = false;
     r->last_stream = nullptr;
+    r->last_order = nullptr;
     r->timing = false;
     r->ev_valid = false;
     r->ev_pending = false;
@@ -1291,6 +1281,7 @@ extern "C" void gs_renderer_destroy(gs_renderer *r) {
                         &r->digit_totals, &r->ranges};
     for (DevArray *a : arrs) dev_free(*a);
     if (r->host_counters) (void)hipHostFree(r->host_counters);
+    if (r->last_order) gs_buffer_release(r->last_order);
     if (r->ev_valid)
         for (auto &e : r->ev) (void)hipEventDestroy(e);
     delete r;
@@ -1477,6 +1468,147 @@ static gs_status sort_depth_keys(const gs_device *dev, void *const keys[2], void
                                                           st, result_side, passes_out);
 }
 
+// (Re)build the block-planar mirror on `st`.  A whole-buffer rebuild in spatial mode first computes
+// the order: bounding box of the positions -> 30-bit Morton keys -> stable radix sort -> order / inv.
+static gs_status build_spatial_order(gs_gaussians_buffer *g, hipStream_t st, size_t len) {
+    gs_device *dev = g->buf->dev;
+    const uint32_t n = (uint32_t)len, pod_words = (uint32_t)(pod_stride(g) / 4);
+    DevArray keys[2], vals[2], gh, dt, partial, bbox;
+    gs_status rc = GS_OK;
+    for (int i = 0; i < 2 && rc == GS_OK; i++) {
+        rc = dev_reserve(keys[i], (size_t)n * 4);
+        if (rc == GS_OK) rc = dev_reserve(vals[i], (size_t)n * 4);
+    }
+    const uint32_t pgrid = n / 256u + 1u < 1024u ? n / 256u + 1u : 1024u;
+    if (rc == GS_OK) rc = dev_reserve(partial, (size_t)pgrid * 24);
+    if (rc == GS_OK) rc = dev_reserve(bbox, 24);
+    int side = 0;
+    uint32_t passes = 0;
+    if (rc == GS_OK) {
+        hipLaunchKernelGGL(gs::k_bbox_partial, dim3(pgrid), dim3(256), 0, st, (const uint32_t *)g->buf->ptr,
+                           pod_words, n, (float *)partial.ptr);
+        hipLaunchKernelGGL(gs::k_bbox_final, dim3(1), dim3(256), 0, st, (const float *)partial.ptr, pgrid,
+                           (float *)bbox.ptr);
+        hipLaunchKernelGGL(gs::k_morton_keys, dim3((n + 255u) / 256u), dim3(256), 0, st,
+                           (const uint32_t *)g->buf->ptr, pod_words, n, (const float *)bbox.ptr,
+                           (uint32_t *)keys[0].ptr, (uint32_t *)vals[0].ptr);
+        void *k2[2] = {keys[0].ptr, keys[1].ptr};
+        void *v2[2] = {vals[0].ptr, vals[1].ptr};
+        rc = sort_pairs_device<uint32_t>(dev, k2, v2, gh, dt, n, 30, st, side, passes);
+    }
+    if (rc == GS_OK) {
+        // the sorted values ARE the order: keep that array as a ref-counted buffer, free the rest
+        gs_buffer *ob = new gs_buffer();
+        ob->dev = dev;
+        ob->ptr = vals[side].ptr;
+        ob->bytes = (size_t)n * 4;
+        ob->owned = true;
+        ob->refs.store(1);
+        vals[side].ptr = nullptr;
+        vals[side].bytes = 0;
+        if (g->order) gs_buffer_release(g->order);
+        g->order = ob;
+        if (g->inv) (void)hipFree(g->inv);
+        g->inv = nullptr;
+        hipError_t e = hipMalloc(&g->inv, (size_t)n * 4);
+        if (e != hipSuccess) rc = fail(GS_ERR_OUT_OF_MEMORY, (size_t)n * 4, 0, 0, "hipMalloc failed: %s", hipGetErrorString(e));
+        else
+            hipLaunchKernelGGL(gs::k_invert_order, dim3((n + 255u) / 256u), dim3(256), 0, st,
+                               (const uint32_t *)ob->ptr, n, (uint32_t *)g->inv);
+    }
+    if (rc == GS_OK && hipGetLastError() != hipSuccess) rc = fail(GS_ERR_HIP, 0, 0, 0, "spatial order launch failed");
+    // the scratch arrays may still be in use by the queued kernels: hipFree synchronises the device
+    for (int i = 0; i < 2; i++) {
+        dev_free(keys[i]);
+        dev_free(vals[i]);
+    }
+    for (DevArray *a : {&gh, &dt, &partial, &bbox}) dev_free(*a);
+    return rc;
+}
+
+static gs_status ensure_planar(gs_gaussians_buffer *g, hipStream_t st) {
+    size_t len = gs_gaussians_buffer_len(g);
+    size_t stride = (len + gs::PLANAR_BLOCK - 1) / gs::PLANAR_BLOCK * gs::PLANAR_BLOCK;   // whole blocks
+    uint32_t chunks = (uint32_t)(pod_stride(g) / 16);
+    if (!g->planar || g->planar_stride != stride) {
+        if (g->planar) GS_HIP(hipFree(g->planar));
+        g->planar = nullptr;
+        GS_HIP(hipMalloc(&g->planar, (stride ? stride : gs::PLANAR_BLOCK) * 16 * chunks));
+        g->planar_stride = stride;
+        g->mark_all();
+    }
+    size_t lo = g->dirty_lo, hi = g->dirty_hi < len ? g->dirty_hi : len;
+    if (lo < hi) {
+        const bool whole = lo == 0 && hi == len;
+        const bool want_order = g->spatial && len > 1;
+        if (whole || want_order != (g->order != nullptr)) {
+            // whole-buffer (re)mirror: this is where the spatial order is (re)computed or dropped
+            if (want_order) {
+                GS_TRY(build_spatial_order(g, st, len));
+            } else {
+                if (g->order) gs_buffer_release(g->order);
+                g->order = nullptr;
+                if (g->inv) GS_HIP(hipFree(g->inv));
+                g->inv = nullptr;
+            }
+            lo = 0;
+            hi = len;
+        }
+        uint64_t count = hi - lo;
+        if (g->order && lo == 0 && hi == len) {
+            uint32_t grid = (uint32_t)((count + gs::REPACK_GROUP - 1) / gs::REPACK_GROUP);
+            hipLaunchKernelGGL(gs::k_repack_planar_ordered, dim3(grid), dim3(256), 0, st,
+                               (const uint4 *)g->buf->ptr, (uint4 *)g->planar, (const uint32_t *)g->order->ptr,
+                               count, chunks);
+        } else if (g->order) {
+            uint64_t total = count * chunks;
+            uint32_t grid = (uint32_t)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+            hipLaunchKernelGGL(gs::k_repack_planar_scatter, dim3(grid), dim3(256), 0, st,
+                               (const uint4 *)g->buf->ptr, (uint4 *)g->planar, (const uint32_t *)g->inv,
+                               (uint64_t)lo, count, chunks);
+        } else {
+            uint32_t grid = (uint32_t)((count + gs::REPACK_GROUP - 1) / gs::REPACK_GROUP);
+            hipLaunchKernelGGL(gs::k_repack_planar, dim3(grid), dim3(256), 0, st,
+                               (const uint4 *)g->buf->ptr, (uint4 *)g->planar, (uint64_t)lo, count, chunks);
+        }
+        GS_HIP(hipGetLastError());
+    }
+    g->dirty_lo = g->dirty_hi = 0;
+    return GS_OK;
+}
+
+extern "C" gs_status gs_gaussians_buffer_set_spatial_order(gs_gaussians_buffer *g, int32_t enabled) {
+    if (!g) return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "null buffer");
+    if (g->spatial != (enabled != 0)) {
+        g->spatial = enabled != 0;
+        g->mark_all();
+    }
+    return GS_OK;
+}
+
+extern "C" int32_t gs_gaussians_buffer_spatial_order(const gs_gaussians_buffer *g) {
+    return g && g->spatial ? 1 : 0;
+}
+
+extern "C" gs_status gs_gaussians_buffer_download_order(gs_gaussians_buffer *g, gs_stream *s,
+                                                        uint32_t *order_out, size_t count) {
+    if (!g || (count && !order_out)) return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "null argument");
+    size_t len = gs_gaussians_buffer_len(g);
+    if (count != len)
+        return fail(GS_ERR_COUNT_MISMATCH, count, len, 0, "Gaussians count mismatch: %zu != %zu", count, len);
+    GS_TRY(use_device(g->buf->dev));
+    hipStream_t st = stream_of(g->buf->dev, s);
+    GS_TRY(ensure_planar(g, st));
+    if (!g->order) {
+        for (size_t i = 0; i < len; i++) order_out[i] = (uint32_t)i;
+        return GS_OK;
+    }
+    GS_HIP(hipStreamSynchronize(st));
+    hipError_t e = hipMemcpy(order_out, g->order->ptr, len * 4, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return fail(GS_ERR_DOWNLOAD, (uint64_t)e, 0, 0, "download failed: %s", hipGetErrorString(e));
+    return GS_OK;
+}
+
 static gs_status reserve_pairs(gs_renderer *r, uint64_t pairs, bool wide) {
     if (pairs <= r->pair_capacity && r->tkeys[0].ptr && wide == r->wide_tiles) return GS_OK;
     uint64_t cap = pairs + pairs / 4 + 4096;
@@ -1529,6 +1661,10 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
 
     mark(ST_REPACK);
     GS_TRY(ensure_planar(g, st));
+    if (r->last_order != g->order) {
+        if (r->last_order) gs_buffer_release(r->last_order);
+        r->last_order = g->order ? gs_buffer_retain(g->order) : nullptr;
+    }
     mark(ST_PRE);
 
     GS_TRY(dev_reserve(r->recs, nn * 4 * gs::REC_WORDS + 16));
@@ -1550,10 +1686,12 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
 
     uint32_t d = 0, visible = 0;
     if (n) {
-        // narrow band (one rank of >= 4) and SH to skip: two-phase loads (see k_preprocess_banded)
+        // Records with SH take the two-phase kernel (geometry chunks first, SH chunks only for the
+        // lanes that survive culling): with the mirror in spatial order whole 128-byte lines of
+        // culled Gaussians are never fetched; with a random order it costs the same as the
+        // single-phase kernel (measured).  GS3D_FORCE_BANDED=0/1 overrides for experiments.
         static const int force_banded = std::getenv("GS3D_FORCE_BANDED") ? std::atoi(std::getenv("GS3D_FORCE_BANDED")) : -1;
-        const bool narrow = 4u * (fc.band_ty1 - fc.band_ty0) <= fc.tiles_y;
-        const bool banded = g->sh != GS_SH_NONE && (force_banded >= 0 ? force_banded != 0 : narrow);
+        const bool banded = g->sh != GS_SH_NONE && (force_banded >= 0 ? force_banded != 0 : true);
         hipLaunchKernelGGL((banded ? k_tbl_preprocess_banded : k_tbl_preprocess)[g->sh][g->cov], dim3(nchunks),
                            dim3(gs::PP_THREADS), 0, st,
                            (const uint4 *)g->planar, n, fc,
@@ -1693,25 +1831,34 @@ extern "C" gs_status gs_renderer_download_projected(gs_renderer *r, gs_projected
     GS_TRY(use_device(r->dev));
     static_assert(sizeof(gs_projected) == 48, "record size");
     if (!n) return GS_OK;
-    std::vector<uint32_t> recs(n * gs::REC_WORDS), depth(n);
-    std::vector<uint2> rect(n);
-    GS_TRY(download_sync(r, recs.data(), r->recs.ptr, n * 4 * gs::REC_WORDS));
-    GS_TRY(download_sync(r, depth.data(), r->depth.ptr, n * 4));
-    GS_TRY(download_sync(r, rect.data(), r->rect.ptr, n * 8));
-    for (size_t i = 0; i < n; i++) {
-        bool vis = depth[i] != 0xffffffffu;
-        uint32_t w = (rect[i].y & 0xffffu) - (rect[i].x & 0xffffu), h = (rect[i].y >> 16) - (rect[i].x >> 16);
+    // the device arrays are indexed by mirror slot; a partial request (n < N) still needs all slots
+    const size_t total = r->n;
+    std::vector<uint32_t> recs(total * gs::REC_WORDS), depth(total), order;
+    std::vector<uint2> rect(total);
+    GS_TRY(download_sync(r, recs.data(), r->recs.ptr, total * 4 * gs::REC_WORDS));
+    GS_TRY(download_sync(r, depth.data(), r->depth.ptr, total * 4));
+    GS_TRY(download_sync(r, rect.data(), r->rect.ptr, total * 8));
+    if (r->last_order) {
+        order.resize(total);
+        GS_TRY(download_sync(r, order.data(), r->last_order->ptr, total * 4));
+    }
+    for (size_t slot = 0; slot < total; slot++) {
+        const size_t i = order.empty() ? slot : order[slot];   // Gaussian index of this slot
+        if (i >= n) continue;
+        bool vis = depth[slot] != 0xffffffffu;
+        uint32_t w = (rect[slot].y & 0xffffu) - (rect[slot].x & 0xffffu),
+                 h = (rect[slot].y >> 16) - (rect[slot].x >> 16);
         if (tiles_out) tiles_out[i] = vis ? w * h : 0u;
         if (proj_out) {
             gs_projected &p = proj_out[i];
             std::memset(&p, 0, sizeof(p));
             if (vis) {
-                std::memcpy(&p, &recs[i * gs::REC_WORDS], 36);
-                std::memcpy(&p.depth, &depth[i], 4);
-                p.tx0 = (uint16_t)(rect[i].x & 0xffffu);
-                p.ty0 = (uint16_t)(rect[i].x >> 16);
-                p.tx1 = (uint16_t)(rect[i].y & 0xffffu);
-                p.ty1 = (uint16_t)(rect[i].y >> 16);
+                std::memcpy(&p, &recs[slot * gs::REC_WORDS], 36);
+                std::memcpy(&p.depth, &depth[slot], 4);
+                p.tx0 = (uint16_t)(rect[slot].x & 0xffffu);
+                p.ty0 = (uint16_t)(rect[slot].x >> 16);
+                p.tx1 = (uint16_t)(rect[slot].y & 0xffffu);
+                p.ty1 = (uint16_t)(rect[slot].y >> 16);
             }
         }
     }
@@ -1727,9 +1874,17 @@ extern "C" gs_status gs_renderer_download_sorted(gs_renderer *r, uint64_t *keys_
     if (pairs_out) *pairs_out = r->d;
     uint64_t m = r->d < capacity ? r->d : capacity;
     if (!m) return GS_OK;
-    std::vector<uint32_t> idx(m);
+    std::vector<uint32_t> idx(m);   // mirror slots
     GS_TRY(download_sync(r, idx.data(), r->tvals[r->tsorted_side].ptr, m * 4));
-    if (idx_out) std::memcpy(idx_out, idx.data(), m * 4);
+    if (idx_out) {
+        if (r->last_order) {
+            std::vector<uint32_t> order(r->n);
+            GS_TRY(download_sync(r, order.data(), r->last_order->ptr, r->n * 4));
+            for (uint64_t j = 0; j < m; j++) idx_out[j] = order[idx[j]];
+        } else {
+            std::memcpy(idx_out, idx.data(), m * 4);
+        }
+    }
     if (keys_out) {
         std::vector<uint32_t> depth(r->n);
         GS_TRY(download_sync(r, depth.data(), r->depth.ptr, r->n * 4));

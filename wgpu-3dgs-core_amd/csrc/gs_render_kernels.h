@@ -159,6 +159,137 @@ __global__ __launch_bounds__(256) void k_repack_planar(const uint4 *__restrict__
 }
 
 // ---------------------------------------------------------------------------------------------
+// spatial mirror order: slot -> Gaussian index by the 30-bit Morton code of the
+// position (10 bits per axis over the bounding box of all positions), ties by index.  Built when
+// the whole buffer is (re)mirrored.  Neighbouring slots are then neighbours in space, so frustum-
+// and band-culled Gaussians cluster into whole 128-byte lines whose SH chunks are never fetched.
+// ---------------------------------------------------------------------------------------------
+
+// position = first 12 bytes of every AoS record
+__global__ __launch_bounds__(256) void k_bbox_partial(const uint32_t *__restrict__ aos, uint32_t pod_words,
+                                                      uint32_t n, float *__restrict__ partial) {
+    __shared__ float s_lo[4][3], s_hi[4][3];
+    float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
+    float hi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+    for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256u) {
+        const uint32_t *w = aos + i * pod_words;
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            float v = u2f(w[a]);
+            lo[a] = fminf(lo[a], v);   // minNum / maxNum: a NaN coordinate is ignored
+            hi[a] = fmaxf(hi[a], v);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+#pragma unroll
+        for (int d = WAVE / 2; d > 0; d >>= 1) {
+            lo[a] = fminf(lo[a], __shfl_xor(lo[a], d, WAVE));
+            hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], d, WAVE));
+        }
+    }
+    const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+    if (lane == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            s_lo[wid][a] = lo[a];
+            s_hi[wid][a] = hi[a];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3u) {
+        const uint32_t a = threadIdx.x;
+        partial[blockIdx.x * 6u + a] = fminf(fminf(s_lo[0][a], s_lo[1][a]), fminf(s_lo[2][a], s_lo[3][a]));
+        partial[blockIdx.x * 6u + 3u + a] = fmaxf(fmaxf(s_hi[0][a], s_hi[1][a]), fmaxf(s_hi[2][a], s_hi[3][a]));
+    }
+}
+
+// one workgroup: partial[count][6] -> bbox[6] = lo xyz, hi xyz
+__global__ __launch_bounds__(256) void k_bbox_final(const float *__restrict__ partial, uint32_t count,
+                                                    float *__restrict__ bbox) {
+    __shared__ float s_v[256][6];
+    float v[6] = {__builtin_inff(), __builtin_inff(), __builtin_inff(),
+                  -__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+    for (uint32_t i = threadIdx.x; i < count; i += 256u) {
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            v[a] = fminf(v[a], partial[i * 6u + a]);
+            v[3 + a] = fmaxf(v[3 + a], partial[i * 6u + 3u + a]);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 6; a++) s_v[threadIdx.x][a] = v[a];
+    __syncthreads();
+    if (threadIdx.x < 6u) {
+        const uint32_t a = threadIdx.x;
+        float r = s_v[0][a];
+        for (uint32_t t = 1; t < 256u; t++) r = a < 3u ? fminf(r, s_v[t][a]) : fmaxf(r, s_v[t][a]);
+        bbox[a] = r;
+    }
+}
+
+__device__ __forceinline__ uint32_t morton_axis(float p, float lo, float hi) {
+    float s = ((p - lo) / (hi - lo)) * 1024.0f;
+    return s >= 1023.0f ? 1023u : (s > 0.0f ? (uint32_t)s : 0u);   // NaN (incl. 0/0 of a flat axis) -> 0
+}
+
+__global__ __launch_bounds__(256) void k_morton_keys(const uint32_t *__restrict__ aos, uint32_t pod_words,
+                                                     uint32_t n, const float *__restrict__ bbox,
+                                                     uint32_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+    uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t *w = aos + (uint64_t)i * pod_words;
+    uint32_t code = 0;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        uint32_t q = morton_axis(u2f(w[a]), bbox[a], bbox[3 + a]);
+#pragma unroll
+        for (int b = 0; b < 10; b++) code |= ((q >> b) & 1u) << (3 * b + a);
+    }
+    keys[i] = code;
+    vals[i] = i;
+}
+
+__global__ __launch_bounds__(256) void k_invert_order(const uint32_t *__restrict__ order, uint32_t n,
+                                                      uint32_t *__restrict__ inv) {
+    uint32_t slot = blockIdx.x * 256u + threadIdx.x;
+    if (slot < n) inv[order[slot]] = slot;
+}
+
+// mirror slots [0, count) <- records order[slot] (whole-buffer rebuild in spatial order)
+__global__ __launch_bounds__(256) void k_repack_planar_ordered(const uint4 *__restrict__ aos,
+                                                               uint4 *__restrict__ planar,
+                                                               const uint32_t *__restrict__ order,
+                                                               uint64_t count, uint32_t chunks) {
+    __shared__ uint4 s_t[REPACK_GROUP * REPACK_MAX_CHUNKS];
+    const uint64_t g0 = (uint64_t)blockIdx.x * REPACK_GROUP;
+    const uint32_t ng = (uint32_t)(count - g0 < REPACK_GROUP ? count - g0 : REPACK_GROUP);
+    const uint32_t total = ng * chunks;
+    for (uint32_t q = threadIdx.x; q < total; q += 256) {
+        const uint32_t t = q / chunks, c = q - t * chunks;   // consecutive threads -> one record's consecutive chunks
+        s_t[q] = aos[(uint64_t)order[g0 + t] * chunks + c];
+    }
+    __syncthreads();
+    for (uint32_t e = threadIdx.x; e < total; e += 256) {
+        const uint32_t c = e / ng, t = e - c * ng;
+        planar[planar_at(c, g0 + t, chunks)] = s_t[t * chunks + c];
+    }
+}
+
+// partial update in spatial order: records [first, first+count) go to their existing slots
+__global__ __launch_bounds__(256) void k_repack_planar_scatter(const uint4 *__restrict__ aos,
+                                                               uint4 *__restrict__ planar,
+                                                               const uint32_t *__restrict__ inv,
+                                                               uint64_t first, uint64_t count, uint32_t chunks) {
+    const uint64_t total = count * chunks;
+    for (uint64_t q = (uint64_t)blockIdx.x * 256u + threadIdx.x; q < total; q += (uint64_t)gridDim.x * 256u) {
+        const uint64_t id = first + q / chunks;
+        const uint32_t c = (uint32_t)(q % chunks);
+        planar[planar_at(c, inv[id], chunks)] = aos[first * chunks + q];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // preprocess (rows x1, x2 of the hot-path table)
 // ---------------------------------------------------------------------------------------------
 
