@@ -235,19 +235,25 @@ def main():
         if roof is not None:
             sr = stage_rooflines(roof_wl, roof)
             pre = sr["preprocess"]
-            traffic = None
+            traffic, fetched = None, None
             pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             if os.path.exists(pmc):
                 try:
-                    traffic = json.load(open(pmc)).get("preprocess_%s_bytes_per_launch" % args.roofline_workload)
+                    j = json.load(open(pmc))
+                    traffic = j.get("preprocess_%s_bytes_per_launch" % args.roofline_workload)
+                    fetched = j.get("preprocess_%s_fetch_bytes" % args.roofline_workload)
                 except Exception:
-                    traffic = None
+                    traffic, fetched = None, None
             line["roofline"] = {
                 "bound": "hbm", "kernel": "k_preprocess_banded<ShSingle,RotScale>",
                 "workload": roof_wl["label"],
                 "achieved": pre["achieved_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": pre["frac"], "traffic": traffic,
                 "algorithmic_bytes_per_launch": pre["bytes"], "avg_launch_ms": pre["ms"],
+                # SH bytes of Gaussians culled before SH evaluation may be skipped; the
+                # fraction is computed on the bytes REQUIRED, the bytes FETCHED (rocprofv3 PMC) beside it
+                "fetched_bytes_per_launch": fetched,
+                "fetched_over_required": (fetched / pre["bytes"]) if fetched else None,
             }
             line["roofline_workload"] = {
                 "value": roof_wl["n"] / (roof["ms_per_frame"] * 1e-3) / 1e6, "unit": "Msplats/s",
