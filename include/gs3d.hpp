@@ -248,6 +248,11 @@ class GaussiansBuffer {   // src/buffer/gaussian.rs:17-229
     void update_range_with_pod(Stream &s, size_t start, const std::vector<uint8_t> &pods) { check(gs_gaussians_buffer_update_range(h_, s.raw(), start, pods.data(), pods.size() / G::size())); }
     std::vector<uint8_t> download(Stream &s) const { std::vector<uint8_t> out(len() * G::size()); check(gs_gaussians_buffer_download(h_, s.raw(), out.data(), len())); return out; }
     std::vector<Gaussian> download_gaussians(Stream &s) const { std::vector<Gaussian> out(len()); check(gs_gaussians_buffer_download_gaussians(h_, s.raw(), out.data(), len())); return out; }
+    // renderer-side mirror order (gs3d.h: spatial by default); order[slot] = Gaussian index
+    void set_spatial_order(bool enabled) { check(gs_gaussians_buffer_set_spatial_order(h_, enabled ? 1 : 0)); }
+    bool spatial_order() const { return gs_gaussians_buffer_spatial_order(h_) != 0; }
+    std::vector<uint32_t> download_order(Stream &s) const { std::vector<uint32_t> out(len()); check(gs_gaussians_buffer_download_order(h_, s.raw(), out.data(), out.size())); return out; }
+    void mark_dirty() { gs_gaussians_buffer_mark_dirty(h_); }
     gs_gaussians_buffer *raw() const { return h_; }
   private:
     GaussiansBuffer() = default;

@@ -84,6 +84,17 @@ int main() {
     catch (const GaussiansBufferTryFromBufferError &e) { REQUIRE(e.buffer_size() == 130 && e.expected_multiple_size() == 128); }
     using R = GaussianPodWithShSingleCov3dRotScaleConfigs;
     GaussiansBuffer<R> rbuf(dev, gs);
+    {   // the mirror order is a permutation of the indices; index order when switched off
+        REQUIRE(rbuf.spatial_order());
+        auto order = rbuf.download_order(s);
+        std::vector<int> seen(order.size(), 0);
+        for (uint32_t id : order) { REQUIRE(id < order.size()); seen[id]++; }
+        for (int c : seen) REQUIRE(c == 1);
+        rbuf.set_spatial_order(false);
+        order = rbuf.download_order(s);
+        for (size_t i = 0; i < order.size(); i++) REQUIRE(order[i] == i);
+        rbuf.set_spatial_order(true);
+    }
     auto back = rbuf.download_gaussians(s);
     REQUIRE(std::memcmp(back.data(), gs.data(), gs.size() * sizeof(Gaussian)) == 0);
     REQUIRE(!gaussian_transform_pod(1.0f, GS_DISPLAY_SPLAT, 4, false, 3.0f).has_value());

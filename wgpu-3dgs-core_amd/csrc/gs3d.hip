@@ -1387,6 +1387,7 @@ static void make_frame_consts(const gs_gaussian_transform_pod *gt, const gs_mode
     fc.band_ty0 = band_ty0 < fc.tiles_y ? band_ty0 : fc.tiles_y;
     fc.band_ty1 = band_ty1 < fc.tiles_y ? band_ty1 : fc.tiles_y;
     if (fc.band_ty1 < fc.band_ty0) fc.band_ty1 = fc.band_ty0;
+    fc.mask_culled_records = 0;
 }
 
 static uint32_t bit_length(uint32_t v) {
@@ -1692,6 +1693,8 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
         // single-phase kernel (measured).  GS3D_FORCE_BANDED=0/1 overrides for experiments.
         static const int force_banded = std::getenv("GS3D_FORCE_BANDED") ? std::atoi(std::getenv("GS3D_FORCE_BANDED")) : -1;
         const bool banded = g->sh != GS_SH_NONE && (force_banded >= 0 ? force_banded != 0 : true);
+        static const int mask_env = std::getenv("GS3D_MASK_REC") ? std::atoi(std::getenv("GS3D_MASK_REC")) : -1;
+        fc.mask_culled_records = mask_env >= 0 ? (uint32_t)mask_env : (g->order != nullptr ? 1u : 0u);
         hipLaunchKernelGGL((banded ? k_tbl_preprocess_banded : k_tbl_preprocess)[g->sh][g->cov], dim3(nchunks),
                            dim3(gs::PP_THREADS), 0, st,
                            (const uint4 *)g->planar, n, fc,

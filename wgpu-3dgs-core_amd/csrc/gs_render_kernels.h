@@ -37,6 +37,7 @@ struct FrameConsts {
     uint32_t width, height;
     uint32_t tiles_x, tiles_y;
     uint32_t band_ty0, band_ty1;   // already clamped to tiles_y
+    uint32_t mask_culled_records;  // k_preprocess_banded: culled lanes skip their 36-byte record store
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -601,10 +602,12 @@ __global__ __launch_bounds__(PP_THREADS) void k_preprocess_banded(
                 dmin = dmin < rec[2].y ? dmin : rec[2].y;
                 dmax = dmax > rec[2].y ? dmax : rec[2].y;
             }
+            if (cnt || !fc.mask_culled_records) {
             uint32_t *o = recs + (uint64_t)i * REC_WORDS;
             *(u32x4_a4 *)(o) = u32x4_a4{rec[0].x, rec[0].y, rec[0].z, rec[0].w};
             *(u32x4_a4 *)(o + 4) = u32x4_a4{rec[1].x, rec[1].y, rec[1].z, rec[1].w};
             o[8] = rec[2].x;
+            }
             depth[i] = cnt ? rec[2].y : 0xffffffffu;
             rect[i] = cnt ? make_uint2(rec[2].z, rec[2].w) : make_uint2(0u, 0u);
             local += cnt;
