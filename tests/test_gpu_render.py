@@ -213,6 +213,57 @@ def test_depth_key_ranges(gs, ob, device, stream, case):
     assert depth_passes == {"same_depth": 0, "two_depths": 1, "wide_range": 4, "narrow_range": 2}[case], st.sort_passes
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_block_culling_is_conservative_over_random_views(gs, ob, device, stream, seed):
+    """Whole 1024-slot blocks are skipped when their bounds prove them invisible.  Random cameras
+    (inside / outside the scene, narrow and wide FOV, near planes cutting through blocks), model
+    transforms with rotation and anisotropic scale, `size` up to 3 and splats up to 8x the usual
+    size: visible count, pair count and every pixel must equal the oracle's, which culls only per
+    Gaussian."""
+    import synth
+    rng = np.random.default_rng(seed)
+    n = 150_000
+    g = synth.scene(n, first=seed * 1000)
+    g["scale"] *= rng.choice([1.0, 3.0, 8.0], size=(n, 1)).astype(np.float32)
+    sh, cov = [(0, 0), (1, 2), (2, 1)][seed - 1]
+    pod = gs.GaussianPod(sh, cov)
+    pods = pod.from_gaussian(g)
+    buf = gs.GaussiansBuffer.new_with_pods(device, pod, pods)
+    order = _mirror_order(ob, buf, stream, sh, cov, pods)
+    W, H = 480, 272
+    img = gs.Buffer(device, size=W * H * 16)
+    r = gs.Renderer(device)
+    culled_some = 0
+    for view in range(14):
+        eye = rng.normal(0, 1, 3) * rng.choice([0.5, 12.0, 40.0])
+        eye[2] -= 14.0 if view % 3 else 0.0
+        target = np.array([rng.uniform(-14, 14), rng.uniform(-8, 8), -rng.uniform(2, 26)])
+        near = float(rng.choice([0.01, 0.5, 3.0]))
+        far = float(rng.choice([15.0, 100.0]))
+        fov = float(rng.uniform(20, 100))
+        ocam = ob.camera_look_at(tuple(eye), tuple(target), (0, 1, 0), float(np.deg2rad(fov)), W, H, near, far)
+        cam = helpers.copy_camera(ocam, gs.Camera)
+        size = float(rng.choice([0.5, 1.0, 3.0]))
+        q = rng.normal(0, 1, 4)
+        q /= np.linalg.norm(q)
+        mt_kw = dict(pos=tuple(rng.normal(0, 2, 3)), rot=tuple(q), scale=tuple(rng.uniform(0.3, 2.5, 3))) if view % 2 else {}
+        gt = gs.gaussian_transform_pod(size, 0, 3, False, float(rng.choice([3.0, 1.5])))
+        ogt = ob.GaussianTransform.from_buffer_copy(bytes(gt))      # bit-identical uniforms on both sides
+        mt = gs.model_transform_pod(**mt_kw) if mt_kw else gs.model_transform_pod()
+        omt = ob.ModelTransform.from_buffer_copy(bytes(mt))
+        band = (3, 9) if view % 4 == 3 else None
+        r.render(stream, buf, gt, mt, cam, img.device_ptr(), band=band)
+        got = img.download(stream, np.float32).reshape(H, W, 4)
+        st = r.stats()
+        exp, d, vis, _ = ob.render(sh, cov, pods, ogt, omt, ocam, band=band, order=order)
+        assert (st.visible, st.pairs) == (vis, d), (view, st.visible, vis, st.pairs, d)
+        y0, y1 = (band[0] * 16, min(band[1] * 16, H)) if band else (0, H)
+        assert np.array_equal(got[y0:y1].view(np.uint32), exp[y0:y1].view(np.uint32)), view
+        culled_some += vis < n // 2
+    assert culled_some >= 3, "the views were meant to cull large parts of the scene"
+    buf.destroy(); img.release(); r.destroy()
+
+
 def test_edge_cases(gs, ob, device, stream):
     """empty buffer, single Gaussian, everything culled, one splat covering the whole screen."""
     import synth

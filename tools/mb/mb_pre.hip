@@ -44,7 +44,7 @@ int main(int argc, char** argv) {
     fc.sh_deg = argc > 1 ? atoi(argv[1]) : 3; fc.width = 1920; fc.height = 1080; fc.tiles_x = 120; fc.tiles_y = 68; fc.band_ty1 = 68;
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     auto launch = [&]() { hipLaunchKernelGGL((gs::k_preprocess<0, 0>), dim3(nchunks), dim3(gs::PP_THREADS), 0, 0,
-        (const uint4*)planar, n, fc, proj, depth, rect, ct, cv, cr); };
+        (const uint4*)planar, n, fc, proj, depth, rect, ct, cv, cr, (const float*)nullptr); };
     for (int w = 0; w < 3; w++) launch();
     CK(hipEventRecord(a));
     for (int r = 0; r < 10; r++) launch();

@@ -570,6 +570,7 @@ struct gs_gaussians_buffer {
     bool spatial;
     gs_buffer *order;
     void *inv;
+    void *block_bounds;      // 8 floats per 1024-slot block (k_block_bounds); null = not available
     void mark(size_t lo, size_t hi) {
         if (lo >= hi) return;
         if (dirty_lo >= dirty_hi) { dirty_lo = lo; dirty_hi = hi; return; }
@@ -612,6 +613,7 @@ extern "C" gs_status gs_gaussians_buffer_from_buffer(gs_buffer *buffer, gs_sh_co
     }
     g->order = nullptr;
     g->inv = nullptr;
+    g->block_bounds = nullptr;
     g->mark_all();
     *out = g;
     return GS_OK;
@@ -645,6 +647,7 @@ extern "C" void gs_gaussians_buffer_destroy(gs_gaussians_buffer *g) {
     (void)hipSetDevice(g->buf->dev->ordinal);
     if (g->planar) (void)hipFree(g->planar);
     if (g->inv) (void)hipFree(g->inv);
+    if (g->block_bounds) (void)hipFree(g->block_bounds);
     if (g->order) gs_buffer_release(g->order);
     gs_buffer_release(g->buf);
     delete g;
@@ -1343,9 +1346,11 @@ extern "C" gs_status gs_renderer_stats(gs_renderer *r, gs_frame_stats *out) {
 }
 
 typedef void (*preprocess_fn)(const uint4 *, uint32_t, gs::FrameConsts, uint32_t *,
-                              uint32_t *, uint2 *, uint32_t *, uint32_t *, uint2 *);
+                              uint32_t *, uint2 *, uint32_t *, uint32_t *, uint2 *, const float *);
+typedef void (*block_bounds_fn)(const uint4 *, uint32_t, float *);
 static preprocess_fn k_tbl_preprocess[4][3] = GS_CFG_TABLE(gs::k_preprocess);
 static preprocess_fn k_tbl_preprocess_banded[4][3] = GS_CFG_TABLE(gs::k_preprocess_banded);
+static block_bounds_fn k_tbl_block_bounds[4][3] = GS_CFG_TABLE(gs::k_block_bounds);
 
 // frame constants from the uniforms
 static void make_frame_consts(const gs_gaussian_transform_pod *gt, const gs_model_transform_pod *mt,
@@ -1388,6 +1393,13 @@ static void make_frame_consts(const gs_gaussian_transform_pod *gt, const gs_mode
     fc.band_ty1 = band_ty1 < fc.tiles_y ? band_ty1 : fc.tiles_y;
     if (fc.band_ty1 < fc.band_ty0) fc.band_ty1 = fc.band_ty0;
     fc.mask_culled_records = 0;
+    // block culling gain (see block_is_culled): |W R_m S_m|_F^2 bounds the squared spectral norm of
+    // the linear part whatever the caller's view matrix is; 0.1 % head room for the f32 arithmetic
+    float ws2 = 0.0f;
+    for (int k = 0; k < 9; k++) ws2 += fc.WS[k] * fc.WS[k];
+    fc.cull_gain = 1.001f * fc.size2 * ws2 *
+                   (fc.fx * fc.fx * (1.0f + fc.limx * fc.limx) + fc.fy * fc.fy * (1.0f + fc.limy * fc.limy));
+    if (!(fc.cull_gain > 0.0f) || !(fc.cull_gain < 1e30f)) fc.cull_gain = 0.0f;   // degenerate uniforms: no block culling
 }
 
 static uint32_t bit_length(uint32_t v) {
@@ -1534,6 +1546,8 @@ static gs_status ensure_planar(gs_gaussians_buffer *g, hipStream_t st) {
     if (!g->planar || g->planar_stride != stride) {
         if (g->planar) GS_HIP(hipFree(g->planar));
         g->planar = nullptr;
+        if (g->block_bounds) GS_HIP(hipFree(g->block_bounds));
+        g->block_bounds = nullptr;
         GS_HIP(hipMalloc(&g->planar, (stride ? stride : gs::PLANAR_BLOCK) * 16 * chunks));
         g->planar_stride = stride;
         g->mark_all();
@@ -1572,6 +1586,13 @@ static gs_status ensure_planar(gs_gaussians_buffer *g, hipStream_t st) {
             hipLaunchKernelGGL(gs::k_repack_planar, dim3(grid), dim3(256), 0, st,
                                (const uint4 *)g->buf->ptr, (uint4 *)g->planar, (uint64_t)lo, count, chunks);
         }
+        GS_HIP(hipGetLastError());
+        // per-block bounds for the preprocess kernels' block culling (recomputed for every block:
+        // 48 bytes per Gaussian, cheaper than tracking which blocks a partial update touched)
+        const uint32_t nblocks = (uint32_t)((len + gs::PLANAR_BLOCK - 1) / gs::PLANAR_BLOCK);
+        if (!g->block_bounds) GS_HIP(hipMalloc(&g->block_bounds, (stride / gs::PLANAR_BLOCK + 1) * 32));
+        hipLaunchKernelGGL(k_tbl_block_bounds[g->sh][g->cov], dim3(nblocks), dim3(gs::PP_THREADS), 0, st,
+                           (const uint4 *)g->planar, (uint32_t)len, (float *)g->block_bounds);
         GS_HIP(hipGetLastError());
     }
     g->dirty_lo = g->dirty_hi = 0;
@@ -1695,12 +1716,15 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
         const bool banded = g->sh != GS_SH_NONE && (force_banded >= 0 ? force_banded != 0 : true);
         static const int mask_env = std::getenv("GS3D_MASK_REC") ? std::atoi(std::getenv("GS3D_MASK_REC")) : -1;
         fc.mask_culled_records = mask_env >= 0 ? (uint32_t)mask_env : (g->order != nullptr ? 1u : 0u);
+        static const bool block_cull_off = std::getenv("GS3D_BLOCK_CULL") && std::getenv("GS3D_BLOCK_CULL")[0] == '0';
+        if (block_cull_off || !g->block_bounds) fc.cull_gain = 0.0f;
         hipLaunchKernelGGL((banded ? k_tbl_preprocess_banded : k_tbl_preprocess)[g->sh][g->cov], dim3(nchunks),
                            dim3(gs::PP_THREADS), 0, st,
                            (const uint4 *)g->planar, n, fc,
                            (uint32_t *)r->recs.ptr, (uint32_t *)r->depth.ptr,
                            (uint2 *)r->rect.ptr, (uint32_t *)r->chunk_tiles.ptr,
-                           (uint32_t *)r->chunk_vis.ptr, (uint2 *)r->chunk_range.ptr);
+                           (uint32_t *)r->chunk_vis.ptr, (uint2 *)r->chunk_range.ptr,
+                           (const float *)g->block_bounds);
         mark(ST_SCAN);
         // the two grand totals (D, V) go straight into pinned host memory (device-visible through
         // the unified address space): no separate copy launch, one stream wait below
@@ -1715,7 +1739,8 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
         hipLaunchKernelGGL(gs::k_compact, dim3(nchunks), dim3(gs::PP_THREADS), 0, st,
                            (const uint32_t *)r->depth.ptr, (const uint32_t *)r->chunk_vis_off.ptr, n,
                            (uint32_t *)r->dkeys[0].ptr, (uint32_t *)r->dvals[0].ptr,
-                           (uint2 *)r->ranges.ptr, num_tiles, (const uint32_t *)(counters + 4));
+                           (uint2 *)r->ranges.ptr, num_tiles, (const uint32_t *)(counters + 4),
+                           (const uint32_t *)r->chunk_vis.ptr);
         GS_HIP(hipGetLastError());
         GS_HIP(hipStreamSynchronize(st));
         d = r->host_counters[0];
@@ -1845,10 +1870,14 @@ extern "C" gs_status gs_renderer_download_projected(gs_renderer *r, gs_projected
         order.resize(total);
         GS_TRY(download_sync(r, order.data(), r->last_order->ptr, total * 4));
     }
+    const size_t nchunks = (total + gs::PP_CHUNK - 1) / gs::PP_CHUNK;
+    std::vector<uint32_t> chunk_vis(nchunks);
+    GS_TRY(download_sync(r, chunk_vis.data(), r->chunk_vis.ptr, nchunks * 4));
     for (size_t slot = 0; slot < total; slot++) {
         const size_t i = order.empty() ? slot : order[slot];   // Gaussian index of this slot
         if (i >= n) continue;
-        bool vis = depth[slot] != 0xffffffffu;
+        // a chunk with no visible Gaussian may have been block-culled: its per-slot arrays are stale
+        bool vis = chunk_vis[slot / gs::PP_CHUNK] != 0u && depth[slot] != 0xffffffffu;
         uint32_t w = (rect[slot].y & 0xffffu) - (rect[slot].x & 0xffffu),
                  h = (rect[slot].y >> 16) - (rect[slot].x >> 16);
         if (tiles_out) tiles_out[i] = vis ? w * h : 0u;

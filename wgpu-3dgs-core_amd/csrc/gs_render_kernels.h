@@ -38,6 +38,7 @@ struct FrameConsts {
     uint32_t tiles_x, tiles_y;
     uint32_t band_ty0, band_ty1;   // already clamped to tiles_y
     uint32_t mask_culled_records;  // k_preprocess_banded: culled lanes skip their 36-byte record store
+    float cull_gain;               // block culling: size^2 * |R_m S_m|_F^2 * (fx^2 (1+limx^2) + fy^2 (1+limy^2)); 0 = off
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -291,6 +292,133 @@ __global__ __launch_bounds__(256) void k_repack_planar_scatter(const uint4 *__re
 }
 
 // ---------------------------------------------------------------------------------------------
+// block bounds and conservative block culling.  With the mirror in spatial order a block of 1024
+// slots is a compact region of space: bb[block] = {lo xyz, hi xyz of the positions, L, 0} with
+// L = max Frobenius norm of the 3D covariances (>= their largest eigenvalue).  A preprocess
+// workgroup whose block provably holds no visible Gaussian returns before reading anything.
+// The test must never drop a Gaussian the exact per-Gaussian tests of project_geom would keep:
+//   * depth: every centre lies in the box, so its view depth lies between the corners' depths;
+//   * screen position: x/z and y/z are ratios of affine functions, so over a box in front of the
+//     camera their extremes are attained at corners;
+//   * radius: Sigma' = size^2 (J W R_m S_m) Sigma (..)^T + 0.3 I, so lambda_max(Sigma') <=
+//     size^2 |J|_F^2 |R_m S_m|_F^2 lambda_max(Sigma) + 0.3, with |J|_F^2 <= (fx^2 (1 + limx^2) +
+//     fy^2 (1 + limy^2)) / z^2 because the Jacobian is evaluated at the clamped position; the
+//     spec's lambda (mid + sqrt(max(0.1, ..))) exceeds the true one by at most 0.32 and
+//     radius = ceil(k sqrt(lambda)).  All comparisons carry explicit slack for f32 rounding and
+//     are written so that NaN / inf bounds never cull.
+// ---------------------------------------------------------------------------------------------
+
+template <int SH, int COV>
+__global__ __launch_bounds__(PP_THREADS) void k_block_bounds(const uint4 *__restrict__ planar, uint32_t n,
+                                                             float *__restrict__ bb) {
+    constexpr int NW = pod_words(SH, COV);
+    constexpr int NC = NW / 4;
+    constexpr int G0 = cov_word0(SH) / 4;
+    constexpr int G1 = (cov_word0(SH) + cov_bytes(COV) / 4 - 1) / 4;
+    __shared__ float s_v[4][7];
+    const uint32_t base = blockIdx.x * PP_CHUNK;
+    float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
+    float hi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+    float L = 0.0f;
+    for (int k = 0; k < PP_ITEMS; k++) {
+        const uint32_t i = base + k * PP_THREADS + threadIdx.x;
+        if (i < n) {
+            uint32_t w[NW];
+            uint4 v0 = planar[planar_at(0, i, NC)];
+            w[0] = v0.x; w[1] = v0.y; w[2] = v0.z; w[3] = v0.w;
+#pragma unroll
+            for (int c = G0; c <= G1; c++) {
+                uint4 v = planar[planar_at(c, i, NC)];
+                w[4 * c + 0] = v.x; w[4 * c + 1] = v.y; w[4 * c + 2] = v.z; w[4 * c + 3] = v.w;
+            }
+            float S[6];
+            gaussian_unpack_cov3d<SH, COV>(w, S);
+            float f2 = ((S[0] * S[0] + S[3] * S[3]) + S[5] * S[5]) + 2.0f * ((S[1] * S[1] + S[2] * S[2]) + S[4] * S[4]);
+            float f = sqrtf(f2);
+            L = f > L ? f : L;                 // NaN never replaces L; +inf does (=> never culled)
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                float p = u2f(w[a]);
+                lo[a] = fminf(lo[a], p);       // NaN positions are ignored: such Gaussians are always culled
+                hi[a] = fmaxf(hi[a], p);
+            }
+        }
+    }
+#pragma unroll
+    for (int d = WAVE / 2; d > 0; d >>= 1) {
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            lo[a] = fminf(lo[a], __shfl_xor(lo[a], d, WAVE));
+            hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], d, WAVE));
+        }
+        float o = __shfl_xor(L, d, WAVE);
+        L = o > L ? o : L;
+    }
+    const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+    if (lane == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            s_v[wid][a] = lo[a];
+            s_v[wid][3 + a] = hi[a];
+        }
+        s_v[wid][6] = L;
+    }
+    __syncthreads();
+    if (threadIdx.x < 8u) {
+        const uint32_t a = threadIdx.x;
+        float r = 0.0f;
+        if (a < 3u) r = fminf(fminf(s_v[0][a], s_v[1][a]), fminf(s_v[2][a], s_v[3][a]));
+        else if (a < 6u) r = fmaxf(fmaxf(s_v[0][a], s_v[1][a]), fmaxf(s_v[2][a], s_v[3][a]));
+        else if (a == 6u) {
+            r = s_v[0][6];
+            for (int w = 1; w < 4; w++) r = s_v[w][6] > r ? s_v[w][6] : r;
+        }
+        bb[blockIdx.x * 8u + a] = r;
+    }
+}
+
+// true = no Gaussian of the block can pass project_geom's visibility tests for this frame / band
+__device__ __forceinline__ bool block_is_culled(const float *__restrict__ bb, const FrameConsts &fc) {
+    const float lo[3] = {bb[0], bb[1], bb[2]}, hi[3] = {bb[3], bb[4], bb[5]};
+    const float L = bb[6];
+    float z0 = __builtin_inff(), z1 = -__builtin_inff();
+    float u0 = __builtin_inff(), u1 = -__builtin_inff(), v0 = __builtin_inff(), v1 = -__builtin_inff();
+    bool finite = true;
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+        float p[3] = {(c & 1) ? hi[0] : lo[0], (c & 2) ? hi[1] : lo[1], (c & 4) ? hi[2] : lo[2]};
+        float pw[4], t[4];
+        mat4_mul_point(fc.M, p, pw);
+        mat4_mul_point(fc.V, pw, t);
+        float xv = t[0], yv = -t[1], zv = -t[2];
+        finite = finite && (fabsf(xv) < 1e30f) && (fabsf(yv) < 1e30f) && (fabsf(zv) < 1e30f);   // false for NaN / inf
+        z0 = fminf(z0, zv);
+        z1 = fmaxf(z1, zv);
+        float u = xv / zv, v = yv / zv;
+        u0 = fminf(u0, u); u1 = fmaxf(u1, u);
+        v0 = fminf(v0, v); v1 = fmaxf(v1, v);
+    }
+    if (!finite) return false;
+    const float ez = 1e-4f * (fabsf(z0) + fabsf(z1)) + 1e-6f;
+    if (z1 + ez <= fc.near_plane) return true;    // every centre is at or behind the near plane
+    if (z0 - ez >= fc.far_plane) return true;
+    if (!(z0 - ez > 0.0f)) return false;          // box reaches the camera plane: x/z is unbounded
+    const float zl = fmaxf(z0 - ez, fc.near_plane);
+    const float lam = fc.cull_gain * L / (zl * zl) + 0.7f;
+    const float r = fc.max_std_dev * sqrtf(lam) * 1.001f + 1.01f;
+    if (!(r < 1e30f)) return false;
+    const float mxa = fc.fx * u0 + fc.cx, mxb = fc.fx * u1 + fc.cx;
+    const float mya = fc.fy * v0 + fc.cy, myb = fc.fy * v1 + fc.cy;
+    const float mx0 = fminf(mxa, mxb), mx1 = fmaxf(mxa, mxb), my0 = fminf(mya, myb), my1 = fmaxf(mya, myb);
+    const float ex = 1e-4f * (fabsf(mx0) + fabsf(mx1)) + 0.05f, ey = 1e-4f * (fabsf(my0) + fabsf(my1)) + 0.05f;
+    if (mx1 + ex + r < 0.0f) return true;
+    if (mx0 - ex - r >= 16.0f * (float)fc.tiles_x) return true;
+    if (my1 + ey + r < 16.0f * (float)fc.band_ty0) return true;
+    if (my0 - ey - r >= 16.0f * (float)fc.band_ty1) return true;
+    return false;
+}
+
+// ---------------------------------------------------------------------------------------------
 // preprocess (rows x1, x2 of the hot-path table)
 // ---------------------------------------------------------------------------------------------
 
@@ -474,7 +602,17 @@ __global__ __launch_bounds__(PP_THREADS) void k_preprocess(
     const uint4 *__restrict__ planar, uint32_t n, FrameConsts fc,
     uint32_t *__restrict__ recs, uint32_t *__restrict__ depth, uint2 *__restrict__ rect,
     uint32_t *__restrict__ chunk_tiles, uint32_t *__restrict__ chunk_vis,
-    uint2 *__restrict__ chunk_depth_range) {
+    uint2 *__restrict__ chunk_depth_range, const float *__restrict__ block_bounds) {
+    // whole block provably invisible (spatial order + block bounds): nothing is read or written
+    // but the three per-chunk scalars; k_compact and the taps skip chunks with zero visible
+    if (fc.cull_gain > 0.0f && block_is_culled(block_bounds + (uint64_t)blockIdx.x * 8u, fc)) {
+        if (threadIdx.x == 0) {
+            chunk_tiles[blockIdx.x] = 0u;
+            chunk_vis[blockIdx.x] = 0u;
+            chunk_depth_range[blockIdx.x] = make_uint2(0xffffffffu, 0u);
+        }
+        return;
+    }
     constexpr int NW = pod_words(SH, COV);
     constexpr int NC = NW / 4;
     __shared__ uint32_t s_red[16];
@@ -551,7 +689,17 @@ __global__ __launch_bounds__(PP_THREADS) void k_preprocess_banded(
     const uint4 *__restrict__ planar, uint32_t n, FrameConsts fc,
     uint32_t *__restrict__ recs, uint32_t *__restrict__ depth, uint2 *__restrict__ rect,
     uint32_t *__restrict__ chunk_tiles, uint32_t *__restrict__ chunk_vis,
-    uint2 *__restrict__ chunk_depth_range) {
+    uint2 *__restrict__ chunk_depth_range, const float *__restrict__ block_bounds) {
+    // whole block provably invisible (spatial order + block bounds): nothing is read or written
+    // but the three per-chunk scalars; k_compact and the taps skip chunks with zero visible
+    if (fc.cull_gain > 0.0f && block_is_culled(block_bounds + (uint64_t)blockIdx.x * 8u, fc)) {
+        if (threadIdx.x == 0) {
+            chunk_tiles[blockIdx.x] = 0u;
+            chunk_vis[blockIdx.x] = 0u;
+            chunk_depth_range[blockIdx.x] = make_uint2(0xffffffffu, 0u);
+        }
+        return;
+    }
     constexpr int NW = pod_words(SH, COV);
     constexpr int NC = NW / 4;
     constexpr int G0 = cov_word0(SH) / 4;                              // first chunk holding covariance words
@@ -754,13 +902,15 @@ __global__ __launch_bounds__(PP_THREADS) void k_compact(const uint32_t *__restri
                                                         uint32_t *__restrict__ dvals,
                                                         uint2 *__restrict__ ranges_to_clear,
                                                         uint32_t num_tiles,
-                                                        const uint32_t *__restrict__ depth_range) {
+                                                        const uint32_t *__restrict__ depth_range,
+                                                        const uint32_t *__restrict__ chunk_vis) {
     __shared__ uint32_t s_scan[4];
     const uint32_t key_bias = depth_range[0];   // minimum visible depth key (k_scan_chunks)
     // side job: clear the per-tile ranges for this frame (saves a separate fill launch; every
     // dependent kernel boundary costs ~4-5 us on this part, which matters for a 0.5 ms frame)
     for (uint32_t t = blockIdx.x * PP_THREADS + threadIdx.x; t < num_tiles; t += gridDim.x * PP_THREADS)
         ranges_to_clear[t] = make_uint2(0u, 0u);
+    if (chunk_vis[blockIdx.x] == 0u) return;   // nothing visible (possibly a block-culled chunk whose depth[] is stale)
     uint32_t base = blockIdx.x * PP_CHUNK + threadIdx.x * PP_ITEMS;
     uint32_t dk[PP_ITEMS];
     uint32_t cnt = 0;
