@@ -264,6 +264,42 @@ def test_block_culling_is_conservative_over_random_views(gs, ob, device, stream,
     buf.destroy(); img.release(); r.destroy()
 
 
+def test_block_culling_with_cancelling_translations(gs, ob, device, stream):
+    """Positions stored far from the origin (+3000) and brought back by the model transform: the
+    matrix products then round at the 1e-4 level, which the block test's slack must cover — views
+    with the near plane and the screen edges cutting through the scene."""
+    import synth
+    rng = np.random.default_rng(9)
+    n = 120_000
+    g = synth.scene(n, first=555)
+    g["pos"] += np.float32(3000.0)
+    sh, cov = 1, 0
+    pod = gs.GaussianPod(sh, cov)
+    pods = pod.from_gaussian(g)
+    buf = gs.GaussiansBuffer.new_with_pods(device, pod, pods)
+    order = _mirror_order(ob, buf, stream, sh, cov, pods)
+    W, H = 400, 240
+    img = gs.Buffer(device, size=W * H * 16)
+    r = gs.Renderer(device)
+    mt = gs.model_transform_pod(pos=(-3000.0, -3000.0, -3000.0))
+    omt = ob.ModelTransform.from_buffer_copy(bytes(mt))
+    gt = gs.gaussian_transform_pod(sh_deg=3)
+    ogt = ob.GaussianTransform.from_buffer_copy(bytes(gt))
+    for view in range(8):
+        eye = (rng.uniform(-10, 10), rng.uniform(-6, 6), -rng.uniform(0, 20))
+        target = (rng.uniform(-14, 14), rng.uniform(-8, 8), -rng.uniform(2, 26))
+        ocam = ob.camera_look_at(eye, target, (0, 1, 0), float(np.deg2rad(rng.uniform(25, 70))), W, H,
+                                 float(rng.choice([0.2, 2.0, 6.0])), 60.0)
+        cam = helpers.copy_camera(ocam, gs.Camera)
+        r.render(stream, buf, gt, mt, cam, img.device_ptr())
+        got = img.download(stream, np.float32).reshape(H, W, 4)
+        st = r.stats()
+        exp, d, vis, _ = ob.render(sh, cov, pods, ogt, omt, ocam, order=order)
+        assert (st.visible, st.pairs) == (vis, d), (view, st.visible, vis)
+        assert np.array_equal(got.view(np.uint32), exp.view(np.uint32)), view
+    buf.destroy(); img.release(); r.destroy()
+
+
 def test_edge_cases(gs, ob, device, stream):
     """empty buffer, single Gaussian, everything culled, one splat covering the whole screen."""
     import synth

@@ -383,6 +383,7 @@ __device__ __forceinline__ bool block_is_culled(const float *__restrict__ bb, co
     const float L = bb[6];
     float z0 = __builtin_inff(), z1 = -__builtin_inff();
     float u0 = __builtin_inff(), u1 = -__builtin_inff(), v0 = __builtin_inff(), v1 = -__builtin_inff();
+    float mag = 0.0f;   // largest |term| sum of the two matrix products: scales their rounding error
     bool finite = true;
 #pragma unroll
     for (int c = 0; c < 8; c++) {
@@ -392,14 +393,28 @@ __device__ __forceinline__ bool block_is_culled(const float *__restrict__ bb, co
         mat4_mul_point(fc.V, pw, t);
         float xv = t[0], yv = -t[1], zv = -t[2];
         finite = finite && (fabsf(xv) < 1e30f) && (fabsf(yv) < 1e30f) && (fabsf(zv) < 1e30f);   // false for NaN / inf
+        // |V| (|M| |p| + |translation|): an upper bound of every intermediate magnitude
+        float a[3];
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+            a[r] = ((fabsf(fc.M[r]) * fabsf(p[0]) + fabsf(fc.M[4 + r]) * fabsf(p[1])) + fabsf(fc.M[8 + r]) * fabsf(p[2])) +
+                   fabsf(fc.M[12 + r]);
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            float b = ((fabsf(fc.V[r]) * a[0] + fabsf(fc.V[4 + r]) * a[1]) + fabsf(fc.V[8 + r]) * a[2]) + fabsf(fc.V[12 + r]);
+            mag = b > mag ? b : mag;
+        }
         z0 = fminf(z0, zv);
         z1 = fmaxf(z1, zv);
         float u = xv / zv, v = yv / zv;
         u0 = fminf(u0, u); u1 = fmaxf(u1, u);
         v0 = fminf(v0, v); v1 = fmaxf(v1, v);
     }
-    if (!finite) return false;
-    const float ez = 1e-4f * (fabsf(z0) + fabsf(z1)) + 1e-6f;
+    if (!finite || !(mag < 1e30f)) return false;
+    // slack for f32 rounding of the transforms (a centre inside the box may come out slightly
+    // outside the corners' hull): ~40 ulp of the largest intermediate, plus a relative part
+    const float ea = 5e-6f * mag + 1e-6f;
+    const float ez = ea + 1e-5f * (fabsf(z0) + fabsf(z1));
     if (z1 + ez <= fc.near_plane) return true;    // every centre is at or behind the near plane
     if (z0 - ez >= fc.far_plane) return true;
     if (!(z0 - ez > 0.0f)) return false;          // box reaches the camera plane: x/z is unbounded
@@ -410,7 +425,10 @@ __device__ __forceinline__ bool block_is_culled(const float *__restrict__ bb, co
     const float mxa = fc.fx * u0 + fc.cx, mxb = fc.fx * u1 + fc.cx;
     const float mya = fc.fy * v0 + fc.cy, myb = fc.fy * v1 + fc.cy;
     const float mx0 = fminf(mxa, mxb), mx1 = fmaxf(mxa, mxb), my0 = fminf(mya, myb), my1 = fmaxf(mya, myb);
-    const float ex = 1e-4f * (fabsf(mx0) + fabsf(mx1)) + 0.05f, ey = 1e-4f * (fabsf(my0) + fabsf(my1)) + 0.05f;
+    // error of x/z: (ea + |x/z| ea) / z, in pixels times the focal length; plus a relative part
+    const float um = fmaxf(fabsf(u0), fabsf(u1)), vm = fmaxf(fabsf(v0), fabsf(v1));
+    const float ex = fabsf(fc.fx) * (ea * (1.0f + um) / zl) * 2.0f + 1e-4f * (fabsf(mx0) + fabsf(mx1)) + 0.05f;
+    const float ey = fabsf(fc.fy) * (ea * (1.0f + vm) / zl) * 2.0f + 1e-4f * (fabsf(my0) + fabsf(my1)) + 0.05f;
     if (mx1 + ex + r < 0.0f) return true;
     if (mx0 - ex - r >= 16.0f * (float)fc.tiles_x) return true;
     if (my1 + ey + r < 16.0f * (float)fc.band_ty0) return true;
