@@ -300,6 +300,47 @@ def test_block_culling_with_cancelling_translations(gs, ob, device, stream):
     buf.destroy(); img.release(); r.destroy()
 
 
+def test_pathological_gaussians_do_not_derail_the_frame(gs, ob, device, stream):
+    """NaN / inf positions, zero, denormal, huge and NaN scales, non-unit and NaN quaternions mixed
+    into a normal scene: every one of them must be culled or rendered exactly as the oracle does
+    (same order, same counts, same pixels), with the mirror order on and off."""
+    import synth
+    g = synth.scene(30000, first=31337)
+    inf, nan = np.float32(np.inf), np.float32(np.nan)
+    bad = [
+        dict(pos=(nan, 0, -5)), dict(pos=(0, nan, nan)), dict(pos=(inf, 0, -5)), dict(pos=(0, 0, -inf)),
+        dict(pos=(-inf, inf, -5)), dict(scale=(0, 0, 0)), dict(scale=(1e-42, 1e-42, 1e-42)),
+        dict(scale=(1e20, 1e20, 1e20)), dict(scale=(nan, 1, 1)), dict(scale=(inf, 0.1, 0.1)),
+        dict(rot=(0, 0, 0, 0)), dict(rot=(nan, 0, 0, 1)), dict(rot=(10, -3, 2, 7)), dict(pos=(0, 0, -0.1)),
+        dict(pos=(0, 0, -100.0)), dict(pos=(0, 0, 0)), dict(scale=(30, 1e-6, 1e-6)),
+    ]
+    for k, b in enumerate(bad):
+        for f, v in b.items():
+            g[f][100 + 97 * k] = v
+    for spatial in (True, False):
+        for sh, cov in ((0, 0), (1, 2), (3, 1)):
+            pod = gs.GaussianPod(sh, cov)
+            pods = pod.from_gaussian(g)
+            assert np.array_equal(pods, ob.pack(sh, cov, g))
+            buf = gs.GaussiansBuffer.new_with_pods(device, pod, pods)
+            buf.set_spatial_order(spatial)
+            cam = helpers.default_camera(gs, 512, 288)
+            ocam = helpers.copy_camera(cam, ob.Camera)
+            img = gs.Buffer(device, size=cam.height * cam.width * 16)
+            r = gs.Renderer(device)
+            gt, mt = gs.gaussian_transform_pod(sh_deg=3), gs.model_transform_pod()
+            r.render(stream, buf, gt, mt, cam, img.device_ptr())
+            got = img.download(stream, np.float32).reshape(cam.height, cam.width, 4)
+            order = _mirror_order(ob, buf, stream, sh, cov, pods)
+            exp, d, vis, _ = ob.render(sh, cov, pods, ob.gaussian_transform(sh_deg=3), ob.model_transform(), ocam,
+                                       order=order)
+            st = r.stats()
+            assert (st.visible, st.pairs) == (vis, d), (spatial, sh, cov)
+            assert np.array_equal(got.view(np.uint32), exp.view(np.uint32)), (spatial, sh, cov)
+            assert np.isfinite(got).all()
+            buf.destroy(); img.release(); r.destroy()
+
+
 def test_edge_cases(gs, ob, device, stream):
     """empty buffer, single Gaussian, everything culled, one splat covering the whole screen."""
     import synth
