@@ -481,7 +481,10 @@ gs_status gs_renderer_stats(gs_renderer *r, gs_frame_stats *out);
 /* One frame: repack (if the Gaussians changed) -> preprocess -> scan/compact -> depth sort of the
  * visible Gaussians -> pair expansion in depth order -> stable tile sort -> tile ranges -> blend.  Renders tile rows [band_ty0, band_ty1) (16-pixel rows; pass 0 and
  * UINT32_MAX for the whole image) into rgba_out_device, a device pointer to the FULL
- * height x width x 4 f32 image; only the band's rows are written. */
+ * height x width x 4 f32 image (16-byte aligned); only the band's rows are written.  All three
+ * GaussianDisplayModes of the transform are rendered (Splat: Gaussian falloff; Ellipse: flat alpha
+ * inside the max_std_dev ellipse; Point: flat alpha inside a 1.5-pixel dot — DESIGN.md §3.5a).
+ * GS_ERR_PAIR_OVERFLOW when the frame would need more than 2^32 (tile, Gaussian) pairs. */
 gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_buffer *gaussians,
                           const gs_gaussian_transform_pod *gaussian_transform,
                           const gs_model_transform_pod *model_transform, const gs_camera *camera,

@@ -243,12 +243,23 @@ def tile_ranges(keys, num_tiles):
     return r
 
 
-def blend(proj, idx, ranges, cam, band=None):
+def blend(proj, idx, ranges, cam, band=None, gt=None):
+    """gt: the GaussianTransform whose display mode / max_std_dev apply (None = splat, 3 sigma)"""
     tiles_y = (cam.height + 15) // 16
     b0, b1 = band if band is not None else (0, tiles_y)
     rgba = np.zeros((cam.height, cam.width, 4), dtype=np.float32)
     idx = np.ascontiguousarray(idx)
-    lib().gso_blend(_p(proj), _p(idx), _p(ranges), C.byref(cam), b0, b1, _p(rgba))
+    mode, k = 0, 3.0
+    if gt is not None:
+        mode = int(gt.flags[0])
+        lib().gso_transform_max_std_dev.restype = C.c_float
+        lib().gso_transform_max_std_dev.argtypes = [C.c_uint32]
+        k = lib().gso_transform_max_std_dev(gt.flags_u32)
+    fn = lib().gso_blend_mode
+    fn.restype = None
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32,
+                   C.c_float]
+    fn(_p(proj), _p(idx), _p(ranges), C.byref(cam), b0, b1, _p(rgba), mode, k)
     return rgba
 
 

@@ -969,6 +969,19 @@ void gso_tile_ranges(const uint64_t *keys, uint64_t d, uint32_t num_tiles, uint3
 /* DESIGN.md §3.5 */
 void gso_blend(const gso_projected *proj, const uint32_t *idx, const uint32_t *ranges,
                const gso_camera *cam, uint32_t band_ty0, uint32_t band_ty1, float *rgba) {
+    gso_blend_mode(proj, idx, ranges, cam, band_ty0, band_ty1, rgba, 0, 3.0f);
+}
+
+/* DESIGN.md §3.5a — GaussianDisplayMode (src/buffer/gaussian_transform.rs:7-14) changes only how a
+ * splat's alpha at a pixel is obtained; EXTERNAL definition (the reference stores the flag, the
+ * viewer interprets it):
+ *   0 splat   alpha = min(0.99, opacity * exp(power)), skipped when power > 0
+ *   1 ellipse alpha = min(0.99, opacity) where -k^2/2 <= power <= 0 (k = max_std_dev): the flat k-sigma ellipse
+ *   2 point   alpha = min(0.99, opacity) where dx^2 + dy^2 <= 1.5^2: a fixed 1.5-pixel dot */
+void gso_blend_mode(const gso_projected *proj, const uint32_t *idx, const uint32_t *ranges,
+                    const gso_camera *cam, uint32_t band_ty0, uint32_t band_ty1, float *rgba,
+                    uint32_t display_mode, float max_std_dev) {
+    const float ellipse_pmin = -0.5f * (max_std_dev * max_std_dev);
     uint32_t W = cam->width, H = cam->height;
     uint32_t tiles_x = (W + 15u) / 16u, tiles_y = (H + 15u) / 16u;
     if (band_ty1 > tiles_y) band_ty1 = tiles_y;
@@ -992,8 +1005,17 @@ void gso_blend(const gso_projected *proj, const uint32_t *idx, const uint32_t *r
                     /* power = ca*dx^2 + cc*dy^2 + cb*dx*dy with the pre-scaled conic */
                     float u = g->ca * dx, v = g->cc * dy, w = g->cb * dx;
                     float power = fmaf(u, dx, fmaf(v, dy, w * dy));
-                    if (power > 0.0f) continue;
-                    float alpha = fminf(0.99f, g->opacity * gso_exp(power));
+                    float alpha;
+                    if (display_mode == 0u) {
+                        if (power > 0.0f) continue;
+                        alpha = fminf(0.99f, g->opacity * gso_exp(power));
+                    } else if (display_mode == 1u) {
+                        if (power > 0.0f || power < ellipse_pmin) continue;
+                        alpha = fminf(0.99f, g->opacity);
+                    } else {
+                        if (dx * dx + dy * dy > 2.25f) continue;
+                        alpha = fminf(0.99f, g->opacity);
+                    }
                     if (alpha < 1.0f / 255.0f) continue;
                     float test_T = T * (1.0f - alpha);
                     if (test_T < 0.0001f) break;
@@ -1049,7 +1071,12 @@ uint64_t gso_render_ordered(int sh, int cov, const void *pods, size_t n, const g
     uint32_t *ranges = (uint32_t *)malloc((size_t)tiles_x * tiles_y * 2 * sizeof(uint32_t));
     gso_tile_ranges(keys, d, tiles_x * tiles_y, ranges);
     double t4 = now_s();
-    if (rgba) gso_blend(proj, idx, ranges, cam, band_ty0, band_ty1, rgba);
+    if (rgba) {
+        uint32_t flags;
+        memcpy(&flags, gt->flags, 4);
+        gso_blend_mode(proj, idx, ranges, cam, band_ty0, band_ty1, rgba, gso_transform_display_mode(flags),
+                       gso_transform_max_std_dev(flags));
+    }
     double t5 = now_s();
     g_stage[0] = t1 - t0;
     g_stage[1] = t2 - t1;

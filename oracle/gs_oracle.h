@@ -174,6 +174,10 @@ void gso_tile_ranges(const uint64_t *keys, uint64_t d, uint32_t num_tiles, uint3
 /* rgba: height*width*4 floats; only rows of tile rows [band_ty0,band_ty1) are written */
 void gso_blend(const gso_projected *proj, const uint32_t *idx, const uint32_t *ranges,
                const gso_camera *cam, uint32_t band_ty0, uint32_t band_ty1, float *rgba);
+/* same with GaussianDisplayMode (0 splat, 1 ellipse, 2 point) */
+void gso_blend_mode(const gso_projected *proj, const uint32_t *idx, const uint32_t *ranges,
+                    const gso_camera *cam, uint32_t band_ty0, uint32_t band_ty1, float *rgba,
+                    uint32_t display_mode, float max_std_dev);
 /* whole frame; optional outputs may be NULL. returns D. */
 uint64_t gso_render(int sh, int cov, const void *pods, size_t n, const gso_gaussian_transform *gt,
                     const gso_model_transform *mt, const gso_camera *cam, uint32_t band_ty0,

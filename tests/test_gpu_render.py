@@ -46,7 +46,7 @@ def _oracle_frame(ob, sh, cov, pods, ogt, omt, ocam, band=None, order=None):
     keys, idx = ob.build_keys(proj, tiles, tiles_x, order=order)
     skeys, sidx = ob.sort_pairs(keys, idx)
     ranges = ob.tile_ranges(skeys, tiles_x * tiles_y)
-    rgba = ob.blend(proj, sidx, ranges, ocam, band=band)
+    rgba = ob.blend(proj, sidx, ranges, ocam, band=band, gt=ogt)
     return proj, tiles, keys, idx, skeys, sidx, ranges, rgba
 
 
@@ -346,6 +346,26 @@ def test_pathological_gaussians_do_not_derail_the_frame(gs, ob, device, stream):
             assert np.array_equal(got.view(np.uint32), exp.view(np.uint32)), (spatial, sh, cov)
             assert np.isfinite(got).all()
             buf.destroy(); img.release(); r.destroy()
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("std", [3.0, 1.5])
+def test_display_modes_ellipse_and_point(gs, ob, device, stream, mode, std):
+    """GaussianDisplayMode Ellipse / Point: same keys, sort and ranges as Splat; the
+    blend uses the flat k-sigma ellipse / the fixed 1.5-px dot.  All stages bit-exact against the oracle."""
+    import synth
+    g = synth.scene(15000, first=77 + mode)
+    g["scale"] *= 2.5
+    st = _compare_frame(gs, ob, device, stream, gs.SH_NORM8, gs.COV3D_ROT_SCALE, g, 512, 300,
+                        gt_kw=dict(mode=mode, sh_deg=2, max_std_dev=std))
+    assert st.pairs > 0
+    # and the three modes really differ
+    pod = gs.GaussianPod(gs.SH_NORM8, gs.COV3D_ROT_SCALE)
+    pods = pod.from_gaussian(g)
+    cam = helpers.default_camera(gs, 512, 300)
+    frames = [_render_gpu(gs, device, stream, pod, pods, gs.gaussian_transform_pod(1.0, m, 2, False, std),
+                          gs.model_transform_pod(), cam)[3] for m in (0, mode)]
+    assert not np.array_equal(frames[0], frames[1])
 
 
 def test_edge_cases(gs, ob, device, stream):

@@ -1393,6 +1393,7 @@ static void make_frame_consts(const gs_gaussian_transform_pod *gt, const gs_mode
     fc.band_ty1 = band_ty1 < fc.tiles_y ? band_ty1 : fc.tiles_y;
     if (fc.band_ty1 < fc.band_ty0) fc.band_ty1 = fc.band_ty0;
     fc.mask_culled_records = 0;
+    fc.ellipse_pmin = -0.5f * (fc.max_std_dev * fc.max_std_dev);
     // block culling gain (see block_is_culled): |W R_m S_m|_F^2 bounds the squared spectral norm of
     // the linear part whatever the caller's view matrix is; 0.1 % head room for the f32 arithmetic
     float ws2 = 0.0f;
@@ -1658,8 +1659,8 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
         return fail(GS_ERR_INVALID_ARGUMENT, (uint64_t)(uintptr_t)rgba, 16, 0,
                     "the RGBA frame must be 16-byte aligned (pixels are stored as float4)");
     uint32_t mode = gt->flags[0];
-    if (mode != GS_DISPLAY_SPLAT)
-        return fail(GS_ERR_INVALID_ARGUMENT, mode, 0, 0, "only GaussianDisplayMode::Splat is implemented");
+    if (mode > GS_DISPLAY_POINT)
+        return fail(GS_ERR_INVALID_ARGUMENT, mode, 0, 0, "unknown GaussianDisplayMode %u", mode);
     GS_TRY(use_device(r->dev));
     hipStream_t st = s->s;
     GS_TRY(collect_timing(r));
@@ -1821,7 +1822,8 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
     mark(ST_BLEND);
     uint32_t band_tiles = (fc.band_ty1 - fc.band_ty0) * fc.tiles_x;
     if (band_tiles) {
-        hipLaunchKernelGGL(gs::k_blend, dim3(band_tiles), dim3(gs::BLEND_THREADS), 0, st,
+        auto blend = mode == GS_DISPLAY_SPLAT ? gs::k_blend<0> : mode == GS_DISPLAY_ELLIPSE ? gs::k_blend<1> : gs::k_blend<2>;
+        hipLaunchKernelGGL(blend, dim3(band_tiles), dim3(gs::BLEND_THREADS), 0, st,
                            (const uint32_t *)r->ranges.ptr, (const uint32_t *)r->tvals[tside].ptr,
                            (const uint32_t *)r->recs.ptr, fc, (float4 *)rgba);
         GS_HIP(hipGetLastError());

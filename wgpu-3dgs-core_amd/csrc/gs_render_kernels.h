@@ -39,6 +39,7 @@ struct FrameConsts {
     uint32_t band_ty0, band_ty1;   // already clamped to tiles_y
     uint32_t mask_culled_records;  // k_preprocess_banded: culled lanes skip their 36-byte record store
     float cull_gain;               // block culling: size^2 * |R_m S_m|_F^2 * (fx^2 (1+limx^2) + fy^2 (1+limy^2)); 0 = off
+    float ellipse_pmin;            // display mode Ellipse: -max_std_dev^2 / 2
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -1419,6 +1420,9 @@ constexpr int BLEND_BATCH = 128;
 // wave64 ballots + mbcnt prefix counts (order preserving).  A wave therefore only walks splats
 // that can contribute to its own 16x8 pixels.  The compaction never changes results: a removed
 // splat has alpha < 1/255 at every pixel of the half-tile, which the pixel loop would skip.
+// MODE = GaussianDisplayMode: 0 splat (the Gaussian falloff), 1 ellipse (flat
+// alpha = min(0.99, opacity) inside the max_std_dev ellipse), 2 point (flat alpha inside a 1.5-px dot).
+template <int MODE>
 __global__ __launch_bounds__(BLEND_THREADS) void k_blend(const uint32_t *__restrict__ ranges,
                                                          const uint32_t *__restrict__ idx,
                                                          const uint32_t *__restrict__ recs,
@@ -1473,9 +1477,22 @@ __global__ __launch_bounds__(BLEND_THREADS) void k_blend(const uint32_t *__restr
             // bound minus 1e-3 (covers the hardware log's and the exp polynomial's error), so a
             // pixel with power < pmin is one the exact alpha test would reject anyway: using pmin
             // in place of the constant -5.6 changes no result, it only skips more work.
-            pmin = fmaxf(-__logf(255.0f * u2f(r1.y)) - 1.0e-3f, -5.6f);
-            keep0 = splat_touches_rect(mx, my, ca, cb, cc, rx0, rx1, ry0, ry0 + 7.0f, pmin - 0.1f);
-            keep1 = splat_touches_rect(mx, my, ca, cb, cc, rx0, rx1, ry0 + 8.0f, ry0 + 15.0f, pmin - 0.1f);
+            if constexpr (MODE == 0) {
+                pmin = fmaxf(-__logf(255.0f * u2f(r1.y)) - 1.0e-3f, -5.6f);
+                keep0 = splat_touches_rect(mx, my, ca, cb, cc, rx0, rx1, ry0, ry0 + 7.0f, pmin - 0.1f);
+                keep1 = splat_touches_rect(mx, my, ca, cb, cc, rx0, rx1, ry0 + 8.0f, ry0 + 15.0f, pmin - 0.1f);
+            } else if constexpr (MODE == 1) {
+                pmin = fc.ellipse_pmin;   // exact bound of the pixel test; the cull below gets slack
+                const float thr = pmin - 0.1f - 1.0e-3f * fabsf(pmin);
+                keep0 = splat_touches_rect(mx, my, ca, cb, cc, rx0, rx1, ry0, ry0 + 7.0f, thr);
+                keep1 = splat_touches_rect(mx, my, ca, cb, cc, rx0, rx1, ry0 + 8.0f, ry0 + 15.0f, thr);
+            } else {
+                // distance from the centre to the half-tile's pixel-centre rectangle vs the 1.5-px dot
+                const float ex = mx - clampf(mx, rx0, rx1);
+                const float ey0 = my - clampf(my, ry0, ry0 + 7.0f), ey1 = my - clampf(my, ry0 + 8.0f, ry0 + 15.0f);
+                keep0 = ex * ex + ey0 * ey0 <= 2.26f;
+                keep1 = ex * ex + ey1 * ey1 <= 2.26f;
+            }
         }
         uint64_t m0 = __ballot(keep0), m1 = __ballot(keep1);
         if (lane == 0) {
@@ -1514,9 +1531,18 @@ __global__ __launch_bounds__(BLEND_THREADS) void k_blend(const uint32_t *__restr
                 t = pk_fma(v, dy, t);
                 const f32x2 power = pk_fma(f32x2{u, u}, f32x2{dx, dx}, t);
                 const float2 cq = s_c[wid][s];   // b, pmin
-                const bool p0 = power.x <= 0.0f && power.x >= cq.y;
-                const bool p1 = power.y <= 0.0f && power.y >= cq.y;
+                bool p0, p1;
+                if constexpr (MODE == 2) {
+                    const f32x2 d2 = f32x2{dx * dx, dx * dx} + dy * dy;
+                    p0 = d2.x <= 2.25f;
+                    p1 = d2.y <= 2.25f;
+                } else {
+                    p0 = power.x <= 0.0f && power.x >= cq.y;
+                    p1 = power.y <= 0.0f && power.y >= cq.y;
+                }
                 if (!__any(p0 || p1)) continue;
+                f32x2 alpha;
+                if constexpr (MODE == 0) {
                 // exp on both pixels.  n = rint(t) is taken with the 1.5*2^23 magic
                 // constant (t + M - M == rint(t) for |t| < 2^22, ties to even like rintf), and the
                 // final ldexp(p, n) is an integer add of n into the exponent field: bits(t + M) =
@@ -1535,7 +1561,11 @@ __global__ __launch_bounds__(BLEND_THREADS) void k_blend(const uint32_t *__restr
                 p = pk_fma(p, f, f32x2{1.0f, 1.0f});
                 const f32x2 e = {u2f(f2u(p.x) + (f2u(tm.x) << 23)), u2f(f2u(p.y) + (f2u(tm.y) << 23))};
                 const f32x2 oe = f32x2{bq.y, bq.y} * e;
-                const f32x2 alpha = {fminf(0.99f, oe.x), fminf(0.99f, oe.y)};
+                alpha = f32x2{fminf(0.99f, oe.x), fminf(0.99f, oe.y)};
+                } else {
+                    const float flat = fminf(0.99f, bq.y);
+                    alpha = f32x2{flat, flat};
+                }
                 const bool act0 = p0 && alpha.x >= (1.0f / 255.0f);
                 const bool act1 = p1 && alpha.y >= (1.0f / 255.0f);
                 // a pixel that skips this splat blends it with alpha 0: T * (1 - 0) == T and
