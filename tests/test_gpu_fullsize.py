@@ -84,7 +84,7 @@ def _check_intermediates(gs, r, g, cam, order):
     return keys, idx
 
 
-@pytest.mark.parametrize("name", ["1m", "10m"])
+@pytest.mark.parametrize("name", ["1m", "10m", "50m"])
 def test_fullsize_frame_matches_oracle_hash(gs, device, stream, name):
     g = GOLD[name]
     pod, buf, scene_hash = _upload(gs, device, stream, g)
@@ -104,7 +104,8 @@ def test_fullsize_frame_matches_oracle_hash(gs, device, stream, name):
     assert int((rgba[..., 3] > 0).sum()) == g["covered_pixels"]
     assert abs(float(rgba.astype(np.float64).sum()) - g["frame_sum"]) <= 1e-6 * g["frame_sum"]
     assert hashlib.sha256(rgba.tobytes()).hexdigest() == g[frame_key], "frame differs from the oracle's"
-    _check_intermediates(gs, r, g, cam, buf.download_order(stream))
+    if g["n"] <= 10_000_000:   # at 50 M the taps would move 175 M pairs through numpy: hashes, V, D and bands only
+        _check_intermediates(gs, r, g, cam, buf.download_order(stream))
     # idempotence: same inputs, same bits (the pipeline has no order-dependent atomics in its results)
     again = _frame(gs, device, stream, r, buf, gt, mt, cam)
     assert np.array_equal(again.view(np.uint32), rgba.view(np.uint32))
