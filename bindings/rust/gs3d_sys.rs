@@ -26,6 +26,7 @@ pub const GS_ERR_DOWNLOAD: gs_status = -22;
 pub const GS_ERR_PAIR_OVERFLOW: gs_status = -23;
 pub const GS_ERR_PLY: gs_status = -24;
 pub const GS_ERR_SPZ: gs_status = -25;
+pub const GS_ERR_PAIR_CAPACITY: gs_status = -26;
 
 // enum gs_sh_config (passed as u32)
 pub const GS_SH_SINGLE: u32 = 0;
@@ -222,6 +223,17 @@ pub struct gs_frame_stats {
     pub stage_ms: [f64; 12],
 }
 
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct gs_frame_result {
+    pub gaussians: u64,
+    pub visible: u64,
+    pub pairs: u64,
+    pub pair_capacity: u64,
+    pub flags: u32,
+    pub launches: u32,
+}
+
 #[link(name = "gs3d_hip")]
 extern "C" {
     pub fn gs_last_error(out: *mut gs_error_info);
@@ -311,6 +323,7 @@ extern "C" {
     pub fn gs_renderer_reset_stats(r: *mut gs_renderer) -> gs_status;
     pub fn gs_renderer_stats(r: *mut gs_renderer, out: *mut gs_frame_stats) -> gs_status;
     pub fn gs_render_frame(r: *mut gs_renderer, s: *mut gs_stream, gaussians: *mut gs_gaussians_buffer, gaussian_transform: *const gs_gaussian_transform_pod, model_transform: *const gs_model_transform_pod, camera: *const gs_camera, band_ty0: u32, band_ty1: u32, rgba_out_device: *mut f32) -> gs_status;
+    pub fn gs_renderer_wait_frame(r: *mut gs_renderer, out: *mut gs_frame_result) -> gs_status;
     pub fn gs_renderer_download_projected(r: *mut gs_renderer, proj_out: *mut gs_projected, tiles_touched_out: *mut u32, n: usize) -> gs_status;
     pub fn gs_renderer_download_sorted(r: *mut gs_renderer, keys_out: *mut u64, idx_out: *mut u32, capacity: u64, pairs_out: *mut u64) -> gs_status;
     pub fn gs_renderer_download_ranges(r: *mut gs_renderer, ranges_out: *mut u32, num_tiles: usize) -> gs_status;

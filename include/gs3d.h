@@ -61,12 +61,16 @@ enum {
     GS_ERR_LOSSY_CONFIG = -21,
     /* DownloadBufferError                                                   src/error.rs:55-63  */
     GS_ERR_DOWNLOAD = -22,
-    /* the (key,index) pair buffer was too small for this frame; call again (it was grown) */
+    /* the frame needs more than 2^32 (tile, Gaussian) pairs: pair indices are 32-bit */
     GS_ERR_PAIR_OVERFLOW = -23,
     /* std::io::Error (InvalidData / UnexpectedEof) of the PLY reader; message = the Rust message */
     GS_ERR_PLY = -24,
     /* std::io::Error of the SPZ reader / header validation; message = the Rust message */
-    GS_ERR_SPZ = -25
+    GS_ERR_SPZ = -25,
+    /* gs_renderer_wait_frame: the frame produced more (tile, Gaussian) pairs than the renderer's pair
+     * buffers hold (a = pairs, b = capacity); its farthest pairs were dropped.  The next frame grows
+     * the buffers: render again. */
+    GS_ERR_PAIR_CAPACITY = -26
 };
 
 /* Thread-local details of the last failing call on this thread.
@@ -459,8 +463,8 @@ typedef struct gs_frame_stats {
     uint32_t sort_passes;
     uint32_t timed_frames;    /* frames accumulated below since the last reset */
     /* accumulated stage time in ms (only while timing is enabled):
-     * 0 repack, 1 preprocess, 2 scan + compaction of visible Gaussians, 3 depth sort,
-     * 4 pair expansion, 5 tile sort, 6 ranges, 7 blend, 8 whole frame */
+     * 0 repack, 1 preprocess + compaction of the visible Gaussians, 2 sizing pass (0 in steady
+     * state), 3 depth sort, 4 pair expansion, 5 tile sort, 6 ranges, 7 blend, 8 whole frame */
     double stage_ms[12];
 } gs_frame_stats;
 
@@ -478,17 +482,43 @@ gs_status gs_renderer_reset_stats(gs_renderer *r);
 /* blocking: synchronises the stream of the last frame first */
 gs_status gs_renderer_stats(gs_renderer *r, gs_frame_stats *out);
 
-/* One frame: repack (if the Gaussians changed) -> preprocess -> scan/compact -> depth sort of the
- * visible Gaussians -> pair expansion in depth order -> stable tile sort -> tile ranges -> blend.  Renders tile rows [band_ty0, band_ty1) (16-pixel rows; pass 0 and
- * UINT32_MAX for the whole image) into rgba_out_device, a device pointer to the FULL
- * height x width x 4 f32 image (16-byte aligned); only the band's rows are written.  All three
- * GaussianDisplayModes of the transform are rendered (Splat: Gaussian falloff; Ellipse: flat alpha
- * inside the max_std_dev ellipse; Point: flat alpha inside a 1.5-pixel dot — DESIGN.md §3.5a).
- * GS_ERR_PAIR_OVERFLOW when the frame would need more than 2^32 (tile, Gaussian) pairs. */
+/* One frame: repack (if the Gaussians changed) -> preprocess + ordered compaction of the visible
+ * Gaussians -> depth sort -> pair expansion in depth order -> stable tile sort -> tile ranges ->
+ * blend.  Renders tile rows [band_ty0, band_ty1) (16-pixel rows; pass 0 and UINT32_MAX for the whole
+ * image) into rgba_out_device, a device pointer to the FULL height x width x 4 f32 image (16-byte
+ * aligned); only the band's rows are written.  All three GaussianDisplayModes of the transform are
+ * rendered (Splat: Gaussian falloff; Ellipse: flat alpha inside the max_std_dev ellipse; Point:
+ * flat alpha inside a 1.5-pixel dot — DESIGN.md §3.5a).
+ *
+ * (A)synchrony — the analogue of ComputeBundle::dispatch recording into a CommandEncoder that
+ * executes at queue.submit (src/compute_bundle.rs:114-132): the call only ENQUEUES work on `s` and
+ * returns; the image is complete when the stream has been synchronised (or gs_renderer_wait_frame
+ * has returned).  The visible count V and the pair count D never come back to the host inside a
+ * frame: grids are sized from host-side bounds and the kernels read V and D on the device.
+ * The one exception is a SIZING frame — the first frame of a renderer, or the first after the
+ * Gaussian count, image size or band changed — which blocks once in the middle to measure D and
+ * size the pair buffers (GS_ERR_PAIR_OVERFLOW if D would exceed 2^32).  Later frames take the
+ * capacity from the measured D of earlier frames (25 % head room, grown lazily: buffer growth calls
+ * hipFree, which synchronises the device).  If a frame nevertheless produces more pairs than fit,
+ * its farthest pairs are dropped and gs_renderer_wait_frame reports GS_ERR_PAIR_CAPACITY. */
 gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_buffer *gaussians,
                           const gs_gaussian_transform_pod *gaussian_transform,
                           const gs_model_transform_pod *model_transform, const gs_camera *camera,
                           uint32_t band_ty0, uint32_t band_ty1, float *rgba_out_device);
+
+typedef struct gs_frame_result {
+    uint64_t gaussians;       /* N */
+    uint64_t visible;         /* V */
+    uint64_t pairs;           /* D (the true count, also when it exceeded the capacity) */
+    uint64_t pair_capacity;   /* pairs the renderer's buffers hold */
+    uint32_t flags;           /* bit 0: pair capacity exceeded; bit 1: device-side wait timed out */
+    uint32_t launches;        /* kernel launches the frame enqueued (after the repack) */
+} gs_frame_result;
+
+/* Blocks until the last frame of `r` has completed and reports how it went: GS_OK,
+ * GS_ERR_PAIR_CAPACITY (render again), GS_ERR_PAIR_OVERFLOW (> 2^32 pairs) or GS_ERR_HIP.
+ * `out` may be NULL. */
+gs_status gs_renderer_wait_frame(gs_renderer *r, gs_frame_result *out);
 
 /* Parity taps on the last frame (blocking).  Sizes: N records / N counts; D keys / D indices;
  * tiles_x*tiles_y*2 ranges. */

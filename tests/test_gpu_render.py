@@ -188,29 +188,48 @@ def test_more_than_65536_tiles_uses_wide_tile_keys(gs, ob, device, stream):
     r.destroy()
 
 
+def _depth_bits(near, far):
+    """bits the depth sort covers: every visible depth lies in (near, far), so the keys
+    bits(depth) - bits(near) are below bits(far) - bits(near) — a bound the host knows without
+    reading anything back from the device"""
+    nb = int(np.float32(max(near, 0.0)).view(np.uint32))
+    fb = int(np.float32(far).view(np.uint32)) if far > 0 else 0
+    return (fb - nb).bit_length() if fb > nb else 0
+
+
+@pytest.mark.parametrize("planes", [(0.001, 100.0), (5.0, 20.0), (0.0, 1000.0), (9.99, 10.02)])
 @pytest.mark.parametrize("case", ["same_depth", "two_depths", "wide_range", "narrow_range"])
-def test_depth_key_ranges(gs, ob, device, stream, case):
-    """The depth sort orders (key - min key) with as few radix passes as the range needs: 0 passes
-    when every visible Gaussian has the same depth (order = index order), 9-bit digits for 19-27
-    significant bits, the 8-bit four-pass path for a near..far span of 1e5."""
+def test_depth_key_ranges(gs, ob, device, stream, case, planes):
+    """The depth sort's pass count comes from the camera's near / far planes alone (no read-back of
+    the scene's depth range inside a frame): 9-bit digits when they save a pass (19-27 bits), 8-bit
+    digits otherwise; scenes with all-equal, two-valued, wide and narrow depth distributions must
+    come out in exactly the oracle's order under every plan."""
     import synth
+    near, far = planes
     g = synth.scene(3000, first=999)
     rng = np.random.default_rng(11)
+    n0 = max(near, 1e-3)
+    span = min(far, 95.0) - n0
+    lo, hi = n0 + 0.02 * span, n0 + 0.98 * span
+    mid = np.float32(0.5 * (lo + hi))
     if case == "same_depth":
-        g["pos"][:, 2] = -7.25
+        g["pos"][:, 2] = -mid
     elif case == "two_depths":
-        g["pos"][:, 2] = np.where(rng.random(len(g)) < 0.5, -3.0, -3.0000002).astype(np.float32)
+        g["pos"][:, 2] = np.where(rng.random(len(g)) < 0.5, -mid, -np.nextafter(mid, np.float32(np.inf))).astype(np.float32)
     elif case == "wide_range":
-        g["pos"][:, 2] = -np.exp(rng.uniform(np.log(0.00102), np.log(95.0), len(g))).astype(np.float32)
+        glo = n0 * 1.02 if n0 * 1.02 < hi else lo     # log-uniform from just behind the near plane where that fits
+        g["pos"][:, 2] = -np.exp(rng.uniform(np.log(glo), np.log(hi), len(g))).astype(np.float32)
         g["pos"][:, :2] *= (-g["pos"][:, 2:3] / 14.0)
     else:
-        g["pos"][:, 2] = (-10.0 - rng.random(len(g)) * 1e-3).astype(np.float32)
+        g["pos"][:, 2] = (-mid * (1.0 - rng.random(len(g)) * 1e-4)).astype(np.float32)
+        g["pos"][:, :2] *= mid / 14.0
     st = _compare_frame(gs, ob, device, stream, gs.SH_NONE, gs.COV3D_ROT_SCALE, g, 640, 360,
-                        gt_kw=dict(sh_deg=0), cam_kw=dict(near=0.001, far=100.0))
+                        gt_kw=dict(sh_deg=0), cam_kw=dict(near=near, far=far))
     assert st.visible > 100
     tile_passes = 2   # 40 x 23 = 920 tiles -> 10 bits -> 5 + 5
-    depth_passes = st.sort_passes - tile_passes
-    assert depth_passes == {"same_depth": 0, "two_depths": 1, "wide_range": 4, "narrow_range": 2}[case], st.sort_passes
+    bits = _depth_bits(near, far)
+    p8, p9 = -(-bits // 8), -(-bits // 9)
+    assert st.sort_passes - tile_passes == min(p8, p9), (st.sort_passes, bits)
 
 
 @pytest.mark.parametrize("seed", [1, 2, 3])

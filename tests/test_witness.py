@@ -117,7 +117,7 @@ def test_hip_frame_matches_witness(gs, device, stream, name):
     """the HIP path straight against the witness (no oracle in between)"""
     w = lambda k: WIT["%s/%s" % (name, k)]
     cam, W, H = _uniforms(gs, name)
-    gt = gs.gaussian_transform_pod(size=float(w("size")), mode=0, sh_deg=int(w("sh_deg")), no_sh0=bool(w("no_sh0")),
+    gt = gs.gaussian_transform_pod(size=float(w("size")), display_mode=0, sh_deg=int(w("sh_deg")), no_sh0=bool(w("no_sh0")),
                                    max_std_dev=float(w("max_std_dev")))
     mt = gs.model_transform_pod(tuple(w("model_pos")), tuple(w("model_rot")), tuple(w("model_scale")))
     pod = gs.GaussianPodWithShSingleCov3dRotScaleConfigs

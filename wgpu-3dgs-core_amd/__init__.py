@@ -20,7 +20,7 @@ import ctypes as C
 import numpy as np
 
 from . import _capi
-from ._capi import Camera, FrameStats, GaussianTransformPod, Limits, ModelTransformPod
+from ._capi import Camera, FrameResult, FrameStats, GaussianTransformPod, Limits, ModelTransformPod
 
 _L = _capi.load()
 
@@ -139,11 +139,22 @@ class PairOverflowError(GsError):
     code = -23
 
 
+class PairCapacityError(GsError):
+    """gs_renderer_wait_frame: the frame produced more pairs than the renderer's buffers hold; its
+    farthest pairs were dropped.  The next frame grows the buffers: render again."""
+    code = -26
+
+    def __init__(self, info):
+        super().__init__(info)
+        self.pairs, self.capacity = info.a, info.b
+
+
 _ERRORS = {c.code: c for c in (InvalidArgumentError, NoDeviceError, HipError, OutOfMemoryError,
                                GaussiansBufferUpdateError, GaussiansBufferUpdateRangeError,
                                GaussiansBufferTryFromBufferError, FixedSizeBufferWrapperError,
                                ResourceCountMismatch, WorkgroupSizeExceedsDeviceLimit,
-                               LossyConfigError, DownloadBufferError, PlyError, SpzError, PairOverflowError)}
+                               LossyConfigError, DownloadBufferError, PlyError, SpzError, PairOverflowError,
+                               PairCapacityError)}
 
 
 def _check(status):
@@ -1062,11 +1073,29 @@ class Renderer:
         return st
 
     def render(self, stream, gaussians, gaussian_transform, model_transform, camera,
-               rgba_device_ptr, band=None):
+               rgba_device_ptr, band=None, check=True):
+        """gs_render_frame.  check=True (the validated use: tests, one-off renders) waits for the
+        frame and, if it exceeded the pair capacity sized from earlier frames, renders it again
+        with the grown buffers; check=False only enqueues (the pipelined use: a viewer's frame
+        loop, bench.py) — call wait_frame() / synchronise the stream before reading the image."""
         b0, b1 = band if band is not None else (0, 0xFFFFFFFF)
-        _check(_L.gs_render_frame(self._h, stream._h, gaussians._h, C.byref(gaussian_transform),
-                                  C.byref(model_transform), C.byref(camera), b0, b1,
-                                  C.c_void_p(rgba_device_ptr)))
+        for attempt in range(4):
+            _check(_L.gs_render_frame(self._h, stream._h, gaussians._h, C.byref(gaussian_transform),
+                                      C.byref(model_transform), C.byref(camera), b0, b1,
+                                      C.c_void_p(rgba_device_ptr)))
+            if not check:
+                return None
+            try:
+                return self.wait_frame()
+            except PairCapacityError:
+                if attempt == 3:
+                    raise
+
+    def wait_frame(self):
+        """blocks until the last frame has completed; raises PairCapacityError / PairOverflowError"""
+        fr = FrameResult()
+        _check(_L.gs_renderer_wait_frame(self._h, C.byref(fr)))
+        return fr
 
     def download_projected(self, n):
         proj = np.zeros(n, dtype=PROJECTED_DTYPE)

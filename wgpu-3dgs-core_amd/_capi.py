@@ -41,6 +41,11 @@ class FrameStats(C.Structure):
                 ("stage_ms", C.c_double * 12)]
 
 
+class FrameResult(C.Structure):
+    _fields_ = [("gaussians", u64), ("visible", u64), ("pairs", u64), ("pair_capacity", u64),
+                ("flags", u32), ("launches", u32)]
+
+
 class BundleDesc(C.Structure):
     _fields_ = [("label", C.c_char_p), ("kernel", i32), ("sh", i32), ("cov", i32),
                 ("bind_group_count", u32), ("bindings_per_group", C.POINTER(u32)),
@@ -154,6 +159,7 @@ SIGNATURES = {
     "gs_renderer_set_timing": (i32, [vp, i32]),
     "gs_renderer_reset_stats": (i32, [vp]),
     "gs_renderer_stats": (i32, [vp, vp]),
+    "gs_renderer_wait_frame": (i32, [vp, vp]),
     "gs_render_frame": (i32, [vp, vp, vp, vp, vp, vp, u32, u32, vp]),
     "gs_renderer_download_projected": (i32, [vp, vp, vp, sz]),
     "gs_renderer_download_sorted": (i32, [vp, vp, vp, u64, vp]),

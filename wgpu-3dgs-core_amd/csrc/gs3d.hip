@@ -80,7 +80,8 @@ extern "C" const char *gs_status_string(gs_status s) {
     case GS_ERR_KERNEL_COMPILE: return "kernel compilation failed";
     case GS_ERR_LOSSY_CONFIG: return "configuration cannot be converted back to a Gaussian";
     case GS_ERR_DOWNLOAD: return "buffer download failed";
-    case GS_ERR_PAIR_OVERFLOW: return "pair buffer overflow";
+    case GS_ERR_PAIR_OVERFLOW: return "more than 2^32 (tile, Gaussian) pairs";
+    case GS_ERR_PAIR_CAPACITY: return "pair capacity exceeded; render again";
     case GS_ERR_PLY: return "PLY read error";
     case GS_ERR_SPZ: return "SPZ read error";
     default: return "unknown";
@@ -386,8 +387,11 @@ extern "C" gs_status gs_device_create(int32_t ordinal, gs_device **out) {
         if (hipMalloc((void **)&bad, 4) == hipSuccess) {
             uint32_t h = 1;
             if (hipMemset(bad, 0, 4) == hipSuccess) {
-                hipLaunchKernelGGL(gs::k_probe_lds_atomic_order, dim3(512), dim3(256), 0, d->internal, 64u,
-                                   0x3D650001u, bad);
+                // both digit widths of the sorts (256 and 512 counters per wave), the scatter's own access pattern
+                hipLaunchKernelGGL(gs::k_probe_lds_atomic_order<8>, dim3(512), dim3(gs::SORT_THREADS), 0, d->internal,
+                                   8u, 0x3D650001u, bad);
+                hipLaunchKernelGGL(gs::k_probe_lds_atomic_order<9>, dim3(512), dim3(gs::SORT_THREADS), 0, d->internal,
+                                   8u, 0x3D650002u, bad);
                 if (hipStreamSynchronize(d->internal) == hipSuccess &&
                     hipMemcpy(&h, bad, 4, hipMemcpyDeviceToHost) == hipSuccess)
                     d->lds_atomic_ordered = (h == 0);
@@ -1222,20 +1226,39 @@ static void dev_free(DevArray &a) {
 // stage indices of gs_frame_stats.stage_ms
 enum { ST_REPACK = 0, ST_PRE, ST_SCAN, ST_DSORT, ST_EXPAND, ST_TSORT, ST_RANGES, ST_BLEND, ST_FRAME, ST_COUNT };
 
+// what sized the scratch of the last frame: a change means the pair count may jump, so the next
+// frame measures it first (one blocking "sizing" frame) instead of trusting the history
+struct FrameShape {
+    uint64_t n = 0;
+    uint32_t width = 0, height = 0, band0 = 0, band1 = 0;
+    bool operator==(const FrameShape &o) const {
+        return n == o.n && width == o.width && height == o.height && band0 == o.band0 && band1 == o.band1;
+    }
+};
+
 struct gs_renderer {
     gs_device *dev;
-    DevArray recs, depth, rect, sorted_rect, chunk_tiles, chunk_vis, chunk_range, chunk_tiles_off, chunk_vis_off, counters;
-    DevArray dkeys[2], dvals[2];          // (depth bits, Gaussian index), capacity N
-    DevArray exp_sums, exp_offsets;
-    DevArray tkeys[2], tvals[2];          // (tile id, Gaussian index), capacity pair_capacity
-    DevArray ghist, digit_totals, ranges;
-    uint32_t *host_counters;  // pinned: [0] = D, [1] = V, [2] = D (depth order; must equal [0])
+    DevArray recs, rect, chunk_tiles, chunk_vis, pre_status, exp_status, state, zero_region, scan_tmp;
+    DevArray dkeys[2], dvals[2];          // (depth bits - bias, mirror slot), capacity N
+    DevArray tkeys[2], tvals[2];          // (tile id, mirror slot), capacity pair_capacity
+    DevArray ghist, digit_totals;
+    gs::FrameResult *results;             // pinned, [2]: one per frame parity
+    uint32_t *host_counters;              // pinned: sizing pass total
     uint64_t pair_capacity;
-    // last frame
-    uint64_t n, d, visible;
+    FrameShape shape;
+    uint32_t gen;                         // frame generation (look-back tag)
+    uint32_t ticket_pre_base, ticket_exp_base;
+    bool state_dirty;                     // a launch failed mid-frame: reset the device state first
+    hipEvent_t done[2];                   // end of the frame of each parity
+    bool done_valid[2];
+    uint32_t done_gen[2];
+    // last frame (host-side knowledge; V and D live in results[gen & 1])
+    uint64_t n;
     uint32_t tiles_x, tiles_y, sort_passes;
+    uint32_t key_bias;
     int dsorted_side, tsorted_side;
     bool wide_tiles;  // tile keys are u32 (more than 65536 tiles) instead of u16
+    uint32_t launches;                    // kernel launches of the last frame (diagnostic)
     hipStream_t last_stream;
     gs_buffer *last_order;   // mirror order of the last frame's buffer (null = index order), for the taps
     // timing
@@ -1253,16 +1276,32 @@ extern "C" gs_status gs_renderer_create(gs_device *dev, gs_renderer **out) {
     gs_renderer *r = new gs_renderer();
     r->dev = dev;
     r->host_counters = nullptr;
+    r->results = nullptr;
     hipError_t e = hipHostMalloc((void **)&r->host_counters, 64, hipHostMallocMapped | hipHostMallocCoherent);
-    if (e != hipSuccess) {
-        delete r;
-        return fail(GS_ERR_HIP, (uint64_t)e, 0, 0, "hipHostMalloc failed: %s", hipGetErrorString(e));
+    if (e == hipSuccess)
+        e = hipHostMalloc((void **)&r->results, 2 * sizeof(gs::FrameResult), hipHostMallocMapped | hipHostMallocCoherent);
+    for (int i = 0; i < 2 && e == hipSuccess; i++) {
+        e = hipEventCreateWithFlags(&r->done[i], hipEventDisableTiming);
+        r->done_valid[i] = false;
+        r->done_gen[i] = 0;
     }
+    if (e != hipSuccess) {
+        if (r->host_counters) (void)hipHostFree(r->host_counters);
+        if (r->results) (void)hipHostFree(r->results);
+        delete r;
+        return fail(GS_ERR_HIP, (uint64_t)e, 0, 0, "renderer allocation failed: %s", hipGetErrorString(e));
+    }
+    std::memset(r->results, 0, 2 * sizeof(gs::FrameResult));
     r->pair_capacity = 0;
-    r->n = r->d = r->visible = 0;
+    r->gen = 0;
+    r->ticket_pre_base = r->ticket_exp_base = 0;
+    r->state_dirty = true;
+    r->n = 0;
     r->tiles_x = r->tiles_y = r->sort_passes = 0;
+    r->key_bias = 0;
     r->dsorted_side = r->tsorted_side = 0;
     r->wide_tiles = false;
+    r->launches = 0;
     r->last_stream = nullptr;
     r->last_order = nullptr;
     r->timing = false;
@@ -1277,13 +1316,15 @@ extern "C" gs_status gs_renderer_create(gs_device *dev, gs_renderer **out) {
 extern "C" void gs_renderer_destroy(gs_renderer *r) {
     if (!r) return;
     (void)hipSetDevice(r->dev->ordinal);
-    DevArray *arrs[] = {&r->recs, &r->depth, &r->rect, &r->sorted_rect, &r->chunk_tiles, &r->chunk_vis, &r->chunk_range,
-                        &r->chunk_tiles_off, &r->chunk_vis_off, &r->counters, &r->dkeys[0],
-                        &r->dkeys[1], &r->dvals[0], &r->dvals[1], &r->exp_sums, &r->exp_offsets,
-                        &r->tkeys[0], &r->tkeys[1], &r->tvals[0], &r->tvals[1], &r->ghist,
-                        &r->digit_totals, &r->ranges};
+    if (r->last_stream) (void)hipStreamSynchronize(r->last_stream);   // kernels of the last frame write pinned memory
+    DevArray *arrs[] = {&r->recs, &r->rect, &r->chunk_tiles, &r->chunk_vis, &r->pre_status, &r->exp_status,
+                        &r->state, &r->zero_region, &r->scan_tmp, &r->dkeys[0], &r->dkeys[1], &r->dvals[0],
+                        &r->dvals[1], &r->tkeys[0], &r->tkeys[1], &r->tvals[0], &r->tvals[1], &r->ghist,
+                        &r->digit_totals};
     for (DevArray *a : arrs) dev_free(*a);
     if (r->host_counters) (void)hipHostFree(r->host_counters);
+    if (r->results) (void)hipHostFree(r->results);
+    for (auto &e : r->done) (void)hipEventDestroy(e);
     if (r->last_order) gs_buffer_release(r->last_order);
     if (r->ev_valid)
         for (auto &e : r->ev) (void)hipEventDestroy(e);
@@ -1327,15 +1368,50 @@ extern "C" gs_status gs_renderer_reset_stats(gs_renderer *r) {
     return GS_OK;
 }
 
+// result block of the most recent frame (valid once its stream work has completed)
+static const gs::FrameResult &last_result(const gs_renderer *r) { return r->results[r->gen & 1u]; }
+
+extern "C" gs_status gs_renderer_wait_frame(gs_renderer *r, gs_frame_result *out) {
+    if (!r) return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "null renderer");
+    GS_TRY(use_device(r->dev));
+    if (out) std::memset(out, 0, sizeof(*out));
+    if (!r->last_stream) return GS_OK;      // no frame yet
+    GS_HIP(hipStreamSynchronize(r->last_stream));
+    const gs::FrameResult &fr = last_result(r);
+    if (out) {
+        out->gaussians = r->n;
+        out->visible = fr.visible;
+        out->pairs = fr.pairs_total;
+        out->pair_capacity = r->pair_capacity;
+        out->flags = fr.flags;
+        out->launches = r->launches;
+    }
+    if (fr.gen != r->gen)
+        return fail(GS_ERR_HIP, fr.gen, r->gen, 0, "the frame did not complete (result generation %u, expected %u)",
+                    fr.gen, r->gen);
+    if (fr.flags & gs::FRAME_FLAG_SPIN_TIMEOUT)
+        return fail(GS_ERR_HIP, fr.flags, 0, 0, "a device-side look-back timed out; the frame is invalid");
+    if (fr.pairs_total > 0xfffffff0ull)
+        return fail(GS_ERR_PAIR_OVERFLOW, r->n, 0, 0,
+                    "the frame needs more than 2^32 (tile, Gaussian) pairs; pair indices are 32-bit");
+    if (fr.flags & gs::FRAME_FLAG_PAIR_OVERFLOW)
+        return fail(GS_ERR_PAIR_CAPACITY, fr.pairs_total, r->pair_capacity, 0,
+                    "the frame produced %llu (tile, Gaussian) pairs but the pair buffers hold %llu: its farthest pairs "
+                    "were dropped; render again (the next frame grows the buffers)",
+                    (unsigned long long)fr.pairs_total, (unsigned long long)r->pair_capacity);
+    return GS_OK;
+}
+
 extern "C" gs_status gs_renderer_stats(gs_renderer *r, gs_frame_stats *out) {
     if (!r || !out) return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "null argument");
     GS_TRY(use_device(r->dev));
-    GS_HIP(hipStreamSynchronize(r->last_stream));
+    if (r->last_stream) GS_HIP(hipStreamSynchronize(r->last_stream));
     GS_TRY(collect_timing(r));
     std::memset(out, 0, sizeof(*out));
+    const gs::FrameResult &fr = last_result(r);
     out->gaussians = r->n;
-    out->visible = r->visible;
-    out->pairs = r->d;
+    out->visible = r->last_stream ? fr.visible : 0;
+    out->pairs = r->last_stream ? fr.pairs_total : 0;
     out->tiles_x = r->tiles_x;
     out->tiles_y = r->tiles_y;
     out->sort_passes = r->sort_passes;
@@ -1345,8 +1421,7 @@ extern "C" gs_status gs_renderer_stats(gs_renderer *r, gs_frame_stats *out) {
     return GS_OK;
 }
 
-typedef void (*preprocess_fn)(const uint4 *, uint32_t, gs::FrameConsts, uint32_t *,
-                              uint32_t *, uint2 *, uint32_t *, uint32_t *, uint2 *, const float *);
+typedef void (*preprocess_fn)(const uint4 *, uint32_t, gs::FrameConsts, gs::PreOut);
 typedef void (*block_bounds_fn)(const uint4 *, uint32_t, float *);
 static preprocess_fn k_tbl_preprocess[4][3] = GS_CFG_TABLE(gs::k_preprocess);
 static preprocess_fn k_tbl_preprocess_banded[4][3] = GS_CFG_TABLE(gs::k_preprocess_banded);
@@ -1412,45 +1487,81 @@ static uint32_t bit_length(uint32_t v) {
     return b;
 }
 
-// Stable LSD radix sort of `count` (key, u32 value) pairs on key bits [0, end_bit), RB bits per
-// pass at most (digit widths balanced over the passes), ping-ponging between side 0 and side 1;
-// the side holding the result is returned.
+// Plan of one stable LSD radix sort: key bits [0, end_bit) in `passes` passes of at most `rb` bits
+// (digit widths balanced over the passes), grid of `nb` workgroups from the host-side BOUND of the
+// element count.  `fused` = the row scan is folded into the scatter kernel (two launches per pass
+// instead of three): every block then reads up to nb/32 + 31 counters per digit, which only pays
+// while the grid is small; each fused pass needs `sb_words` zeroed words (super-block sums).
+struct SortPlan {
+    uint32_t passes = 0, rb = 8, nb = 0, tile = 0, end_bit = 0;
+    bool fused = false;
+    uint32_t sb_stride = 0, sb_words = 0;
+};
+
+static SortPlan plan_sort(uint32_t count_bound, uint32_t end_bit, uint32_t rb, uint32_t tile, bool allow_fused) {
+    SortPlan p;
+    p.rb = rb;
+    p.tile = tile;
+    p.end_bit = end_bit;
+    p.passes = (end_bit + rb - 1) / rb;
+    p.nb = (uint32_t)(((uint64_t)count_bound + tile - 1) / tile);
+    const uint32_t R = 1u << rb;
+    static const bool fuse_off = std::getenv("GS3D_FUSED_SCAN") && std::getenv("GS3D_FUSED_SCAN")[0] == '0';
+    p.fused = allow_fused && !fuse_off && p.nb > 0 && (uint64_t)p.nb * R <= 300000ull;
+    p.sb_stride = (p.nb + gs::SORT_SB - 1) / gs::SORT_SB;
+    p.sb_words = p.fused ? R * p.sb_stride : 0;
+    return p;
+}
+
+// depth keys: 9-bit digits when that saves a pass (e.g. 27 significant bits: 3 passes instead of 4);
+// otherwise 8-bit digits, whose 256-bin tiles write longer runs and fit more workgroups per CU
+static uint32_t depth_radix_bits(uint32_t key_bits) {
+    return (key_bits + 8) / 9 < (key_bits + 7) / 8 ? (uint32_t)gs::RADIX_BITS_MAX : (uint32_t)gs::RADIX_BITS;
+}
+
+// Runs the plan on `st`, ping-ponging between side 0 and side 1; the side holding the result is
+// returned.  `sc` carries the host bound and, optionally, the device word holding the real count.
+// `sb` = zeroed super-block sums, plan.sb_words per pass (fused plans only).
 template <typename K, int RB>
-static gs_status sort_pairs_device_rb(const gs_device *dev, void *const keys[2], void *const vals[2],
-                                      DevArray &ghist, DevArray &digit_totals, uint32_t count,
-                                      uint32_t end_bit, hipStream_t st, int &result_side,
-                                      uint32_t &passes_out) {
+static gs_status run_sort_rb(const gs_device *dev, const SortPlan &plan, void *const keys[2], void *const vals[2],
+                             DevArray &ghist, DevArray &digit_totals, gs::SortCount sc, uint32_t *sb,
+                             hipStream_t st, int &result_side, uint32_t &launches) {
     constexpr uint32_t R = 1u << RB;
-    uint32_t passes = (end_bit + RB - 1) / RB;
-    passes_out = passes;
     result_side = 0;
-    if (count == 0 || passes == 0) return GS_OK;
-    const uint32_t tile = (uint32_t)gs::sort_tile<K>();
-    uint32_t nb = (uint32_t)(((uint64_t)count + tile - 1) / tile);
+    if (sc.count == 0 || plan.passes == 0) return GS_OK;
+    const uint32_t nb = plan.nb;
     GS_TRY(dev_reserve(ghist, (size_t)nb * R * 4));
     GS_TRY(dev_reserve(digit_totals, R * 4));
     int side = 0;
     uint32_t shift = 0;
-    for (uint32_t p = 0; p < passes; p++) {
-        // balanced digit widths: e.g. 13 bits -> 7 + 6, 15 -> 8 + 7, 25 -> 9 + 8 + 8, 32 -> 8 + 8 + 8 + 8
-        const uint32_t bits = (end_bit - shift + (passes - p) - 1) / (passes - p);
+    for (uint32_t p = 0; p < plan.passes; p++) {
+        // balanced digit widths: e.g. 13 bits -> 7 + 6, 15 -> 8 + 7, 27 -> 9 + 9 + 9, 32 -> 8 + 8 + 8 + 8
+        const uint32_t bits = (plan.end_bit - shift + (plan.passes - p) - 1) / (plan.passes - p);
         const uint32_t digit_mask = (1u << bits) - 1u;
         const K *kin = (const K *)keys[side];
         const uint32_t *vin = (const uint32_t *)vals[side];
         K *kout = (K *)keys[side ^ 1];
         uint32_t *vout = (uint32_t *)vals[side ^ 1];
-        hipLaunchKernelGGL((gs::k_sort_hist<K, RB>), dim3(nb), dim3(gs::SORT_THREADS), 0, st, kin, count,
-                           shift, digit_mask, (uint32_t *)ghist.ptr, nb);
-        hipLaunchKernelGGL(gs::k_sort_scan_rows, dim3(R), dim3(256), 0, st,
-                           (uint32_t *)ghist.ptr, nb, (uint32_t *)digit_totals.ptr);
-        if (dev->lds_atomic_ordered)
-            hipLaunchKernelGGL((gs::k_sort_scatter<K, true, RB>), dim3(nb), dim3(gs::SORT_THREADS), 0, st, kin,
-                               vin, kout, vout, count, shift, digit_mask, (const uint32_t *)ghist.ptr, nb,
-                               (const uint32_t *)digit_totals.ptr);
-        else
-            hipLaunchKernelGGL((gs::k_sort_scatter<K, false, RB>), dim3(nb), dim3(gs::SORT_THREADS), 0, st, kin,
-                               vin, kout, vout, count, shift, digit_mask, (const uint32_t *)ghist.ptr, nb,
-                               (const uint32_t *)digit_totals.ptr);
+        uint32_t *sbp = plan.fused ? sb + (size_t)p * plan.sb_words : nullptr;
+        hipLaunchKernelGGL((gs::k_sort_hist<K, RB>), dim3(nb), dim3(gs::SORT_THREADS), 0, st, kin, sc, shift,
+                           digit_mask, (uint32_t *)ghist.ptr, sbp, plan.sb_stride);
+        launches++;
+        if (!plan.fused) {
+            hipLaunchKernelGGL((gs::k_sort_scan_rows<gs::sort_tile<K>()>), dim3(R), dim3(256), 0, st,
+                               (uint32_t *)ghist.ptr, nb, sc, (uint32_t *)digit_totals.ptr);
+            launches++;
+        }
+#define GS_SCATTER(FAST, FUSED)                                                                                  \
+    hipLaunchKernelGGL((gs::k_sort_scatter<K, FAST, RB, FUSED>), dim3(nb), dim3(gs::SORT_THREADS), 0, st, kin,  \
+                       vin, kout, vout, sc, shift, digit_mask, (const uint32_t *)ghist.ptr,                     \
+                       (const uint32_t *)digit_totals.ptr, (const uint32_t *)sbp, plan.sb_stride)
+        if (dev->lds_atomic_ordered) {
+            if (plan.fused) GS_SCATTER(true, true); else GS_SCATTER(true, false);
+        } else {
+            if (plan.fused) GS_SCATTER(false, true); else GS_SCATTER(false, false);
+        }
+#undef GS_SCATTER
+        launches++;
         shift += bits;
         side ^= 1;
     }
@@ -1460,26 +1571,29 @@ static gs_status sort_pairs_device_rb(const gs_device *dev, void *const keys[2],
 }
 
 template <typename K>
+static gs_status run_sort(const gs_device *dev, const SortPlan &plan, void *const keys[2], void *const vals[2],
+                          DevArray &ghist, DevArray &digit_totals, gs::SortCount sc, uint32_t *sb, hipStream_t st,
+                          int &result_side, uint32_t &launches) {
+    if (plan.rb == (uint32_t)gs::RADIX_BITS_MAX) {
+        if constexpr (sizeof(K) == 4)
+            return run_sort_rb<K, gs::RADIX_BITS_MAX>(dev, plan, keys, vals, ghist, digit_totals, sc, sb, st,
+                                                      result_side, launches);
+    }
+    return run_sort_rb<K, gs::RADIX_BITS>(dev, plan, keys, vals, ghist, digit_totals, sc, sb, st, result_side,
+                                          launches);
+}
+
+// host-known count, three kernels per pass (spatial order build, stand-alone sort)
+template <typename K>
 static gs_status sort_pairs_device(const gs_device *dev, void *const keys[2], void *const vals[2],
                                    DevArray &ghist, DevArray &digit_totals, uint32_t count,
                                    uint32_t end_bit, hipStream_t st, int &result_side,
                                    uint32_t &passes_out) {
-    return sort_pairs_device_rb<K, gs::RADIX_BITS>(dev, keys, vals, ghist, digit_totals, count, end_bit, st,
-                                                   result_side, passes_out);
-}
-
-// Depth keys: 9-bit digits when that saves a pass (e.g. 25 significant bits: 3 passes instead of
-// 4); otherwise 8-bit digits, whose 256-bin tiles write longer runs and fit more workgroups per CU.
-static gs_status sort_depth_keys(const gs_device *dev, void *const keys[2], void *const vals[2],
-                                 DevArray &ghist, DevArray &digit_totals, uint32_t count,
-                                 uint32_t key_bits, hipStream_t st, int &result_side,
-                                 uint32_t &passes_out) {
-    const uint32_t p8 = (key_bits + 7) / 8, p9 = (key_bits + 8) / 9;
-    if (p9 < p8)
-        return sort_pairs_device_rb<uint32_t, gs::RADIX_BITS_MAX>(dev, keys, vals, ghist, digit_totals, count,
-                                                                  key_bits, st, result_side, passes_out);
-    return sort_pairs_device_rb<uint32_t, gs::RADIX_BITS>(dev, keys, vals, ghist, digit_totals, count, key_bits,
-                                                          st, result_side, passes_out);
+    const SortPlan plan = plan_sort(count, end_bit, gs::RADIX_BITS, (uint32_t)gs::sort_tile<K>(), false);
+    passes_out = plan.passes;
+    uint32_t launches = 0;
+    return run_sort<K>(dev, plan, keys, vals, ghist, digit_totals, gs::SortCount{count, nullptr}, nullptr, st,
+                       result_side, launches);
 }
 
 // (Re)build the block-planar mirror on `st`.  A whole-buffer rebuild in spatial mode first computes
@@ -1634,14 +1748,33 @@ extern "C" gs_status gs_gaussians_buffer_download_order(gs_gaussians_buffer *g, 
 
 static gs_status reserve_pairs(gs_renderer *r, uint64_t pairs, bool wide) {
     if (pairs <= r->pair_capacity && r->tkeys[0].ptr && wide == r->wide_tiles) return GS_OK;
-    uint64_t cap = pairs + pairs / 4 + 4096;
+    uint64_t cap = pairs;
     if (cap < r->pair_capacity) cap = r->pair_capacity;
+    if (cap > 0xfffffff0ull) cap = 0xfffffff0ull;   // pair indices are 32-bit
     for (int i = 0; i < 2; i++) {
-        GS_TRY(dev_reserve(r->tkeys[i], cap * (wide ? 4 : 2)));
-        GS_TRY(dev_reserve(r->tvals[i], cap * 4));
+        GS_TRY(dev_reserve(r->tkeys[i], cap * (wide ? 4 : 2) + 64));
+        GS_TRY(dev_reserve(r->tvals[i], cap * 4 + 64));
     }
     r->pair_capacity = cap;
     r->wide_tiles = wide;
+    return GS_OK;
+}
+
+// pair capacity for a frame expected to produce `d` pairs: 25 % head room for a moving camera
+static uint64_t capacity_for(uint64_t d) { return d + d / 4 + 65536; }
+
+static uint32_t float_bits(float f) {
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    return u;
+}
+
+// device memory that must start out as zeros (look-back words carry a generation tag instead of
+// being cleared every frame; tickets only ever count up)
+static gs_status reserve_zeroed(DevArray &a, size_t bytes, hipStream_t st) {
+    if (a.bytes >= bytes && a.ptr) return GS_OK;
+    GS_TRY(dev_reserve(a, bytes));
+    GS_HIP(hipMemsetAsync(a.ptr, 0, a.bytes, st));
     return GS_OK;
 }
 
@@ -1661,6 +1794,8 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
     uint32_t mode = gt->flags[0];
     if (mode > GS_DISPLAY_POINT)
         return fail(GS_ERR_INVALID_ARGUMENT, mode, 0, 0, "unknown GaussianDisplayMode %u", mode);
+    if (!(cam->near_plane >= 0.0f))
+        return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "the near plane must be >= 0 (depth keys are the bits of a positive float)");
     GS_TRY(use_device(r->dev));
     hipStream_t st = s->s;
     GS_TRY(collect_timing(r));
@@ -1676,11 +1811,30 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
     uint32_t n = (uint32_t)n64;
     uint32_t nchunks = (n + gs::PP_CHUNK - 1) / gs::PP_CHUNK;
     uint32_t num_tiles = fc.tiles_x * fc.tiles_y;
-    // one 1024-Gaussian chunk may touch at most chunk * num_tiles pairs: keep that inside 32 bits
+    // one 256-Gaussian expansion chunk may touch at most 256 * num_tiles pairs: keep that inside 32 bits
     if ((uint64_t)fc.tiles_x * fc.tiles_y > (1ull << 22))
         return fail(GS_ERR_INVALID_ARGUMENT, cam->width, cam->height, 0, "more than 2^22 tiles");
     const bool wide = num_tiles > 65536u;
     const size_t nn = n ? n : 1, nc = nchunks ? nchunks : 1;
+
+    // ---- what the previous frames told us (never blocks: an unfinished frame is simply not consulted) ----
+    uint64_t want_capacity = r->pair_capacity;
+    for (int i = 0; i < 2; i++) {
+        if (!r->done_valid[i] || hipEventQuery(r->done[i]) != hipSuccess) continue;
+        const gs::FrameResult &fr = r->results[i];
+        if (fr.gen != r->done_gen[i] || fr.pairs_total > 0xfffffff0ull) continue;
+        // grow when the last measured D leaves less than 1/8 of head room
+        if (fr.pairs_total + fr.pairs_total / 8 > r->pair_capacity && capacity_for(fr.pairs_total) > want_capacity)
+            want_capacity = capacity_for(fr.pairs_total);
+    }
+    (void)hipGetLastError();   // hipEventQuery reports hipErrorNotReady through the sticky error too
+    FrameShape shape;
+    shape.n = n;
+    shape.width = cam->width;
+    shape.height = cam->height;
+    shape.band0 = fc.band_ty0;
+    shape.band1 = fc.band_ty1;
+    const bool sizing = n != 0 && (r->pair_capacity == 0 || !(shape == r->shape) || r->state_dirty);
 
     mark(ST_REPACK);
     GS_TRY(ensure_planar(g, st));
@@ -1691,24 +1845,81 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
     mark(ST_PRE);
 
     GS_TRY(dev_reserve(r->recs, nn * 4 * gs::REC_WORDS + 16));
-    GS_TRY(dev_reserve(r->depth, nn * 4));
     GS_TRY(dev_reserve(r->rect, nn * 8));
-    GS_TRY(dev_reserve(r->sorted_rect, nn * 8));
     GS_TRY(dev_reserve(r->chunk_tiles, nc * 4));
     GS_TRY(dev_reserve(r->chunk_vis, nc * 4));
-    GS_TRY(dev_reserve(r->chunk_range, nc * 8));
-    GS_TRY(dev_reserve(r->chunk_tiles_off, nc * 4));
-    GS_TRY(dev_reserve(r->chunk_vis_off, nc * 4));
-    GS_TRY(dev_reserve(r->counters, 64));
-    GS_TRY(dev_reserve(r->ranges, (size_t)num_tiles * 8));
+    GS_TRY(dev_reserve(r->scan_tmp, nc * 4));
     for (int i = 0; i < 2; i++) {
         GS_TRY(dev_reserve(r->dkeys[i], nn * 4));
         GS_TRY(dev_reserve(r->dvals[i], nn * 4));
     }
-    uint32_t *counters = (uint32_t *)r->counters.ptr;
+    const uint32_t exp_grid = (n + gs::EXP_CHUNK - 1) / gs::EXP_CHUNK;   // V <= N
+    GS_TRY(reserve_zeroed(r->pre_status, nc * 8, st));
+    GS_TRY(reserve_zeroed(r->exp_status, (size_t)(exp_grid ? exp_grid : 1) * 8, st));
+    GS_TRY(reserve_zeroed(r->state, sizeof(gs::FrameState), st));
 
-    uint32_t d = 0, visible = 0;
-    if (n) {
+    // a new generation; on wrap of the narrowest tag (22 bits) or after a failed frame the
+    // look-back words and tickets start from scratch
+    r->gen++;
+    if (r->state_dirty || (r->gen & gs::LbWord<40>::GEN_MASK) == 0u) {
+        if ((r->gen & gs::LbWord<40>::GEN_MASK) == 0u) r->gen++;
+        GS_HIP(hipMemsetAsync(r->pre_status.ptr, 0, r->pre_status.bytes, st));
+        GS_HIP(hipMemsetAsync(r->exp_status.ptr, 0, r->exp_status.bytes, st));
+        GS_HIP(hipMemsetAsync(r->state.ptr, 0, sizeof(gs::FrameState), st));
+        r->ticket_pre_base = r->ticket_exp_base = 0;
+    }
+    r->state_dirty = true;     // cleared at the end of a fully enqueued frame
+    const uint32_t gen = r->gen;
+    gs::FrameState *state = (gs::FrameState *)r->state.ptr;
+    gs::FrameResult *result = &r->results[gen & 1u];
+    r->n = n;
+    r->tiles_x = fc.tiles_x;
+    r->tiles_y = fc.tiles_y;
+    r->last_stream = st;
+    r->launches = 0;
+
+    // depth keys = bits of the (positive) view depth minus the bits of the near plane: every visible
+    // depth lies in (near, far), so only bit_length(bits(far) - bits(near)) bits need sorting — a
+    // bound the host knows without looking at the scene
+    const uint32_t near_bits = float_bits(cam->near_plane > 0.0f ? cam->near_plane : 0.0f);
+    const uint32_t far_bits = cam->far_plane > 0.0f ? float_bits(cam->far_plane) : 0u;
+    const uint32_t dbits = far_bits > near_bits ? bit_length(far_bits - near_bits) : 0u;
+    r->key_bias = near_bits;
+    const uint32_t tile_bits = bit_length(num_tiles ? num_tiles - 1 : 0);
+
+    if (n == 0) {
+        // nothing to project: clear the ranges, blend the background
+        GS_TRY(dev_reserve(r->zero_region, (size_t)num_tiles * 8));
+        GS_HIP(hipMemsetAsync(r->zero_region.ptr, 0, (size_t)num_tiles * 8, st));
+        GS_TRY(reserve_pairs(r, 1, wide));
+        result->visible = 0;
+        result->pairs_total = 0;
+        result->flags = 0;
+        result->gen = gen;
+        mark(ST_SCAN); mark(ST_DSORT); mark(ST_EXPAND); mark(ST_TSORT); mark(ST_RANGES);
+        r->sort_passes = 0;
+        r->dsorted_side = r->tsorted_side = 0;
+    } else {
+        // ---- plans (host-side bounds only) ----
+        const SortPlan dplan = plan_sort(n, dbits, depth_radix_bits(dbits), (uint32_t)gs::sort_tile<uint32_t>(), true);
+        auto tile_plan = [&](uint64_t cap) {
+            return plan_sort((uint32_t)cap, tile_bits, gs::RADIX_BITS,
+                             wide ? (uint32_t)gs::sort_tile<uint32_t>() : (uint32_t)gs::sort_tile<uint16_t>(), true);
+        };
+        // the clear job of this frame: tile ranges + super-block sums of the fused sort passes.  The
+        // tile sort's share depends on the pair capacity, which a sizing frame only learns after
+        // preprocess: reserve for the worst case of a fused plan (<= 300000 words per pass)
+        const size_t ranges_words = (size_t)num_tiles * 2;
+        const size_t dsb_words = (size_t)dplan.passes * dplan.sb_words;
+        const size_t tsb_max = (size_t)((tile_bits + 7) / 8) * 300000u;
+        GS_TRY(dev_reserve(r->zero_region, (ranges_words + dsb_words + tsb_max) * 4));
+        uint32_t *zero = (uint32_t *)r->zero_region.ptr;
+        uint32_t *dsb = zero + ranges_words, *tsb = dsb + dsb_words;
+
+        if (!sizing && want_capacity > r->pair_capacity) GS_TRY(reserve_pairs(r, want_capacity, wide));
+        if (!sizing) GS_TRY(reserve_pairs(r, r->pair_capacity, wide));   // key width may have changed
+        SortPlan tplan = tile_plan(r->pair_capacity);
+
         // Records with SH take the two-phase kernel (geometry chunks first, SH chunks only for the
         // lanes that survive culling): with the mirror in spatial order whole 128-byte lines of
         // culled Gaussians are never fetched; with a random order it costs the same as the
@@ -1721,127 +1932,131 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
         // SH-less records are 48 bytes: the block test (one more dependent load per workgroup)
         // costs more than skipping them saves (measured at 1 M: +4 us on a 20 us kernel)
         if (block_cull_off || !g->block_bounds || !banded) fc.cull_gain = 0.0f;
+
+        gs::PreOut po;
+        po.recs = (uint32_t *)r->recs.ptr;
+        po.rect = (uint2 *)r->rect.ptr;
+        po.dkeys = (uint32_t *)r->dkeys[0].ptr;
+        po.dvals = (uint32_t *)r->dvals[0].ptr;
+        po.chunk_tiles = (uint32_t *)r->chunk_tiles.ptr;
+        po.chunk_vis = (uint32_t *)r->chunk_vis.ptr;
+        po.status = (unsigned long long *)r->pre_status.ptr;
+        po.state = state;
+        po.result = result;
+        po.zero_ptr = zero;
+        // a sizing frame does not know the tile plan yet: clear the whole reserved region
+        po.zero_words = (uint32_t)(ranges_words + dsb_words + (sizing ? tsb_max : (size_t)tplan.passes * tplan.sb_words));
+        po.gen = gen;
+        po.ticket_base = r->ticket_pre_base;
+        po.key_bias = near_bits;
+        po.nchunks = nchunks;
+        po.block_bounds = (const float *)g->block_bounds;
         hipLaunchKernelGGL((banded ? k_tbl_preprocess_banded : k_tbl_preprocess)[g->sh][g->cov], dim3(nchunks),
-                           dim3(gs::PP_THREADS), 0, st,
-                           (const uint4 *)g->planar, n, fc,
-                           (uint32_t *)r->recs.ptr, (uint32_t *)r->depth.ptr,
-                           (uint2 *)r->rect.ptr, (uint32_t *)r->chunk_tiles.ptr,
-                           (uint32_t *)r->chunk_vis.ptr, (uint2 *)r->chunk_range.ptr,
-                           (const float *)g->block_bounds);
+                           dim3(gs::PP_THREADS), 0, st, (const uint4 *)g->planar, n, fc, po);
+        GS_HIP(hipGetLastError());
+        r->ticket_pre_base += nchunks;
+        r->launches++;
         mark(ST_SCAN);
-        // the two grand totals (D, V) go straight into pinned host memory (device-visible through
-        // the unified address space): no separate copy launch, one stream wait below
-        gs::ScanJob jt{(const uint32_t *)r->chunk_tiles.ptr, (uint32_t *)r->chunk_tiles_off.ptr,
-                       r->host_counters + 0, nchunks};
-        gs::ScanJob jv{(const uint32_t *)r->chunk_vis.ptr, (uint32_t *)r->chunk_vis_off.ptr,
-                       r->host_counters + 1, nchunks, (const uint2 *)r->chunk_range.ptr,
-                       counters + 4, r->host_counters + 2};   // + (min, max) of the visible depth keys
-        hipLaunchKernelGGL(gs::k_scan_chunks, dim3(2), dim3(1024), 0, st, jt, jv);
-        GS_HIP(hipGetLastError());
-        // compaction does not depend on the counts: enqueue it before waiting for them
-        hipLaunchKernelGGL(gs::k_compact, dim3(nchunks), dim3(gs::PP_THREADS), 0, st,
-                           (const uint32_t *)r->depth.ptr, (const uint32_t *)r->chunk_vis_off.ptr, n,
-                           (uint32_t *)r->dkeys[0].ptr, (uint32_t *)r->dvals[0].ptr,
-                           (uint2 *)r->ranges.ptr, num_tiles, (const uint32_t *)(counters + 4),
-                           (const uint32_t *)r->chunk_vis.ptr);
-        GS_HIP(hipGetLastError());
-        GS_HIP(hipStreamSynchronize(st));
-        d = r->host_counters[0];
-        visible = r->host_counters[1];
-        if (d == 0xffffffffu)
-            return fail(GS_ERR_PAIR_OVERFLOW, n, 0, 0,
-                        "the frame needs more than 2^32 (tile, Gaussian) pairs; pair indices are 32-bit");
-    } else {
-        mark(ST_SCAN);
-    }
-    mark(ST_DSORT);
-    // depth sort of the visible Gaussians: u32 keys = bits of the (positive) view depth minus the
-    // smallest visible key, so only bit_length(max - min) bits need sorting
-    int dside = 0;
-    uint32_t dpasses = 0;
-    if (visible) {
-        void *k2[2] = {r->dkeys[0].ptr, r->dkeys[1].ptr};
-        void *v2[2] = {r->dvals[0].ptr, r->dvals[1].ptr};
-        const uint32_t dmin = r->host_counters[2], dmax = r->host_counters[3];
-        const uint32_t key_bits = dmax >= dmin ? bit_length(dmax - dmin) : 32u;
-        GS_TRY(sort_depth_keys(r->dev, k2, v2, r->ghist, r->digit_totals, visible, key_bits, st, dside, dpasses));
-    }
-    mark(ST_EXPAND);
-    GS_TRY(reserve_pairs(r, d, wide));
-    uint32_t vchunks = (visible + gs::EXP_CHUNK - 1) / gs::EXP_CHUNK;
-    if (visible) {
-        GS_TRY(dev_reserve(r->exp_sums, (size_t)vchunks * 4));
-        GS_TRY(dev_reserve(r->exp_offsets, (size_t)vchunks * 4));
-        const uint32_t *order = (const uint32_t *)r->dvals[dside].ptr;
-        hipLaunchKernelGGL(gs::k_expand_count, dim3(vchunks), dim3(gs::EXP_CHUNK), 0, st, order,
-                           (const uint2 *)r->rect.ptr, visible, (uint2 *)r->sorted_rect.ptr,
-                           (uint32_t *)r->exp_sums.ptr);
-        gs::ScanJob je{(const uint32_t *)r->exp_sums.ptr, (uint32_t *)r->exp_offsets.ptr, counters + 2,
-                       vchunks};
-        hipLaunchKernelGGL(gs::k_scan_chunks, dim3(1), dim3(1024), 0, st, je, je);
+
+        if (sizing) {
+            // First frame of this shape: measure D before sizing the pair buffers (the only blocking
+            // step; steady-state frames take the capacity from the history instead)
+            gs::ScanJob jt{(const uint32_t *)r->chunk_tiles.ptr, (uint32_t *)r->scan_tmp.ptr, r->host_counters, nchunks};
+            hipLaunchKernelGGL(gs::k_scan_chunks, dim3(1), dim3(1024), 0, st, jt, jt);
+            GS_HIP(hipGetLastError());
+            GS_HIP(hipStreamSynchronize(st));
+            const uint32_t d = r->host_counters[0];
+            if (d == 0xffffffffu) {
+                r->shape = FrameShape();
+                return fail(GS_ERR_PAIR_OVERFLOW, n, 0, 0,
+                            "the frame needs more than 2^32 (tile, Gaussian) pairs; pair indices are 32-bit");
+            }
+            const uint64_t cap = capacity_for(d) > want_capacity ? capacity_for(d) : want_capacity;
+            GS_TRY(reserve_pairs(r, cap, wide));
+            tplan = tile_plan(r->pair_capacity);
+        }
+        r->shape = shape;
+        const uint32_t capacity = (uint32_t)r->pair_capacity;
+        mark(ST_DSORT);
+
+        // ---- depth sort of the visible Gaussians (count V on the device, grid from N) ----
+        int dside = 0;
+        {
+            void *k2[2] = {r->dkeys[0].ptr, r->dkeys[1].ptr};
+            void *v2[2] = {r->dvals[0].ptr, r->dvals[1].ptr};
+            GS_TRY(run_sort<uint32_t>(r->dev, dplan, k2, v2, r->ghist, r->digit_totals,
+                                      gs::SortCount{n, &state->visible}, dsb, st, dside, r->launches));
+        }
+        mark(ST_EXPAND);
+
+        // ---- pairs in depth order ----
+        gs::ExpandIO eo;
+        eo.order = (const uint32_t *)r->dvals[dside].ptr;
+        eo.rect = (const uint2 *)r->rect.ptr;
+        eo.tvals = (uint32_t *)r->tvals[0].ptr;
+        eo.status = (unsigned long long *)r->exp_status.ptr;
+        eo.state = state;
+        eo.result = result;
+        eo.capacity = capacity;
+        eo.tiles_x = fc.tiles_x;
+        eo.gen = gen;
+        eo.ticket_base = r->ticket_exp_base;
         if (wide)
-            hipLaunchKernelGGL(gs::k_expand_emit<uint32_t>, dim3(vchunks), dim3(gs::EXP_CHUNK), 0, st,
-                               order, (const uint2 *)r->sorted_rect.ptr,
-                               (const uint32_t *)r->exp_offsets.ptr, visible, fc.tiles_x,
-                               (uint32_t *)r->tkeys[0].ptr, (uint32_t *)r->tvals[0].ptr,
-                               (uint32_t)(r->pair_capacity > 0xffffffffull ? 0xffffffffull : r->pair_capacity));
+            hipLaunchKernelGGL(gs::k_expand<uint32_t>, dim3(exp_grid), dim3(gs::EXP_CHUNK), 0, st, eo,
+                               (uint32_t *)r->tkeys[0].ptr);
         else
-            hipLaunchKernelGGL(gs::k_expand_emit<uint16_t>, dim3(vchunks), dim3(gs::EXP_CHUNK), 0, st,
-                               order, (const uint2 *)r->sorted_rect.ptr,
-                               (const uint32_t *)r->exp_offsets.ptr, visible, fc.tiles_x,
-                               (uint16_t *)r->tkeys[0].ptr, (uint32_t *)r->tvals[0].ptr,
-                               (uint32_t)(r->pair_capacity > 0xffffffffull ? 0xffffffffull : r->pair_capacity));
+            hipLaunchKernelGGL(gs::k_expand<uint16_t>, dim3(exp_grid), dim3(gs::EXP_CHUNK), 0, st, eo,
+                               (uint16_t *)r->tkeys[0].ptr);
         GS_HIP(hipGetLastError());
-    }
-    mark(ST_TSORT);
-    // stable sort on the tile id alone (pairs are already in depth order)
-    int tside = 0;
-    uint32_t tpasses = 0;
-    {
-        void *k2[2] = {r->tkeys[0].ptr, r->tkeys[1].ptr};
-        void *v2[2] = {r->tvals[0].ptr, r->tvals[1].ptr};
-        uint32_t tile_bits = bit_length(num_tiles ? num_tiles - 1 : 0);
-        if (wide)
-            GS_TRY(sort_pairs_device<uint32_t>(r->dev, k2, v2, r->ghist, r->digit_totals, d, tile_bits, st,
-                                               tside, tpasses));
-        else
-            GS_TRY(sort_pairs_device<uint16_t>(r->dev, k2, v2, r->ghist, r->digit_totals, d, tile_bits, st,
-                                               tside, tpasses));
-    }
-    mark(ST_RANGES);
-    if (!n) GS_HIP(hipMemsetAsync(r->ranges.ptr, 0, (size_t)num_tiles * 8, st));   // otherwise k_compact cleared them
-    if (d) {
-        if (wide)
-            hipLaunchKernelGGL(gs::k_tile_ranges<uint32_t>, dim3((uint32_t)(((uint64_t)d + 1023) / 1024)), dim3(256), 0, st,
-                               (const uint32_t *)r->tkeys[tside].ptr, d, (uint32_t *)r->ranges.ptr);
-        else
-            hipLaunchKernelGGL(gs::k_tile_ranges<uint16_t>, dim3((uint32_t)(((uint64_t)d + 2047) / 2048)), dim3(256), 0, st,
-                               (const uint16_t *)r->tkeys[tside].ptr, d, (uint32_t *)r->ranges.ptr);
-        GS_HIP(hipGetLastError());
+        r->ticket_exp_base += exp_grid;
+        r->launches++;
+        mark(ST_TSORT);
+
+        // ---- stable sort on the tile id alone (pairs are already in depth order) ----
+        int tside = 0;
+        const gs::SortCount tc{capacity, &state->pairs};
+        {
+            void *k2[2] = {r->tkeys[0].ptr, r->tkeys[1].ptr};
+            void *v2[2] = {r->tvals[0].ptr, r->tvals[1].ptr};
+            if (wide)
+                GS_TRY(run_sort<uint32_t>(r->dev, tplan, k2, v2, r->ghist, r->digit_totals, tc, tsb, st, tside, r->launches));
+            else
+                GS_TRY(run_sort<uint16_t>(r->dev, tplan, k2, v2, r->ghist, r->digit_totals, tc, tsb, st, tside, r->launches));
+        }
+        mark(ST_RANGES);
+        if (capacity) {
+            if (wide)
+                hipLaunchKernelGGL(gs::k_tile_ranges<uint32_t>, dim3((uint32_t)(((uint64_t)capacity + 1023) / 1024)), dim3(256), 0, st,
+                                   (const uint32_t *)r->tkeys[tside].ptr, tc, zero);
+            else
+                hipLaunchKernelGGL(gs::k_tile_ranges<uint16_t>, dim3((uint32_t)(((uint64_t)capacity + 2047) / 2048)), dim3(256), 0, st,
+                                   (const uint16_t *)r->tkeys[tside].ptr, tc, zero);
+            GS_HIP(hipGetLastError());
+            r->launches++;
+        }
+        r->sort_passes = dplan.passes + tplan.passes;
+        r->dsorted_side = dside;
+        r->tsorted_side = tside;
     }
     mark(ST_BLEND);
     uint32_t band_tiles = (fc.band_ty1 - fc.band_ty0) * fc.tiles_x;
     if (band_tiles) {
         auto blend = mode == GS_DISPLAY_SPLAT ? gs::k_blend<0> : mode == GS_DISPLAY_ELLIPSE ? gs::k_blend<1> : gs::k_blend<2>;
         hipLaunchKernelGGL(blend, dim3(band_tiles), dim3(gs::BLEND_THREADS), 0, st,
-                           (const uint32_t *)r->ranges.ptr, (const uint32_t *)r->tvals[tside].ptr,
+                           (const uint32_t *)r->zero_region.ptr, (const uint32_t *)r->tvals[r->tsorted_side].ptr,
                            (const uint32_t *)r->recs.ptr, fc, (float4 *)rgba);
         GS_HIP(hipGetLastError());
+        r->launches++;
     }
     mark(ST_FRAME);
     if (timing) {
         (void)hipEventRecord(r->ev[ST_COUNT], st);
         r->ev_pending = true;
     }
-    r->n = n;
-    r->d = d;
-    r->visible = visible;
-    r->tiles_x = fc.tiles_x;
-    r->tiles_y = fc.tiles_y;
-    r->sort_passes = dpasses + tpasses;
-    r->dsorted_side = dside;
-    r->tsorted_side = tside;
-    r->last_stream = st;
+    GS_HIP(hipEventRecord(r->done[gen & 1u], st));
+    r->done_valid[gen & 1u] = true;
+    r->done_gen[gen & 1u] = gen;
+    r->state_dirty = false;
     return GS_OK;
 }
 
@@ -1854,8 +2069,24 @@ static gs_status download_sync(gs_renderer *r, void *dst, const void *src, size_
     return GS_OK;
 }
 
-// The device keeps the projected data as three dense arrays (36-byte blend record, depth key,
-// tile rect); the 48-byte gs_projected view of DESIGN.md §3.3 is assembled here.
+// depth bits of every mirror slot of the last frame (0xffffffff = culled), rebuilt from the depth
+// sort's (key - bias, slot) pairs: the frame keeps no dense depth array
+static gs_status download_slot_depths(gs_renderer *r, std::vector<uint32_t> &depth) {
+    depth.assign(r->n, 0xffffffffu);
+    if (!r->last_stream) return GS_OK;
+    GS_HIP(hipStreamSynchronize(r->last_stream));
+    const size_t v = last_result(r).visible;
+    if (!v) return GS_OK;
+    std::vector<uint32_t> keys(v), slots(v);
+    GS_TRY(download_sync(r, keys.data(), r->dkeys[r->dsorted_side].ptr, v * 4));
+    GS_TRY(download_sync(r, slots.data(), r->dvals[r->dsorted_side].ptr, v * 4));
+    for (size_t j = 0; j < v; j++)
+        if (slots[j] < r->n) depth[slots[j]] = keys[j] + r->key_bias;
+    return GS_OK;
+}
+
+// The device keeps the projected data as dense per-slot arrays (36-byte blend record, tile rect)
+// plus the compacted depth keys; the 48-byte gs_projected view of DESIGN.md §3.3 is assembled here.
 extern "C" gs_status gs_renderer_download_projected(gs_renderer *r, gs_projected *proj_out,
                                                     uint32_t *tiles_out, size_t n) {
     if (!r) return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "null renderer");
@@ -1865,23 +2096,21 @@ extern "C" gs_status gs_renderer_download_projected(gs_renderer *r, gs_projected
     if (!n) return GS_OK;
     // the device arrays are indexed by mirror slot; a partial request (n < N) still needs all slots
     const size_t total = r->n;
-    std::vector<uint32_t> recs(total * gs::REC_WORDS), depth(total), order;
+    std::vector<uint32_t> recs(total * gs::REC_WORDS), depth, order;
     std::vector<uint2> rect(total);
     GS_TRY(download_sync(r, recs.data(), r->recs.ptr, total * 4 * gs::REC_WORDS));
-    GS_TRY(download_sync(r, depth.data(), r->depth.ptr, total * 4));
+    GS_TRY(download_slot_depths(r, depth));
     GS_TRY(download_sync(r, rect.data(), r->rect.ptr, total * 8));
     if (r->last_order) {
         order.resize(total);
         GS_TRY(download_sync(r, order.data(), r->last_order->ptr, total * 4));
     }
-    const size_t nchunks = (total + gs::PP_CHUNK - 1) / gs::PP_CHUNK;
-    std::vector<uint32_t> chunk_vis(nchunks);
-    GS_TRY(download_sync(r, chunk_vis.data(), r->chunk_vis.ptr, nchunks * 4));
     for (size_t slot = 0; slot < total; slot++) {
         const size_t i = order.empty() ? slot : order[slot];   // Gaussian index of this slot
         if (i >= n) continue;
-        // a chunk with no visible Gaussian may have been block-culled: its per-slot arrays are stale
-        bool vis = chunk_vis[slot / gs::PP_CHUNK] != 0u && depth[slot] != 0xffffffffu;
+        // a slot absent from the depth keys is culled (its chunk may even have been block-culled,
+        // in which case its per-slot arrays are stale)
+        const bool vis = depth[slot] != 0xffffffffu;
         uint32_t w = (rect[slot].y & 0xffffu) - (rect[slot].x & 0xffffu),
                  h = (rect[slot].y >> 16) - (rect[slot].x >> 16);
         if (tiles_out) tiles_out[i] = vis ? w * h : 0u;
@@ -1907,8 +2136,11 @@ extern "C" gs_status gs_renderer_download_sorted(gs_renderer *r, uint64_t *keys_
                                                  uint64_t capacity, uint64_t *pairs_out) {
     if (!r) return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "null renderer");
     GS_TRY(use_device(r->dev));
-    if (pairs_out) *pairs_out = r->d;
-    uint64_t m = r->d < capacity ? r->d : capacity;
+    if (r->last_stream) GS_HIP(hipStreamSynchronize(r->last_stream));
+    uint64_t d = r->last_stream ? last_result(r).pairs_total : 0;
+    if (d > r->pair_capacity) d = r->pair_capacity;     // an overflowed frame only holds this many
+    if (pairs_out) *pairs_out = d;
+    uint64_t m = d < capacity ? d : capacity;
     if (!m) return GS_OK;
     std::vector<uint32_t> idx(m);   // mirror slots
     GS_TRY(download_sync(r, idx.data(), r->tvals[r->tsorted_side].ptr, m * 4));
@@ -1922,8 +2154,8 @@ extern "C" gs_status gs_renderer_download_sorted(gs_renderer *r, uint64_t *keys_
         }
     }
     if (keys_out) {
-        std::vector<uint32_t> depth(r->n);
-        GS_TRY(download_sync(r, depth.data(), r->depth.ptr, r->n * 4));
+        std::vector<uint32_t> depth;
+        GS_TRY(download_slot_depths(r, depth));
         if (r->wide_tiles) {
             std::vector<uint32_t> t(m);
             GS_TRY(download_sync(r, t.data(), r->tkeys[r->tsorted_side].ptr, m * 4));
@@ -1943,7 +2175,7 @@ extern "C" gs_status gs_renderer_download_ranges(gs_renderer *r, uint32_t *range
     if (num_tiles > (size_t)r->tiles_x * r->tiles_y)
         return fail(GS_ERR_INVALID_ARGUMENT, num_tiles, 0, 0, "too many tiles");
     GS_TRY(use_device(r->dev));
-    return download_sync(r, ranges_out, r->ranges.ptr, num_tiles * 8);
+    return download_sync(r, ranges_out, r->zero_region.ptr, num_tiles * 8);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -1,15 +1,18 @@
 // gs_render_kernels.h — hand-written gfx950 kernels of the render hot path:
-//   repack      AoS PODs -> chunk-planar mirror (16-byte chunks, one plane per chunk index)
+//   repack      AoS PODs -> block-planar mirror (16-byte chunks, one plane per chunk index and block)
 //   preprocess  unpack + model/view transform + SH evaluation + 3D->2D covariance projection
-//               + cull + tile rect  (HBM-read bound: the roofline kernel)
-//   scan        exclusive prefix of per-Gaussian tile counts (chunk sums fused into preprocess,
-//               per-chunk scan fused into emit)
-//   emit        64-bit (tile, depth) keys + u32 Gaussian index per overlapped tile
-//   sort        device-wide stable LSD radix sort, 8-bit digits, wave64 ballot ranking
+//               + cull + tile rect (HBM-read bound: the roofline kernel), fused with the ordered
+//               compaction of the visible Gaussians (decoupled look-back over the workgroups)
+//   depth sort  stable LSD radix sort of the V visible Gaussians on the bits of their view depth
+//   expand      (tile id, Gaussian) pairs in depth order, one per overlapped tile: gather of the
+//               tile rects, scan (decoupled look-back) and wave-cooperative emission in one kernel
+//   tile sort   stable LSD radix sort of the D pairs on the tile id alone (u16 keys up to 65536 tiles)
 //   ranges      per-tile [start, end) from key boundaries
-//   blend       one 256-thread workgroup per 16x16 tile, sorted splats staged through LDS,
-//               wave64 ballot compaction of non-contributing splats, front-to-back alpha blend
-// No MFMA anywhere: nothing here is a dense contraction.  wave = 64 lanes throughout.
+//   blend       one 128-thread workgroup per 16x16 tile, sorted splats staged through LDS,
+//               wave64 ballot compaction of non-contributing splats, packed-f32 front-to-back blend
+// All counts that only the device knows (V, D) stay on the device: grids are sized from host-side
+// upper bounds and surplus workgroups exit.  No MFMA anywhere: nothing here is a dense contraction.
+// wave = 64 lanes throughout.
 #pragma once
 
 #include "gs_kernel_lib.h"
@@ -123,6 +126,104 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_256(uint32_t v, uint32_
     total = w0 + w1 + w2 + w3;
     __syncthreads();
     return wave_off + inc - v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// device-resident frame state + decoupled look-back (single-pass chained scan over workgroups)
+// ---------------------------------------------------------------------------------------------
+
+// What only the device knows about the frame in flight.  The host never waits for it: grids are
+// sized from upper bounds (V <= N, D <= pair capacity), kernels read the counts from here, and the
+// results reach the host through `FrameResult` in pinned memory, read lazily.
+struct FrameState {
+    uint32_t ticket_pre;     // arrival tickets of k_preprocess*, monotonic over frames (host tracks the base)
+    uint32_t ticket_exp;     // same for k_expand
+    uint32_t visible;        // V
+    uint32_t pairs;          // min(D, pair capacity): what the tile sort / ranges / blend work on
+    uint32_t flags;          // FRAME_FLAG_*
+    uint32_t pad[3];
+};
+constexpr uint32_t FRAME_FLAG_PAIR_OVERFLOW = 1u;   // D exceeded the pair capacity: farthest pairs dropped
+constexpr uint32_t FRAME_FLAG_SPIN_TIMEOUT = 2u;    // a look-back gave up waiting (never expected)
+
+// pinned host memory, one per frame parity; written by the last workgroups of preprocess / expand
+struct FrameResult {
+    uint32_t visible;
+    uint32_t flags;
+    uint64_t pairs_total;    // true D, also when it exceeded the capacity
+    uint32_t gen;            // frame generation this result belongs to (written last)
+    uint32_t pad[3];
+};
+
+// Look-back status word: one naturally aligned 8-byte granule {generation | state | value}, stored
+// and polled with relaxed agent-scope atomics (sc1: L2-coherent across the 8 XCDs).  Flag and data
+// travel in the same granule, so no fence or ordering is needed around it.  The generation tag makes
+// zeroing the array between frames unnecessary: a word of an older frame reads as "not yet".
+constexpr uint32_t LB_NONE = 0u, LB_AGGREGATE = 1u, LB_INCLUSIVE = 2u;
+template <int VALUE_BITS> struct LbWord {
+    static constexpr int GEN_BITS = 62 - VALUE_BITS;
+    static constexpr uint64_t VALUE_MASK = (1ull << VALUE_BITS) - 1ull;
+    static constexpr uint32_t GEN_MASK = (uint32_t)((1ull << GEN_BITS) - 1ull);
+    static __device__ __forceinline__ uint64_t make(uint32_t gen, uint32_t state, uint64_t value) {
+        return ((uint64_t)(gen & GEN_MASK) << (VALUE_BITS + 2)) | ((uint64_t)state << VALUE_BITS) |
+               (value > VALUE_MASK ? VALUE_MASK : value);      // saturating: overflow stays detectable
+    }
+    static __device__ __forceinline__ uint32_t state_of(uint64_t w, uint32_t gen) {
+        return (uint32_t)(w >> (VALUE_BITS + 2)) == (gen & GEN_MASK) ? (uint32_t)(w >> VALUE_BITS) & 3u : LB_NONE;
+    }
+    static __device__ __forceinline__ uint64_t value_of(uint64_t w) { return w & VALUE_MASK; }
+};
+
+__device__ __forceinline__ void lb_store(unsigned long long *p, uint64_t w) {
+    __hip_atomic_store(p, (unsigned long long)w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint64_t lb_load(const unsigned long long *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// wave sum of a 64-bit value, uniform in every lane (all 64 lanes active)
+__device__ __forceinline__ uint64_t wave_reduce_add64(uint64_t v) {
+#pragma unroll
+    for (int d = WAVE / 2; d > 0; d >>= 1) v += __shfl_xor((unsigned long long)v, d, WAVE);
+    return v;
+}
+
+// Called by ONE full wave of workgroup `chunk` after it has published its aggregate: returns the
+// sum of the aggregates of all chunks < chunk (the exclusive prefix), uniform in every lane.  Lane l
+// inspects predecessor chunk-1-l, so one step covers 64 predecessors; the walk stops at the nearest
+// predecessor whose inclusive prefix is known.  Tickets are handed out in arrival order, so every
+// predecessor is already running or finished: the wait is bounded by one workgroup's lifetime.  The
+// spin itself is bounded too (a stuck wait sets FRAME_FLAG_SPIN_TIMEOUT instead of hanging the GPU).
+template <int VALUE_BITS>
+__device__ __forceinline__ uint64_t lookback_exclusive(const unsigned long long *status, uint32_t chunk,
+                                                       uint32_t gen, uint32_t lane, uint32_t *flags) {
+    typedef LbWord<VALUE_BITS> W;
+    uint64_t exclusive = 0;
+    int64_t idx = (int64_t)chunk - 1 - (int64_t)lane;
+    for (;;) {
+        uint64_t w = 0;
+        uint32_t st = LB_INCLUSIVE;      // chunks before the first count as "inclusive 0"
+        uint32_t first = 64;
+        for (uint32_t spins = 0;; spins++) {
+            if (idx >= 0) {
+                w = lb_load(status + idx);
+                st = W::state_of(w, gen);
+            }
+            const uint64_t valid = __ballot(st != LB_NONE), incl = __ballot(st == LB_INCLUSIVE);
+            first = incl ? (uint32_t)__builtin_ctzll(incl) : 64u;
+            const uint64_t need = first >= 63u ? ~0ull : ((2ull << first) - 1ull);   // lanes 0..first
+            if ((valid & need) == need) break;
+            if (spins > (1u << 22)) {    // ~seconds: give up, flag the frame, let the grid drain
+                if (lane == 0) atomicOr(flags, FRAME_FLAG_SPIN_TIMEOUT);
+                return exclusive;
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        const uint64_t v = (idx >= 0 && lane <= first) ? W::value_of(w) : 0ull;
+        exclusive += wave_reduce_add64(v);
+        if (first < 64u) return exclusive;
+        idx -= 64;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -601,45 +702,149 @@ __device__ __forceinline__ uint32_t project_one(const uint32_t *w, const FrameCo
 typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 constexpr int REC_WORDS = 9;   // blend record: mx, my, ca, cb, cc, opacity, r, g, b  (36 bytes)
 
+// Everything a preprocess workgroup writes besides the per-slot records (passed by value).
+struct PreOut {
+    uint32_t *recs;                  // [N][9] blend records, by mirror slot
+    uint2 *rect;                     // [N] tile rects (0 = culled), by mirror slot
+    uint32_t *dkeys, *dvals;         // [V] (depth bits - key_bias, slot) of the visible slots, in slot order
+    uint32_t *chunk_tiles;           // [chunks] sum of tiles touched (sizing pass, taps)
+    uint32_t *chunk_vis;             // [chunks] visible count (taps: 0 = the chunk may be block-culled and stale)
+    unsigned long long *status;      // [chunks] look-back words (LbWord<32>)
+    FrameState *state;
+    FrameResult *result;             // pinned host memory
+    uint32_t *zero_ptr;              // per-frame clear job spread over the grid (radix super-block sums, tile ranges)
+    uint32_t zero_words;
+    uint32_t gen, ticket_base, key_bias, nchunks;
+    const float *block_bounds;
+};
+
+// Arrival ticket = chunk index of this workgroup (dispatch order is not architecturally defined;
+// the ticket order is what makes "every predecessor is running or done" true for the look-back).
+// Also takes its share of the per-frame clear job.
+__device__ __forceinline__ uint32_t pre_begin(const PreOut &io, uint32_t *s_chunk) {
+    if (threadIdx.x == 0) *s_chunk = atomicAdd(&io.state->ticket_pre, 1u) - io.ticket_base;
+    __syncthreads();
+    const uint32_t chunk = *s_chunk;
+    for (uint32_t i = chunk * PP_THREADS + threadIdx.x; i < io.zero_words; i += io.nchunks * PP_THREADS)
+        io.zero_ptr[i] = 0u;
+    return chunk;
+}
+
+// wave 0 of the workgroup: publish the aggregate, look back, publish the inclusive prefix;
+// the last chunk also publishes the frame's V.  Returns the exclusive prefix (uniform).
+__device__ __forceinline__ uint32_t pre_publish(const PreOut &io, uint32_t chunk, uint32_t aggregate,
+                                                uint32_t lane) {
+    typedef LbWord<32> W;
+    if (lane == 0 && chunk + 1u < io.nchunks) lb_store(io.status + chunk, W::make(io.gen, LB_AGGREGATE, aggregate));
+    const uint32_t excl = (uint32_t)lookback_exclusive<32>(io.status, chunk, io.gen, lane, &io.state->flags);
+    if (lane == 0) {
+        lb_store(io.status + chunk, W::make(io.gen, LB_INCLUSIVE, (uint64_t)excl + aggregate));
+        if (chunk + 1u == io.nchunks) {
+            const uint32_t v = excl + aggregate;
+            io.state->visible = v;
+            io.state->pairs = 0u;            // k_expand's last workgroup sets it (no workgroup when V = 0)
+            io.result->visible = v;
+            if (v == 0u) {
+                io.result->pairs_total = 0ull;
+                io.result->flags = io.state->flags;
+                io.result->gen = io.gen;
+            }
+        }
+    }
+    return excl;
+}
+
+// Common tail of the preprocess kernels: ordered compaction of the chunk's visible slots.
+// s_key[j][t] = depth key (already biased) of slot base + j*PP_THREADS + t, 0xffffffff = culled.
+__device__ __forceinline__ void pre_finish(const PreOut &io, uint32_t chunk, uint32_t local_tiles,
+                                           uint32_t (*s_key)[PP_THREADS], uint32_t *s_cnt, uint32_t *s_misc) {
+    const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+    __syncthreads();
+    uint32_t key[PP_ITEMS];
+    uint64_t m[PP_ITEMS];
+#pragma unroll
+    for (int j = 0; j < PP_ITEMS; j++) {
+        key[j] = s_key[j][threadIdx.x];
+        m[j] = __ballot(key[j] != 0xffffffffu);
+        if (lane == 0) s_cnt[j * 4 + wid] = (uint32_t)__popcll(m[j]);
+    }
+    local_tiles = wave_reduce_add(local_tiles);
+    if (lane == 0) s_misc[wid] = local_tiles;
+    __syncthreads();
+    uint32_t before[PP_ITEMS], total = 0;   // visible slots of the chunk in front of (round j, my wave)
+#pragma unroll
+    for (int j = 0; j < PP_ITEMS; j++) {
+        before[j] = total;
+#pragma unroll
+        for (uint32_t w = 0; w < 4; w++) {
+            const uint32_t c = s_cnt[j * 4 + w];
+            if (w < wid) before[j] += c;
+            total += c;
+        }
+    }
+    if (wid == 0) {
+        const uint32_t excl = pre_publish(io, chunk, total, lane);
+        if (lane == 0) {
+            s_misc[4] = excl;
+            io.chunk_tiles[chunk] = (s_misc[0] + s_misc[1]) + (s_misc[2] + s_misc[3]);
+            io.chunk_vis[chunk] = total;
+        }
+    }
+    __syncthreads();
+    const uint32_t excl = s_misc[4];
+    const uint32_t base = chunk * PP_CHUNK;
+#pragma unroll
+    for (int j = 0; j < PP_ITEMS; j++) {
+        if (key[j] != 0xffffffffu) {
+            const uint32_t pos = excl + before[j] + mbcnt(m[j]);
+            io.dkeys[pos] = key[j];
+            io.dvals[pos] = base + j * PP_THREADS + threadIdx.x;
+        }
+    }
+}
+
+// whole block provably invisible: nothing is read, nothing visible; wave 0 keeps the look-back chain going
+__device__ __forceinline__ void pre_finish_culled(const PreOut &io, uint32_t chunk) {
+    if (threadIdx.x >= 64u) return;
+    pre_publish(io, chunk, 0u, threadIdx.x);
+    if (threadIdx.x == 0) {
+        io.chunk_tiles[chunk] = 0u;
+        io.chunk_vis[chunk] = 0u;
+    }
+}
+
 // Grid: one workgroup per PP_CHUNK Gaussians (= one block of the block-planar mirror).  One
 // global_load_dwordx4 per (lane, chunk): a wave reads 1 KiB contiguous per instruction.
-// Outputs per Gaussian, all written DENSELY (culled lanes store too): the 36-byte blend record,
-// the depth key (0xffffffff when culled) and the 8-byte tile rect (0 when culled).  Masking the
-// stores of culled lanes would leave holes in every 64-byte sector, which turns the writes into
-// read-modify-writes and costs 0.15 ms at 10 M Gaussians (measured); a dense store of a few
-// don't-care bytes is cheaper.  Per workgroup: tile-count sum and visible count (both feed scans).
+// Outputs per Gaussian, written DENSELY (culled lanes store too): the 36-byte blend record and the
+// 8-byte tile rect (0 when culled).  Masking the stores of culled lanes would leave holes in every
+// 64-byte sector, which turns the writes into read-modify-writes and costs 0.15 ms at 10 M
+// Gaussians on a randomly ordered mirror (measured); a dense store of a few don't-care bytes is
+// cheaper.  The visible slots' (depth key, slot) pairs are compacted in slot order straight into
+// the depth sort's input (pre_finish): no dense depth array, no separate scan / compaction kernels.
 //
 // What bounds it (tools/mb/mb_rw.hip, 10 M x 224 B on MI355X): the read pattern alone streams at
 // 6.3 TB/s (0.354 ms); every written byte costs about three read bytes, whatever the store
 // pattern — 4 B/Gaussian +0.035 ms, 12 B +0.083 ms, 48 B +0.165 ms as whole-array planes, as one
-// contiguous span per workgroup, staged through LDS and burst out, or as these 36+4+8-byte
-// streams.  This kernel runs within 2 % of that read+write floor; the order of loads and stores
-// in the loop, non-temporal hints and compacting away the culled records (-24 % written bytes)
-// were each measured and change nothing.
+// contiguous span per workgroup, staged through LDS and burst out, or as these streams.
 template <int SH, int COV>
-__global__ __launch_bounds__(PP_THREADS) void k_preprocess(
-    const uint4 *__restrict__ planar, uint32_t n, FrameConsts fc,
-    uint32_t *__restrict__ recs, uint32_t *__restrict__ depth, uint2 *__restrict__ rect,
-    uint32_t *__restrict__ chunk_tiles, uint32_t *__restrict__ chunk_vis,
-    uint2 *__restrict__ chunk_depth_range, const float *__restrict__ block_bounds) {
-    // whole block provably invisible (spatial order + block bounds): nothing is read or written
-    // but the three per-chunk scalars; k_compact and the taps skip chunks with zero visible
-    if (fc.cull_gain > 0.0f && block_is_culled(block_bounds + (uint64_t)blockIdx.x * 8u, fc)) {
-        if (threadIdx.x == 0) {
-            chunk_tiles[blockIdx.x] = 0u;
-            chunk_vis[blockIdx.x] = 0u;
-            chunk_depth_range[blockIdx.x] = make_uint2(0xffffffffu, 0u);
-        }
+__global__ __launch_bounds__(PP_THREADS) void k_preprocess(const uint4 *__restrict__ planar, uint32_t n,
+                                                           FrameConsts fc, PreOut io) {
+    __shared__ uint32_t s_key[PP_ITEMS][PP_THREADS];
+    __shared__ uint32_t s_cnt[PP_ITEMS * 4];
+    __shared__ uint32_t s_misc[8];
+    const uint32_t chunk = pre_begin(io, &s_misc[7]);
+    if (fc.cull_gain > 0.0f && block_is_culled(io.block_bounds + (uint64_t)chunk * 8u, fc)) {
+        pre_finish_culled(io, chunk);
         return;
     }
     constexpr int NW = pod_words(SH, COV);
     constexpr int NC = NW / 4;
-    __shared__ uint32_t s_red[16];
-    uint32_t base = blockIdx.x * PP_CHUNK;
-    uint32_t local = 0, local_vis = 0, dmin = 0xffffffffu, dmax = 0u;
+    const uint32_t base = chunk * PP_CHUNK;
+    uint32_t local = 0;
 #pragma unroll 1
     for (int k = 0; k < PP_ITEMS; k++) {
-        uint32_t i = base + k * PP_THREADS + threadIdx.x;
+        const uint32_t i = base + k * PP_THREADS + threadIdx.x;
+        uint32_t dkey = 0xffffffffu;
         if (i < n) {
             // Issue ALL of the record's loads back to back (NC x 1 KiB per wave in flight), then
             // pin them with empty asm statements: without this the compiler sinks each load next
@@ -658,77 +863,46 @@ __global__ __launch_bounds__(PP_THREADS) void k_preprocess(
                 w[4 * c + 3] = v[c].w;
             }
             uint4 rec[3];
-            uint32_t cnt = project_one<SH, COV>(w, fc, rec);
-            uint32_t *o = recs + (uint64_t)i * REC_WORDS;
+            const uint32_t cnt = project_one<SH, COV>(w, fc, rec);
+            uint32_t *o = io.recs + (uint64_t)i * REC_WORDS;
             *(u32x4_a4 *)(o) = u32x4_a4{rec[0].x, rec[0].y, rec[0].z, rec[0].w};
             *(u32x4_a4 *)(o + 4) = u32x4_a4{rec[1].x, rec[1].y, rec[1].z, rec[1].w};
             o[8] = rec[2].x;
-            depth[i] = cnt ? rec[2].y : 0xffffffffu;
-            rect[i] = cnt ? make_uint2(rec[2].z, rec[2].w) : make_uint2(0u, 0u);
+            io.rect[i] = cnt ? make_uint2(rec[2].z, rec[2].w) : make_uint2(0u, 0u);
             local += cnt;
-            local_vis += cnt ? 1u : 0u;
-            if (cnt) {
-                dmin = dmin < rec[2].y ? dmin : rec[2].y;
-                dmax = dmax > rec[2].y ? dmax : rec[2].y;
-            }
+            if (cnt) dkey = rec[2].y - io.key_bias;
         }
+        s_key[k][threadIdx.x] = dkey;
     }
-    local = wave_reduce_add(local);
-    local_vis = wave_reduce_add(local_vis);
-    dmin = wave_reduce_min(dmin);
-    dmax = wave_reduce_max(dmax);
-    uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
-    if (lane == 0) {
-        s_red[wid] = local;
-        s_red[4 + wid] = local_vis;
-        s_red[8 + wid] = dmin;
-        s_red[12 + wid] = dmax;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        chunk_tiles[blockIdx.x] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
-        chunk_vis[blockIdx.x] = (s_red[4] + s_red[5]) + (s_red[6] + s_red[7]);
-        // range of the visible depth keys: the depth sort only has to order (key - min), which for
-        // real scenes has 24-27 significant bits instead of 32 (fewer radix passes)
-        uint32_t lo = min(min(s_red[8], s_red[9]), min(s_red[10], s_red[11]));
-        uint32_t hi = max(max(s_red[12], s_red[13]), max(s_red[14], s_red[15]));
-        chunk_depth_range[blockIdx.x] = make_uint2(lo, hi);
-    }
+    pre_finish(io, chunk, local, s_key, s_cnt, s_misc);
 }
 
-// Two-phase variant for narrow tile-row bands (one rank of a multi-GPU frame): phase 1
-// loads only the chunks that hold position, colour and covariance, projects and band-culls; only
-// the surviving lanes then load their SH chunks (EXEC-masked loads: a 128-byte line none of whose
-// lanes survived is not fetched).  With Gaussians in user order a line of an SH plane holds 8
-// unrelated Gaussians, so at 8 bands about half of the SH lines are skipped (at 2 bands almost
-// none, and the second dependent round trip costs latency: the host uses this kernel only when the
-// band covers at most a quarter of the tile rows).  Same arithmetic, same outputs as k_preprocess.
+// Two-phase variant for records with SH: phase 1 loads only the chunks that hold position, colour
+// and covariance, projects and culls; only the surviving lanes then load their SH chunks
+// (EXEC-masked loads: a 128-byte line none of whose lanes survived is not fetched).  With the
+// mirror in spatial order the Gaussians a view (or a rank's tile-row band) culls fill whole lines.
+// Same arithmetic, same outputs as k_preprocess.
 template <int SH, int COV>
-__global__ __launch_bounds__(PP_THREADS) void k_preprocess_banded(
-    const uint4 *__restrict__ planar, uint32_t n, FrameConsts fc,
-    uint32_t *__restrict__ recs, uint32_t *__restrict__ depth, uint2 *__restrict__ rect,
-    uint32_t *__restrict__ chunk_tiles, uint32_t *__restrict__ chunk_vis,
-    uint2 *__restrict__ chunk_depth_range, const float *__restrict__ block_bounds) {
-    // whole block provably invisible (spatial order + block bounds): nothing is read or written
-    // but the three per-chunk scalars; k_compact and the taps skip chunks with zero visible
-    if (fc.cull_gain > 0.0f && block_is_culled(block_bounds + (uint64_t)blockIdx.x * 8u, fc)) {
-        if (threadIdx.x == 0) {
-            chunk_tiles[blockIdx.x] = 0u;
-            chunk_vis[blockIdx.x] = 0u;
-            chunk_depth_range[blockIdx.x] = make_uint2(0xffffffffu, 0u);
-        }
+__global__ __launch_bounds__(PP_THREADS) void k_preprocess_banded(const uint4 *__restrict__ planar, uint32_t n,
+                                                                  FrameConsts fc, PreOut io) {
+    __shared__ uint32_t s_key[PP_ITEMS][PP_THREADS];
+    __shared__ uint32_t s_cnt[PP_ITEMS * 4];
+    __shared__ uint32_t s_misc[8];
+    const uint32_t chunk = pre_begin(io, &s_misc[7]);
+    if (fc.cull_gain > 0.0f && block_is_culled(io.block_bounds + (uint64_t)chunk * 8u, fc)) {
+        pre_finish_culled(io, chunk);
         return;
     }
     constexpr int NW = pod_words(SH, COV);
     constexpr int NC = NW / 4;
     constexpr int G0 = cov_word0(SH) / 4;                              // first chunk holding covariance words
     constexpr int G1 = (cov_word0(SH) + cov_bytes(COV) / 4 - 1) / 4;   // last one
-    __shared__ uint32_t s_red[16];
-    uint32_t base = blockIdx.x * PP_CHUNK;
-    uint32_t local = 0, local_vis = 0, dmin = 0xffffffffu, dmax = 0u;
+    const uint32_t base = chunk * PP_CHUNK;
+    uint32_t local = 0;
 #pragma unroll 1
     for (int k = 0; k < PP_ITEMS; k++) {
-        uint32_t i = base + k * PP_THREADS + threadIdx.x;
+        const uint32_t i = base + k * PP_THREADS + threadIdx.x;
+        uint32_t dkey = 0xffffffffu;
         if (i < n) {
             uint32_t w[NW];
             uint4 v0 = planar[planar_at(0, i, NC)];
@@ -749,7 +923,7 @@ __global__ __launch_bounds__(PP_THREADS) void k_preprocess_banded(
             }
             uint4 rec[3];
             float d[3];
-            uint32_t cnt = project_geom<SH, COV>(w, fc, rec, d);
+            const uint32_t cnt = project_geom<SH, COV>(w, fc, rec, d);
             if (cnt) {
                 constexpr int S0 = 1, S1 = G0 - 1;   // SH-only chunks (G0.. were loaded above)
                 if constexpr (S1 >= S0) {
@@ -766,44 +940,25 @@ __global__ __launch_bounds__(PP_THREADS) void k_preprocess_banded(
                     }
                 }
                 shade_one<SH>(w, fc, d, rec);
-                dmin = dmin < rec[2].y ? dmin : rec[2].y;
-                dmax = dmax > rec[2].y ? dmax : rec[2].y;
+                dkey = rec[2].y - io.key_bias;
             }
             if (cnt || !fc.mask_culled_records) {
-            uint32_t *o = recs + (uint64_t)i * REC_WORDS;
-            *(u32x4_a4 *)(o) = u32x4_a4{rec[0].x, rec[0].y, rec[0].z, rec[0].w};
-            *(u32x4_a4 *)(o + 4) = u32x4_a4{rec[1].x, rec[1].y, rec[1].z, rec[1].w};
-            o[8] = rec[2].x;
+                uint32_t *o = io.recs + (uint64_t)i * REC_WORDS;
+                *(u32x4_a4 *)(o) = u32x4_a4{rec[0].x, rec[0].y, rec[0].z, rec[0].w};
+                *(u32x4_a4 *)(o + 4) = u32x4_a4{rec[1].x, rec[1].y, rec[1].z, rec[1].w};
+                o[8] = rec[2].x;
             }
-            depth[i] = cnt ? rec[2].y : 0xffffffffu;
-            rect[i] = cnt ? make_uint2(rec[2].z, rec[2].w) : make_uint2(0u, 0u);
+            io.rect[i] = cnt ? make_uint2(rec[2].z, rec[2].w) : make_uint2(0u, 0u);
             local += cnt;
-            local_vis += cnt ? 1u : 0u;
         }
+        s_key[k][threadIdx.x] = dkey;
     }
-    local = wave_reduce_add(local);
-    local_vis = wave_reduce_add(local_vis);
-    dmin = wave_reduce_min(dmin);
-    dmax = wave_reduce_max(dmax);
-    uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
-    if (lane == 0) {
-        s_red[wid] = local;
-        s_red[4 + wid] = local_vis;
-        s_red[8 + wid] = dmin;
-        s_red[12 + wid] = dmax;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        chunk_tiles[blockIdx.x] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
-        chunk_vis[blockIdx.x] = (s_red[4] + s_red[5]) + (s_red[6] + s_red[7]);
-        uint32_t lo = min(min(s_red[8], s_red[9]), min(s_red[10], s_red[11]));
-        uint32_t hi = max(max(s_red[12], s_red[13]), max(s_red[14], s_red[15]));
-        chunk_depth_range[blockIdx.x] = make_uint2(lo, hi);
-    }
+    pre_finish(io, chunk, local, s_key, s_cnt, s_misc);
 }
 
 // ---------------------------------------------------------------------------------------------
-// scan of per-chunk sums: one workgroup per array (blockIdx.x selects it)
+// scan of per-chunk sums: one workgroup per array (blockIdx.x selects it).  Used by the stand-alone
+// gs_exclusive_scan_u32 and by the frame's sizing pass (exact 64-bit-safe grand total of the tiles).
 // ---------------------------------------------------------------------------------------------
 
 struct ScanJob {
@@ -811,11 +966,6 @@ struct ScanJob {
     uint32_t *offsets;   // exclusive prefix per chunk
     uint32_t *total;     // grand total (may point into pinned host memory)
     uint32_t num;
-    // optional: (min, max) pairs per chunk reduced to one pair, written to range_out[0..1] (device)
-    // and range_host[0..1] (pinned host); null = no range job
-    const uint2 *ranges;
-    uint32_t *range_out;
-    uint32_t *range_host;
 };
 
 __global__ __launch_bounds__(1024) void k_scan_chunks(ScanJob j0, ScanJob j1) {
@@ -825,31 +975,14 @@ __global__ __launch_bounds__(1024) void k_scan_chunks(ScanJob j0, ScanJob j1) {
     __shared__ unsigned long long s_total64;   // exact grand total: past 32 bits it is reported as 0xffffffff
     const ScanJob job = blockIdx.x == 0 ? j0 : j1;
     uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
-    __shared__ uint32_t s_lo, s_hi;
     __shared__ uint32_t s_half[2];
     if (threadIdx.x == 0) {
         s_carry = 0;
         s_total64 = 0;
         s_half[0] = 0;
         s_half[1] = 0;
-        s_lo = 0xffffffffu;
-        s_hi = 0u;
     }
     __syncthreads();
-    if (job.ranges) {
-        uint32_t lo = 0xffffffffu, hi = 0u;
-        for (uint32_t i = threadIdx.x; i < job.num; i += 1024u) {
-            uint2 r = job.ranges[i];
-            lo = lo < r.x ? lo : r.x;
-            hi = hi > r.y ? hi : r.y;
-        }
-        lo = wave_reduce_min(lo);
-        hi = wave_reduce_max(hi);
-        if (lane == 0) {
-            atomicMin(&s_lo, lo);
-            atomicMax(&s_hi, hi);
-        }
-    }
     for (uint32_t base = 0; base < job.num; base += 1024u * PER) {
         uint32_t i0 = base + threadIdx.x * PER;
         uint32_t v[PER];
@@ -900,54 +1033,7 @@ __global__ __launch_bounds__(1024) void k_scan_chunks(ScanJob j0, ScanJob j1) {
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) {
-        *job.total = s_total64 > 0xfffffff0ull ? 0xffffffffu : s_carry;
-        if (job.ranges) {   // (all barriers of the loop above lie between the atomics and this read)
-            job.range_out[0] = s_lo;
-            job.range_out[1] = s_hi;
-            job.range_host[0] = s_lo;
-            job.range_host[1] = s_hi;
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// compact: visible Gaussians -> (depth bits, index) pairs in index order (input of the depth sort)
-// ---------------------------------------------------------------------------------------------
-
-__global__ __launch_bounds__(PP_THREADS) void k_compact(const uint32_t *__restrict__ depth,
-                                                        const uint32_t *__restrict__ vis_offsets,
-                                                        uint32_t n, uint32_t *__restrict__ dkeys,
-                                                        uint32_t *__restrict__ dvals,
-                                                        uint2 *__restrict__ ranges_to_clear,
-                                                        uint32_t num_tiles,
-                                                        const uint32_t *__restrict__ depth_range,
-                                                        const uint32_t *__restrict__ chunk_vis) {
-    __shared__ uint32_t s_scan[4];
-    const uint32_t key_bias = depth_range[0];   // minimum visible depth key (k_scan_chunks)
-    // side job: clear the per-tile ranges for this frame (saves a separate fill launch; every
-    // dependent kernel boundary costs ~4-5 us on this part, which matters for a 0.5 ms frame)
-    for (uint32_t t = blockIdx.x * PP_THREADS + threadIdx.x; t < num_tiles; t += gridDim.x * PP_THREADS)
-        ranges_to_clear[t] = make_uint2(0u, 0u);
-    if (chunk_vis[blockIdx.x] == 0u) return;   // nothing visible (possibly a block-culled chunk whose depth[] is stale)
-    uint32_t base = blockIdx.x * PP_CHUNK + threadIdx.x * PP_ITEMS;
-    uint32_t dk[PP_ITEMS];
-    uint32_t cnt = 0;
-#pragma unroll
-    for (int k = 0; k < PP_ITEMS; k++) {
-        dk[k] = base + k < n ? depth[base + k] : 0xffffffffu;
-        cnt += dk[k] != 0xffffffffu;
-    }
-    uint32_t total;
-    uint32_t off = vis_offsets[blockIdx.x] + block_exclusive_scan_256(cnt, s_scan, total);
-#pragma unroll
-    for (int k = 0; k < PP_ITEMS; k++) {
-        if (dk[k] != 0xffffffffu) {
-            dkeys[off] = dk[k] - key_bias;
-            dvals[off] = base + k;
-            off++;
-        }
-    }
+    if (threadIdx.x == 0) *job.total = s_total64 > 0xfffffff0ull ? 0xffffffffu : s_carry;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -957,53 +1043,52 @@ __global__ __launch_bounds__(PP_THREADS) void k_compact(const uint32_t *__restri
 // 64-bit (tile << 32 | depth) key.
 // ---------------------------------------------------------------------------------------------
 
-constexpr int EXP_CHUNK = 256;   // Gaussians per workgroup in the expansion kernels
+constexpr int EXP_CHUNK = 256;   // Gaussians per workgroup in the expansion kernel
 
-// Gather the tile rects into depth order (the only random access of the expansion: 8 bytes per
-// visible Gaussian from a compact array) and produce the per-chunk tile-count sums.
-__global__ __launch_bounds__(EXP_CHUNK) void k_expand_count(const uint32_t *__restrict__ order,
-                                                            const uint2 *__restrict__ rect,
-                                                            uint32_t v_count,
-                                                            uint2 *__restrict__ sorted_rect,
-                                                            uint32_t *__restrict__ sums) {
-    __shared__ uint32_t s_red[4];
-    uint32_t j = blockIdx.x * EXP_CHUNK + threadIdx.x;
-    uint32_t v = 0;
-    if (j < v_count) {
-        uint2 r = rect[order[j]];
-        sorted_rect[j] = r;
-        v = ((r.y & 0xffffu) - (r.x & 0xffffu)) * ((r.y >> 16) - (r.x >> 16));
-    }
-    v = wave_reduce_add(v);
-    if ((threadIdx.x & 63u) == 0) s_red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    if (threadIdx.x == 0) sums[blockIdx.x] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
-}
+struct ExpandIO {
+    const uint32_t *order;           // [V] mirror slots in depth order (values of the depth sort)
+    const uint2 *rect;               // [N] tile rects by slot
+    uint32_t *tvals;                 // [capacity] out: slot of every pair
+    unsigned long long *status;      // [grid] look-back words (LbWord<40>)
+    FrameState *state;
+    FrameResult *result;             // pinned host memory
+    uint32_t capacity;               // pair capacity (pairs beyond it are dropped and flagged)
+    uint32_t tiles_x;
+    uint32_t gen, ticket_base;
+};
 
-// Cooperative, load-balanced expansion at wave granularity.  A wave owns 64 consecutive Gaussians
-// of the depth order; their tile counts are scanned with shuffles, and the wave then produces its
-// output slots 64 at a time: every Gaussian whose first slot falls in the current 64-slot window
-// drops a marker there (LDS), an inclusive max-scan over the lanes turns the markers into "owner
-// of this slot", and each lane fetches its owner's rect with a cross-lane permute.  Windows that
-// lie entirely inside one large splat (no marker) skip the scan.  Consecutive lanes write
-// consecutive slots, so stores are coalesced whatever the splat sizes.  (The depth order puts the
-// nearest = largest splats first, so the first workgroups are the heaviest; small workgroups of
-// 256 Gaussians keep that critical path short, and the dispatcher starts them first.)
+// One kernel per frame for the whole expansion.  A workgroup owns EXP_CHUNK consecutive Gaussians
+// of the depth order: it gathers their tile rects (the only random access of the key path: 8 bytes
+// per visible Gaussian), scans the tile counts (DPP), obtains the offset of its first pair by
+// decoupled look-back over the preceding workgroups, and emits its pairs cooperatively at wave
+// granularity: a wave produces its output slots 64 at a time; every Gaussian whose first slot falls
+// in the current 64-slot window drops a marker there (LDS), an inclusive max-scan over the lanes
+// turns the markers into "owner of this slot", and each lane fetches its owner's (first slot, id,
+// rect origin, width) with one 16-byte LDS read.  Windows that lie entirely inside one large splat
+// (no marker) skip the scan.  Consecutive lanes write consecutive slots, so stores are coalesced
+// whatever the splat sizes.  (The depth order puts the nearest = largest splats first, so the first
+// workgroups are the heaviest; small workgroups keep that critical path short.)
+// The grid covers the host's upper bound of V (= N); workgroups past the real V exit at once.
 template <typename TK>
-__global__ __launch_bounds__(EXP_CHUNK) void k_expand_emit(
-    const uint32_t *__restrict__ order, const uint2 *__restrict__ sorted_rect,
-    const uint32_t *__restrict__ chunk_offsets, uint32_t v_count, uint32_t tiles_x,
-    TK *__restrict__ tkeys, uint32_t *__restrict__ tvals, uint32_t capacity) {
+__global__ __launch_bounds__(EXP_CHUNK) void k_expand(ExpandIO io, TK *__restrict__ tkeys) {
+    typedef LbWord<40> W;
     __shared__ uint32_t s_scan[4];
     __shared__ uint32_t s_mark[4][WAVE];
     __shared__ uint4 s_tab[4][WAVE];   // per lane: first slot, Gaussian id, rect origin, rect width
+    __shared__ uint32_t s_chunk;
+    __shared__ unsigned long long s_base;
     const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
-    const uint32_t j = blockIdx.x * EXP_CHUNK + threadIdx.x;
+    if (threadIdx.x == 0) s_chunk = atomicAdd(&io.state->ticket_exp, 1u) - io.ticket_base;
+    __syncthreads();
+    const uint32_t chunk = s_chunk;
+    const uint32_t v_count = io.state->visible;
+    if ((uint64_t)chunk * EXP_CHUNK >= v_count) return;
+    const uint32_t j = chunk * EXP_CHUNK + threadIdx.x;
     uint32_t g = 0, cnt = 0, origin = 0, width = 1;
     if (j < v_count) {
-        g = order[j];
-        uint2 r = sorted_rect[j];
-        uint32_t w = (r.y & 0xffffu) - (r.x & 0xffffu), h = (r.y >> 16) - (r.x >> 16);
+        g = io.order[j];
+        const uint2 r = io.rect[g];
+        const uint32_t w = (r.y & 0xffffu) - (r.x & 0xffffu), h = (r.y >> 16) - (r.x >> 16);
         origin = r.x;
         width = w ? w : 1u;
         cnt = w * h;
@@ -1014,9 +1099,31 @@ __global__ __launch_bounds__(EXP_CHUNK) void k_expand_emit(
     if (lane == 63u) s_scan[wid] = incl;
     s_tab[wid][lane] = make_uint4(excl, g, origin, width);
     __syncthreads();
-    uint32_t w0 = s_scan[0], w1 = s_scan[1], w2 = s_scan[2];
-    uint32_t wave_off = wid == 0 ? 0u : wid == 1 ? w0 : wid == 2 ? w0 + w1 : w0 + w1 + w2;
-    const uint32_t out0 = chunk_offsets[blockIdx.x] + wave_off;
+    const uint32_t w0 = s_scan[0], w1 = s_scan[1], w2 = s_scan[2], w3 = s_scan[3];
+    if (wid == 0) {
+        // a chunk touches at most 256 * 2^22 tiles: the aggregate fits 32 bits, the prefix needs 40
+        const uint64_t aggregate = (uint64_t)w0 + w1 + w2 + w3;
+        const bool last = (uint64_t)(chunk + 1u) * EXP_CHUNK >= v_count;
+        if (lane == 0 && !last) lb_store(io.status + chunk, W::make(io.gen, LB_AGGREGATE, aggregate));
+        const uint64_t before = lookback_exclusive<40>(io.status, chunk, io.gen, lane, &io.state->flags);
+        if (lane == 0) {
+            lb_store(io.status + chunk, W::make(io.gen, LB_INCLUSIVE, before + aggregate));
+            s_base = before;
+            if (last) {   // the frame's D
+                const uint64_t d = before + aggregate;     // saturates at 2^40 - 1: still "too many"
+                const uint32_t over = d > (uint64_t)io.capacity ? FRAME_FLAG_PAIR_OVERFLOW : 0u;
+                io.state->pairs = over ? io.capacity : (uint32_t)d;
+                io.result->pairs_total = d;
+                io.result->flags = io.state->flags | over;
+                io.result->gen = io.gen;
+            }
+        }
+    }
+    __syncthreads();
+    const uint64_t base64 = s_base;
+    if (base64 >= (uint64_t)io.capacity) return;            // everything of this chunk is past the capacity
+    const uint32_t wave_off = wid == 0 ? 0u : wid == 1 ? w0 : wid == 2 ? w0 + w1 : w0 + w1 + w2;
+    const uint64_t out0 = base64 + wave_off;
     uint32_t carry = 0;
     for (uint32_t win = 0; win < wave_total; win += WAVE) {
         const bool starts_here = cnt != 0u && excl >= win && excl < win + WAVE;
@@ -1032,8 +1139,8 @@ __global__ __launch_bounds__(EXP_CHUNK) void k_expand_emit(
         }
         const uint4 ot = s_tab[wid][owner];   // one 16-byte LDS read instead of four cross-lane permutes
         const uint32_t o_excl = ot.x, o_g = ot.y, o_org = ot.z, o_w = ot.w;
-        uint32_t e = win + lane;
-        uint32_t local = e - o_excl;
+        const uint32_t e = win + lane;
+        const uint32_t local = e - o_excl;
         // local / o_w without the 35-instruction integer division: local < 2^22 (<= 2^22 tiles) and
         // o_w < 2^16 are exact in f32, the reciprocal estimate is off by at most one, fixed up exactly
         uint32_t row = (uint32_t)((float)local * __builtin_amdgcn_rcpf((float)o_w));
@@ -1045,11 +1152,11 @@ __global__ __launch_bounds__(EXP_CHUNK) void k_expand_emit(
             row++;
             col -= o_w;
         }
-        uint32_t tile = ((o_org >> 16) + row) * tiles_x + (o_org & 0xffffu) + col;
-        uint32_t o = out0 + e;
-        if (e < wave_total && o < capacity) {
+        const uint32_t tile = ((o_org >> 16) + row) * io.tiles_x + (o_org & 0xffffu) + col;
+        const uint64_t o = out0 + e;
+        if (e < wave_total && o < (uint64_t)io.capacity) {
             tkeys[o] = (TK)tile;
-            tvals[o] = o_g;
+            io.tvals[o] = o_g;
         }
     }
 }
@@ -1074,32 +1181,52 @@ template <> struct SortCfg<uint32_t> { static constexpr int ITEMS = 16; };
 template <> struct SortCfg<uint16_t> { static constexpr int ITEMS = 32; };
 template <typename K> constexpr int sort_tile() { return SORT_THREADS * SortCfg<K>::ITEMS; }
 
-// ghist layout: [digit][block] (digit-major) so that the row scan reads contiguous memory.
-// Tile ids and depth exponents are highly repetitive, so neighbouring lanes often hit the same
-// bin; eight private copies (lane & 7) cut the same-address LDS atomic serialisation 8-fold.
+// Where a sort's element count comes from: a host value, or (count_dev != null) a device word
+// clamped to the host-side bound `count` that sized the grid and the histogram rows.
+struct SortCount {
+    uint32_t count;
+    const uint32_t *count_dev;
+    __device__ __forceinline__ uint32_t get() const {
+        if (!count_dev) return count;
+        const uint32_t c = *count_dev;
+        return c < count ? c : count;
+    }
+};
+
+constexpr uint32_t SORT_SB = 32;   // blocks per super-block of the fused row scan
+
+// ghist layout: [digit][block] (digit-major, row stride = the grid size) so that a row scan reads
+// contiguous memory.  Tile ids and depth exponents are highly repetitive, so neighbouring lanes
+// often hit the same bin; the private copies (lane & (COPIES-1)) cut the same-address LDS atomic
+// serialisation.  With sb_sums != null the block also adds its counts to the sums of its
+// super-block of SORT_SB blocks (integer atomics: order-independent, so still deterministic); the
+// scatter kernel then derives its offsets itself and the separate row-scan launch disappears.
 template <typename K, int RB>
-__global__ __launch_bounds__(SORT_THREADS) void k_sort_hist(const K *__restrict__ keys,
-                                                            uint32_t count, uint32_t shift,
-                                                            uint32_t digit_mask,
+__global__ __launch_bounds__(SORT_THREADS) void k_sort_hist(const K *__restrict__ keys, SortCount sc,
+                                                            uint32_t shift, uint32_t digit_mask,
                                                             uint32_t *__restrict__ ghist,
-                                                            uint32_t num_blocks) {
+                                                            uint32_t *__restrict__ sb_sums, uint32_t sb_stride) {
     constexpr int ITEMS = SortCfg<K>::ITEMS;
+    constexpr uint32_t TILE = SORT_THREADS * ITEMS;
     constexpr int R = 1 << RB;
     constexpr int COPIES = 2048 / R;   // 8 KiB of private copies: 8 x 256 or 4 x 512 bins
     constexpr int DPT = R / SORT_THREADS;
+    const uint32_t count = sc.get();
+    const uint32_t num_blocks = gridDim.x;
+    if ((uint64_t)blockIdx.x * TILE >= count) return;   // past the real count: the row entries are never read
     __shared__ uint32_t s_hist[COPIES][R];
 #pragma unroll
     for (int c = 0; c < COPIES; c++)
 #pragma unroll
         for (int q = 0; q < DPT; q++) s_hist[c][threadIdx.x + q * SORT_THREADS] = 0;
     __syncthreads();
-    const uint32_t base = blockIdx.x * (SORT_THREADS * ITEMS);
+    const uint32_t base = blockIdx.x * TILE;
     const uint32_t copy = threadIdx.x & (uint32_t)(COPIES - 1);
     // 16-byte loads: the order of the keys does not matter for a histogram
     constexpr int PER_VEC = 16 / sizeof(K);
     constexpr int VECS = ITEMS / PER_VEC;
     static_assert(ITEMS % PER_VEC == 0, "tile must be a whole number of 16-byte vectors per thread");
-    if (base + SORT_THREADS * ITEMS <= count) {
+    if (count - base >= TILE) {
         const uint4 *src = (const uint4 *)(keys + base);
 #pragma unroll
         for (int v = 0; v < VECS; v++) {
@@ -1115,10 +1242,11 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_hist(const K *__restrict_
             }
         }
     } else {
+        const uint32_t valid = count - base;
 #pragma unroll
         for (int k = 0; k < ITEMS; k++) {
-            uint32_t i = base + k * SORT_THREADS + threadIdx.x;
-            if (i < count) atomicAdd(&s_hist[copy][(uint32_t)(keys[i] >> shift) & digit_mask], 1u);
+            uint32_t i = k * SORT_THREADS + threadIdx.x;
+            if (i < valid) atomicAdd(&s_hist[copy][(uint32_t)(keys[base + i] >> shift) & digit_mask], 1u);
         }
     }
     __syncthreads();
@@ -1129,15 +1257,19 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_hist(const K *__restrict_
 #pragma unroll
         for (int c = 0; c < COPIES; c++) sum += s_hist[c][digit];
         ghist[(uint64_t)digit * num_blocks + blockIdx.x] = sum;
+        if (sb_sums && sum) atomicAdd(&sb_sums[digit * sb_stride + blockIdx.x / SORT_SB], sum);
     }
 }
 
-// One workgroup per digit: exclusive scan of its row (over blocks) in place; row total out.
-__global__ __launch_bounds__(256) void k_sort_scan_rows(uint32_t *__restrict__ ghist,
-                                                        uint32_t num_blocks,
-                                                        uint32_t *__restrict__ digit_totals) {
+// One workgroup per digit: exclusive scan of its row (over the blocks that hold data) in place; row
+// total out.  Only used when the grid is too large for the fused scan of k_sort_scatter.
+template <int TILE>
+__global__ __launch_bounds__(256) void k_sort_scan_rows(uint32_t *__restrict__ ghist, uint32_t row_stride,
+                                                        SortCount sc, uint32_t *__restrict__ digit_totals) {
     __shared__ uint32_t s_scan[4];
-    uint32_t *row = ghist + (uint64_t)blockIdx.x * num_blocks;
+    const uint32_t count = sc.get();
+    const uint32_t num_blocks = (uint32_t)(((uint64_t)count + TILE - 1) / TILE);
+    uint32_t *row = ghist + (uint64_t)blockIdx.x * row_stride;
     uint32_t carry = 0;
     for (uint32_t base = 0; base < num_blocks; base += 256u) {
         uint32_t i = base + threadIdx.x;
@@ -1157,14 +1289,16 @@ __global__ __launch_bounds__(256) void k_sort_scan_rows(uint32_t *__restrict__ g
 // hands out its pre-add values in increasing lane order when several lanes hit the same address
 // (measured: tools/mb/mb_ldsatomic.hip, 0 violations in 5e7 operations).  One such atomic per key
 // then IS the stable rank.  This is not an architectural guarantee, so gs_device_create probes it
-// (k_probe_lds_atomic_order) and the host falls back to the ballot-based ranking if the probe
-// ever fails.
-template <typename K, bool FAST_RANK, int RB>
+// with this kernel's own access pattern for both digit widths (k_probe_lds_atomic_order<RB>) and
+// the host falls back to the ballot-based ranking if the probe ever fails.
+// FUSED_SCAN: the block derives its digit offsets from the super-block sums and the raw histogram
+// rows (k_sort_hist with sb_sums) instead of reading rows pre-scanned by k_sort_scan_rows.
+template <typename K, bool FAST_RANK, int RB, bool FUSED_SCAN>
 __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
     const K *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, K *__restrict__ keys_out,
-    uint32_t *__restrict__ vals_out, uint32_t count, uint32_t shift, uint32_t digit_mask,
-    const uint32_t *__restrict__ ghist, uint32_t num_blocks,
-    const uint32_t *__restrict__ digit_totals) {
+    uint32_t *__restrict__ vals_out, SortCount sc, uint32_t shift, uint32_t digit_mask,
+    const uint32_t *__restrict__ ghist, const uint32_t *__restrict__ digit_totals,
+    const uint32_t *__restrict__ sb_sums, uint32_t sb_stride) {
     constexpr int ITEMS = SortCfg<K>::ITEMS;
     constexpr int TILE = SORT_THREADS * ITEMS;
     constexpr int R = 1 << RB;
@@ -1177,6 +1311,9 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
     __shared__ uint32_t s_vals[TILE];
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
+    const uint32_t count = sc.get();
+    const uint32_t num_blocks = gridDim.x;                 // row stride of ghist
+    if ((uint64_t)blockIdx.x * TILE >= count) return;      // grid sized from an upper bound of the count
 #pragma unroll
     for (int w = 0; w < 4; w++)
 #pragma unroll
@@ -1184,16 +1321,17 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
     __syncthreads();
 
     const uint32_t tile_base = blockIdx.x * TILE;
-    const uint32_t wave_base = tile_base + wid * (ITEMS * WAVE);
+    const uint32_t valid = count - tile_base < (uint32_t)TILE ? count - tile_base : (uint32_t)TILE;
+    const uint32_t wave_off = wid * (ITEMS * WAVE);
     K key[ITEMS];
     uint32_t val[ITEMS];
     uint32_t rank[ITEMS];
 #pragma unroll
     for (int k = 0; k < ITEMS; k++) {
-        uint32_t i = wave_base + k * WAVE + lane;
-        bool ok = i < count;
-        key[k] = ok ? keys_in[i] : (K)~(K)0;
-        val[k] = ok ? vals_in[i] : 0u;
+        const uint32_t e = wave_off + k * WAVE + lane;     // element of the tile (no 32-bit wrap near 2^32)
+        const bool ok = e < valid;
+        key[k] = ok ? keys_in[tile_base + e] : (K)~(K)0;
+        val[k] = ok ? vals_in[tile_base + e] : 0u;
     }
     if constexpr (FAST_RANK) {
 #pragma unroll
@@ -1247,18 +1385,40 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
     }
     // global base of every digit: sum of totals of smaller digits + this block's row prefix
     {
-        uint32_t tot[DPT], mine = 0;
+        uint32_t tot[DPT], pre[DPT], mine = 0;
+        if constexpr (FUSED_SCAN) {
+            // row prefix = whole super-blocks in front of mine + the blocks of my super-block in
+            // front of me; digit total = all super-blocks that hold data
+            const uint32_t nvalid = (uint32_t)(((uint64_t)count + TILE - 1) / TILE);
+            const uint32_t nsb = (nvalid + SORT_SB - 1) / SORT_SB, my_sb = blockIdx.x / SORT_SB;
 #pragma unroll
-        for (int q = 0; q < DPT; q++) {
-            tot[q] = digit_totals[tid * DPT + q];
-            mine += tot[q];
+            for (int q = 0; q < DPT; q++) {
+                const uint32_t digit = tid * DPT + q;
+                uint32_t t = 0, p = 0;
+                for (uint32_t sb = 0; sb < nsb; sb++) {
+                    const uint32_t v = sb_sums[digit * sb_stride + sb];
+                    t += v;
+                    p += sb < my_sb ? v : 0u;
+                }
+                for (uint32_t b = my_sb * SORT_SB; b < blockIdx.x; b++) p += ghist[(uint64_t)digit * num_blocks + b];
+                tot[q] = t;
+                pre[q] = p;
+                mine += t;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < DPT; q++) {
+                tot[q] = digit_totals[tid * DPT + q];
+                pre[q] = ghist[(uint64_t)(tid * DPT + q) * num_blocks + blockIdx.x];
+                mine += tot[q];
+            }
         }
         uint32_t t2;
         uint32_t digit_base = block_exclusive_scan_256(mine, s_scan, t2);
 #pragma unroll
         for (int q = 0; q < DPT; q++) {
             const uint32_t digit = tid * DPT + q;
-            s_global[digit] = digit_base + ghist[(uint64_t)digit * num_blocks + blockIdx.x];
+            s_global[digit] = digit_base + pre[q];
             digit_base += tot[q];
         }
     }
@@ -1273,7 +1433,6 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
         s_vals[pos] = val[k];
     }
     __syncthreads();
-    uint32_t valid = count - tile_base < (uint32_t)TILE ? count - tile_base : (uint32_t)TILE;
 #pragma unroll
     for (int k = 0; k < ITEMS; k++) {
         uint32_t pos = k * SORT_THREADS + tid;
@@ -1287,33 +1446,52 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
     }
 }
 
-// Probe for FAST_RANK: every wave adds 1 to LDS counters chosen by a hash; bad[0] counts lanes whose
-// returned value is not (count before this round) + (lower lanes with the same address).
-__global__ __launch_bounds__(256) void k_probe_lds_atomic_order(uint32_t rounds, uint32_t seed,
-                                                                uint32_t *__restrict__ bad) {
-    __shared__ uint32_t s_cnt[4][RADIX];
+// Probe for FAST_RANK, run by gs_device_create for both digit widths the sorts use (RB = 8: 256
+// counters, RB = 9: 512 counters per wave, the depth sort's layout): every wave issues returning
+// adds to its own row of LDS counters exactly as k_sort_scatter does — ITEMS back-to-back atomics
+// per lane on digits taken from registers — and then checks every returned value against the
+// ballot-based rank.  bad[0] counts the lanes whose value is not (count before this round) +
+// (lower lanes with the same digit).  Digits mix uniform values, few values, runs and all-equal rounds.
+template <int RB>
+__global__ __launch_bounds__(SORT_THREADS) void k_probe_lds_atomic_order(uint32_t rounds, uint32_t seed,
+                                                                         uint32_t *__restrict__ bad) {
+    constexpr int R = 1 << RB;
+    constexpr int ITEMS = 16;
+    __shared__ uint32_t s_cnt[4][R];      // what the atomics hit
+    __shared__ uint32_t s_ref[4][R];      // reference counters advanced by the ballot ranking
     const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
-#pragma unroll
-    for (int w = 0; w < 4; w++) s_cnt[w][threadIdx.x] = 0;
+    for (int q = threadIdx.x; q < 4 * R; q += SORT_THREADS) {
+        (&s_cnt[0][0])[q] = 0;
+        (&s_ref[0][0])[q] = 0;
+    }
     __syncthreads();
     uint32_t errors = 0;
     for (uint32_t r = 0; r < rounds; r++) {
-        uint32_t x = (blockIdx.x * rounds + r) * 256u + threadIdx.x + seed;
-        x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
-        // mix of uniform digits, few digits, runs and all-equal rounds
-        uint32_t mode = r & 3u;
-        uint32_t d = mode == 0 ? (x & 255u) : mode == 1 ? (x & 3u) : mode == 2 ? ((lane >> 3) & 255u) : 7u;
-        uint64_t peers = ~0ull;
+        uint32_t d[ITEMS], got[ITEMS];
 #pragma unroll
-        for (int b = 0; b < RADIX_BITS; b++) {
-            uint64_t m = __ballot((d >> b) & 1u);
-            peers &= ((d >> b) & 1u) ? m : ~m;
+        for (int k = 0; k < ITEMS; k++) {
+            uint32_t x = ((blockIdx.x * rounds + r) * ITEMS + k) * 256u + threadIdx.x + seed;
+            x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+            const uint32_t mode = (r + k) & 3u;
+            d[k] = (mode == 0 ? x : mode == 1 ? (x & 3u) * 37u : mode == 2 ? (lane >> 3) + 250u : 7u + 256u) & (R - 1);
         }
-        uint32_t expect = s_cnt[wid][d] + mbcnt(peers);
-        __builtin_amdgcn_wave_barrier();
-        uint32_t got = atomicAdd(&s_cnt[wid][d], 1u);
-        __builtin_amdgcn_wave_barrier();
-        errors += got != expect;
+#pragma unroll
+        for (int k = 0; k < ITEMS; k++) got[k] = atomicAdd(&s_cnt[wid][d[k]], 1u);   // back to back, as in the sort
+#pragma unroll
+        for (int k = 0; k < ITEMS; k++) {
+            uint64_t peers = ~0ull;
+#pragma unroll
+            for (int b = 0; b < RB; b++) {
+                uint64_t m = __ballot((d[k] >> b) & 1u);
+                peers &= ((d[k] >> b) & 1u) ? m : ~m;
+            }
+            const uint32_t before = mbcnt(peers);
+            const uint32_t old = s_ref[wid][d[k]];
+            errors += got[k] != old + before;
+            __builtin_amdgcn_wave_barrier();
+            if (before == 0u) s_ref[wid][d[k]] = old + (uint32_t)__popcll(peers);
+            __builtin_amdgcn_wave_barrier();
+        }
     }
     if (errors) atomicAdd(bad, errors);
 }
@@ -1326,13 +1504,15 @@ __global__ __launch_bounds__(256) void k_probe_lds_atomic_order(uint32_t rounds,
 template <typename TK> constexpr int range_items() { return 16 / sizeof(TK); }
 
 template <typename TK>
-__global__ __launch_bounds__(256) void k_tile_ranges(const TK *__restrict__ tkeys, uint32_t count,
+__global__ __launch_bounds__(256) void k_tile_ranges(const TK *__restrict__ tkeys, SortCount sc,
                                                      uint32_t *__restrict__ ranges) {
     constexpr int N = range_items<TK>();
-    const uint32_t j0 = (blockIdx.x * 256u + threadIdx.x) * N;
-    if (j0 >= count) return;
+    const uint32_t count = sc.get();
+    const uint64_t j64 = ((uint64_t)blockIdx.x * 256u + threadIdx.x) * N;
+    if (j64 >= count) return;
+    const uint32_t j0 = (uint32_t)j64;
     uint32_t tile[N];
-    if (j0 + N <= count) {
+    if (count - j0 >= (uint32_t)N) {
         uint4 q = *(const uint4 *)(tkeys + j0);
         uint32_t w[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
