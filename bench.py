@@ -68,7 +68,7 @@ def run_workload(gs, synth, torch, dist, dev, stream, rank, world, wl, steps, wa
     r = gs.Renderer(dev)
 
     def step():
-        r.render(stream, buf, gt, mt, cam, frame.data_ptr(), band=band)
+        r.render(stream, buf, gt, mt, cam, frame.data_ptr(), band=band, check=False)
         par.gather_frame(dist, frame, rank, world, H)
 
     def sync_all():

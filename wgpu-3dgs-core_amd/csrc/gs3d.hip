@@ -1238,7 +1238,7 @@ struct FrameShape {
 
 struct gs_renderer {
     gs_device *dev;
-    DevArray recs, rect, chunk_tiles, chunk_vis, pre_status, exp_status, state, zero_region, scan_tmp;
+    DevArray recs, depth, rect, sorted_rect, exp_sums, chunk_tiles, chunk_vis, state, zero_region, scan_tmp;
     DevArray dkeys[2], dvals[2];          // (depth bits - bias, mirror slot), capacity N
     DevArray tkeys[2], tvals[2];          // (tile id, mirror slot), capacity pair_capacity
     DevArray ghist, digit_totals;
@@ -1246,9 +1246,7 @@ struct gs_renderer {
     uint32_t *host_counters;              // pinned: sizing pass total
     uint64_t pair_capacity;
     FrameShape shape;
-    uint32_t gen;                         // frame generation (look-back tag)
-    uint32_t ticket_pre_base, ticket_exp_base;
-    bool state_dirty;                     // a launch failed mid-frame: reset the device state first
+    uint32_t gen;                         // frame generation (tags the pinned results)
     hipEvent_t done[2];                   // end of the frame of each parity
     bool done_valid[2];
     uint32_t done_gen[2];
@@ -1294,8 +1292,6 @@ extern "C" gs_status gs_renderer_create(gs_device *dev, gs_renderer **out) {
     std::memset(r->results, 0, 2 * sizeof(gs::FrameResult));
     r->pair_capacity = 0;
     r->gen = 0;
-    r->ticket_pre_base = r->ticket_exp_base = 0;
-    r->state_dirty = true;
     r->n = 0;
     r->tiles_x = r->tiles_y = r->sort_passes = 0;
     r->key_bias = 0;
@@ -1317,7 +1313,7 @@ extern "C" void gs_renderer_destroy(gs_renderer *r) {
     if (!r) return;
     (void)hipSetDevice(r->dev->ordinal);
     if (r->last_stream) (void)hipStreamSynchronize(r->last_stream);   // kernels of the last frame write pinned memory
-    DevArray *arrs[] = {&r->recs, &r->rect, &r->chunk_tiles, &r->chunk_vis, &r->pre_status, &r->exp_status,
+    DevArray *arrs[] = {&r->recs, &r->depth, &r->rect, &r->sorted_rect, &r->exp_sums, &r->chunk_tiles, &r->chunk_vis,
                         &r->state, &r->zero_region, &r->scan_tmp, &r->dkeys[0], &r->dkeys[1], &r->dvals[0],
                         &r->dvals[1], &r->tkeys[0], &r->tkeys[1], &r->tvals[0], &r->tvals[1], &r->ghist,
                         &r->digit_totals};
@@ -1389,8 +1385,6 @@ extern "C" gs_status gs_renderer_wait_frame(gs_renderer *r, gs_frame_result *out
     if (fr.gen != r->gen)
         return fail(GS_ERR_HIP, fr.gen, r->gen, 0, "the frame did not complete (result generation %u, expected %u)",
                     fr.gen, r->gen);
-    if (fr.flags & gs::FRAME_FLAG_SPIN_TIMEOUT)
-        return fail(GS_ERR_HIP, fr.flags, 0, 0, "a device-side look-back timed out; the frame is invalid");
     if (fr.pairs_total > 0xfffffff0ull)
         return fail(GS_ERR_PAIR_OVERFLOW, r->n, 0, 0,
                     "the frame needs more than 2^32 (tile, Gaussian) pairs; pair indices are 32-bit");
@@ -1487,81 +1481,78 @@ static uint32_t bit_length(uint32_t v) {
     return b;
 }
 
-// Plan of one stable LSD radix sort: key bits [0, end_bit) in `passes` passes of at most `rb` bits
-// (digit widths balanced over the passes), grid of `nb` workgroups from the host-side BOUND of the
-// element count.  `fused` = the row scan is folded into the scatter kernel (two launches per pass
-// instead of three): every block then reads up to nb/32 + 31 counters per digit, which only pays
-// while the grid is small; each fused pass needs `sb_words` zeroed words (super-block sums).
-struct SortPlan {
-    uint32_t passes = 0, rb = 8, nb = 0, tile = 0, end_bit = 0;
-    bool fused = false;
-    uint32_t sb_stride = 0, sb_words = 0;
-};
-
-static SortPlan plan_sort(uint32_t count_bound, uint32_t end_bit, uint32_t rb, uint32_t tile, bool allow_fused) {
-    SortPlan p;
-    p.rb = rb;
-    p.tile = tile;
-    p.end_bit = end_bit;
-    p.passes = (end_bit + rb - 1) / rb;
-    p.nb = (uint32_t)(((uint64_t)count_bound + tile - 1) / tile);
-    const uint32_t R = 1u << rb;
-    static const bool fuse_off = std::getenv("GS3D_FUSED_SCAN") && std::getenv("GS3D_FUSED_SCAN")[0] == '0';
-    p.fused = allow_fused && !fuse_off && p.nb > 0 && (uint64_t)p.nb * R <= 300000ull;
-    p.sb_stride = (p.nb + gs::SORT_SB - 1) / gs::SORT_SB;
-    p.sb_words = p.fused ? R * p.sb_stride : 0;
-    return p;
-}
-
 // depth keys: 9-bit digits when that saves a pass (e.g. 27 significant bits: 3 passes instead of 4);
 // otherwise 8-bit digits, whose 256-bin tiles write longer runs and fit more workgroups per CU
 static uint32_t depth_radix_bits(uint32_t key_bits) {
     return (key_bits + 8) / 9 < (key_bits + 7) / 8 ? (uint32_t)gs::RADIX_BITS_MAX : (uint32_t)gs::RADIX_BITS;
 }
 
-// Runs the plan on `st`, ping-ponging between side 0 and side 1; the side holding the result is
-// returned.  `sc` carries the host bound and, optionally, the device word holding the real count.
-// `sb` = zeroed super-block sums, plan.sb_words per pass (fused plans only).
+// The frame's compacting first pass (see gs_render_kernels.h, COMPACT): dense keys in, the index is
+// the value, chunks without visible Gaussians are skipped, V comes out in *visible_out.
+struct SortCompact {
+    const uint32_t *dense_keys = nullptr;   // [N] keys by slot, 0xffffffff = culled (read by pass 0 instead of keys[0])
+    const uint32_t *chunk_vis = nullptr;
+    uint32_t *visible_out = nullptr;
+    uint32_t dense_count = 0;        // N: the first pass runs over all slots
+};
+
+// Stable LSD radix sort of (key, u32 value) pairs on key bits [0, end_bit), RB bits per pass at
+// most (digit widths balanced over the passes), ping-ponging between side 0 and side 1; the side
+// holding the result is returned.  `sc` = host bound of the count (sizes the grid) and, optionally,
+// the device word holding the real count.  With `compact`, pass 0 reads keys[0] as the dense key
+// array of preprocess and ignores vals[0].
 template <typename K, int RB>
-static gs_status run_sort_rb(const gs_device *dev, const SortPlan &plan, void *const keys[2], void *const vals[2],
-                             DevArray &ghist, DevArray &digit_totals, gs::SortCount sc, uint32_t *sb,
-                             hipStream_t st, int &result_side, uint32_t &launches) {
+static gs_status run_sort_rb(const gs_device *dev, void *const keys[2], void *const vals[2], DevArray &ghist,
+                             DevArray &digit_totals, gs::SortCount sc, uint32_t end_bit, const SortCompact *compact,
+                             hipStream_t st, int &result_side, uint32_t &passes_out, uint32_t &launches) {
     constexpr uint32_t R = 1u << RB;
+    constexpr uint32_t TILE = (uint32_t)gs::sort_tile<K>();
+    uint32_t passes = (end_bit + RB - 1) / RB;
+    if (compact && passes == 0) passes = 1;      // the compaction (and V) must happen even for a 0-bit key range
+    passes_out = passes;
     result_side = 0;
-    if (sc.count == 0 || plan.passes == 0) return GS_OK;
-    const uint32_t nb = plan.nb;
+    if (sc.count == 0 || passes == 0) return GS_OK;
+    const uint32_t nb = (uint32_t)(((uint64_t)sc.count + TILE - 1) / TILE);
     GS_TRY(dev_reserve(ghist, (size_t)nb * R * 4));
     GS_TRY(dev_reserve(digit_totals, R * 4));
     int side = 0;
     uint32_t shift = 0;
-    for (uint32_t p = 0; p < plan.passes; p++) {
+    for (uint32_t p = 0; p < passes; p++) {
         // balanced digit widths: e.g. 13 bits -> 7 + 6, 15 -> 8 + 7, 27 -> 9 + 9 + 9, 32 -> 8 + 8 + 8 + 8
-        const uint32_t bits = (plan.end_bit - shift + (plan.passes - p) - 1) / (plan.passes - p);
+        const uint32_t bits = end_bit > shift ? (end_bit - shift + (passes - p) - 1) / (passes - p) : 0u;
         const uint32_t digit_mask = (1u << bits) - 1u;
-        const K *kin = (const K *)keys[side];
+        const bool first = compact && p == 0;
+        const K *kin = first ? (const K *)compact->dense_keys : (const K *)keys[side];
         const uint32_t *vin = (const uint32_t *)vals[side];
         K *kout = (K *)keys[side ^ 1];
         uint32_t *vout = (uint32_t *)vals[side ^ 1];
-        uint32_t *sbp = plan.fused ? sb + (size_t)p * plan.sb_words : nullptr;
-        hipLaunchKernelGGL((gs::k_sort_hist<K, RB>), dim3(nb), dim3(gs::SORT_THREADS), 0, st, kin, sc, shift,
-                           digit_mask, (uint32_t *)ghist.ptr, sbp, plan.sb_stride);
-        launches++;
-        if (!plan.fused) {
-            hipLaunchKernelGGL((gs::k_sort_scan_rows<gs::sort_tile<K>()>), dim3(R), dim3(256), 0, st,
-                               (uint32_t *)ghist.ptr, nb, sc, (uint32_t *)digit_totals.ptr);
-            launches++;
-        }
-#define GS_SCATTER(FAST, FUSED)                                                                                  \
-    hipLaunchKernelGGL((gs::k_sort_scatter<K, FAST, RB, FUSED>), dim3(nb), dim3(gs::SORT_THREADS), 0, st, kin,  \
-                       vin, kout, vout, sc, shift, digit_mask, (const uint32_t *)ghist.ptr,                     \
-                       (const uint32_t *)digit_totals.ptr, (const uint32_t *)sbp, plan.sb_stride)
-        if (dev->lds_atomic_ordered) {
-            if (plan.fused) GS_SCATTER(true, true); else GS_SCATTER(true, false);
+        const gs::SortCount psc = first ? gs::SortCount{compact->dense_count, nullptr} : sc;
+        const uint32_t pnb = first ? (uint32_t)(((uint64_t)compact->dense_count + TILE - 1) / TILE) : nb;
+        if (first) GS_TRY(dev_reserve(ghist, (size_t)pnb * R * 4));
+        const uint32_t *cv = first ? compact->chunk_vis : nullptr;
+        uint32_t *vo = first ? compact->visible_out : nullptr;
+#define GS_SORT_PASS(COMPACT)                                                                                     \
+    do {                                                                                                          \
+        hipLaunchKernelGGL((gs::k_sort_hist<K, RB, COMPACT>), dim3(pnb), dim3(gs::SORT_THREADS), 0, st, kin, psc, \
+                           shift, digit_mask, (uint32_t *)ghist.ptr, cv);                                         \
+        hipLaunchKernelGGL((gs::k_sort_scan_rows<(int)TILE>), dim3(R), dim3(256), 0, st, (uint32_t *)ghist.ptr,   \
+                           pnb, psc, (uint32_t *)digit_totals.ptr);                                               \
+        if (dev->lds_atomic_ordered)                                                                              \
+            hipLaunchKernelGGL((gs::k_sort_scatter<K, true, RB, COMPACT>), dim3(pnb), dim3(gs::SORT_THREADS), 0,  \
+                               st, kin, vin, kout, vout, psc, shift, digit_mask, (const uint32_t *)ghist.ptr,     \
+                               (const uint32_t *)digit_totals.ptr, cv, vo);                                       \
+        else                                                                                                      \
+            hipLaunchKernelGGL((gs::k_sort_scatter<K, false, RB, COMPACT>), dim3(pnb), dim3(gs::SORT_THREADS), 0, \
+                               st, kin, vin, kout, vout, psc, shift, digit_mask, (const uint32_t *)ghist.ptr,     \
+                               (const uint32_t *)digit_totals.ptr, cv, vo);                                       \
+    } while (0)
+        if constexpr (sizeof(K) == 4) {
+            if (first) GS_SORT_PASS(true); else GS_SORT_PASS(false);
         } else {
-            if (plan.fused) GS_SCATTER(false, true); else GS_SCATTER(false, false);
+            GS_SORT_PASS(false);
         }
-#undef GS_SCATTER
-        launches++;
+#undef GS_SORT_PASS
+        launches += 3;
         shift += bits;
         side ^= 1;
     }
@@ -1570,30 +1561,15 @@ static gs_status run_sort_rb(const gs_device *dev, const SortPlan &plan, void *c
     return GS_OK;
 }
 
-template <typename K>
-static gs_status run_sort(const gs_device *dev, const SortPlan &plan, void *const keys[2], void *const vals[2],
-                          DevArray &ghist, DevArray &digit_totals, gs::SortCount sc, uint32_t *sb, hipStream_t st,
-                          int &result_side, uint32_t &launches) {
-    if (plan.rb == (uint32_t)gs::RADIX_BITS_MAX) {
-        if constexpr (sizeof(K) == 4)
-            return run_sort_rb<K, gs::RADIX_BITS_MAX>(dev, plan, keys, vals, ghist, digit_totals, sc, sb, st,
-                                                      result_side, launches);
-    }
-    return run_sort_rb<K, gs::RADIX_BITS>(dev, plan, keys, vals, ghist, digit_totals, sc, sb, st, result_side,
-                                          launches);
-}
-
-// host-known count, three kernels per pass (spatial order build, stand-alone sort)
+// host-known count (spatial order build, stand-alone sort)
 template <typename K>
 static gs_status sort_pairs_device(const gs_device *dev, void *const keys[2], void *const vals[2],
                                    DevArray &ghist, DevArray &digit_totals, uint32_t count,
                                    uint32_t end_bit, hipStream_t st, int &result_side,
                                    uint32_t &passes_out) {
-    const SortPlan plan = plan_sort(count, end_bit, gs::RADIX_BITS, (uint32_t)gs::sort_tile<K>(), false);
-    passes_out = plan.passes;
     uint32_t launches = 0;
-    return run_sort<K>(dev, plan, keys, vals, ghist, digit_totals, gs::SortCount{count, nullptr}, nullptr, st,
-                       result_side, launches);
+    return run_sort_rb<K, gs::RADIX_BITS>(dev, keys, vals, ghist, digit_totals, gs::SortCount{count, nullptr}, end_bit,
+                                          nullptr, st, result_side, passes_out, launches);
 }
 
 // (Re)build the block-planar mirror on `st`.  A whole-buffer rebuild in spatial mode first computes
@@ -1834,7 +1810,7 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
     shape.height = cam->height;
     shape.band0 = fc.band_ty0;
     shape.band1 = fc.band_ty1;
-    const bool sizing = n != 0 && (r->pair_capacity == 0 || !(shape == r->shape) || r->state_dirty);
+    const bool sizing = n != 0 && (r->pair_capacity == 0 || !(shape == r->shape));
 
     mark(ST_REPACK);
     GS_TRY(ensure_planar(g, st));
@@ -1845,7 +1821,9 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
     mark(ST_PRE);
 
     GS_TRY(dev_reserve(r->recs, nn * 4 * gs::REC_WORDS + 16));
+    GS_TRY(dev_reserve(r->depth, nn * 4));
     GS_TRY(dev_reserve(r->rect, nn * 8));
+    GS_TRY(dev_reserve(r->sorted_rect, nn * 8));
     GS_TRY(dev_reserve(r->chunk_tiles, nc * 4));
     GS_TRY(dev_reserve(r->chunk_vis, nc * 4));
     GS_TRY(dev_reserve(r->scan_tmp, nc * 4));
@@ -1854,21 +1832,10 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
         GS_TRY(dev_reserve(r->dvals[i], nn * 4));
     }
     const uint32_t exp_grid = (n + gs::EXP_CHUNK - 1) / gs::EXP_CHUNK;   // V <= N
-    GS_TRY(reserve_zeroed(r->pre_status, nc * 8, st));
-    GS_TRY(reserve_zeroed(r->exp_status, (size_t)(exp_grid ? exp_grid : 1) * 8, st));
+    GS_TRY(dev_reserve(r->exp_sums, (size_t)(exp_grid ? exp_grid : 1) * 4));
     GS_TRY(reserve_zeroed(r->state, sizeof(gs::FrameState), st));
 
-    // a new generation; on wrap of the narrowest tag (22 bits) or after a failed frame the
-    // look-back words and tickets start from scratch
     r->gen++;
-    if (r->state_dirty || (r->gen & gs::LbWord<40>::GEN_MASK) == 0u) {
-        if ((r->gen & gs::LbWord<40>::GEN_MASK) == 0u) r->gen++;
-        GS_HIP(hipMemsetAsync(r->pre_status.ptr, 0, r->pre_status.bytes, st));
-        GS_HIP(hipMemsetAsync(r->exp_status.ptr, 0, r->exp_status.bytes, st));
-        GS_HIP(hipMemsetAsync(r->state.ptr, 0, sizeof(gs::FrameState), st));
-        r->ticket_pre_base = r->ticket_exp_base = 0;
-    }
-    r->state_dirty = true;     // cleared at the end of a fully enqueued frame
     const uint32_t gen = r->gen;
     gs::FrameState *state = (gs::FrameState *)r->state.ptr;
     gs::FrameResult *result = &r->results[gen & 1u];
@@ -1900,25 +1867,16 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
         r->sort_passes = 0;
         r->dsorted_side = r->tsorted_side = 0;
     } else {
-        // ---- plans (host-side bounds only) ----
-        const SortPlan dplan = plan_sort(n, dbits, depth_radix_bits(dbits), (uint32_t)gs::sort_tile<uint32_t>(), true);
-        auto tile_plan = [&](uint64_t cap) {
-            return plan_sort((uint32_t)cap, tile_bits, gs::RADIX_BITS,
-                             wide ? (uint32_t)gs::sort_tile<uint32_t>() : (uint32_t)gs::sort_tile<uint16_t>(), true);
-        };
-        // the clear job of this frame: tile ranges + super-block sums of the fused sort passes.  The
-        // tile sort's share depends on the pair capacity, which a sizing frame only learns after
-        // preprocess: reserve for the worst case of a fused plan (<= 300000 words per pass)
-        const size_t ranges_words = (size_t)num_tiles * 2;
-        const size_t dsb_words = (size_t)dplan.passes * dplan.sb_words;
-        const size_t tsb_max = (size_t)((tile_bits + 7) / 8) * 300000u;
-        GS_TRY(dev_reserve(r->zero_region, (ranges_words + dsb_words + tsb_max) * 4));
+        // the clear job of this frame, spread over the preprocess grid: tile ranges + the
+        // expansion's super-chunk sums
+        const size_t ranges_words = (size_t)num_tiles * 2;                                   // even: keeps the u64 sums aligned
+        const size_t esb_words = 2 * ((size_t)exp_grid / gs::EXP_SB + 1);                    // u64 super-chunk sums of the expansion
+        GS_TRY(dev_reserve(r->zero_region, (ranges_words + esb_words) * 4));
         uint32_t *zero = (uint32_t *)r->zero_region.ptr;
-        uint32_t *dsb = zero + ranges_words, *tsb = dsb + dsb_words;
+        uint32_t *esb = zero + ranges_words;
 
         if (!sizing && want_capacity > r->pair_capacity) GS_TRY(reserve_pairs(r, want_capacity, wide));
         if (!sizing) GS_TRY(reserve_pairs(r, r->pair_capacity, wide));   // key width may have changed
-        SortPlan tplan = tile_plan(r->pair_capacity);
 
         // Records with SH take the two-phase kernel (geometry chunks first, SH chunks only for the
         // lanes that survive culling): with the mirror in spatial order whole 128-byte lines of
@@ -1936,25 +1894,16 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
         gs::PreOut po;
         po.recs = (uint32_t *)r->recs.ptr;
         po.rect = (uint2 *)r->rect.ptr;
-        po.dkeys = (uint32_t *)r->dkeys[0].ptr;
-        po.dvals = (uint32_t *)r->dvals[0].ptr;
+        po.depth = (uint32_t *)r->depth.ptr;
         po.chunk_tiles = (uint32_t *)r->chunk_tiles.ptr;
         po.chunk_vis = (uint32_t *)r->chunk_vis.ptr;
-        po.status = (unsigned long long *)r->pre_status.ptr;
-        po.state = state;
-        po.result = result;
         po.zero_ptr = zero;
-        // a sizing frame does not know the tile plan yet: clear the whole reserved region
-        po.zero_words = (uint32_t)(ranges_words + dsb_words + (sizing ? tsb_max : (size_t)tplan.passes * tplan.sb_words));
-        po.gen = gen;
-        po.ticket_base = r->ticket_pre_base;
+        po.zero_words = (uint32_t)(ranges_words + esb_words);
         po.key_bias = near_bits;
-        po.nchunks = nchunks;
         po.block_bounds = (const float *)g->block_bounds;
         hipLaunchKernelGGL((banded ? k_tbl_preprocess_banded : k_tbl_preprocess)[g->sh][g->cov], dim3(nchunks),
                            dim3(gs::PP_THREADS), 0, st, (const uint4 *)g->planar, n, fc, po);
         GS_HIP(hipGetLastError());
-        r->ticket_pre_base += nchunks;
         r->launches++;
         mark(ST_SCAN);
 
@@ -1973,19 +1922,30 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
             }
             const uint64_t cap = capacity_for(d) > want_capacity ? capacity_for(d) : want_capacity;
             GS_TRY(reserve_pairs(r, cap, wide));
-            tplan = tile_plan(r->pair_capacity);
         }
         r->shape = shape;
         const uint32_t capacity = (uint32_t)r->pair_capacity;
         mark(ST_DSORT);
 
-        // ---- depth sort of the visible Gaussians (count V on the device, grid from N) ----
+        // ---- depth sort of the visible Gaussians; its first pass reads the dense per-slot keys and
+        //      compacts (count V stays on the device, grids from N) ----
         int dside = 0;
+        uint32_t dpasses = 0;
         {
             void *k2[2] = {r->dkeys[0].ptr, r->dkeys[1].ptr};
             void *v2[2] = {r->dvals[0].ptr, r->dvals[1].ptr};
-            GS_TRY(run_sort<uint32_t>(r->dev, dplan, k2, v2, r->ghist, r->digit_totals,
-                                      gs::SortCount{n, &state->visible}, dsb, st, dside, r->launches));
+            SortCompact cp;
+            cp.dense_keys = (const uint32_t *)r->depth.ptr;
+            cp.chunk_vis = (const uint32_t *)r->chunk_vis.ptr;
+            cp.visible_out = &state->visible;
+            cp.dense_count = n;
+            const gs::SortCount dc{n, &state->visible};
+            if (depth_radix_bits(dbits) == (uint32_t)gs::RADIX_BITS_MAX)
+                GS_TRY((run_sort_rb<uint32_t, gs::RADIX_BITS_MAX>(r->dev, k2, v2, r->ghist, r->digit_totals, dc, dbits, &cp,
+                                                                  st, dside, dpasses, r->launches)));
+            else
+                GS_TRY((run_sort_rb<uint32_t, gs::RADIX_BITS>(r->dev, k2, v2, r->ghist, r->digit_totals, dc, dbits, &cp, st,
+                                                              dside, dpasses, r->launches)));
         }
         mark(ST_EXPAND);
 
@@ -1993,35 +1953,39 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
         gs::ExpandIO eo;
         eo.order = (const uint32_t *)r->dvals[dside].ptr;
         eo.rect = (const uint2 *)r->rect.ptr;
+        eo.sorted_rect = (uint2 *)r->sorted_rect.ptr;
+        eo.sums = (uint32_t *)r->exp_sums.ptr;
+        eo.sb_sums = (unsigned long long *)esb;
         eo.tvals = (uint32_t *)r->tvals[0].ptr;
-        eo.status = (unsigned long long *)r->exp_status.ptr;
         eo.state = state;
         eo.result = result;
         eo.capacity = capacity;
         eo.tiles_x = fc.tiles_x;
         eo.gen = gen;
-        eo.ticket_base = r->ticket_exp_base;
+        hipLaunchKernelGGL(gs::k_expand_count, dim3(exp_grid), dim3(gs::EXP_CHUNK), 0, st, eo);
         if (wide)
-            hipLaunchKernelGGL(gs::k_expand<uint32_t>, dim3(exp_grid), dim3(gs::EXP_CHUNK), 0, st, eo,
+            hipLaunchKernelGGL(gs::k_expand_emit<uint32_t>, dim3(exp_grid), dim3(gs::EXP_CHUNK), 0, st, eo,
                                (uint32_t *)r->tkeys[0].ptr);
         else
-            hipLaunchKernelGGL(gs::k_expand<uint16_t>, dim3(exp_grid), dim3(gs::EXP_CHUNK), 0, st, eo,
+            hipLaunchKernelGGL(gs::k_expand_emit<uint16_t>, dim3(exp_grid), dim3(gs::EXP_CHUNK), 0, st, eo,
                                (uint16_t *)r->tkeys[0].ptr);
         GS_HIP(hipGetLastError());
-        r->ticket_exp_base += exp_grid;
-        r->launches++;
+        r->launches += 2;
         mark(ST_TSORT);
 
         // ---- stable sort on the tile id alone (pairs are already in depth order) ----
         int tside = 0;
+        uint32_t tpasses = 0;
         const gs::SortCount tc{capacity, &state->pairs};
         {
             void *k2[2] = {r->tkeys[0].ptr, r->tkeys[1].ptr};
             void *v2[2] = {r->tvals[0].ptr, r->tvals[1].ptr};
             if (wide)
-                GS_TRY(run_sort<uint32_t>(r->dev, tplan, k2, v2, r->ghist, r->digit_totals, tc, tsb, st, tside, r->launches));
+                GS_TRY((run_sort_rb<uint32_t, gs::RADIX_BITS>(r->dev, k2, v2, r->ghist, r->digit_totals, tc, tile_bits, nullptr,
+                                                              st, tside, tpasses, r->launches)));
             else
-                GS_TRY(run_sort<uint16_t>(r->dev, tplan, k2, v2, r->ghist, r->digit_totals, tc, tsb, st, tside, r->launches));
+                GS_TRY((run_sort_rb<uint16_t, gs::RADIX_BITS>(r->dev, k2, v2, r->ghist, r->digit_totals, tc, tile_bits, nullptr,
+                                                              st, tside, tpasses, r->launches)));
         }
         mark(ST_RANGES);
         if (capacity) {
@@ -2034,7 +1998,7 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
             GS_HIP(hipGetLastError());
             r->launches++;
         }
-        r->sort_passes = dplan.passes + tplan.passes;
+        r->sort_passes = dpasses + tpasses;
         r->dsorted_side = dside;
         r->tsorted_side = tside;
     }
@@ -2056,7 +2020,6 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
     GS_HIP(hipEventRecord(r->done[gen & 1u], st));
     r->done_valid[gen & 1u] = true;
     r->done_gen[gen & 1u] = gen;
-    r->state_dirty = false;
     return GS_OK;
 }
 
@@ -2069,19 +2032,19 @@ static gs_status download_sync(gs_renderer *r, void *dst, const void *src, size_
     return GS_OK;
 }
 
-// depth bits of every mirror slot of the last frame (0xffffffff = culled), rebuilt from the depth
-// sort's (key - bias, slot) pairs: the frame keeps no dense depth array
+// depth bits of every mirror slot of the last frame (0xffffffff = culled): the dense keys of
+// preprocess plus the key bias; chunks without visible Gaussians may be block-culled and stale
 static gs_status download_slot_depths(gs_renderer *r, std::vector<uint32_t> &depth) {
     depth.assign(r->n, 0xffffffffu);
-    if (!r->last_stream) return GS_OK;
-    GS_HIP(hipStreamSynchronize(r->last_stream));
-    const size_t v = last_result(r).visible;
-    if (!v) return GS_OK;
-    std::vector<uint32_t> keys(v), slots(v);
-    GS_TRY(download_sync(r, keys.data(), r->dkeys[r->dsorted_side].ptr, v * 4));
-    GS_TRY(download_sync(r, slots.data(), r->dvals[r->dsorted_side].ptr, v * 4));
-    for (size_t j = 0; j < v; j++)
-        if (slots[j] < r->n) depth[slots[j]] = keys[j] + r->key_bias;
+    if (!r->last_stream || !r->n) return GS_OK;
+    const size_t nchunks = (r->n + gs::PP_CHUNK - 1) / gs::PP_CHUNK;
+    std::vector<uint32_t> chunk_vis(nchunks);
+    GS_TRY(download_sync(r, depth.data(), r->depth.ptr, r->n * 4));
+    GS_TRY(download_sync(r, chunk_vis.data(), r->chunk_vis.ptr, nchunks * 4));
+    for (size_t slot = 0; slot < r->n; slot++) {
+        if (chunk_vis[slot / gs::PP_CHUNK] == 0u) depth[slot] = 0xffffffffu;
+        else if (depth[slot] != 0xffffffffu) depth[slot] += r->key_bias;
+    }
     return GS_OK;
 }
 

@@ -129,101 +129,33 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_256(uint32_t v, uint32_
 }
 
 // ---------------------------------------------------------------------------------------------
-// device-resident frame state + decoupled look-back (single-pass chained scan over workgroups)
+// device-resident frame state
 // ---------------------------------------------------------------------------------------------
 
 // What only the device knows about the frame in flight.  The host never waits for it: grids are
 // sized from upper bounds (V <= N, D <= pair capacity), kernels read the counts from here, and the
 // results reach the host through `FrameResult` in pinned memory, read lazily.
 struct FrameState {
-    uint32_t ticket_pre;     // arrival tickets of k_preprocess*, monotonic over frames (host tracks the base)
-    uint32_t ticket_exp;     // same for k_expand
-    uint32_t visible;        // V
+    uint32_t visible;        // V: written by the first depth-sort pass (which also compacts)
     uint32_t pairs;          // min(D, pair capacity): what the tile sort / ranges / blend work on
-    uint32_t flags;          // FRAME_FLAG_*
-    uint32_t pad[3];
+    uint32_t pad[6];
 };
 constexpr uint32_t FRAME_FLAG_PAIR_OVERFLOW = 1u;   // D exceeded the pair capacity: farthest pairs dropped
-constexpr uint32_t FRAME_FLAG_SPIN_TIMEOUT = 2u;    // a look-back gave up waiting (never expected)
 
-// pinned host memory, one per frame parity; written by the last workgroups of preprocess / expand
+// pinned host memory, one per frame parity; written by workgroup 0 of k_expand_emit
 struct FrameResult {
     uint32_t visible;
     uint32_t flags;
     uint64_t pairs_total;    // true D, also when it exceeded the capacity
-    uint32_t gen;            // frame generation this result belongs to (written last)
+    uint32_t gen;            // frame generation this result belongs to
     uint32_t pad[3];
 };
-
-// Look-back status word: one naturally aligned 8-byte granule {generation | state | value}, stored
-// and polled with relaxed agent-scope atomics (sc1: L2-coherent across the 8 XCDs).  Flag and data
-// travel in the same granule, so no fence or ordering is needed around it.  The generation tag makes
-// zeroing the array between frames unnecessary: a word of an older frame reads as "not yet".
-constexpr uint32_t LB_NONE = 0u, LB_AGGREGATE = 1u, LB_INCLUSIVE = 2u;
-template <int VALUE_BITS> struct LbWord {
-    static constexpr int GEN_BITS = 62 - VALUE_BITS;
-    static constexpr uint64_t VALUE_MASK = (1ull << VALUE_BITS) - 1ull;
-    static constexpr uint32_t GEN_MASK = (uint32_t)((1ull << GEN_BITS) - 1ull);
-    static __device__ __forceinline__ uint64_t make(uint32_t gen, uint32_t state, uint64_t value) {
-        return ((uint64_t)(gen & GEN_MASK) << (VALUE_BITS + 2)) | ((uint64_t)state << VALUE_BITS) |
-               (value > VALUE_MASK ? VALUE_MASK : value);      // saturating: overflow stays detectable
-    }
-    static __device__ __forceinline__ uint32_t state_of(uint64_t w, uint32_t gen) {
-        return (uint32_t)(w >> (VALUE_BITS + 2)) == (gen & GEN_MASK) ? (uint32_t)(w >> VALUE_BITS) & 3u : LB_NONE;
-    }
-    static __device__ __forceinline__ uint64_t value_of(uint64_t w) { return w & VALUE_MASK; }
-};
-
-__device__ __forceinline__ void lb_store(unsigned long long *p, uint64_t w) {
-    __hip_atomic_store(p, (unsigned long long)w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ uint64_t lb_load(const unsigned long long *p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 
 // wave sum of a 64-bit value, uniform in every lane (all 64 lanes active)
 __device__ __forceinline__ uint64_t wave_reduce_add64(uint64_t v) {
 #pragma unroll
     for (int d = WAVE / 2; d > 0; d >>= 1) v += __shfl_xor((unsigned long long)v, d, WAVE);
     return v;
-}
-
-// Called by ONE full wave of workgroup `chunk` after it has published its aggregate: returns the
-// sum of the aggregates of all chunks < chunk (the exclusive prefix), uniform in every lane.  Lane l
-// inspects predecessor chunk-1-l, so one step covers 64 predecessors; the walk stops at the nearest
-// predecessor whose inclusive prefix is known.  Tickets are handed out in arrival order, so every
-// predecessor is already running or finished: the wait is bounded by one workgroup's lifetime.  The
-// spin itself is bounded too (a stuck wait sets FRAME_FLAG_SPIN_TIMEOUT instead of hanging the GPU).
-template <int VALUE_BITS>
-__device__ __forceinline__ uint64_t lookback_exclusive(const unsigned long long *status, uint32_t chunk,
-                                                       uint32_t gen, uint32_t lane, uint32_t *flags) {
-    typedef LbWord<VALUE_BITS> W;
-    uint64_t exclusive = 0;
-    int64_t idx = (int64_t)chunk - 1 - (int64_t)lane;
-    for (;;) {
-        uint64_t w = 0;
-        uint32_t st = LB_INCLUSIVE;      // chunks before the first count as "inclusive 0"
-        uint32_t first = 64;
-        for (uint32_t spins = 0;; spins++) {
-            if (idx >= 0) {
-                w = lb_load(status + idx);
-                st = W::state_of(w, gen);
-            }
-            const uint64_t valid = __ballot(st != LB_NONE), incl = __ballot(st == LB_INCLUSIVE);
-            first = incl ? (uint32_t)__builtin_ctzll(incl) : 64u;
-            const uint64_t need = first >= 63u ? ~0ull : ((2ull << first) - 1ull);   // lanes 0..first
-            if ((valid & need) == need) break;
-            if (spins > (1u << 22)) {    // ~seconds: give up, flag the frame, let the grid drain
-                if (lane == 0) atomicOr(flags, FRAME_FLAG_SPIN_TIMEOUT);
-                return exclusive;
-            }
-            __builtin_amdgcn_s_sleep(2);
-        }
-        const uint64_t v = (idx >= 0 && lane <= first) ? W::value_of(w) : 0ull;
-        exclusive += wave_reduce_add64(v);
-        if (first < 64u) return exclusive;
-        idx -= 64;
-    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -702,149 +634,84 @@ __device__ __forceinline__ uint32_t project_one(const uint32_t *w, const FrameCo
 typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 constexpr int REC_WORDS = 9;   // blend record: mx, my, ca, cb, cc, opacity, r, g, b  (36 bytes)
 
-// Everything a preprocess workgroup writes besides the per-slot records (passed by value).
+// Everything a preprocess workgroup writes (passed by value).
 struct PreOut {
     uint32_t *recs;                  // [N][9] blend records, by mirror slot
     uint2 *rect;                     // [N] tile rects (0 = culled), by mirror slot
-    uint32_t *dkeys, *dvals;         // [V] (depth bits - key_bias, slot) of the visible slots, in slot order
-    uint32_t *chunk_tiles;           // [chunks] sum of tiles touched (sizing pass, taps)
-    uint32_t *chunk_vis;             // [chunks] visible count (taps: 0 = the chunk may be block-culled and stale)
-    unsigned long long *status;      // [chunks] look-back words (LbWord<32>)
-    FrameState *state;
-    FrameResult *result;             // pinned host memory
-    uint32_t *zero_ptr;              // per-frame clear job spread over the grid (radix super-block sums, tile ranges)
+    uint32_t *depth;                 // [N] depth bits - key_bias, 0xffffffff = culled, by mirror slot
+    uint32_t *chunk_tiles;           // [chunks] sum of tiles touched (sizing pass)
+    uint32_t *chunk_vis;             // [chunks] visible count; 0 = the chunk was (possibly) block-culled and its
+                                     //          per-slot arrays are stale: consumers must skip it
+    uint32_t *zero_ptr;              // per-frame clear job spread over the grid (tile ranges, expansion sums)
     uint32_t zero_words;
-    uint32_t gen, ticket_base, key_bias, nchunks;
+    uint32_t key_bias;
     const float *block_bounds;
 };
 
-// Arrival ticket = chunk index of this workgroup (dispatch order is not architecturally defined;
-// the ticket order is what makes "every predecessor is running or done" true for the look-back).
-// Also takes its share of the per-frame clear job.
-__device__ __forceinline__ uint32_t pre_begin(const PreOut &io, uint32_t *s_chunk) {
-    if (threadIdx.x == 0) *s_chunk = atomicAdd(&io.state->ticket_pre, 1u) - io.ticket_base;
-    __syncthreads();
-    const uint32_t chunk = *s_chunk;
-    for (uint32_t i = chunk * PP_THREADS + threadIdx.x; i < io.zero_words; i += io.nchunks * PP_THREADS)
+// this workgroup's share of the per-frame clear job
+__device__ __forceinline__ void pre_begin(const PreOut &io) {
+    for (uint32_t i = blockIdx.x * PP_THREADS + threadIdx.x; i < io.zero_words; i += gridDim.x * PP_THREADS)
         io.zero_ptr[i] = 0u;
-    return chunk;
 }
 
-// wave 0 of the workgroup: publish the aggregate, look back, publish the inclusive prefix;
-// the last chunk also publishes the frame's V.  Returns the exclusive prefix (uniform).
-__device__ __forceinline__ uint32_t pre_publish(const PreOut &io, uint32_t chunk, uint32_t aggregate,
-                                                uint32_t lane) {
-    typedef LbWord<32> W;
-    if (lane == 0 && chunk + 1u < io.nchunks) lb_store(io.status + chunk, W::make(io.gen, LB_AGGREGATE, aggregate));
-    const uint32_t excl = (uint32_t)lookback_exclusive<32>(io.status, chunk, io.gen, lane, &io.state->flags);
-    if (lane == 0) {
-        lb_store(io.status + chunk, W::make(io.gen, LB_INCLUSIVE, (uint64_t)excl + aggregate));
-        if (chunk + 1u == io.nchunks) {
-            const uint32_t v = excl + aggregate;
-            io.state->visible = v;
-            io.state->pairs = 0u;            // k_expand's last workgroup sets it (no workgroup when V = 0)
-            io.result->visible = v;
-            if (v == 0u) {
-                io.result->pairs_total = 0ull;
-                io.result->flags = io.state->flags;
-                io.result->gen = io.gen;
-            }
-        }
-    }
-    return excl;
-}
-
-// Common tail of the preprocess kernels: ordered compaction of the chunk's visible slots.
-// s_key[j][t] = depth key (already biased) of slot base + j*PP_THREADS + t, 0xffffffff = culled.
-__device__ __forceinline__ void pre_finish(const PreOut &io, uint32_t chunk, uint32_t local_tiles,
-                                           uint32_t (*s_key)[PP_THREADS], uint32_t *s_cnt, uint32_t *s_misc) {
-    const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
-    __syncthreads();
-    uint32_t key[PP_ITEMS];
-    uint64_t m[PP_ITEMS];
-#pragma unroll
-    for (int j = 0; j < PP_ITEMS; j++) {
-        key[j] = s_key[j][threadIdx.x];
-        m[j] = __ballot(key[j] != 0xffffffffu);
-        if (lane == 0) s_cnt[j * 4 + wid] = (uint32_t)__popcll(m[j]);
-    }
+// per-chunk sums (tiles touched, visible count)
+__device__ __forceinline__ void pre_finish(const PreOut &io, uint32_t local_tiles, uint32_t local_vis,
+                                           uint32_t *s_red) {
     local_tiles = wave_reduce_add(local_tiles);
-    if (lane == 0) s_misc[wid] = local_tiles;
-    __syncthreads();
-    uint32_t before[PP_ITEMS], total = 0;   // visible slots of the chunk in front of (round j, my wave)
-#pragma unroll
-    for (int j = 0; j < PP_ITEMS; j++) {
-        before[j] = total;
-#pragma unroll
-        for (uint32_t w = 0; w < 4; w++) {
-            const uint32_t c = s_cnt[j * 4 + w];
-            if (w < wid) before[j] += c;
-            total += c;
-        }
-    }
-    if (wid == 0) {
-        const uint32_t excl = pre_publish(io, chunk, total, lane);
-        if (lane == 0) {
-            s_misc[4] = excl;
-            io.chunk_tiles[chunk] = (s_misc[0] + s_misc[1]) + (s_misc[2] + s_misc[3]);
-            io.chunk_vis[chunk] = total;
-        }
+    local_vis = wave_reduce_add(local_vis);
+    const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+    if (lane == 0) {
+        s_red[wid] = local_tiles;
+        s_red[4 + wid] = local_vis;
     }
     __syncthreads();
-    const uint32_t excl = s_misc[4];
-    const uint32_t base = chunk * PP_CHUNK;
-#pragma unroll
-    for (int j = 0; j < PP_ITEMS; j++) {
-        if (key[j] != 0xffffffffu) {
-            const uint32_t pos = excl + before[j] + mbcnt(m[j]);
-            io.dkeys[pos] = key[j];
-            io.dvals[pos] = base + j * PP_THREADS + threadIdx.x;
-        }
+    if (threadIdx.x == 0) {
+        io.chunk_tiles[blockIdx.x] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+        io.chunk_vis[blockIdx.x] = (s_red[4] + s_red[5]) + (s_red[6] + s_red[7]);
     }
 }
 
-// whole block provably invisible: nothing is read, nothing visible; wave 0 keeps the look-back chain going
-__device__ __forceinline__ void pre_finish_culled(const PreOut &io, uint32_t chunk) {
-    if (threadIdx.x >= 64u) return;
-    pre_publish(io, chunk, 0u, threadIdx.x);
+// whole block provably invisible: nothing is read, nothing is written but the two chunk scalars
+__device__ __forceinline__ void pre_finish_culled(const PreOut &io) {
     if (threadIdx.x == 0) {
-        io.chunk_tiles[chunk] = 0u;
-        io.chunk_vis[chunk] = 0u;
+        io.chunk_tiles[blockIdx.x] = 0u;
+        io.chunk_vis[blockIdx.x] = 0u;
     }
 }
 
 // Grid: one workgroup per PP_CHUNK Gaussians (= one block of the block-planar mirror).  One
 // global_load_dwordx4 per (lane, chunk): a wave reads 1 KiB contiguous per instruction.
-// Outputs per Gaussian, written DENSELY (culled lanes store too): the 36-byte blend record and the
-// 8-byte tile rect (0 when culled).  Masking the stores of culled lanes would leave holes in every
-// 64-byte sector, which turns the writes into read-modify-writes and costs 0.15 ms at 10 M
-// Gaussians on a randomly ordered mirror (measured); a dense store of a few don't-care bytes is
-// cheaper.  The visible slots' (depth key, slot) pairs are compacted in slot order straight into
-// the depth sort's input (pre_finish): no dense depth array, no separate scan / compaction kernels.
+// Outputs per Gaussian, written DENSELY (culled lanes store too): the 36-byte blend record, the
+// depth key (0xffffffff when culled) and the 8-byte tile rect (0 when culled).  Masking the stores
+// of culled lanes would leave holes in every 64-byte sector, which turns the writes into
+// read-modify-writes and costs 0.15 ms at 10 M Gaussians on a randomly ordered mirror (measured); a
+// dense store of a few don't-care bytes is cheaper.  There is no compaction step: the first pass of
+// the depth sort reads the dense keys and simply does not rank the culled ones.
 //
 // What bounds it (tools/mb/mb_rw.hip, 10 M x 224 B on MI355X): the read pattern alone streams at
 // 6.3 TB/s (0.354 ms); every written byte costs about three read bytes, whatever the store
 // pattern — 4 B/Gaussian +0.035 ms, 12 B +0.083 ms, 48 B +0.165 ms as whole-array planes, as one
 // contiguous span per workgroup, staged through LDS and burst out, or as these streams.
+// (Tried in round 2 and rejected: compacting the visible (key, slot) pairs here with a decoupled
+// look-back over the workgroups.  The inclusive frontier advances one look-back window per status
+// round trip across the XCDs, and every waiting workgroup keeps its registers: 0.43 -> 0.54 ms with
+// a 64-wide window, 0.60 ms with a 256-wide one.)
 template <int SH, int COV>
 __global__ __launch_bounds__(PP_THREADS) void k_preprocess(const uint4 *__restrict__ planar, uint32_t n,
                                                            FrameConsts fc, PreOut io) {
-    __shared__ uint32_t s_key[PP_ITEMS][PP_THREADS];
-    __shared__ uint32_t s_cnt[PP_ITEMS * 4];
-    __shared__ uint32_t s_misc[8];
-    const uint32_t chunk = pre_begin(io, &s_misc[7]);
-    if (fc.cull_gain > 0.0f && block_is_culled(io.block_bounds + (uint64_t)chunk * 8u, fc)) {
-        pre_finish_culled(io, chunk);
+    __shared__ uint32_t s_red[8];
+    pre_begin(io);
+    if (fc.cull_gain > 0.0f && block_is_culled(io.block_bounds + (uint64_t)blockIdx.x * 8u, fc)) {
+        pre_finish_culled(io);
         return;
     }
     constexpr int NW = pod_words(SH, COV);
     constexpr int NC = NW / 4;
-    const uint32_t base = chunk * PP_CHUNK;
-    uint32_t local = 0;
+    const uint32_t base = blockIdx.x * PP_CHUNK;
+    uint32_t local = 0, local_vis = 0;
 #pragma unroll 1
     for (int k = 0; k < PP_ITEMS; k++) {
         const uint32_t i = base + k * PP_THREADS + threadIdx.x;
-        uint32_t dkey = 0xffffffffu;
         if (i < n) {
             // Issue ALL of the record's loads back to back (NC x 1 KiB per wave in flight), then
             // pin them with empty asm statements: without this the compiler sinks each load next
@@ -868,13 +735,13 @@ __global__ __launch_bounds__(PP_THREADS) void k_preprocess(const uint4 *__restri
             *(u32x4_a4 *)(o) = u32x4_a4{rec[0].x, rec[0].y, rec[0].z, rec[0].w};
             *(u32x4_a4 *)(o + 4) = u32x4_a4{rec[1].x, rec[1].y, rec[1].z, rec[1].w};
             o[8] = rec[2].x;
+            io.depth[i] = cnt ? rec[2].y - io.key_bias : 0xffffffffu;
             io.rect[i] = cnt ? make_uint2(rec[2].z, rec[2].w) : make_uint2(0u, 0u);
             local += cnt;
-            if (cnt) dkey = rec[2].y - io.key_bias;
+            local_vis += cnt ? 1u : 0u;
         }
-        s_key[k][threadIdx.x] = dkey;
     }
-    pre_finish(io, chunk, local, s_key, s_cnt, s_misc);
+    pre_finish(io, local, local_vis, s_red);
 }
 
 // Two-phase variant for records with SH: phase 1 loads only the chunks that hold position, colour
@@ -885,24 +752,21 @@ __global__ __launch_bounds__(PP_THREADS) void k_preprocess(const uint4 *__restri
 template <int SH, int COV>
 __global__ __launch_bounds__(PP_THREADS) void k_preprocess_banded(const uint4 *__restrict__ planar, uint32_t n,
                                                                   FrameConsts fc, PreOut io) {
-    __shared__ uint32_t s_key[PP_ITEMS][PP_THREADS];
-    __shared__ uint32_t s_cnt[PP_ITEMS * 4];
-    __shared__ uint32_t s_misc[8];
-    const uint32_t chunk = pre_begin(io, &s_misc[7]);
-    if (fc.cull_gain > 0.0f && block_is_culled(io.block_bounds + (uint64_t)chunk * 8u, fc)) {
-        pre_finish_culled(io, chunk);
+    __shared__ uint32_t s_red[8];
+    pre_begin(io);
+    if (fc.cull_gain > 0.0f && block_is_culled(io.block_bounds + (uint64_t)blockIdx.x * 8u, fc)) {
+        pre_finish_culled(io);
         return;
     }
     constexpr int NW = pod_words(SH, COV);
     constexpr int NC = NW / 4;
     constexpr int G0 = cov_word0(SH) / 4;                              // first chunk holding covariance words
     constexpr int G1 = (cov_word0(SH) + cov_bytes(COV) / 4 - 1) / 4;   // last one
-    const uint32_t base = chunk * PP_CHUNK;
-    uint32_t local = 0;
+    const uint32_t base = blockIdx.x * PP_CHUNK;
+    uint32_t local = 0, local_vis = 0;
 #pragma unroll 1
     for (int k = 0; k < PP_ITEMS; k++) {
         const uint32_t i = base + k * PP_THREADS + threadIdx.x;
-        uint32_t dkey = 0xffffffffu;
         if (i < n) {
             uint32_t w[NW];
             uint4 v0 = planar[planar_at(0, i, NC)];
@@ -940,7 +804,6 @@ __global__ __launch_bounds__(PP_THREADS) void k_preprocess_banded(const uint4 *_
                     }
                 }
                 shade_one<SH>(w, fc, d, rec);
-                dkey = rec[2].y - io.key_bias;
             }
             if (cnt || !fc.mask_culled_records) {
                 uint32_t *o = io.recs + (uint64_t)i * REC_WORDS;
@@ -948,12 +811,13 @@ __global__ __launch_bounds__(PP_THREADS) void k_preprocess_banded(const uint4 *_
                 *(u32x4_a4 *)(o + 4) = u32x4_a4{rec[1].x, rec[1].y, rec[1].z, rec[1].w};
                 o[8] = rec[2].x;
             }
+            io.depth[i] = cnt ? rec[2].y - io.key_bias : 0xffffffffu;
             io.rect[i] = cnt ? make_uint2(rec[2].z, rec[2].w) : make_uint2(0u, 0u);
             local += cnt;
+            local_vis += cnt ? 1u : 0u;
         }
-        s_key[k][threadIdx.x] = dkey;
     }
-    pre_finish(io, chunk, local, s_key, s_cnt, s_misc);
+    pre_finish(io, local, local_vis, s_red);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1043,51 +907,107 @@ __global__ __launch_bounds__(1024) void k_scan_chunks(ScanJob j0, ScanJob j1) {
 // 64-bit (tile << 32 | depth) key.
 // ---------------------------------------------------------------------------------------------
 
-constexpr int EXP_CHUNK = 256;   // Gaussians per workgroup in the expansion kernel
+constexpr int EXP_CHUNK = 256;   // Gaussians per workgroup in the expansion kernels
+constexpr uint32_t EXP_SB = 128;   // chunks per super-chunk of the expansion's offset sums
 
 struct ExpandIO {
     const uint32_t *order;           // [V] mirror slots in depth order (values of the depth sort)
     const uint2 *rect;               // [N] tile rects by slot
+    uint2 *sorted_rect;              // [V] tile rects in depth order (count -> emit)
+    uint32_t *sums;                  // [grid] tile count of every chunk
+    unsigned long long *sb_sums;     // [grid / EXP_SB + 1] tile count of every super-chunk (zeroed per frame)
     uint32_t *tvals;                 // [capacity] out: slot of every pair
-    unsigned long long *status;      // [grid] look-back words (LbWord<40>)
     FrameState *state;
     FrameResult *result;             // pinned host memory
     uint32_t capacity;               // pair capacity (pairs beyond it are dropped and flagged)
     uint32_t tiles_x;
-    uint32_t gen, ticket_base;
+    uint32_t gen;
 };
 
-// One kernel per frame for the whole expansion.  A workgroup owns EXP_CHUNK consecutive Gaussians
-// of the depth order: it gathers their tile rects (the only random access of the key path: 8 bytes
-// per visible Gaussian), scans the tile counts (DPP), obtains the offset of its first pair by
-// decoupled look-back over the preceding workgroups, and emits its pairs cooperatively at wave
-// granularity: a wave produces its output slots 64 at a time; every Gaussian whose first slot falls
-// in the current 64-slot window drops a marker there (LDS), an inclusive max-scan over the lanes
-// turns the markers into "owner of this slot", and each lane fetches its owner's (first slot, id,
-// rect origin, width) with one 16-byte LDS read.  Windows that lie entirely inside one large splat
-// (no marker) skip the scan.  Consecutive lanes write consecutive slots, so stores are coalesced
-// whatever the splat sizes.  (The depth order puts the nearest = largest splats first, so the first
-// workgroups are the heaviest; small workgroups keep that critical path short.)
+// Expansion, part 1: gather the tile rects into depth order (the only random access of the key
+// path: 8 bytes per visible Gaussian from a compact array) and sum the tile counts per chunk of
+// EXP_CHUNK Gaussians and per super-chunk of EXP_SB chunks (one 64-bit atomic per workgroup).
 // The grid covers the host's upper bound of V (= N); workgroups past the real V exit at once.
+__global__ __launch_bounds__(EXP_CHUNK) void k_expand_count(ExpandIO io) {
+    __shared__ uint32_t s_red[4];
+    const uint32_t v_count = io.state->visible;
+    if ((uint64_t)blockIdx.x * EXP_CHUNK >= v_count) return;
+    const uint32_t j = blockIdx.x * EXP_CHUNK + threadIdx.x;
+    uint32_t v = 0;
+    if (j < v_count) {
+        const uint2 r = io.rect[io.order[j]];
+        io.sorted_rect[j] = r;
+        v = ((r.y & 0xffffu) - (r.x & 0xffffu)) * ((r.y >> 16) - (r.x >> 16));
+    }
+    v = wave_reduce_add(v);
+    if ((threadIdx.x & 63u) == 0) s_red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t total = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);   // <= 256 * 2^22
+        io.sums[blockIdx.x] = total;
+        if (total) atomicAdd(io.sb_sums + blockIdx.x / EXP_SB, (unsigned long long)total);
+    }
+}
+
+// Expansion, part 2.  A workgroup owns EXP_CHUNK consecutive Gaussians of the depth order.  The
+// offset of its first pair is the sum of the super-chunks in front of its own plus the chunks of
+// its super-chunk in front of it (a few hundred values read cooperatively: no scan kernel, no
+// serial chain).  Pairs are emitted cooperatively at wave granularity: a wave produces its output
+// slots 64 at a time; every Gaussian whose first slot falls in the current 64-slot window drops a
+// marker there (LDS), an inclusive max-scan over the lanes turns the markers into "owner of this
+// slot", and each lane fetches its owner's (first slot, id, rect origin, width) with one 16-byte
+// LDS read.  Windows that lie entirely inside one large splat (no marker) skip the scan.
+// Consecutive lanes write consecutive slots, so stores are coalesced whatever the splat sizes.
+// (The depth order puts the nearest = largest splats first, so the first workgroups are the
+// heaviest; small workgroups keep that critical path short.)  Workgroup 0 also publishes D.
 template <typename TK>
-__global__ __launch_bounds__(EXP_CHUNK) void k_expand(ExpandIO io, TK *__restrict__ tkeys) {
-    typedef LbWord<40> W;
+__global__ __launch_bounds__(EXP_CHUNK) void k_expand_emit(ExpandIO io, TK *__restrict__ tkeys) {
     __shared__ uint32_t s_scan[4];
     __shared__ uint32_t s_mark[4][WAVE];
     __shared__ uint4 s_tab[4][WAVE];   // per lane: first slot, Gaussian id, rect origin, rect width
-    __shared__ uint32_t s_chunk;
-    __shared__ unsigned long long s_base;
+    __shared__ unsigned long long s_part[4];
     const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
-    if (threadIdx.x == 0) s_chunk = atomicAdd(&io.state->ticket_exp, 1u) - io.ticket_base;
-    __syncthreads();
-    const uint32_t chunk = s_chunk;
+    const uint32_t chunk = blockIdx.x;
     const uint32_t v_count = io.state->visible;
-    if ((uint64_t)chunk * EXP_CHUNK >= v_count) return;
+    if ((uint64_t)chunk * EXP_CHUNK >= v_count && chunk != 0u) return;
+    const uint32_t nchunks = (uint32_t)(((uint64_t)v_count + EXP_CHUNK - 1) / EXP_CHUNK);
+    const uint32_t nsb = (nchunks + EXP_SB - 1) / EXP_SB, my_sb = chunk / EXP_SB;
+
+    // offset of this chunk's first pair (and, in workgroup 0, the frame's D)
+    uint64_t part = 0, all = 0;
+    for (uint32_t q = threadIdx.x; q < nsb; q += EXP_CHUNK) {
+        const uint64_t v = io.sb_sums[q];
+        if (q < my_sb) part += v;
+        all += v;
+    }
+    for (uint32_t c = my_sb * EXP_SB + threadIdx.x; c < chunk; c += EXP_CHUNK) part += io.sums[c];
+    part = wave_reduce_add64(part);
+    if (lane == 0) s_part[wid] = part;
+    __syncthreads();
+    const uint64_t base64 = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
+    if (chunk == 0u) {
+        __syncthreads();
+        all = wave_reduce_add64(all);
+        if (lane == 0) s_part[wid] = all;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint64_t d = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
+            const uint32_t over = d > (uint64_t)io.capacity ? FRAME_FLAG_PAIR_OVERFLOW : 0u;
+            io.state->pairs = over ? io.capacity : (uint32_t)d;
+            io.result->visible = v_count;
+            io.result->pairs_total = d;
+            io.result->flags = over;
+            io.result->gen = io.gen;
+        }
+        if (v_count == 0u) return;
+    }
+    if (base64 >= (uint64_t)io.capacity) return;            // everything of this chunk is past the capacity
+
     const uint32_t j = chunk * EXP_CHUNK + threadIdx.x;
     uint32_t g = 0, cnt = 0, origin = 0, width = 1;
     if (j < v_count) {
         g = io.order[j];
-        const uint2 r = io.rect[g];
+        const uint2 r = io.sorted_rect[j];
         const uint32_t w = (r.y & 0xffffu) - (r.x & 0xffffu), h = (r.y >> 16) - (r.x >> 16);
         origin = r.x;
         width = w ? w : 1u;
@@ -1099,29 +1019,7 @@ __global__ __launch_bounds__(EXP_CHUNK) void k_expand(ExpandIO io, TK *__restric
     if (lane == 63u) s_scan[wid] = incl;
     s_tab[wid][lane] = make_uint4(excl, g, origin, width);
     __syncthreads();
-    const uint32_t w0 = s_scan[0], w1 = s_scan[1], w2 = s_scan[2], w3 = s_scan[3];
-    if (wid == 0) {
-        // a chunk touches at most 256 * 2^22 tiles: the aggregate fits 32 bits, the prefix needs 40
-        const uint64_t aggregate = (uint64_t)w0 + w1 + w2 + w3;
-        const bool last = (uint64_t)(chunk + 1u) * EXP_CHUNK >= v_count;
-        if (lane == 0 && !last) lb_store(io.status + chunk, W::make(io.gen, LB_AGGREGATE, aggregate));
-        const uint64_t before = lookback_exclusive<40>(io.status, chunk, io.gen, lane, &io.state->flags);
-        if (lane == 0) {
-            lb_store(io.status + chunk, W::make(io.gen, LB_INCLUSIVE, before + aggregate));
-            s_base = before;
-            if (last) {   // the frame's D
-                const uint64_t d = before + aggregate;     // saturates at 2^40 - 1: still "too many"
-                const uint32_t over = d > (uint64_t)io.capacity ? FRAME_FLAG_PAIR_OVERFLOW : 0u;
-                io.state->pairs = over ? io.capacity : (uint32_t)d;
-                io.result->pairs_total = d;
-                io.result->flags = io.state->flags | over;
-                io.result->gen = io.gen;
-            }
-        }
-    }
-    __syncthreads();
-    const uint64_t base64 = s_base;
-    if (base64 >= (uint64_t)io.capacity) return;            // everything of this chunk is past the capacity
+    const uint32_t w0 = s_scan[0], w1 = s_scan[1], w2 = s_scan[2];
     const uint32_t wave_off = wid == 0 ? 0u : wid == 1 ? w0 : wid == 2 ? w0 + w1 : w0 + w1 + w2;
     const uint64_t out0 = base64 + wave_off;
     uint32_t carry = 0;
@@ -1193,24 +1091,29 @@ struct SortCount {
     }
 };
 
-constexpr uint32_t SORT_SB = 32;   // blocks per super-block of the fused row scan
+// COMPACT passes (the first pass of the frame's depth sort, u32 keys only): the input is the DENSE
+// per-slot key array of preprocess — key 0xffffffff = culled — plus the per-chunk visible counts
+// (0 = the chunk's keys are stale, skip it); the value of an element is its index (the mirror
+// slot).  Culled elements are simply not counted and not ranked, so the pass performs the ordered
+// compaction of the visible Gaussians for free: the output of the pass is the dense, stably
+// partitioned (key, slot) list of the V visible ones, and workgroup 0 publishes V.
+constexpr uint32_t SORT_INVALID_KEY = 0xffffffffu;
 
-// ghist layout: [digit][block] (digit-major, row stride = the grid size) so that a row scan reads
+// ghist layout: [digit][block] (digit-major, row stride = the grid size) so that the row scan reads
 // contiguous memory.  Tile ids and depth exponents are highly repetitive, so neighbouring lanes
 // often hit the same bin; the private copies (lane & (COPIES-1)) cut the same-address LDS atomic
-// serialisation.  With sb_sums != null the block also adds its counts to the sums of its
-// super-block of SORT_SB blocks (integer atomics: order-independent, so still deterministic); the
-// scatter kernel then derives its offsets itself and the separate row-scan launch disappears.
-template <typename K, int RB>
+// serialisation.
+template <typename K, int RB, bool COMPACT>
 __global__ __launch_bounds__(SORT_THREADS) void k_sort_hist(const K *__restrict__ keys, SortCount sc,
                                                             uint32_t shift, uint32_t digit_mask,
                                                             uint32_t *__restrict__ ghist,
-                                                            uint32_t *__restrict__ sb_sums, uint32_t sb_stride) {
+                                                            const uint32_t *__restrict__ chunk_vis) {
     constexpr int ITEMS = SortCfg<K>::ITEMS;
     constexpr uint32_t TILE = SORT_THREADS * ITEMS;
     constexpr int R = 1 << RB;
     constexpr int COPIES = 2048 / R;   // 8 KiB of private copies: 8 x 256 or 4 x 512 bins
     constexpr int DPT = R / SORT_THREADS;
+    static_assert(!COMPACT || (sizeof(K) == 4 && TILE % PP_CHUNK == 0), "compacting pass: u32 keys, whole chunks per tile");
     const uint32_t count = sc.get();
     const uint32_t num_blocks = gridDim.x;
     if ((uint64_t)blockIdx.x * TILE >= count) return;   // past the real count: the row entries are never read
@@ -1230,6 +1133,9 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_hist(const K *__restrict_
         const uint4 *src = (const uint4 *)(keys + base);
 #pragma unroll
         for (int v = 0; v < VECS; v++) {
+            // vector v of the tile covers elements [v * 1024, (v + 1) * 1024) for u32 keys = one preprocess chunk
+            if constexpr (COMPACT)
+                if (chunk_vis[(base >> 10) + v] == 0u) continue;
             uint4 q = src[v * SORT_THREADS + threadIdx.x];
             uint32_t w[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
@@ -1238,7 +1144,8 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_hist(const K *__restrict_
                 if constexpr (sizeof(K) == 2) k = (K)(w[e >> 1] >> (16 * (e & 1)));
                 else if constexpr (sizeof(K) == 4) k = (K)w[e];
                 else k = (K)(((uint64_t)w[2 * e + 1] << 32) | w[2 * e]);
-                atomicAdd(&s_hist[copy][(uint32_t)(k >> shift) & digit_mask], 1u);
+                if (!COMPACT || (uint32_t)k != SORT_INVALID_KEY)
+                    atomicAdd(&s_hist[copy][(uint32_t)(k >> shift) & digit_mask], 1u);
             }
         }
     } else {
@@ -1246,7 +1153,12 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_hist(const K *__restrict_
 #pragma unroll
         for (int k = 0; k < ITEMS; k++) {
             uint32_t i = k * SORT_THREADS + threadIdx.x;
-            if (i < valid) atomicAdd(&s_hist[copy][(uint32_t)(keys[base + i] >> shift) & digit_mask], 1u);
+            if (i < valid) {
+                const K key = keys[base + i];
+                bool ok = true;
+                if constexpr (COMPACT) ok = (uint32_t)key != SORT_INVALID_KEY && chunk_vis[(base + i) >> 10] != 0u;
+                if (ok) atomicAdd(&s_hist[copy][(uint32_t)(key >> shift) & digit_mask], 1u);
+            }
         }
     }
     __syncthreads();
@@ -1257,12 +1169,11 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_hist(const K *__restrict_
 #pragma unroll
         for (int c = 0; c < COPIES; c++) sum += s_hist[c][digit];
         ghist[(uint64_t)digit * num_blocks + blockIdx.x] = sum;
-        if (sb_sums && sum) atomicAdd(&sb_sums[digit * sb_stride + blockIdx.x / SORT_SB], sum);
     }
 }
 
 // One workgroup per digit: exclusive scan of its row (over the blocks that hold data) in place; row
-// total out.  Only used when the grid is too large for the fused scan of k_sort_scatter.
+// total out.
 template <int TILE>
 __global__ __launch_bounds__(256) void k_sort_scan_rows(uint32_t *__restrict__ ghist, uint32_t row_stride,
                                                         SortCount sc, uint32_t *__restrict__ digit_totals) {
@@ -1289,16 +1200,15 @@ __global__ __launch_bounds__(256) void k_sort_scan_rows(uint32_t *__restrict__ g
 // hands out its pre-add values in increasing lane order when several lanes hit the same address
 // (measured: tools/mb/mb_ldsatomic.hip, 0 violations in 5e7 operations).  One such atomic per key
 // then IS the stable rank.  This is not an architectural guarantee, so gs_device_create probes it
-// with this kernel's own access pattern for both digit widths (k_probe_lds_atomic_order<RB>) and
-// the host falls back to the ballot-based ranking if the probe ever fails.
-// FUSED_SCAN: the block derives its digit offsets from the super-block sums and the raw histogram
-// rows (k_sort_hist with sb_sums) instead of reading rows pre-scanned by k_sort_scan_rows.
-template <typename K, bool FAST_RANK, int RB, bool FUSED_SCAN>
+// with this kernel's own access pattern for both digit widths and with partially masked waves
+// (k_probe_lds_atomic_order<RB>) and the host falls back to the ballot-based ranking if the probe
+// ever fails.
+template <typename K, bool FAST_RANK, int RB, bool COMPACT>
 __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
     const K *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, K *__restrict__ keys_out,
     uint32_t *__restrict__ vals_out, SortCount sc, uint32_t shift, uint32_t digit_mask,
     const uint32_t *__restrict__ ghist, const uint32_t *__restrict__ digit_totals,
-    const uint32_t *__restrict__ sb_sums, uint32_t sb_stride) {
+    const uint32_t *__restrict__ chunk_vis, uint32_t *__restrict__ visible_out) {
     constexpr int ITEMS = SortCfg<K>::ITEMS;
     constexpr int TILE = SORT_THREADS * ITEMS;
     constexpr int R = 1 << RB;
@@ -1321,45 +1231,52 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
     __syncthreads();
 
     const uint32_t tile_base = blockIdx.x * TILE;
-    const uint32_t valid = count - tile_base < (uint32_t)TILE ? count - tile_base : (uint32_t)TILE;
+    const uint32_t in_tile = count - tile_base < (uint32_t)TILE ? count - tile_base : (uint32_t)TILE;
     const uint32_t wave_off = wid * (ITEMS * WAVE);
+    // COMPACT: a wave's ITEMS*64 = 1024 elements are exactly one preprocess chunk
+    bool chunk_ok = true;
+    if constexpr (COMPACT) chunk_ok = wave_off < in_tile && chunk_vis[(tile_base + wave_off) >> 10] != 0u;
     K key[ITEMS];
     uint32_t val[ITEMS];
     uint32_t rank[ITEMS];
 #pragma unroll
     for (int k = 0; k < ITEMS; k++) {
         const uint32_t e = wave_off + k * WAVE + lane;     // element of the tile (no 32-bit wrap near 2^32)
-        const bool ok = e < valid;
+        const bool ok = e < in_tile && chunk_ok;
         key[k] = ok ? keys_in[tile_base + e] : (K)~(K)0;
-        val[k] = ok ? vals_in[tile_base + e] : 0u;
+        if constexpr (COMPACT) val[k] = tile_base + e;
+        else val[k] = ok ? vals_in[tile_base + e] : 0u;
     }
     if constexpr (FAST_RANK) {
 #pragma unroll
         for (int k = 0; k < ITEMS; k++) {
             uint32_t d = (uint32_t)(key[k] >> shift) & digit_mask;
-            rank[k] = atomicAdd(&s_wave_hist[wid][d], 1u);
+            if (!COMPACT || (uint32_t)key[k] != SORT_INVALID_KEY) rank[k] = atomicAdd(&s_wave_hist[wid][d], 1u);
         }
     } else {
 #pragma unroll
         for (int k = 0; k < ITEMS; k++) {
             uint32_t d = (uint32_t)(key[k] >> shift) & digit_mask;
-            // wave64 match-any on the digit: peers = lanes holding the same digit
-            uint64_t peers = ~0ull;
+            const bool live = !COMPACT || (uint32_t)key[k] != SORT_INVALID_KEY;
+            // wave64 match-any on the digit: peers = live lanes holding the same digit
+            uint64_t peers = __ballot(live);
 #pragma unroll
             for (int b = 0; b < RB; b++) {
                 uint64_t m = __ballot((d >> b) & 1u);
                 peers &= ((d >> b) & 1u) ? m : ~m;
             }
-            uint32_t before = mbcnt(peers);             // same-digit lanes below me
+            uint32_t before = mbcnt(peers);             // same-digit live lanes below me
             uint32_t old = s_wave_hist[wid][d];
             rank[k] = old + before;
-            if (before == 0u) s_wave_hist[wid][d] = old + (uint32_t)__popcll(peers);
+            __builtin_amdgcn_wave_barrier();
+            if (live && before == 0u) s_wave_hist[wid][d] = old + (uint32_t)__popcll(peers);
             __builtin_amdgcn_wave_barrier();
         }
     }
     __syncthreads();
 
     // per digit: offsets of each wave inside the digit run, block digit count
+    uint32_t live_total;      // elements this block scatters
     {
         uint32_t c[DPT][4], dc[DPT], mine = 0;
 #pragma unroll
@@ -1370,8 +1287,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
             dc[q] = (c[q][0] + c[q][1]) + (c[q][2] + c[q][3]);
             mine += dc[q];
         }
-        uint32_t total;
-        uint32_t bin_start = block_exclusive_scan_256(mine, s_scan, total);
+        uint32_t bin_start = block_exclusive_scan_256(mine, s_scan, live_total);
 #pragma unroll
         for (int q = 0; q < DPT; q++) {
             const uint32_t digit = tid * DPT + q;
@@ -1385,58 +1301,41 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
     }
     // global base of every digit: sum of totals of smaller digits + this block's row prefix
     {
-        uint32_t tot[DPT], pre[DPT], mine = 0;
-        if constexpr (FUSED_SCAN) {
-            // row prefix = whole super-blocks in front of mine + the blocks of my super-block in
-            // front of me; digit total = all super-blocks that hold data
-            const uint32_t nvalid = (uint32_t)(((uint64_t)count + TILE - 1) / TILE);
-            const uint32_t nsb = (nvalid + SORT_SB - 1) / SORT_SB, my_sb = blockIdx.x / SORT_SB;
+        uint32_t tot[DPT], mine = 0;
 #pragma unroll
-            for (int q = 0; q < DPT; q++) {
-                const uint32_t digit = tid * DPT + q;
-                uint32_t t = 0, p = 0;
-                for (uint32_t sb = 0; sb < nsb; sb++) {
-                    const uint32_t v = sb_sums[digit * sb_stride + sb];
-                    t += v;
-                    p += sb < my_sb ? v : 0u;
-                }
-                for (uint32_t b = my_sb * SORT_SB; b < blockIdx.x; b++) p += ghist[(uint64_t)digit * num_blocks + b];
-                tot[q] = t;
-                pre[q] = p;
-                mine += t;
-            }
-        } else {
-#pragma unroll
-            for (int q = 0; q < DPT; q++) {
-                tot[q] = digit_totals[tid * DPT + q];
-                pre[q] = ghist[(uint64_t)(tid * DPT + q) * num_blocks + blockIdx.x];
-                mine += tot[q];
-            }
+        for (int q = 0; q < DPT; q++) {
+            tot[q] = digit_totals[tid * DPT + q];
+            mine += tot[q];
         }
-        uint32_t t2;
-        uint32_t digit_base = block_exclusive_scan_256(mine, s_scan, t2);
+        uint32_t all;
+        uint32_t digit_base = block_exclusive_scan_256(mine, s_scan, all);
 #pragma unroll
         for (int q = 0; q < DPT; q++) {
             const uint32_t digit = tid * DPT + q;
-            s_global[digit] = digit_base + pre[q];
+            s_global[digit] = digit_base + ghist[(uint64_t)digit * num_blocks + blockIdx.x];
             digit_base += tot[q];
         }
+        if constexpr (COMPACT)
+            if (blockIdx.x == 0 && tid == 0) *visible_out = all;     // V = everything the pass ranked
     }
     __syncthreads();
 
     // local reorder through LDS so that each digit run is written by consecutive lanes
 #pragma unroll
     for (int k = 0; k < ITEMS; k++) {
+        if (COMPACT && (uint32_t)key[k] == SORT_INVALID_KEY) continue;
         uint32_t d = (uint32_t)(key[k] >> shift) & digit_mask;
         uint32_t pos = s_wave_hist[wid][d] + rank[k];
         s_keys[pos] = key[k];
         s_vals[pos] = val[k];
     }
     __syncthreads();
+    // without COMPACT the padding of a partial tile carries the all-ones key and sorts to the end
+    const uint32_t live = COMPACT ? live_total : in_tile;
 #pragma unroll
     for (int k = 0; k < ITEMS; k++) {
         uint32_t pos = k * SORT_THREADS + tid;
-        if (pos < valid) {
+        if (pos < live) {
             K kk = s_keys[pos];
             uint32_t d = (uint32_t)(kk >> shift) & digit_mask;
             uint32_t dst = s_global[d] + (pos - s_bin_start[d]);
@@ -1475,11 +1374,16 @@ __global__ __launch_bounds__(SORT_THREADS) void k_probe_lds_atomic_order(uint32_
             const uint32_t mode = (r + k) & 3u;
             d[k] = (mode == 0 ? x : mode == 1 ? (x & 3u) * 37u : mode == 2 ? (lane >> 3) + 250u : 7u + 256u) & (R - 1);
         }
+        // odd rounds mask out a data-dependent subset of the lanes, as the compacting pass does
+        bool live[ITEMS];
 #pragma unroll
-        for (int k = 0; k < ITEMS; k++) got[k] = atomicAdd(&s_cnt[wid][d[k]], 1u);   // back to back, as in the sort
+        for (int k = 0; k < ITEMS; k++) live[k] = !(r & 1u) || ((d[k] * 2654435761u) >> 29) != 0u;
+#pragma unroll
+        for (int k = 0; k < ITEMS; k++)
+            if (live[k]) got[k] = atomicAdd(&s_cnt[wid][d[k]], 1u);   // back to back, as in the sort
 #pragma unroll
         for (int k = 0; k < ITEMS; k++) {
-            uint64_t peers = ~0ull;
+            uint64_t peers = __ballot(live[k]);
 #pragma unroll
             for (int b = 0; b < RB; b++) {
                 uint64_t m = __ballot((d[k] >> b) & 1u);
@@ -1487,9 +1391,9 @@ __global__ __launch_bounds__(SORT_THREADS) void k_probe_lds_atomic_order(uint32_
             }
             const uint32_t before = mbcnt(peers);
             const uint32_t old = s_ref[wid][d[k]];
-            errors += got[k] != old + before;
+            errors += live[k] && got[k] != old + before;
             __builtin_amdgcn_wave_barrier();
-            if (before == 0u) s_ref[wid][d[k]] = old + (uint32_t)__popcll(peers);
+            if (live[k] && before == 0u) s_ref[wid][d[k]] = old + (uint32_t)__popcll(peers);
             __builtin_amdgcn_wave_barrier();
         }
     }
