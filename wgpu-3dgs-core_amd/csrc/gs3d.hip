@@ -1962,7 +1962,8 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
         eo.capacity = capacity;
         eo.tiles_x = fc.tiles_x;
         eo.gen = gen;
-        hipLaunchKernelGGL(gs::k_expand_count, dim3(exp_grid), dim3(gs::EXP_CHUNK), 0, st, eo);
+        hipLaunchKernelGGL(gs::k_expand_count, dim3((exp_grid + gs::EXP_COUNT_CHUNKS - 1) / gs::EXP_COUNT_CHUNKS),
+                           dim3(gs::EXP_CHUNK), 0, st, eo);
         if (wide)
             hipLaunchKernelGGL(gs::k_expand_emit<uint32_t>, dim3(exp_grid), dim3(gs::EXP_CHUNK), 0, st, eo,
                                (uint32_t *)r->tkeys[0].ptr);
@@ -2005,7 +2006,14 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
     mark(ST_BLEND);
     uint32_t band_tiles = (fc.band_ty1 - fc.band_ty0) * fc.tiles_x;
     if (band_tiles) {
-        auto blend = mode == GS_DISPLAY_SPLAT ? gs::k_blend<0> : mode == GS_DISPLAY_ELLIPSE ? gs::k_blend<1> : gs::k_blend<2>;
+        // GS3D_BLEND_GROUPS = 1 (half-tile lists), 2 (8x8 blocks) or 4 (8x4 blocks, default)
+        static const int groups = std::getenv("GS3D_BLEND_GROUPS") ? std::atoi(std::getenv("GS3D_BLEND_GROUPS")) : 4;
+        typedef void (*blend_fn)(const uint32_t *, const uint32_t *, const uint32_t *, gs::FrameConsts, float4 *);
+        static const blend_fn tbl[3][3] = {
+            {gs::k_blend<0>, gs::k_blend_grouped<0, 2>, gs::k_blend_grouped<0, 4>},
+            {gs::k_blend<1>, gs::k_blend_grouped<1, 2>, gs::k_blend_grouped<1, 4>},
+            {gs::k_blend<2>, gs::k_blend_grouped<2, 2>, gs::k_blend_grouped<2, 4>}};
+        const blend_fn blend = tbl[mode][groups == 1 ? 0 : groups == 2 ? 1 : 2];
         hipLaunchKernelGGL(blend, dim3(band_tiles), dim3(gs::BLEND_THREADS), 0, st,
                            (const uint32_t *)r->zero_region.ptr, (const uint32_t *)r->tvals[r->tsorted_side].ptr,
                            (const uint32_t *)r->recs.ptr, fc, (float4 *)rgba);

@@ -926,26 +926,45 @@ struct ExpandIO {
 
 // Expansion, part 1: gather the tile rects into depth order (the only random access of the key
 // path: 8 bytes per visible Gaussian from a compact array) and sum the tile counts per chunk of
-// EXP_CHUNK Gaussians and per super-chunk of EXP_SB chunks (one 64-bit atomic per workgroup).
+// EXP_CHUNK Gaussians and per super-chunk of EXP_SB chunks.  A workgroup covers EXP_COUNT_CHUNKS
+// chunks (8 independent gathers in flight per thread) and issues ONE 64-bit atomic for all of them,
+// so a super-chunk's word sees EXP_SB / EXP_COUNT_CHUNKS = 16 adds (one add per chunk: 128 adds
+// serialised on one address, 26 us instead of 9 at 1 M).
 // The grid covers the host's upper bound of V (= N); workgroups past the real V exit at once.
+constexpr uint32_t EXP_COUNT_CHUNKS = 8;
+static_assert(EXP_SB % EXP_COUNT_CHUNKS == 0, "a count workgroup must not straddle super-chunks");
 __global__ __launch_bounds__(EXP_CHUNK) void k_expand_count(ExpandIO io) {
-    __shared__ uint32_t s_red[4];
+    __shared__ uint32_t s_red[EXP_COUNT_CHUNKS][4];
     const uint32_t v_count = io.state->visible;
-    if ((uint64_t)blockIdx.x * EXP_CHUNK >= v_count) return;
-    const uint32_t j = blockIdx.x * EXP_CHUNK + threadIdx.x;
-    uint32_t v = 0;
-    if (j < v_count) {
-        const uint2 r = io.rect[io.order[j]];
-        io.sorted_rect[j] = r;
-        v = ((r.y & 0xffffu) - (r.x & 0xffffu)) * ((r.y >> 16) - (r.x >> 16));
+    const uint32_t first_chunk = blockIdx.x * EXP_COUNT_CHUNKS;
+    if ((uint64_t)first_chunk * EXP_CHUNK >= v_count) return;
+    uint32_t slot[EXP_COUNT_CHUNKS];
+#pragma unroll
+    for (uint32_t c = 0; c < EXP_COUNT_CHUNKS; c++) {
+        const uint64_t j = (uint64_t)(first_chunk + c) * EXP_CHUNK + threadIdx.x;
+        slot[c] = j < v_count ? io.order[j] : 0xffffffffu;
     }
-    v = wave_reduce_add(v);
-    if ((threadIdx.x & 63u) == 0) s_red[threadIdx.x >> 6] = v;
+    uint2 r[EXP_COUNT_CHUNKS];
+#pragma unroll
+    for (uint32_t c = 0; c < EXP_COUNT_CHUNKS; c++) r[c] = slot[c] != 0xffffffffu ? io.rect[slot[c]] : make_uint2(0u, 0u);
+    const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+#pragma unroll
+    for (uint32_t c = 0; c < EXP_COUNT_CHUNKS; c++) {
+        const uint64_t j = (uint64_t)(first_chunk + c) * EXP_CHUNK + threadIdx.x;
+        if (j < v_count) io.sorted_rect[j] = r[c];
+        uint32_t v = ((r[c].y & 0xffffu) - (r[c].x & 0xffffu)) * ((r[c].y >> 16) - (r[c].x >> 16));
+        v = wave_reduce_add(v);
+        if (lane == 0) s_red[c][wid] = v;
+    }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        const uint32_t total = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);   // <= 256 * 2^22
-        io.sums[blockIdx.x] = total;
-        if (total) atomicAdd(io.sb_sums + blockIdx.x / EXP_SB, (unsigned long long)total);
+    if (threadIdx.x < EXP_COUNT_CHUNKS) {
+        const uint32_t c = threadIdx.x;
+        const uint32_t total = (s_red[c][0] + s_red[c][1]) + (s_red[c][2] + s_red[c][3]);   // <= 256 * 2^22
+        if ((uint64_t)(first_chunk + c) * EXP_CHUNK < v_count) io.sums[first_chunk + c] = total;
+        uint64_t all = total;      // the 8 chunk totals live in lanes 0..7 of wave 0
+#pragma unroll
+        for (int d = 1; d < (int)EXP_COUNT_CHUNKS; d <<= 1) all += __shfl_xor((unsigned long long)all, d, WAVE);
+        if (c == 0 && all) atomicAdd(io.sb_sums + first_chunk / EXP_SB, (unsigned long long)all);
     }
 }
 
@@ -1667,6 +1686,231 @@ __global__ __launch_bounds__(BLEND_THREADS) void k_blend(const uint32_t *__restr
                 C0 = pk_fma(f32x2{bq.z, bq.z}, wgt, C0);
                 C1 = pk_fma(f32x2{bq.w, bq.w}, wgt, C1);
                 C2 = pk_fma(f32x2{cq.x, cq.x}, wgt, C2);
+                T = test_T;
+                if (remaining == 0u) break;
+            }
+        }
+    }
+    if (in0) {
+        float4 o;
+        o.x = __builtin_fmaf(T.x, fc.bg[0], C0.x);
+        o.y = __builtin_fmaf(T.x, fc.bg[1], C1.x);
+        o.z = __builtin_fmaf(T.x, fc.bg[2], C2.x);
+        o.w = 1.0f - T.x;
+        rgba[(uint64_t)py0 * fc.width + px] = o;
+    }
+    if (in1) {
+        float4 o;
+        o.x = __builtin_fmaf(T.y, fc.bg[0], C0.y);
+        o.y = __builtin_fmaf(T.y, fc.bg[1], C1.y);
+        o.z = __builtin_fmaf(T.y, fc.bg[2], C2.y);
+        o.w = 1.0f - T.y;
+        rgba[(uint64_t)py1 * fc.width + px] = o;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// blend, grouped form: culling at sub-block granularity with the packed arithmetic kept
+// ---------------------------------------------------------------------------------------------
+
+// Exact maximum of the concave exponent over a pixel-centre rectangle, from the two edges that
+// face the splat centre (the maximum of a concave quadratic over a rectangle that does not contain
+// its apex lies on the boundary visible from the apex: the nearer vertical and the nearer
+// horizontal edge; evaluating an edge that is not visible only adds a value attained on the
+// rectangle, so the result never exceeds the true maximum).  Two clamped parabolas instead of four.
+__device__ __forceinline__ bool splat_touches_rect2(float mx, float my, float ca, float cb, float cc,
+                                                    float rx0, float rx1, float ry0, float ry1, float thr) {
+    const float dx_lo = mx - rx1, dx_hi = mx - rx0, dy_lo = my - ry1, dy_hi = my - ry0;
+    const bool in_x = dx_lo <= 0.0f && dx_hi >= 0.0f, in_y = dy_lo <= 0.0f && dy_hi >= 0.0f;
+    const float dxn = fabsf(dx_lo) < fabsf(dx_hi) ? dx_lo : dx_hi;   // offset to the nearer vertical edge
+    const float dyn = fabsf(dy_lo) < fabsf(dy_hi) ? dy_lo : dy_hi;
+    const float mv = parabola_max(cc, cb * dxn, ca * dxn * dxn, dy_lo, dy_hi);
+    const float mh = parabola_max(ca, cb * dyn, cc * dyn * dyn, dx_lo, dx_hi);
+    return (in_x && in_y) || !(fmaxf(mv, mh) < thr);
+}
+
+// One workgroup (2 waves) = one 16x16 tile, wave h = pixel rows 8h..8h+7, two pixels per lane on
+// packed f32 — as k_blend — but the wave's 64 lanes are split into G lane groups that own
+// different sub-blocks of the half-tile (G = 2: two 8x8 blocks, G = 4: four 8x4 blocks) and walk
+// DIFFERENT splat lists in lock step: one wave instruction stream serves G (splat, block) pairs.
+// A splat of a few pixels radius touches far fewer 8x4 blocks x 32 pixels than 16x8 half-tiles x
+// 128 pixels, so the number of loop iterations drops (1 M scene: x0.65 for G = 4, x0.77 for
+// G = 2, tools/blend_sim.py) at an unchanged instruction count per iteration.  The staged splat
+// records are stored once per batch; the per-block lists hold one-byte indices into them, padded
+// with the index of a null record whose exponent test never passes, so lanes whose list is shorter
+// than the wave's longest simply idle.  Results are bit-identical to k_blend: culling only removes
+// (splat, block) pairs whose alpha is below 1/255 at every pixel of the block.
+template <int MODE, int G>
+__global__ __launch_bounds__(BLEND_THREADS) void k_blend_grouped(const uint32_t *__restrict__ ranges,
+                                                                 const uint32_t *__restrict__ idx,
+                                                                 const uint32_t *__restrict__ recs,
+                                                                 FrameConsts fc, float4 *__restrict__ rgba) {
+    static_assert(G == 2 || G == 4, "lane groups per wave");
+    constexpr int GL = WAVE / G;              // lanes per group
+    constexpr int BH = 16 / G;                // block height: G = 2 -> 8, G = 4 -> 4 (block width is 8; GL lanes x 2 pixels)
+    constexpr int NL = 2 * G;                 // lists per tile
+    constexpr uint32_t NULL_REC = BLEND_BATCH;
+    __shared__ float4 s_a[BLEND_BATCH + 1];   // mx, my, ca, cb
+    __shared__ float4 s_b[BLEND_BATCH + 1];   // cc, pmin, opacity, r
+    __shared__ float2 s_c[BLEND_BATCH + 1];   // g, b
+    __shared__ __attribute__((aligned(16))) uint8_t s_list[NL][BLEND_BATCH];
+    __shared__ uint32_t s_cnt[2][NL];         // [staging wave][list]
+    __shared__ uint32_t s_alive[2];
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
+    const uint32_t tile = fc.band_ty0 * fc.tiles_x + blockIdx.x;
+    const uint32_t ty = tile / fc.tiles_x, tx = tile % fc.tiles_x;
+    const uint32_t gi = lane / GL, lg = lane % GL;
+    const uint32_t bx = gi & 1u, by = G == 4 ? gi >> 1 : 0u;
+    const uint32_t px = tx * 16u + bx * 8u + (lg & 7u);
+    const uint32_t py0 = ty * 16u + wid * 8u + by * BH + (lg >> 3), py1 = py0 + BH / 2;
+    const float pxf = (float)px + 0.5f;
+    const uint32_t my_list = wid * G + gi;
+    const float tx0 = (float)(tx * 16u) + 0.5f, ty0 = (float)(ty * 16u) + 0.5f;   // tile origin, pixel centres
+
+    const uint32_t start = ranges[2 * tile], end = ranges[2 * tile + 1];
+    f32x2 T = {1.0f, 1.0f}, C0 = {0.0f, 0.0f}, C1 = {0.0f, 0.0f}, C2 = {0.0f, 0.0f};
+    const bool in0 = px < fc.width && py0 < fc.height, in1 = px < fc.width && py1 < fc.height;
+    constexpr float DEAD = 1.0e15f;           // finished / out-of-image pixels are parked far away (see k_blend)
+    f32x2 pyf = {in0 ? (float)py0 + 0.5f : DEAD, in1 ? (float)py1 + 0.5f : DEAD};
+    uint32_t remaining = __builtin_amdgcn_readfirstlane(
+        (uint32_t)__popcll(__ballot(in0)) + (uint32_t)__popcll(__ballot(in1)));
+    if (tid == 0) {   // the null record: power = 0 everywhere, pmin = 1 -> "power >= pmin" never holds
+        s_a[NULL_REC] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        s_b[NULL_REC] = make_float4(0.0f, 1.0f, 0.0f, 0.0f);
+        s_c[NULL_REC] = make_float2(0.0f, 0.0f);
+    }
+
+    for (uint32_t b0 = start; b0 < end; b0 += BLEND_BATCH) {
+        // stop fetching once every pixel of the tile is finished
+        if (lane == 0) s_alive[wid] = remaining;
+        __syncthreads();
+        if ((s_alive[0] | s_alive[1]) == 0u) break;
+
+        // lists start out as all-null (the previous batch's loops ended before the barrier above)
+        {
+            uint32_t *l32 = (uint32_t *)&s_list[0][0];
+            constexpr uint32_t fill = NULL_REC * 0x01010101u;
+            for (uint32_t q = tid; q < NL * BLEND_BATCH / 4; q += BLEND_THREADS) l32[q] = fill;
+        }
+        // stage one splat per thread, test it against every block of the tile; the verdicts live as
+        // wave ballots in scalar registers (a per-lane array of 2G flags cost 40 vector registers)
+        const uint32_t j = b0 + tid;
+        float mx = 0.0f, my = 0.0f, ca = 0.0f, cb = 0.0f, cc = 0.0f, thr = 0.0f;
+        const bool have = j < end;
+        if (have) {
+            const uint32_t *rec = recs + (uint64_t)idx[j] * REC_WORDS;
+            const u32x4_a4 r0 = *(const u32x4_a4 *)(rec);
+            const u32x4_a4 r1 = *(const u32x4_a4 *)(rec + 4);
+            const uint32_t r2x = rec[8];
+            mx = u2f(r0.x); my = u2f(r0.y); ca = u2f(r0.z); cb = u2f(r0.w); cc = u2f(r1.x);
+            float pmin;
+            if constexpr (MODE == 0) pmin = fmaxf(-__logf(255.0f * u2f(r1.y)) - 1.0e-3f, -5.6f);
+            else pmin = fc.ellipse_pmin;
+            thr = MODE == 0 ? pmin - 0.1f : pmin - 0.1f - 1.0e-3f * fabsf(pmin);
+            s_a[tid] = make_float4(mx, my, ca, cb);
+            s_b[tid] = make_float4(cc, pmin, u2f(r1.y), u2f(r1.z));
+            s_c[tid] = make_float2(u2f(r1.w), u2f(r2x));
+        }
+        uint64_t m[NL];
+#pragma unroll
+        for (int l = 0; l < NL; l++) {
+            const int lw = l / G, lgi = l % G;                 // wave and group of list l
+            const float rx0 = tx0 + 8.0f * (float)(lgi & 1);
+            const float ry0 = ty0 + 8.0f * (float)lw + (G == 4 ? (float)BH * (float)(lgi >> 1) : 0.0f);
+            bool keep;
+            if constexpr (MODE == 2) {
+                const float ex = mx - clampf(mx, rx0, rx0 + 7.0f), ey = my - clampf(my, ry0, ry0 + (float)(BH - 1));
+                keep = ex * ex + ey * ey <= 2.26f;
+            } else {
+                keep = splat_touches_rect2(mx, my, ca, cb, cc, rx0, rx0 + 7.0f, ry0, ry0 + (float)(BH - 1), thr);
+            }
+            m[l] = __ballot(have && keep);
+            if (lane == 0) s_cnt[wid][l] = (uint32_t)__popcll(m[l]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int l = 0; l < NL; l++)
+            if ((m[l] >> lane) & 1ull) s_list[l][(wid ? s_cnt[0][l] : 0u) + mbcnt(m[l])] = (uint8_t)tid;
+        // trip count of MY wave: its longest list (wave-uniform)
+        uint32_t trip = 0;
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            const uint32_t c = s_cnt[0][wid * G + g] + s_cnt[1][wid * G + g];
+            trip = c > trip ? c : trip;
+        }
+        trip = __builtin_amdgcn_readfirstlane(trip);
+        __syncthreads();
+
+        if (remaining != 0u) {
+            // the list entries are read two iterations ahead and the records one ahead, so that an
+            // iteration never waits for a dependent pair of LDS reads (lists are padded with the
+            // null index, and s_list rows are followed by readable LDS: no bounds checks needed
+            // beyond clamping the look-ahead to the row)
+            const uint8_t *mine = s_list[my_list];
+            uint32_t cur = mine[0];
+            uint32_t nxt = mine[1];
+            float4 a = s_a[cur], bq = s_b[cur];
+            for (uint32_t s = 0; s < trip; s++) {
+                const uint32_t me = cur;
+                const float4 a_now = a, bq_now = bq;
+                cur = nxt;
+                nxt = mine[s + 2 < (uint32_t)BLEND_BATCH ? s + 2 : (uint32_t)BLEND_BATCH - 1];
+                a = s_a[cur];
+                bq = s_b[cur];
+                const float dx = a_now.x - pxf;
+                const f32x2 dy = f32x2{a_now.y, a_now.y} - pyf;
+                const float u = a_now.z * dx, wq = a_now.w * dx;
+                const f32x2 v = f32x2{bq_now.x, bq_now.x} * dy;
+                f32x2 t = f32x2{wq, wq} * dy;
+                t = pk_fma(v, dy, t);
+                const f32x2 power = pk_fma(f32x2{u, u}, f32x2{dx, dx}, t);
+                bool p0, p1;
+                if constexpr (MODE == 2) {
+                    const f32x2 d2 = f32x2{dx * dx, dx * dx} + dy * dy;
+                    p0 = d2.x <= 2.25f && bq_now.y <= 0.0f;      // the null record carries pmin = 1
+                    p1 = d2.y <= 2.25f && bq_now.y <= 0.0f;
+                } else {
+                    p0 = power.x <= 0.0f && power.x >= bq_now.y;
+                    p1 = power.y <= 0.0f && power.y >= bq_now.y;
+                }
+                if (!__any(p0 || p1)) continue;
+                const float2 cq = s_c[me];   // g, b
+                f32x2 alpha;
+                if constexpr (MODE == 0) {
+                    // exp exactly as in k_blend
+                    const f32x2 tt = power * f32x2{1.44269504088896340736f, 1.44269504088896340736f};
+                    const f32x2 tm = tt + f32x2{12582912.0f, 12582912.0f};
+                    const f32x2 n = tm - f32x2{12582912.0f, 12582912.0f};
+                    const f32x2 f = tt - n;
+                    f32x2 p = {0x1.5f0896p-10f, 0x1.5f0896p-10f};
+                    p = pk_fma(p, f, f32x2{0x1.3cbf6cp-7f, 0x1.3cbf6cp-7f});
+                    p = pk_fma(p, f, f32x2{0x1.c6af6cp-5f, 0x1.c6af6cp-5f});
+                    p = pk_fma(p, f, f32x2{0x1.ebfa4ap-3f, 0x1.ebfa4ap-3f});
+                    p = pk_fma(p, f, f32x2{0x1.62e430p-1f, 0x1.62e430p-1f});
+                    p = pk_fma(p, f, f32x2{1.0f, 1.0f});
+                    const f32x2 e = {u2f(f2u(p.x) + (f2u(tm.x) << 23)), u2f(f2u(p.y) + (f2u(tm.y) << 23))};
+                    const f32x2 oe = f32x2{bq_now.z, bq_now.z} * e;
+                    alpha = f32x2{fminf(0.99f, oe.x), fminf(0.99f, oe.y)};
+                } else {
+                    const float flat = fminf(0.99f, bq_now.z);
+                    alpha = f32x2{flat, flat};
+                }
+                const bool act0 = p0 && alpha.x >= (1.0f / 255.0f);
+                const bool act1 = p1 && alpha.y >= (1.0f / 255.0f);
+                f32x2 alpha_eff = {act0 ? alpha.x : 0.0f, act1 ? alpha.y : 0.0f};
+                f32x2 test_T = T * (f32x2{1.0f, 1.0f} - alpha_eff);
+                const bool fin0 = act0 && test_T.x < 0.0001f, fin1 = act1 && test_T.y < 0.0001f;
+                if (__any(fin0 || fin1)) {   // rare: some pixel reached T < 1e-4 -> it stops here
+                    if (fin0) { pyf.x = DEAD; alpha_eff.x = 0.0f; test_T.x = T.x; }
+                    if (fin1) { pyf.y = DEAD; alpha_eff.y = 0.0f; test_T.y = T.y; }
+                    remaining = __builtin_amdgcn_readfirstlane(
+                        remaining - ((uint32_t)__popcll(__ballot(fin0)) + (uint32_t)__popcll(__ballot(fin1))));
+                }
+                const f32x2 wgt = alpha_eff * T;
+                C0 = pk_fma(f32x2{bq_now.w, bq_now.w}, wgt, C0);
+                C1 = pk_fma(f32x2{cq.x, cq.x}, wgt, C1);
+                C2 = pk_fma(f32x2{cq.y, cq.y}, wgt, C2);
                 T = test_T;
                 if (remaining == 0u) break;
             }
