@@ -57,3 +57,23 @@ for hy in range(2):
     new8+=np.maximum.reduce(lists).sum()
     e[hy]=sum(l.sum() for l in lists)/4
 print('8x4 quarter-waves (max of 4 lists):',new8,'ratio',new8/cur,' ideal:',sum(e.values())/cur)
+# 4x4 blocks, eighth-waves (8 lanes x 2 px): wave w covers half w: 8 blocks (4 across x 2 down)
+new16=0; ideal16=0
+for hy in range(2):
+    lists=[]
+    for by in range(2):
+        for bx in range(4):
+            m=touches(x0+4*bx,x0+4*bx+3,y0+8*hy+4*by,y0+8*hy+4*by+3)
+            lists.append(grp_sum(m))
+    new16+=np.maximum.reduce(lists).sum(); ideal16+=sum(l.sum() for l in lists)/8
+print('4x4 eighth-waves (max of 8 lists):',new16,'ratio',new16/cur,' ideal:',ideal16/cur)
+# 8x2 blocks, eighth-waves
+new82=0; ideal82=0
+for hy in range(2):
+    lists=[]
+    for by in range(4):
+        for bx in range(2):
+            m=touches(x0+8*bx,x0+8*bx+7,y0+8*hy+2*by,y0+8*hy+2*by+1)
+            lists.append(grp_sum(m))
+    new82+=np.maximum.reduce(lists).sum(); ideal82+=sum(l.sum() for l in lists)/8
+print('8x2 eighth-waves (max of 8 lists):',new82,'ratio',new82/cur,' ideal:',ideal82/cur)

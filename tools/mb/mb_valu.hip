@@ -1,0 +1,73 @@
+// VALU issue cost per instruction kind on gfx950, measured at 1, 2, 4 and 8 waves per SIMD:
+// is v_pk_fma_f32 (two IEEE fma per lane) as cheap to issue as v_fma_f32?  what do compares,
+// selects and the scalar mask arithmetic around them cost?  (decides how k_blend spends its cycles)
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr int UNROLL = 16;   // independent chains per thread
+
+template <int KIND>
+__global__ __launch_bounds__(256) void k(float *out, int iters, float seed) {
+    float a[UNROLL];
+    f32x2 p[UNROLL];
+    for (int i = 0; i < UNROLL; i++) { a[i] = seed + i + threadIdx.x; p[i] = f32x2{a[i], a[i] + 1.0f}; }
+    const float c0 = seed * 0.5f, c1 = seed * 0.25f;
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int i = 0; i < UNROLL; i++) {
+            if constexpr (KIND == 0) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(c0), "v"(c1));
+            if constexpr (KIND == 1) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[i]) : "v"(f32x2{c0, c0}), "v"(f32x2{c1, c1}));
+            if constexpr (KIND == 2) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[i]) : "v"(c0));
+            if constexpr (KIND == 3) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p[i]) : "v"(f32x2{c0, c0}));
+            if constexpr (KIND == 4) asm volatile("v_min_f32 %0, %0, %1" : "+v"(a[i]) : "v"(c0));
+            if constexpr (KIND == 5) asm volatile("v_cmp_ge_f32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(c0) : "vcc");
+            if constexpr (KIND == 6) asm volatile("v_lshl_add_u32 %0, %0, 1, %1" : "+v"(a[i]) : "v"(c0));
+            if constexpr (KIND == 7) asm volatile("v_exp_f32 %0, %0" : "+v"(a[i]));
+            if constexpr (KIND == 8) asm volatile("v_cmp_ge_f32 s[20:21], %0, %1\n\ts_and_b64 s[22:23], s[20:21], s[22:23]" : : "v"(a[i]), "v"(c0) : "s20", "s21", "s22", "s23", "scc");   // s_and_b64 writes SCC: undeclared, it broke the loop branch
+            if constexpr (KIND == 9) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[i]) : "v"(f32x2{c0, c0}));
+        }
+    }
+    float s = 0;
+    for (int i = 0; i < UNROLL; i++) s += a[i] + p[i].x + p[i].y;
+    if (s == 12345.678f) out[threadIdx.x] = s;
+}
+
+template <int KIND>
+static void run(const char *name, int instr_per_item) {
+    float *out; CK(hipMalloc(&out, 4096));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const int iters = 4096;
+    printf("%-34s", name);
+    for (int wps : {1, 2, 4, 8}) {               // waves per SIMD: blocks of 256 threads = 1 wave per SIMD each
+        const int blocks = 256 * wps;
+        hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(256), 0, 0, out, 16, 1.0f);
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(256), 0, 0, out, iters, 1.0f);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        // wave-instructions issued per SIMD = wps * iters * UNROLL * instr_per_item
+        const double inst = (double)wps * iters * UNROLL * instr_per_item;
+        printf("  %dw: %5.2f ns/inst", wps, ms * 1e6 / inst);
+    }
+    printf("\n");
+}
+
+int main() {
+    setvbuf(stdout, NULL, _IONBF, 0);
+    run<0>("v_fma_f32", 1);
+    run<1>("v_pk_fma_f32", 1);
+    run<2>("v_mul_f32", 1);
+    run<3>("v_pk_mul_f32", 1);
+    run<9>("v_pk_add_f32", 1);
+    run<4>("v_min_f32", 1);
+    run<5>("v_cmp_ge_f32 + v_cndmask (2)", 2);
+    run<6>("v_lshl_add_u32", 1);
+    run<7>("v_exp_f32", 1);
+    run<8>("v_cmp -> sgpr + s_and_b64 (2)", 2);
+    printf("(ns per wave-instruction per SIMD; at 2.4 GHz one cycle = 0.417 ns)\n");
+    return 0;
+}

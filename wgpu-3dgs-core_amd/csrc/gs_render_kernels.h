@@ -1812,21 +1812,63 @@ __global__ __launch_bounds__(BLEND_THREADS) void k_blend_grouped(const uint32_t 
             s_b[tid] = make_float4(cc, pmin, u2f(r1.y), u2f(r1.z));
             s_c[tid] = make_float2(u2f(r1.w), u2f(r2x));
         }
+        // The tile's 2G blocks form a grid of 2 columns x G rows (8 wide, BH high).  The exact
+        // maximum of the concave exponent over a block comes from the block's two edges facing the
+        // splat centre (splat_touches_rect2): the facing vertical edge depends only on the column,
+        // the facing horizontal edge only on the row, so the parabola coefficients and their
+        // unconstrained optima are set up once per column / row and a block costs two clamps
+        // (v_med3), four fmas and a compare.  (fma is fine here: the cull is conservative, not part
+        // of the bit-exact result.)
+        constexpr int NROW = G;                            // block rows of the tile (2 columns each)
         uint64_t m[NL];
+        if constexpr (MODE == 2) {
 #pragma unroll
-        for (int l = 0; l < NL; l++) {
-            const int lw = l / G, lgi = l % G;                 // wave and group of list l
-            const float rx0 = tx0 + 8.0f * (float)(lgi & 1);
-            const float ry0 = ty0 + 8.0f * (float)lw + (G == 4 ? (float)BH * (float)(lgi >> 1) : 0.0f);
-            bool keep;
-            if constexpr (MODE == 2) {
+            for (int l = 0; l < NL; l++) {
+                const int lw = l / G, lgi = l % G;
+                const float rx0 = tx0 + 8.0f * (float)(lgi & 1);
+                const float ry0 = ty0 + 8.0f * (float)lw + (G == 4 ? (float)BH * (float)(lgi >> 1) : 0.0f);
                 const float ex = mx - clampf(mx, rx0, rx0 + 7.0f), ey = my - clampf(my, ry0, ry0 + (float)(BH - 1));
-                keep = ex * ex + ey * ey <= 2.26f;
-            } else {
-                keep = splat_touches_rect2(mx, my, ca, cb, cc, rx0, rx0 + 7.0f, ry0, ry0 + (float)(BH - 1), thr);
+                m[l] = __builtin_amdgcn_ballot_w64(have && ex * ex + ey * ey <= 2.26f);
             }
-            m[l] = __ballot(have && keep);
-            if (lane == 0) s_cnt[wid][l] = (uint32_t)__popcll(m[l]);
+        } else {
+            const float rcc = __builtin_amdgcn_rcpf(cc), rca = __builtin_amdgcn_rcpf(ca);
+            float c_lo[2], c_hi[2], c_q1[2], c_q0[2], c_t[2];
+            bool c_in[2];
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                const float x0c = tx0 + 8.0f * (float)c;
+                c_lo[c] = mx - (x0c + 7.0f);
+                c_hi[c] = mx - x0c;
+                c_in[c] = c_lo[c] <= 0.0f && c_hi[c] >= 0.0f;
+                const float dn = fabsf(c_lo[c]) < fabsf(c_hi[c]) ? c_lo[c] : c_hi[c];   // nearer vertical edge
+                c_q1[c] = cb * dn;
+                c_q0[c] = ca * dn * dn;
+                c_t[c] = -0.5f * c_q1[c] * rcc;            // optimum of cc t^2 + q1 t + q0 along the edge
+            }
+#pragma unroll
+            for (int r = 0; r < NROW; r++) {
+                const float y0r = ty0 + (float)(BH * r);
+                const float r_lo = my - (y0r + (float)(BH - 1)), r_hi = my - y0r;
+                const bool r_in = r_lo <= 0.0f && r_hi >= 0.0f;
+                const float dn = fabsf(r_lo) < fabsf(r_hi) ? r_lo : r_hi;               // nearer horizontal edge
+                const float r_q1 = cb * dn, r_q0 = cc * dn * dn;
+                const float r_t = -0.5f * r_q1 * rca;
+#pragma unroll
+                for (int c = 0; c < 2; c++) {
+                    const float tv = __builtin_amdgcn_fmed3f(c_t[c], r_lo, r_hi);
+                    const float mv = __builtin_fmaf(__builtin_fmaf(cc, tv, c_q1[c]), tv, c_q0[c]);
+                    const float th = __builtin_amdgcn_fmed3f(r_t, c_lo[c], c_hi[c]);
+                    const float mh = __builtin_fmaf(__builtin_fmaf(ca, th, r_q1), th, r_q0);
+                    const bool keep = (c_in[c] && r_in) || !(fmaxf(mv, mh) < thr);
+                    // list of block (column c, row r): rows 0..G/2-1 belong to wave 0
+                    const int l = (r / (NROW / 2)) * G + (r % (NROW / 2)) * 2 + c;
+                    m[l] = __builtin_amdgcn_ballot_w64(have && keep);
+                }
+            }
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int l = 0; l < NL; l++) s_cnt[wid][l] = (uint32_t)__popcll(m[l]);
         }
         __syncthreads();
 #pragma unroll
@@ -1843,77 +1885,88 @@ __global__ __launch_bounds__(BLEND_THREADS) void k_blend_grouped(const uint32_t 
         __syncthreads();
 
         if (remaining != 0u) {
-            // the list entries are read two iterations ahead and the records one ahead, so that an
-            // iteration never waits for a dependent pair of LDS reads (lists are padded with the
-            // null index, and s_list rows are followed by readable LDS: no bounds checks needed
-            // beyond clamping the look-ahead to the row)
-            const uint8_t *mine = s_list[my_list];
-            uint32_t cur = mine[0];
-            uint32_t nxt = mine[1];
-            float4 a = s_a[cur], bq = s_b[cur];
-            for (uint32_t s = 0; s < trip; s++) {
-                const uint32_t me = cur;
-                const float4 a_now = a, bq_now = bq;
-                cur = nxt;
-                nxt = mine[s + 2 < (uint32_t)BLEND_BATCH ? s + 2 : (uint32_t)BLEND_BATCH - 1];
-                a = s_a[cur];
-                bq = s_b[cur];
-                const float dx = a_now.x - pxf;
-                const f32x2 dy = f32x2{a_now.y, a_now.y} - pyf;
-                const float u = a_now.z * dx, wq = a_now.w * dx;
-                const f32x2 v = f32x2{bq_now.x, bq_now.x} * dy;
-                f32x2 t = f32x2{wq, wq} * dy;
-                t = pk_fma(v, dy, t);
-                const f32x2 power = pk_fma(f32x2{u, u}, f32x2{dx, dx}, t);
-                bool p0, p1;
-                if constexpr (MODE == 2) {
-                    const f32x2 d2 = f32x2{dx * dx, dx * dx} + dy * dy;
-                    p0 = d2.x <= 2.25f && bq_now.y <= 0.0f;      // the null record carries pmin = 1
-                    p1 = d2.y <= 2.25f && bq_now.y <= 0.0f;
-                } else {
-                    p0 = power.x <= 0.0f && power.x >= bq_now.y;
-                    p1 = power.y <= 0.0f && power.y >= bq_now.y;
-                }
-                if (!__any(p0 || p1)) continue;
-                const float2 cq = s_c[me];   // g, b
-                f32x2 alpha;
-                if constexpr (MODE == 0) {
-                    // exp exactly as in k_blend
-                    const f32x2 tt = power * f32x2{1.44269504088896340736f, 1.44269504088896340736f};
-                    const f32x2 tm = tt + f32x2{12582912.0f, 12582912.0f};
-                    const f32x2 n = tm - f32x2{12582912.0f, 12582912.0f};
-                    const f32x2 f = tt - n;
-                    f32x2 p = {0x1.5f0896p-10f, 0x1.5f0896p-10f};
-                    p = pk_fma(p, f, f32x2{0x1.3cbf6cp-7f, 0x1.3cbf6cp-7f});
-                    p = pk_fma(p, f, f32x2{0x1.c6af6cp-5f, 0x1.c6af6cp-5f});
-                    p = pk_fma(p, f, f32x2{0x1.ebfa4ap-3f, 0x1.ebfa4ap-3f});
-                    p = pk_fma(p, f, f32x2{0x1.62e430p-1f, 0x1.62e430p-1f});
-                    p = pk_fma(p, f, f32x2{1.0f, 1.0f});
-                    const f32x2 e = {u2f(f2u(p.x) + (f2u(tm.x) << 23)), u2f(f2u(p.y) + (f2u(tm.y) << 23))};
-                    const f32x2 oe = f32x2{bq_now.z, bq_now.z} * e;
-                    alpha = f32x2{fminf(0.99f, oe.x), fminf(0.99f, oe.y)};
-                } else {
-                    const float flat = fminf(0.99f, bq_now.z);
-                    alpha = f32x2{flat, flat};
-                }
-                const bool act0 = p0 && alpha.x >= (1.0f / 255.0f);
-                const bool act1 = p1 && alpha.y >= (1.0f / 255.0f);
-                f32x2 alpha_eff = {act0 ? alpha.x : 0.0f, act1 ? alpha.y : 0.0f};
-                f32x2 test_T = T * (f32x2{1.0f, 1.0f} - alpha_eff);
-                const bool fin0 = act0 && test_T.x < 0.0001f, fin1 = act1 && test_T.y < 0.0001f;
-                if (__any(fin0 || fin1)) {   // rare: some pixel reached T < 1e-4 -> it stops here
-                    if (fin0) { pyf.x = DEAD; alpha_eff.x = 0.0f; test_T.x = T.x; }
-                    if (fin1) { pyf.y = DEAD; alpha_eff.y = 0.0f; test_T.y = T.y; }
-                    remaining = __builtin_amdgcn_readfirstlane(
-                        remaining - ((uint32_t)__popcll(__ballot(fin0)) + (uint32_t)__popcll(__ballot(fin1))));
-                }
-                const f32x2 wgt = alpha_eff * T;
-                C0 = pk_fma(f32x2{bq_now.w, bq_now.w}, wgt, C0);
-                C1 = pk_fma(f32x2{cq.x, cq.x}, wgt, C1);
-                C2 = pk_fma(f32x2{cq.y, cq.y}, wgt, C2);
-                T = test_T;
-                if (remaining == 0u) break;
+            // Two splats per trip, in registers A and B: while A is blended B's record is already
+            // on its way from LDS and the indices of the next pair are being read (one 16-bit read:
+            // lists are rows of bytes, the trip count is rounded up to even and the padding is the
+            // null index, so the extra step of an odd list blends nothing).  One structured loop,
+            // one conditional block per step: no continue / break inside (hipcc turned those into a
+            // scalar state machine of ~25 instructions and 5 branches per iteration).
+            const uint16_t *mine = (const uint16_t *)s_list[my_list];
+            const uint32_t trips = (trip + 1u) >> 1;
+            uint32_t pair = mine[0];
+            float4 a_A = s_a[pair & 0xffu], b_A = s_b[pair & 0xffu];
+            uint32_t id_A = pair & 0xffu;
+#define GS_BLEND_STEP(AREC, BREC, ID)                                                                          \
+    {                                                                                                         \
+        const float dx = AREC.x - pxf;                                                                        \
+        const f32x2 dy = f32x2{AREC.y, AREC.y} - pyf;                                                         \
+        const float u = AREC.z * dx, wq = AREC.w * dx;                                                        \
+        const f32x2 v = f32x2{BREC.x, BREC.x} * dy;                                                           \
+        f32x2 t = f32x2{wq, wq} * dy;                                                                         \
+        t = pk_fma(v, dy, t);                                                                                 \
+        const f32x2 power = pk_fma(f32x2{u, u}, f32x2{dx, dx}, t);                                            \
+        bool p0, p1;                                                                                          \
+        if constexpr (MODE == 2) {                                                                            \
+            const f32x2 d2 = f32x2{dx * dx, dx * dx} + dy * dy;                                               \
+            p0 = d2.x <= 2.25f && BREC.y <= 0.0f; /* the null record carries pmin = 1 */                      \
+            p1 = d2.y <= 2.25f && BREC.y <= 0.0f;                                                             \
+        } else {                                                                                              \
+            p0 = power.x <= 0.0f && power.x >= BREC.y;                                                        \
+            p1 = power.y <= 0.0f && power.y >= BREC.y;                                                        \
+        }                                                                                                     \
+        if (__builtin_amdgcn_ballot_w64(p0 || p1) != 0ull) {                                                  \
+            const float2 cq = s_c[ID]; /* g, b */                                                             \
+            f32x2 alpha;                                                                                      \
+            if constexpr (MODE == 0) {                                                                        \
+                /* exp exactly as in k_blend */                                              \
+                const f32x2 tt = power * f32x2{1.44269504088896340736f, 1.44269504088896340736f};             \
+                const f32x2 tm = tt + f32x2{12582912.0f, 12582912.0f};                                        \
+                const f32x2 n = tm - f32x2{12582912.0f, 12582912.0f};                                         \
+                const f32x2 f = tt - n;                                                                       \
+                f32x2 p = {0x1.5f0896p-10f, 0x1.5f0896p-10f};                                                 \
+                p = pk_fma(p, f, f32x2{0x1.3cbf6cp-7f, 0x1.3cbf6cp-7f});                                      \
+                p = pk_fma(p, f, f32x2{0x1.c6af6cp-5f, 0x1.c6af6cp-5f});                                      \
+                p = pk_fma(p, f, f32x2{0x1.ebfa4ap-3f, 0x1.ebfa4ap-3f});                                      \
+                p = pk_fma(p, f, f32x2{0x1.62e430p-1f, 0x1.62e430p-1f});                                      \
+                p = pk_fma(p, f, f32x2{1.0f, 1.0f});                                                          \
+                const f32x2 e = {u2f(f2u(p.x) + (f2u(tm.x) << 23)), u2f(f2u(p.y) + (f2u(tm.y) << 23))};       \
+                const f32x2 oe = f32x2{BREC.z, BREC.z} * e;                                                   \
+                alpha = f32x2{fminf(0.99f, oe.x), fminf(0.99f, oe.y)};                                        \
+            } else {                                                                                          \
+                const float flat = fminf(0.99f, BREC.z);                                                      \
+                alpha = f32x2{flat, flat};                                                                    \
+            }                                                                                                 \
+            const bool act0 = p0 && alpha.x >= (1.0f / 255.0f);                                               \
+            const bool act1 = p1 && alpha.y >= (1.0f / 255.0f);                                               \
+            /* a pixel that skips this splat blends it with alpha 0: T * (1 - 0) == T and */                  \
+            /* fma(rgb, 0 * T, C) == C exactly, so no selects are needed on T and C */                        \
+            f32x2 alpha_eff = {act0 ? alpha.x : 0.0f, act1 ? alpha.y : 0.0f};                                 \
+            f32x2 test_T = T * (f32x2{1.0f, 1.0f} - alpha_eff);                                               \
+            const bool fin0 = act0 && test_T.x < 0.0001f, fin1 = act1 && test_T.y < 0.0001f;                  \
+            const uint64_t f0 = __builtin_amdgcn_ballot_w64(fin0), f1 = __builtin_amdgcn_ballot_w64(fin1);    \
+            if ((f0 | f1) != 0ull) { /* rare: some pixel reached T < 1e-4 -> it stops here */                 \
+                if (fin0) { pyf.x = DEAD; alpha_eff.x = 0.0f; test_T.x = T.x; }                               \
+                if (fin1) { pyf.y = DEAD; alpha_eff.y = 0.0f; test_T.y = T.y; }                               \
+                remaining -= (uint32_t)__popcll(f0) + (uint32_t)__popcll(f1);                                 \
+            }                                                                                                 \
+            const f32x2 wgt = alpha_eff * T;                                                                  \
+            C0 = pk_fma(f32x2{BREC.w, BREC.w}, wgt, C0);                                                      \
+            C1 = pk_fma(f32x2{cq.x, cq.x}, wgt, C1);                                                          \
+            C2 = pk_fma(f32x2{cq.y, cq.y}, wgt, C2);                                                          \
+            T = test_T;                                                                                       \
+        }                                                                                                     \
+    }
+            for (uint32_t q = 0; q < trips && remaining != 0u; q++) {
+                const uint32_t id_B = pair >> 8;
+                const float4 a_B = s_a[id_B], b_B = s_b[id_B];
+                pair = mine[q + 1 < (uint32_t)(BLEND_BATCH / 2) ? q + 1 : q];      // indices of the next trip
+                GS_BLEND_STEP(a_A, b_A, id_A)
+                id_A = pair & 0xffu;
+                a_A = s_a[id_A];
+                b_A = s_b[id_A];
+                GS_BLEND_STEP(a_B, b_B, id_B)
             }
+#undef GS_BLEND_STEP
         }
     }
     if (in0) {
