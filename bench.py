@@ -3,15 +3,18 @@
 
     python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
 
-A "step" is one frame (repack-if-dirty -> preprocess -> scan/compact -> depth sort -> pair
-expansion -> tile sort -> ranges -> blend [-> RCCL all-gather of the RGBA rows when N > 1]) of a
-synthetic random-Gaussian
-scene at 1920x1080 with the scene already resident in HBM.  The headline `value` is BASELINE.json's
-metric, Msplats/s = Gaussians / frame time, on configs[1] (1 M Gaussians, SH degree 0); the
-`roofline` object is measured on configs[2] (10 M Gaussians, SH degree 3, 224-byte records), the
-configuration BASELINE.json quotes the HBM-read roofline on.  Prints ONE JSON line on rank 0.
+A "step" is one frame (repack-if-dirty -> preprocess -> depth sort (its first pass compacts the
+visible Gaussians) -> pair expansion -> tile sort -> ranges -> blend [-> RCCL all-gather of the RGBA
+bands when N > 1]) of a synthetic random-Gaussian scene with the scene already resident in HBM; the
+frames are enqueued back to back (gs_render_frame does not block in steady state).  The headline
+`value` is BASELINE.json's metric, Msplats/s = Gaussians / frame time, on configs[1] (1 M Gaussians,
+SH degree 0, 1080p).  The `roofline` object is measured on configs[2] (10 M Gaussians, SH degree 3,
+224-byte records, 1080p), the configuration BASELINE.json quotes the HBM-read roofline on;
+`roofline_nocull` is the same scene seen from a camera that culls nothing.  `workloads` carries
+configs[3] (10 M at 3840x2160) and configs[4] (50 M, fp16 SH).  Prints ONE JSON line on rank 0.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -24,14 +27,21 @@ for p in (ROOT, os.path.join(ROOT, "tools")):
 
 import numpy as np  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+SIMDS, CLOCK_GHZ = 1024, 2.4   # 256 CUs x 4 SIMDs, max clock (MI355X_MICROARCH.md chip table)
 
+DEFAULT_EYE = (0.0, 0.0, 0.0)
 WORKLOADS = {
-    # name: (N, sh config, cov config, sh_deg, payload bytes per Gaussian, W, H)
+    # payload = algorithmic bytes per Gaussian the preprocess stage must read
     "1m": dict(n=1_000_000, sh=3, cov=0, sh_deg=0, payload=44, width=1920, height=1080,
                label="1M synthetic Gaussians, SH degree 0 (ShNone/RotScale 48 B), 1920x1080"),
     "10m": dict(n=10_000_000, sh=0, cov=0, sh_deg=3, payload=224, width=1920, height=1080,
                 label="10M synthetic Gaussians, SH degree 3 (ShSingle/RotScale 224 B), 1920x1080"),
+    # the same scene from 12.5 units further back: every Gaussian is inside the frustum (V = N), so
+    # nothing can be skipped by culling: bytes fetched = bytes required
+    "10m-nocull": dict(n=10_000_000, sh=0, cov=0, sh_deg=3, payload=224, width=1920, height=1080,
+                       eye=(0.0, 0.0, 12.5),
+                       label="10M synthetic Gaussians, SH degree 3, 1920x1080, camera pulled back to z=+12.5 (V = N)"),
     "10m-4k": dict(n=10_000_000, sh=0, cov=0, sh_deg=3, payload=224, width=3840, height=2160,
                    label="10M synthetic Gaussians, SH degree 3, 3840x2160"),
     "50m": dict(n=50_000_000, sh=1, cov=0, sh_deg=3, payload=134, width=1920, height=1080,
@@ -53,29 +63,55 @@ def upload_scene(gs, synth, dev, stream, wl, chunk=1_000_000):
     return pod, buf
 
 
-def run_workload(gs, synth, torch, dist, dev, stream, rank, world, wl, steps, warmup, timing_steps):
-    """Returns dict with ms_per_frame (max over ranks), stats, per-stage ms (rank 0)."""
+def _camera(gs, wl):
+    eye = wl.get("eye", DEFAULT_EYE)
+    return gs.camera_look_at(eye, (eye[0], eye[1], eye[2] - 1.0), (0, 1, 0), float(np.deg2rad(60.0)),
+                             wl["width"], wl["height"], 0.1, 100.0)
+
+
+def run_workload(gs, synth, torch, dist, dev, stream, rank, world, wl, steps, warmup, timing_steps,
+                 frame_samples, rebalance=True):
+    """Times `steps` pipelined frames between barriers (max over ranks), then `frame_samples`
+    individually event-timed frames (median / min / p95), then a short run with HIP-event stage
+    timing.  Returns a dict (rank-0 view; per-rank numbers where world > 1)."""
     from importlib import import_module
     par = import_module("wgpu_3dgs_core_amd.parallel")
     W, H = wl["width"], wl["height"]
     pod, buf = upload_scene(gs, synth, dev, stream, wl)
-    cam = gs.camera_look_at((0, 0, 0), (0, 0, -1), (0, 1, 0), float(np.deg2rad(60.0)), W, H, 0.1, 100.0)
+    cam = _camera(gs, wl)
     gt = gs.gaussian_transform_pod(sh_deg=wl["sh_deg"])
     mt = gs.model_transform_pod()
-    frame = par.allocate_frame(torch, H, W, world, "cuda")
-    _, bands, _ = par.band_plan(H, world)
-    band = bands[rank]
+    plan = par.BandPlan(H, world)
+    gbuf = par.allocate_gather(torch, plan, W, "cuda")
     r = gs.Renderer(dev)
+    tiles_x, tiles_y = (W + 15) // 16, (H + 15) // 16
+
+    def render(check=False):
+        return r.render(stream, buf, gt, mt, cam, par.band_target_ptr(gbuf, plan, rank, W), band=plan.bands[rank],
+                        check=check)
 
     def step():
-        r.render(stream, buf, gt, mt, cam, frame.data_ptr(), band=band, check=False)
-        par.gather_frame(dist, frame, rank, world, H)
+        render()
+        par.gather_bands(dist, gbuf, plan, rank)
+        return par.assemble(torch, gbuf, plan) if world > 1 else gbuf
 
     def sync_all():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    plan_kind = "floor(g*R/G) tile rows"
+    if world > 1 and rebalance:
+        # one calibration frame: every rank measures the pairs per tile row of its own band, the
+        # counts are summed over the ranks and the bands are re-cut to equal cost
+        render(check=True)
+        rows = par.row_costs_from_ranges(r.download_ranges(tiles_x * tiles_y), tiles_x, tiles_y, fixed=0.0)
+        t = torch.from_numpy(rows).cuda()
+        dist.all_reduce(t)
+        plan = plan.rebalanced(t.cpu().numpy() + 64.0 * tiles_x)
+        gbuf = par.allocate_gather(torch, plan, W, "cuda")
+        plan_kind = "tile rows re-cut to equal pairs (one calibration frame)"
+    fr = render(check=True)          # sizes the pair buffers for this band (blocking once)
     for _ in range(warmup):
         step()
     sync_all()
@@ -84,76 +120,229 @@ def run_workload(gs, synth, torch, dist, dev, stream, rank, world, wl, steps, wa
         step()
     sync_all()
     dt = time.perf_counter() - t0
+    rank_ms = dt * 1e3 / steps
+    per_rank = [rank_ms]
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        per_rank = [float(x.item()) * 1e3 / steps for x in allt]
+        dt = max(float(x.item()) for x in allt)
+
+    # per-frame distribution: event pairs on the launch stream around single frames
+    samples = []
+    if frame_samples:
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(frame_samples)]
+        for a, b in evs:
+            a.record()
+            step()
+            b.record()
+        sync_all()
+        samples = sorted(a.elapsed_time(b) for a, b in evs)
+    # render-only and gather-only times per rank (world > 1), pipelined
+    render_ms = gather_ms = None
+    if world > 1:
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            render()
+        torch.cuda.synchronize()
+        render_ms = (time.perf_counter() - t0) * 1e3 / steps
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            par.gather_bands(dist, gbuf, plan, rank)
+        torch.cuda.synchronize()
+        gather_ms = (time.perf_counter() - t0) * 1e3 / steps
+        t = torch.tensor([render_ms, gather_ms], dtype=torch.float64, device="cuda")
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        render_ms = [float(x[0].item()) for x in allt]
+        gather_ms = [float(x[1].item()) for x in allt]
     # separate short run with HIP-event stage timing on the launch stream
-    r.set_timing(True)
-    r.reset_stats()
-    for _ in range(timing_steps):
-        step()
-    sync_all()
+    stages = {}
     st = r.stats()
-    stages = {name: st.stage_ms[i] / max(st.timed_frames, 1) for i, name in enumerate(gs.STAGE_NAMES)}
-    checksum = float(frame[:H].double().sum().item())
-    out = dict(ms_per_frame=dt * 1e3 / steps, visible=int(st.visible), pairs=int(st.pairs),
-               sort_passes=int(st.sort_passes), stages_ms=stages, checksum=checksum,
-               timed_frames=int(st.timed_frames))
+    if timing_steps:
+        r.set_timing(True)
+        r.reset_stats()
+        for _ in range(timing_steps):
+            step()
+        sync_all()
+        st = r.stats()
+        stages = {name: st.stage_ms[i] / max(st.timed_frames, 1) for i, name in enumerate(gs.STAGE_NAMES)}
+    img = step()
+    sync_all()
+    checksum = float(img[:H].double().sum().item())
+    visible, pairs = int(st.visible), int(st.pairs)
+    if world > 1:   # totals over the bands
+        t = torch.tensor([pairs], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t)
+        pairs = int(t.item())
+    out = dict(ms_per_frame=dt * 1e3 / steps, visible=visible, pairs=pairs, sort_passes=int(st.sort_passes),
+               stages_ms=stages, checksum=checksum, launches=int(fr.launches), pair_capacity=int(fr.pair_capacity),
+               per_rank_ms=per_rank, render_ms_per_rank=render_ms, gather_ms_per_rank=gather_ms,
+               bands=plan.bands, band_plan=plan_kind)
+    if samples:
+        out["frame_ms"] = dict(samples=len(samples), median=samples[len(samples) // 2], min=samples[0],
+                               p95=samples[min(len(samples) - 1, int(0.95 * len(samples)))], max=samples[-1],
+                               timer="hipEvent pairs around single frames on the launch stream")
     r.destroy()
     buf.destroy()
-    del frame
+    del gbuf
     return out
 
 
-def stage_rooflines(wl, res):
-    """Algorithmic bytes per launch over the event-timed stage duration.  The
-    key/sort figure uses the survey's formulation (64-bit keys, 6 passes) as the common yardstick:
-    `keys_sort` = scan + depth sort + expansion + tile sort of this implementation."""
+def stage_models(wl, res):
+    """Per stage: the bytes THIS implementation's kernels have to move, from the counts of the
+    frame (N, V, D) — not a generic model — over the event-timed stage duration.  All are HBM
+    read + write streams except the blend, which is VALU-bound and carries no HBM fraction."""
     n, d, v = wl["n"], res["pairs"], res["visible"]
     px = wl["width"] * wl["height"]
     st = res["stages_ms"]
+    if not st:
+        return {}
     tiles = ((wl["width"] + 15) // 16) * ((wl["height"] + 15) // 16)
-    nominal_passes = -(-(32 + max(tiles - 1, 1).bit_length()) // 8)
-    alg = {
-        "preprocess": (n * wl["payload"], st["preprocess"]),                   # B_pre_read
-        "keys_sort": (d * 12 + nominal_passes * d * 12 * 2,                    # B_key + B_sort
-                      st["scan"] + st["depth_sort"] + st["expand"] + st["tile_sort"]),
-        "blend": (d * (4 + 48) + px * 16, st["blend"]),                        # B_blend_read + B_out
+    tile_bits = max(tiles - 1, 1).bit_length()
+    tpasses = -(-tile_bits // 8)
+    tkey = 2 if tiles <= 65536 else 4
+    dpasses = max(res["sort_passes"] - tpasses, 1)
+    models = {
+        "preprocess": (n * wl["payload"] + v * 36 + n * 12,
+                       "read N x payload; write 36-B records of the V visible, 4-B key + 8-B rect of all N"),
+        "depth_sort": (n * 4 * 2 + v * 8 + (dpasses - 1) * v * 8 * 3,
+                       "first pass reads the N dense keys twice (hist, scatter) and writes V x 8 B; "
+                       "each further pass reads V x 8 B twice and writes it once"),
+        "expand": (v * (4 + 8) + v * 8 + v * (4 + 8) + d * (tkey + 4),
+                   "count: V x (4-B slot + 8-B rect gather) -> V x 8 B; emit: V x 12 B in, D x (key + 4 B) out"),
+        "tile_sort": (tpasses * d * (tkey + (tkey + 4) * 2),
+                      "per pass: D keys (hist) + D x (key + 4 B) read and written (scatter)"),
+        "ranges": (d * tkey + tiles * 8, "D keys read, tile ranges written"),
     }
     out = {}
-    for k, (b, ms) in alg.items():
+    for k, (b, what) in models.items():
+        ms = st[k]
         gbs = b / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-        out[k] = dict(bytes=b, ms=ms, achieved_gbs=gbs, frac=gbs / HBM_PEAK_GBS)
-    total = sum(b for b, _ in alg.values()) + v * 48 + n * 4
-    ms = st["frame"]
-    gbs = total / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-    out["frame"] = dict(bytes=total, ms=ms, achieved_gbs=gbs, frac=gbs / HBM_PEAK_GBS)
+        out[k] = dict(bound="hbm", model_bytes=b, model=what, ms=ms, achieved_gbs=gbs, frac=gbs / HBM_PEAK_GBS)
+    out["blend"] = dict(bound="valu", ms=st["blend"], pairs=d, pixels=px,
+                        note="VALU-issue bound (profiles/: SQ_ACTIVE_INST_VALU vs kernel time); its HBM traffic is "
+                             "a few per cent of the frame's and is not priced against the HBM roofline")
     return out
 
 
+def kernel_source_stamp():
+    h = hashlib.sha256()
+    for f in ("gs_render_kernels.h", "gs_kernel_lib.h"):
+        h.update(open(os.path.join(ROOT, "wgpu-3dgs-core_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_record(key):
+    """Counters collected by separate rocprofv3 --pmc passes (tools/profile.sh -> profiles/pmc_traffic.json).
+    They are only quoted while the kernel sources are the ones that were profiled."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(path):
+        return None, "no profiles/pmc_traffic.json"
+    try:
+        j = json.load(open(path))
+    except Exception as e:     # noqa: BLE001
+        return None, "unreadable: %s" % e
+    rec = j.get(key)
+    if rec is None:
+        return None, "no entry %r" % key
+    if j.get("kernel_source_stamp") != kernel_source_stamp():
+        return None, "stale: kernels changed since the PMC passes (stamp %s != %s)" % (
+            j.get("kernel_source_stamp"), kernel_source_stamp())
+    return rec, None
+
+
+def roofline_object(wl_name, wl, res):
+    """roofline of the preprocess kernel on `wl`: achieved = ALGORITHMIC bytes per launch (payload
+    bytes x Gaussians per launch) / average launch duration (HIP events on the launch stream)."""
+    ms = res["stages_ms"]["preprocess"]
+    alg = wl["n"] * wl["payload"]
+    gbs = alg / (ms * 1e-3) / 1e9
+    pmc, why = pmc_record("preprocess_%s" % wl_name)
+    obj = {
+        "bound": "hbm",
+        "kernel": "k_preprocess_banded<ShSingle,RotScale>" if wl["sh"] != 3 else "k_preprocess<ShNone,RotScale>",
+        "workload": wl["label"],
+        "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+        "algorithmic_bytes_per_launch": alg, "avg_launch_ms": ms,
+        "visible": res["visible"], "gaussians": wl["n"],
+        "traffic": None,
+    }
+    if pmc:
+        fetched, written = pmc["fetch_bytes"], pmc["write_bytes"]
+        obj["traffic"] = fetched + written
+        obj["fetched_bytes_per_launch"] = fetched
+        obj["written_bytes_per_launch"] = written
+        obj["fetched_over_required"] = fetched / alg
+        # the physical rates of the same launch: what HBM actually delivered
+        obj["physical_read_gbs"] = fetched / (ms * 1e-3) / 1e9
+        obj["physical_read_frac"] = obj["physical_read_gbs"] / HBM_PEAK_GBS
+        obj["physical_traffic_gbs"] = (fetched + written) / (ms * 1e-3) / 1e9
+        obj["physical_traffic_frac"] = obj["physical_traffic_gbs"] / HBM_PEAK_GBS
+    else:
+        obj["traffic_note"] = why
+    return obj
+
+
+def blend_valu_object(res):
+    pmc, why = pmc_record("blend_1m")
+    ms = res["stages_ms"].get("blend")
+    obj = {"bound": "valu", "kernel": "k_blend_grouped<Splat,4>", "avg_launch_ms": ms, "pairs": res["pairs"]}
+    if pmc and ms:
+        cycles = ms * 1e-3 * CLOCK_GHZ * 1e9 * SIMDS
+        obj.update(valu_insts_per_launch=pmc["SQ_INSTS_VALU"], salu_insts_per_launch=pmc.get("SQ_INSTS_SALU"),
+                   lds_insts_per_launch=pmc.get("SQ_INSTS_LDS"),
+                   valu_active_cycles=pmc["SQ_ACTIVE_INST_VALU"] * 4,      # the counter is in quad-cycles
+                   valu_busy_frac=pmc["SQ_ACTIVE_INST_VALU"] * 4 / cycles,
+                   valu_insts_per_pair=pmc["SQ_INSTS_VALU"] * 64 / max(res["pairs"], 1),
+                   note="fraction of the %d SIMDs' issue cycles at %.1f GHz spent issuing VALU instructions; "
+                        "fp32 vector peak 157.3 TFLOP/s is 64 FLOP/clk/SIMD" % (SIMDS, CLOCK_GHZ))
+    else:
+        obj["note"] = why
+    return obj
+
+
 def cpu_baseline(wl, frames):
-    """The CPU oracle (a restatement of the reference's conventions, NOT the reference binary —
-    the Rust/WGSL reference cannot run here) timed on this host's cores on the same workload."""
+    """The CPU oracle (a restatement of the reference's conventions, NOT the reference binary — the
+    Rust/WGSL reference cannot run here) timed on this host's cores on the same workload: OpenMP on
+    all cores (median of `frames` frames) and one frame on a single thread, per-stage seconds of
+    both."""
     import synth
     from oracle import binding as ob
     ob.build()
-    threads = ob.lib().gso_get_max_threads()
+    L = ob.lib()
+    threads = L.gso_get_max_threads()
     g = synth.scene(wl["n"])
     pods = ob.pack(wl["sh"], wl["cov"], g)
-    cam = ob.camera_look_at((0, 0, 0), (0, 0, -1), (0, 1, 0), float(np.deg2rad(60.0)), wl["width"],
+    eye = wl.get("eye", DEFAULT_EYE)
+    cam = ob.camera_look_at(eye, (eye[0], eye[1], eye[2] - 1.0), (0, 1, 0), float(np.deg2rad(60.0)), wl["width"],
                             wl["height"], 0.1, 100.0)
     gt, mt = ob.gaussian_transform(sh_deg=wl["sh_deg"]), ob.model_transform()
-    times = []
-    for _ in range(frames):
-        t0 = time.perf_counter()
-        ob.render(wl["sh"], wl["cov"], pods, gt, mt, cam, want_image=True)
-        times.append(time.perf_counter() - t0)
-    med = float(np.median(times))
+    names = ["preprocess", "keys", "sort", "ranges", "blend"]
+
+    def run(count):
+        times, stages = [], None
+        for _ in range(count):
+            t0 = time.perf_counter()
+            _, _, _, st = ob.render(wl["sh"], wl["cov"], pods, gt, mt, cam, want_image=True)
+            times.append(time.perf_counter() - t0)
+            stages = st
+        return float(np.median(times)), dict(zip(names, [round(x, 4) for x in stages]))
+
+    med, st_omp = run(frames)
+    L.gso_set_threads(1)
+    one, st_one = run(1)
+    L.gso_set_threads(int(threads))
     return dict(value=wl["n"] / med / 1e6, unit="Msplats/s", cores=int(threads), kind="port",
-                ms_per_frame=med * 1e3,
-                sample="%d whole frames of workload '%s' (oracle/gs_oracle.c, OpenMP, median)" % (
-                    frames, wl["label"]))
+                ms_per_frame=med * 1e3, stage_seconds=st_omp,
+                single_thread=dict(value=wl["n"] / one / 1e6, unit="Msplats/s", cores=1, ms_per_frame=one * 1e3,
+                                   stage_seconds=st_one),
+                sample="%d whole frames (median) on %d OpenMP threads + 1 whole frame on 1 thread of workload '%s' "
+                       "(oracle/gs_oracle.c: every stage OpenMP-parallel; the blend visits every (pixel, splat) "
+                       "of a tile without culling)" % (frames, threads, wl["label"]))
 
 
 def main():
@@ -165,8 +354,12 @@ def main():
     ap.add_argument("--roofline-workload", default="10m", choices=sorted(WORKLOADS))
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--extra-workloads", default="10m-4k,50m",
+                    help="comma-separated workloads also run and reported under `workloads` ('' = none)")
     ap.add_argument("--cpu-frames", type=int, default=3)
     ap.add_argument("--timing-steps", type=int, default=20)
+    ap.add_argument("--frame-samples", type=int, default=100)
+    ap.add_argument("--no-rebalance", action="store_true", help="N > 1: keep the floor(g*R/G) band plan")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--force-device", type=int, default=-1, help="rehearsal: put every rank on this GPU")
     args = ap.parse_args()
@@ -187,12 +380,14 @@ def main():
     if args.force_device >= 0:
         local = args.force_device
     torch.cuda.set_device(local)
+    backend = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(args.backend)
+        backend = dist.get_backend()
 
     import synth
     import wgpu_3dgs_core_amd as gs
@@ -200,17 +395,39 @@ def main():
     # launch on torch's current stream so the RCCL all-gather is ordered behind the blend kernel
     stream = dev.wrap_stream(torch.cuda.current_stream().cuda_stream)
 
+    def run(name, steps, warmup, samples):
+        return run_workload(gs, synth, torch, dist, dev, stream, rank, world, WORKLOADS[name], steps, warmup,
+                            args.timing_steps, samples, rebalance=not args.no_rebalance)
+
     wl = WORKLOADS[args.workload]
-    res = run_workload(gs, synth, torch, dist, dev, stream, rank, world, wl, args.steps, args.warmup,
-                       args.timing_steps)
-    roof_wl, roof = None, None
+    res = run(args.workload, args.steps, args.warmup, args.frame_samples)
+    rsteps, rwarm = max(5, min(args.steps, 20)), max(2, min(args.warmup, 5))
+    roof = nocull = None
     if not args.no_roofline:
-        roof_wl = WORKLOADS[args.roofline_workload]
-        rsteps = max(5, min(args.steps, 20))
-        roof = run_workload(gs, synth, torch, dist, dev, stream, rank, world, roof_wl, rsteps,
-                            max(2, min(args.warmup, 5)), args.timing_steps)
+        roof = run(args.roofline_workload, rsteps, rwarm, args.frame_samples)
+        if args.roofline_workload == "10m" and world == 1:
+            nocull = run("10m-nocull", rsteps, rwarm, 0)
+    extras = {}
+    for name in [x for x in args.extra_workloads.split(",") if x]:
+        if name in (args.workload, args.roofline_workload) or args.no_roofline:
+            continue
+        extras[name] = run(name, min(rsteps, 10), rwarm, 20)
 
     if rank == 0:
+        def summary(w, rr):
+            d = {"workload": w["label"], "value": w["n"] / (rr["ms_per_frame"] * 1e-3) / 1e6, "unit": "Msplats/s",
+                 "ms_per_step": rr["ms_per_frame"], "frame_ms": rr.get("frame_ms"), "visible": rr["visible"],
+                 "pairs": rr["pairs"], "launches_per_frame": rr["launches"], "stages_ms": rr["stages_ms"],
+                 "stage_models": stage_models(w, rr)}
+            if rr["stages_ms"]:
+                pre = rr["stages_ms"]["preprocess"]
+                d["preprocess_read_frac"] = w["n"] * w["payload"] / (pre * 1e-3) / 1e9 / HBM_PEAK_GBS
+            if world > 1:
+                d.update(per_rank_ms=rr["per_rank_ms"], per_rank_ms_min=min(rr["per_rank_ms"]),
+                         per_rank_ms_max=max(rr["per_rank_ms"]), render_ms_per_rank=rr["render_ms_per_rank"],
+                         gather_ms_per_rank=rr["gather_ms_per_rank"], bands=rr["bands"], band_plan=rr["band_plan"])
+            return d
+
         value = wl["n"] / (res["ms_per_frame"] * 1e-3) / 1e6
         line = {
             "metric": "Msplats/s @1080p (Gaussians per second through proj+sort+blend)",
@@ -227,39 +444,30 @@ def main():
             "data": "synthetic",
             "config": {"workload": wl["label"], "gaussians": wl["n"], "visible": res["visible"],
                        "pairs": res["pairs"], "sort_passes": res["sort_passes"],
-                       "parallelism": "tile-row bands x%d + RCCL all-gather" % world if world > 1
-                       else "single GPU", "image_checksum": res["checksum"]},
+                       "launches_per_frame": res["launches"],
+                       "parallelism": "tile-row bands x%d + one RCCL all-gather (%s)" % (world, res["band_plan"])
+                       if world > 1 else "single GPU", "image_checksum": res["checksum"]},
+            "frame_ms": res.get("frame_ms"),
             "stages_ms": res["stages_ms"],
-            "stage_rooflines": stage_rooflines(wl, res),
+            "stage_models": stage_models(wl, res),
+            "blend": blend_valu_object(res) if args.workload == "1m" and world == 1 else None,
         }
+        if world > 1:
+            line["distributed"] = {"backend": backend, "world_size": dist.get_world_size(),
+                                   "per_rank_ms": res["per_rank_ms"], "per_rank_ms_min": min(res["per_rank_ms"]),
+                                   "per_rank_ms_max": max(res["per_rank_ms"]),
+                                   "render_ms_per_rank": res["render_ms_per_rank"],
+                                   "gather_ms_per_rank": res["gather_ms_per_rank"], "bands": res["bands"],
+                                   "band_plan": res["band_plan"]}
         if roof is not None:
-            sr = stage_rooflines(roof_wl, roof)
-            pre = sr["preprocess"]
-            traffic, fetched = None, None
-            pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-            if os.path.exists(pmc):
-                try:
-                    j = json.load(open(pmc))
-                    traffic = j.get("preprocess_%s_bytes_per_launch" % args.roofline_workload)
-                    fetched = j.get("preprocess_%s_fetch_bytes" % args.roofline_workload)
-                except Exception:
-                    traffic, fetched = None, None
-            line["roofline"] = {
-                "bound": "hbm", "kernel": "k_preprocess_banded<ShSingle,RotScale>",
-                "workload": roof_wl["label"],
-                "achieved": pre["achieved_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": pre["frac"], "traffic": traffic,
-                "algorithmic_bytes_per_launch": pre["bytes"], "avg_launch_ms": pre["ms"],
-                # SH bytes of Gaussians culled before SH evaluation may be skipped; the
-                # fraction is computed on the bytes REQUIRED, the bytes FETCHED (rocprofv3 PMC) beside it
-                "fetched_bytes_per_launch": fetched,
-                "fetched_over_required": (fetched / pre["bytes"]) if fetched else None,
-            }
-            line["roofline_workload"] = {
-                "value": roof_wl["n"] / (roof["ms_per_frame"] * 1e-3) / 1e6, "unit": "Msplats/s",
-                "ms_per_step": roof["ms_per_frame"], "visible": roof["visible"], "pairs": roof["pairs"],
-                "stages_ms": roof["stages_ms"], "stage_rooflines": sr,
-            }
+            roof_wl = WORKLOADS[args.roofline_workload]
+            line["roofline"] = roofline_object(args.roofline_workload, roof_wl, roof)
+            line["roofline_workload"] = summary(roof_wl, roof)
+            if nocull is not None:
+                line["roofline_nocull"] = roofline_object("10m-nocull", WORKLOADS["10m-nocull"], nocull)
+                line["roofline_nocull"]["frame"] = summary(WORKLOADS["10m-nocull"], nocull)
+        if extras:
+            line["workloads"] = {k: summary(WORKLOADS[k], v) for k, v in extras.items()}
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(wl, args.cpu_frames)
         print(json.dumps(line), flush=True)

@@ -855,21 +855,35 @@ void gso_preprocess(int sh, int cov, const void *pods, size_t n, const gso_gauss
  * that order. */
 uint64_t gso_build_keys_ordered(const gso_projected *proj, const uint32_t *tiles_touched, size_t n,
                                 uint32_t tiles_x, uint64_t *keys, uint32_t *idx, const uint32_t *order) {
+    if (!keys) {   /* count only */
+        uint64_t d = 0;
+        for (size_t i = 0; i < n; i++) d += tiles_touched[i];
+        return d;
+    }
+    /* offset of every slot's first pair (serial prefix: one add per Gaussian), then the slots fill
+     * their pairs independently (OpenMP): same pairs in the same places as the serial walk */
+    uint64_t *off = (uint64_t *)malloc((n + 1) * sizeof(uint64_t));
     uint64_t d = 0;
     for (size_t slot = 0; slot < n; slot++) {
-        size_t i = order ? order[slot] : slot;
+        off[slot] = d;
+        d += tiles_touched[order ? order[slot] : slot];
+    }
+    off[n] = d;
+#pragma omp parallel for schedule(static, 4096)
+    for (long slot = 0; slot < (long)n; slot++) {
+        size_t i = order ? order[slot] : (size_t)slot;
         if (!tiles_touched[i]) continue;
         const gso_projected *p = &proj[i];
         uint32_t depth_bits = f2u(p->depth);
+        uint64_t o = off[slot];
         for (uint32_t ty = p->ty0; ty < p->ty1; ty++)
             for (uint32_t tx = p->tx0; tx < p->tx1; tx++) {
-                if (keys) {
-                    keys[d] = ((uint64_t)(ty * tiles_x + tx) << 32) | depth_bits;
-                    idx[d] = (uint32_t)i;
-                }
-                d++;
+                keys[o] = ((uint64_t)(ty * tiles_x + tx) << 32) | depth_bits;
+                idx[o] = (uint32_t)i;
+                o++;
             }
     }
+    free(off);
     return d;
 }
 
@@ -920,31 +934,63 @@ void gso_spatial_order(const void *pods, size_t n, size_t pod_bytes, uint32_t *o
     free(tmp);
 }
 
-/* Stable LSD radix sort on the 64-bit key (ties keep emission order). */
+/* Stable LSD radix sort on the 64-bit key (ties keep emission order).  Parallel over contiguous
+ * chunks of the input (one per OpenMP thread): per-chunk histograms, offsets by (digit, chunk) so
+ * that chunk order is preserved inside every digit, each chunk scatters in order — the same
+ * permutation as the serial counting sort, whatever the thread count. */
 void gso_sort_pairs(uint64_t *keys, uint32_t *idx, uint64_t d) {
     if (d < 2) return;
     uint64_t *k2 = (uint64_t *)malloc(d * sizeof(uint64_t));
     uint32_t *i2 = (uint32_t *)malloc(d * sizeof(uint32_t));
     uint64_t *ka = keys, *kb = k2;
     uint32_t *ia = idx, *ib = i2;
+    int nt = 1;
+#ifdef _OPENMP
+    nt = omp_get_max_threads();
+#endif
+    if (nt < 1) nt = 1;
+    if ((uint64_t)nt > d / 4096 + 1) nt = (int)(d / 4096 + 1);
+    size_t *hist = (size_t *)malloc((size_t)nt * 256 * sizeof(size_t));
     for (int pass = 0; pass < 8; pass++) {
         int shift = pass * 8;
-        size_t hist[256] = {0};
-        for (uint64_t j = 0; j < d; j++) hist[(ka[j] >> shift) & 0xff]++;
+        memset(hist, 0, (size_t)nt * 256 * sizeof(size_t));
+#pragma omp parallel num_threads(nt)
+        {
+            int t = 0;
+#ifdef _OPENMP
+            t = omp_get_thread_num();
+#endif
+            uint64_t j0 = d * (uint64_t)t / (uint64_t)nt, j1 = d * (uint64_t)(t + 1) / (uint64_t)nt;
+            size_t *h = hist + (size_t)t * 256;
+            for (uint64_t j = j0; j < j1; j++) h[(ka[j] >> shift) & 0xff]++;
+        }
         int trivial = 0;
-        for (int b = 0; b < 256; b++)
-            if (hist[b] == d) trivial = 1;
-        if (trivial) continue;
         size_t sum = 0;
         for (int b = 0; b < 256; b++) {
-            size_t c = hist[b];
-            hist[b] = sum;
-            sum += c;
+            size_t tot = 0;
+            for (int t = 0; t < nt; t++) tot += hist[(size_t)t * 256 + b];
+            if (tot == d) trivial = 1;
         }
-        for (uint64_t j = 0; j < d; j++) {
-            size_t dst = hist[(ka[j] >> shift) & 0xff]++;
-            kb[dst] = ka[j];
-            ib[dst] = ia[j];
+        if (trivial) continue;
+        for (int b = 0; b < 256; b++)
+            for (int t = 0; t < nt; t++) {
+                size_t c = hist[(size_t)t * 256 + b];
+                hist[(size_t)t * 256 + b] = sum;
+                sum += c;
+            }
+#pragma omp parallel num_threads(nt)
+        {
+            int t = 0;
+#ifdef _OPENMP
+            t = omp_get_thread_num();
+#endif
+            uint64_t j0 = d * (uint64_t)t / (uint64_t)nt, j1 = d * (uint64_t)(t + 1) / (uint64_t)nt;
+            size_t *h = hist + (size_t)t * 256;
+            for (uint64_t j = j0; j < j1; j++) {
+                size_t dst = h[(ka[j] >> shift) & 0xff]++;
+                kb[dst] = ka[j];
+                ib[dst] = ia[j];
+            }
         }
         uint64_t *tk = ka; ka = kb; kb = tk;
         uint32_t *ti = ia; ia = ib; ib = ti;
@@ -953,6 +999,7 @@ void gso_sort_pairs(uint64_t *keys, uint32_t *idx, uint64_t d) {
         memcpy(keys, ka, d * sizeof(uint64_t));
         memcpy(idx, ia, d * sizeof(uint32_t));
     }
+    free(hist);
     free(k2);
     free(i2);
 }

@@ -145,6 +145,52 @@ def test_fullsize_4k_frame_matches_oracle_hash(gs, device, stream):
     buf.destroy()
 
 
+def test_sharded_path_single_gpu_4k(gs, device, stream):
+    """The 8-GPU decomposition of the 4K frame (BASELINE config 4), driven through the SAME code
+    path bench.py uses for N > 1 — BandPlan, band_target_ptr into the gather buffer, assemble — with
+    the 8 "ranks" played one after the other on this GPU (the all-gather is what is left out: every
+    rank's chunk is simply already there).  Default floor(g R / G) bands and a cost-balanced plan
+    must both reproduce the oracle's frame hash."""
+    import torch
+    from importlib import import_module
+    par = import_module("wgpu_3dgs_core_amd.parallel")
+    g = GOLD["10m-4k"]
+    pod, buf, scene_hash = _upload(gs, device, stream, g)
+    assert scene_hash == g["scene_sha256"]
+    W, H = g["width"], g["height"]
+    cam = helpers.default_camera(gs, W, H)
+    gt, mt = gs.gaussian_transform_pod(sh_deg=g["sh_deg"]), gs.model_transform_pod()
+    key = "frame_sha256" if buf.spatial_order() else "frame_sha256_index_order"
+    tstream = device.wrap_stream(torch.cuda.current_stream().cuda_stream)
+    r = gs.Renderer(device)
+    plan = par.BandPlan(H, 8)
+    assert [b - a for a, b in plan.bands] == [16, 17, 17, 17, 17, 17, 17, 17]
+    row_pairs = np.zeros(plan.tiles_y)
+    tiles_x = (W + 15) // 16
+    for attempt in range(2):
+        gbuf = par.allocate_gather(torch, plan, W, "cuda")
+        pairs = 0
+        for rank in range(8):
+            r.render(tstream, buf, gt, mt, cam, par.band_target_ptr(gbuf, plan, rank, W), band=plan.bands[rank])
+            pairs += r.stats().pairs
+            if attempt == 0:
+                a, b = plan.bands[rank]
+                rows = par.row_costs_from_ranges(r.download_ranges(tiles_x * plan.tiles_y), tiles_x, plan.tiles_y, fixed=0.0)
+                row_pairs[a:b] = rows[a:b]
+        torch.cuda.synchronize()
+        img = par.assemble(torch, gbuf, plan).cpu().numpy()
+        assert img.shape == (H, W, 4)
+        assert pairs == g["pairs"]
+        assert hashlib.sha256(img.tobytes()).hexdigest() == g[key], "sharded frame differs (plan %s)" % (plan.bands,)
+        # second round: bands re-cut to equal pairs
+        cost = lambda pl: max(row_pairs[a:b].sum() for a, b in pl.bands)
+        new = plan.rebalanced(row_pairs + 64.0 * tiles_x)
+        assert cost(new) <= cost(plan)
+        plan = new
+    r.destroy()
+    buf.destroy()
+
+
 def test_fullsize_background_identity(gs, device, stream):
     """out(bg).rgb = out(0).rgb + (1 - alpha) * bg, alpha independent of bg — at 1 M / 1080p."""
     g = GOLD["1m"]

@@ -1,7 +1,9 @@
 """world_size-2 (and 3) `gloo` test of the multi-GPU frame sharding logic on CPU:
-band plan, per-rank band rendering, all-gather reassembly; the gathered frame must equal the
-single-rank frame bit for bit.  The band renderer here is the CPU oracle (tests may use it); on
-GPUs bench.py plugs the HIP renderer into the same functions."""
+band plans (default and cost-balanced), per-rank band rendering into the gather buffer, the
+all-gather and the reassembly; the gathered frame must equal the single-rank frame bit for bit.
+The band renderer here is the CPU oracle (tests may use it); on GPUs bench.py plugs the HIP
+renderer into the same functions (tests/test_gpu_render.py::test_sharded_path_single_gpu drives
+the HIP renderer through them on one GPU)."""
 import os
 import socket
 import sys
@@ -20,60 +22,103 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, height, width, out_dir):
+def _par():
+    from importlib import import_module
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    return import_module("wgpu_3dgs_core_amd.parallel")
+
+
+def _worker(rank, world, port, height, width, out_dir, balanced):
     sys.path[:0] = [ROOT, os.path.join(ROOT, "tools")]
     import torch
     import torch.distributed as dist
-    from importlib import import_module
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import synth
     from oracle import binding as ob
-    par = import_module("wgpu_3dgs_core_amd.parallel")
+    par = _par()
     g = synth.scene(4000)
     pods = ob.pack(3, 0, g)
     cam = ob.camera_look_at((0, 0, 0), (0, 0, -1), (0, 1, 0), float(np.deg2rad(60)), width, height)
     gt, mt = ob.gaussian_transform(sh_deg=0), ob.model_transform()
-    frame = par.allocate_frame(torch, height, width, world, "cpu")
+    plan = par.BandPlan(height, world)
+    if balanced:
+        # per-row cost measured by every rank on its own band, exchanged, then a common re-cut
+        proj, tiles = ob.preprocess(3, 0, pods, gt, mt, cam, band=plan.bands[rank])
+        keys, _ = ob.build_keys(proj, tiles, (width + 15) // 16)
+        rows = ((keys >> np.uint64(32)).astype(np.int64) // ((width + 15) // 16))
+        mine = torch.from_numpy(np.bincount(rows, minlength=plan.tiles_y).astype(np.float64))
+        dist.all_reduce(mine)
+        plan = plan.rebalanced(mine.numpy() + 8.0)
+    buf = par.allocate_gather(torch, plan, width, "cpu")
+    flat = buf.view(-1)
 
-    def render_band(band, fr):
+    def render_band(band, base_ptr):
         part = ob.render(3, 0, pods, gt, mt, cam, band=band)[0]
         y0, y1 = band[0] * 16, min(band[1] * 16, height)
-        fr[y0:y1] = torch.from_numpy(part[y0:y1])
+        # what the HIP renderer does with the base pointer: image row y -> base + y * width * 16 bytes
+        off = (base_ptr - buf.data_ptr()) // 4
+        for y in range(y0, y1):
+            flat[off + y * width * 4:off + (y + 1) * width * 4] = torch.from_numpy(part[y].reshape(-1))
 
-    img = par.render_sharded(dist, frame, rank, world, height, render_band)
+    img = par.render_sharded(dist, torch, buf, plan, rank, width, render_band)
     np.save(os.path.join(out_dir, "rank%d.npy" % rank), img.numpy())
+    np.save(os.path.join(out_dir, "bands%d.npy" % rank), np.array(plan.bands))
     dist.barrier()
     dist.destroy_process_group()
 
 
 def test_band_plan():
-    from importlib import import_module
-    sys.path[:0] = [ROOT]
-    par = import_module("wgpu_3dgs_core_amd.parallel")
-    rows, bands, padded = par.band_plan(1080, 8)
-    assert rows == 9 and bands[0] == (0, 9) and bands[-1] == (63, 68) and padded == 1152
-    assert par.band_plan(2160, 8)[1][-1] == (119, 135)
+    par = _par()
+    p = par.BandPlan(1080, 8)
+    assert p.bands == [(0, 8), (8, 17), (17, 25), (25, 34), (34, 42), (42, 51), (51, 59), (59, 68)]   # floor(g R / G)
+    assert p.chunk_rows == 9 * 16
+    assert [b - a for a, b in par.BandPlan(2160, 8).bands] == [16, 17, 17, 17, 17, 17, 17, 17]
     for h in (16, 200, 1080, 2160):
         for w in (1, 2, 3, 4, 8):
-            _, b, pad = par.band_plan(h, w)
+            q = par.BandPlan(h, w)
             tiles_y = (h + 15) // 16
-            assert b[0][0] == 0 and b[-1][1] == tiles_y and pad >= h
-            assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+            assert q.bands[0][0] == 0 and q.bands[-1][1] == tiles_y
+            assert all(q.bands[i][1] == q.bands[i + 1][0] for i in range(w - 1))
+            assert q.chunk_rows * w >= min(h, tiles_y * 16)
+            assert q.pixel_rows(w - 1)[1] == h
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_frame_equals_single_rank(tmp_path, world):
+def test_rebalanced_plan_equalises_cost():
+    par = _par()
+    p = par.BandPlan(1080, 8)
+    ty = np.arange(68)
+    cost = 100.0 + 2000.0 * np.exp(-((ty - 33.5) / 12.0) ** 2)      # heavy centre rows
+    q = p.rebalanced(cost)
+    per = lambda plan: np.array([cost[a:b].sum() for a, b in plan.bands])
+    assert per(q).max() < 0.75 * per(p).max()
+    assert per(q).max() <= 1.25 * cost.sum() / 8
+    assert all(b > a for a, b in q.bands)
+    # degenerate inputs: zero cost -> default plan; fewer rows than ranks -> empty bands allowed
+    assert p.rebalanced(np.zeros(68)).bands == p.bands
+    small = par.BandPlan(32, 4).rebalanced(np.array([5.0, 1.0]))
+    assert small.bands[0][0] == 0 and small.bands[-1][1] == 2
+    # a single heavy row cannot be split: every other rank still gets work
+    spike = np.ones(68); spike[10] = 1e6
+    s = p.rebalanced(spike)
+    assert all(b > a for a, b in s.bands)
+
+
+@pytest.mark.parametrize("world,balanced", [(2, False), (3, False), (3, True)])
+def test_sharded_frame_equals_single_rank(tmp_path, world, balanced):
     import torch.multiprocessing as mp
     from oracle import binding as ob
     import synth
     height, width = 200, 320
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, height, width, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, height, width, str(tmp_path), balanced), nprocs=world, join=True)
     g = synth.scene(4000)
     cam = ob.camera_look_at((0, 0, 0), (0, 0, -1), (0, 1, 0), float(np.deg2rad(60)), width, height)
     full = ob.render(3, 0, ob.pack(3, 0, g), ob.gaussian_transform(sh_deg=0), ob.model_transform(), cam)[0]
+    bands0 = np.load(os.path.join(str(tmp_path), "bands0.npy"))
     for r in range(world):
         got = np.load(os.path.join(str(tmp_path), "rank%d.npy" % r))
         assert got.shape == full.shape
         assert np.array_equal(got.view(np.uint32), full.view(np.uint32)), "rank %d" % r
+        assert np.array_equal(np.load(os.path.join(str(tmp_path), "bands%d.npy" % r)), bands0)   # same plan everywhere

@@ -54,16 +54,6 @@ def main():
                 "%.3e" % r["fetch_bytes_per_launch"] if r["fetch_bytes_per_launch"] is not None else "-",
                 "%.3e" % r["write_bytes_per_launch"] if r["write_bytes_per_launch"] is not None else "-",
                 "%.0f" % r["hbm_gbs"] if r["hbm_gbs"] is not None else "-"))
-    # per-launch HBM traffic of the roofline kernel, consumed by bench.py as roofline.traffic
-    for r in rows:
-        if r["kernel"].startswith("k_preprocess") and r["fetch_bytes_per_launch"] is not None:
-            traffic = (r["fetch_bytes_per_launch"] or 0) + (r["write_bytes_per_launch"] or 0)
-            json.dump({"preprocess_%s_bytes_per_launch" % wl: traffic,
-                       "preprocess_%s_fetch_bytes" % wl: r["fetch_bytes_per_launch"],
-                       "preprocess_%s_write_bytes" % wl: r["write_bytes_per_launch"],
-                       "source": "%s_%s_summary.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 per gfx950 note)" % (tag, wl)},
-                      open(os.path.join(root, "gpurun_out", "profiles_out", "pmc_traffic_%s.json" % wl), "w"), indent=1)
-            break
     print(open(base + ".md").read())
 
 

@@ -1,50 +1,105 @@
 """Multi-GPU frame sharding: the scene is replicated, the IMAGE is
-partitioned by 16-pixel tile rows, one process per GPU, and one RCCL all-gather of the f32 RGBA
-rows (torch.distributed, backend "nccl" = RCCL over xGMI) reassembles the frame on every rank.
+partitioned by 16-pixel tile rows, one process per GPU, and ONE all-gather of the f32 RGBA rows
+(torch.distributed, backend "nccl" = RCCL over xGMI) hands every rank every band.
 
 Row sharding changes no per-pixel arithmetic and no per-tile order, so the N-GPU image equals the
 1-GPU image bit for bit.  PyTorch is used here only for device memory and the collective.
+
+Bands are contiguous runs of tile rows.  The default plan gives rank g the rows
+[floor(g R / G), floor((g + 1) R / G)) (8/9 rows at 1080p on 8 GPUs).  Tile rows are
+not equally expensive — the rows through the image centre hold several times the pairs of the
+border rows — so `BandPlan.rebalanced` re-cuts the bands from per-row costs measured on an
+earlier frame (pairs per tile row) so that every rank gets about the same cost.
+
+Exchange layout: every rank renders its band straight into ITS chunk of a gather buffer of
+G equal chunks (chunk = the tallest band, in pixel rows); one in-place all-gather fills the other
+chunks; `assemble` returns the contiguous image.  Equal chunks keep the exchange a single
+fixed-size collective whatever the plan.
 """
 import numpy as np
 
 TILE = 16
 
 
+class BandPlan:
+    """bands[g] = (ty0, ty1): tile rows of rank g; chunk_rows = pixel rows of one gather chunk."""
+
+    def __init__(self, height, world_size, bands=None):
+        self.height = int(height)
+        self.world_size = int(world_size)
+        self.tiles_y = (self.height + TILE - 1) // TILE
+        if bands is None:
+            r, g = self.tiles_y, self.world_size
+            bands = [((k * r) // g, ((k + 1) * r) // g) for k in range(g)]
+        self.bands = [(int(a), int(b)) for a, b in bands]
+        assert len(self.bands) == self.world_size
+        assert self.bands[0][0] == 0 and self.bands[-1][1] == self.tiles_y
+        assert all(self.bands[i][1] == self.bands[i + 1][0] for i in range(self.world_size - 1))
+        assert all(b >= a for a, b in self.bands)
+        self.chunk_rows = max(1, max(b - a for a, b in self.bands)) * TILE
+
+    def pixel_rows(self, rank):
+        """[y0, y1) of rank's band in image rows (clipped to the image height)"""
+        a, b = self.bands[rank]
+        return a * TILE, min(b * TILE, self.height)
+
+    def rebalanced(self, row_cost):
+        """A plan whose bands carry about equal cost.  row_cost[ty] >= 0 is the measured cost of tile
+        row ty (e.g. pairs in that row plus a constant for the per-row fixed work).  Greedy cut of the
+        cumulative cost at k/G of the total; every rank keeps at least one row while rows remain."""
+        cost = np.asarray(row_cost, dtype=np.float64)
+        assert cost.shape == (self.tiles_y,) and (cost >= 0).all()
+        g, r = self.world_size, self.tiles_y
+        cum = np.concatenate([[0.0], np.cumsum(cost)])
+        total = cum[-1]
+        if total <= 0 or g == 1:
+            return BandPlan(self.height, g)
+        cuts = [0]
+        for k in range(1, g):
+            target = total * k / g
+            c = int(np.searchsorted(cum, target, side="left"))
+            if c > 0 and abs(cum[c - 1] - target) <= abs(cum[min(c, r)] - target):
+                c -= 1                                   # the cut nearest to the target
+            lo = cuts[-1] + (1 if r >= g else 0)         # every rank keeps a row while there are enough rows
+            hi = r - (g - k) if r >= g else r
+            cuts.append(min(max(c, lo), hi))
+        cuts.append(r)
+        return BandPlan(self.height, g, list(zip(cuts[:-1], cuts[1:])))
+
+
 def band_plan(height, world_size):
-    """Uniform bands of `rows` tile rows per rank (the last ranks may own fewer real rows).
-
-    Returns (rows_per_rank, [(ty0, ty1) per rank], padded_height_px).  Uniform chunks make the
-    exchange a single equal-sized all-gather with no per-rank size negotiation."""
-    tiles_y = (height + TILE - 1) // TILE
-    rows = (tiles_y + world_size - 1) // world_size
-    bands = []
-    for r in range(world_size):
-        ty0 = min(r * rows, tiles_y)
-        ty1 = min((r + 1) * rows, tiles_y)
-        bands.append((ty0, ty1))
-    return rows, bands, rows * world_size * TILE
+    """(bands, padded pixel rows of the gather buffer) of the default plan"""
+    p = BandPlan(height, world_size)
+    return p.bands, p.chunk_rows * world_size
 
 
-def allocate_frame(torch, height, width, world_size, device):
-    """Padded frame tensor [padded_height, width, 4] f32; rows >= height are never written."""
-    _, _, padded = band_plan(height, world_size)
-    return torch.zeros((padded, width, 4), dtype=torch.float32, device=device)
+def allocate_gather(torch, plan, width, device):
+    """Gather buffer [G * chunk_rows, width, 4] f32: chunk g holds band g from its first row on;
+    the rows of a chunk past its band's height are never written."""
+    return torch.zeros((plan.world_size * plan.chunk_rows, width, 4), dtype=torch.float32, device=device)
 
 
-def gather_frame(dist, frame, rank, world_size, height):
-    """All-gather every rank's band into `frame` in place (each rank contributes rows
-    [rank*chunk, (rank+1)*chunk) of the padded frame)."""
-    if world_size == 1:
+def band_target_ptr(buf, plan, rank, width):
+    """Device pointer to hand to the renderer as the FULL-frame base so that image row y of rank's
+    band lands on row (y - band_y0) of rank's chunk: the renderer only ever writes the band's rows,
+    so the (virtual) rows above them are never touched."""
+    y0, _ = plan.pixel_rows(rank)
+    return buf.data_ptr() + (rank * plan.chunk_rows - y0) * width * 16
+
+
+def gather_bands(dist, buf, plan, rank):
+    """One all-gather, in place: every rank contributes its chunk of `buf`.  The form of the
+    collective is chosen once from the backend (never by catching an error from a collective: ranks
+    that disagree about which collective they are in deadlock)."""
+    g = plan.world_size
+    if g == 1:
         return
-    rows, _, padded = band_plan(height, world_size)
-    chunk = rows * TILE
-    assert frame.shape[0] == padded
-    mine = frame[rank * chunk:(rank + 1) * chunk]
-    try:
-        dist.all_gather_into_tensor(frame, mine)
-    except (RuntimeError, NotImplementedError, AttributeError):
-        # backends without the fused form (older gloo): list form on chunk views
-        parts = [frame[r * chunk:(r + 1) * chunk] for r in range(world_size)]
+    c = plan.chunk_rows
+    mine = buf[rank * c:(rank + 1) * c]
+    if dist.get_backend() == "nccl":        # RCCL: fused form, output aliases the input chunk
+        dist.all_gather_into_tensor(buf, mine)
+    else:                                   # gloo (CPU rehearsals): list form on chunk views
+        parts = [buf[r * c:(r + 1) * c] for r in range(g)]
         recv = [p if r != rank else p.clone() for r, p in enumerate(parts)]
         dist.all_gather(recv, mine.contiguous())
         for r, p in enumerate(parts):
@@ -52,10 +107,27 @@ def gather_frame(dist, frame, rank, world_size, height):
                 p.copy_(recv[r])
 
 
-def render_sharded(dist, frame, rank, world_size, height, render_band):
-    """render_band((ty0, ty1), frame) must render this rank's tile rows into `frame` (the padded
-    full-frame tensor); then the bands are exchanged."""
-    _, bands, _ = band_plan(height, world_size)
-    render_band(bands[rank], frame)
-    gather_frame(dist, frame, rank, world_size, height)
-    return frame[:height]
+def assemble(torch, buf, plan):
+    """The contiguous [height, width, 4] image from the gathered chunks (one device copy)."""
+    c = plan.chunk_rows
+    rows = []
+    for r in range(plan.world_size):
+        y0, y1 = plan.pixel_rows(r)
+        if y1 > y0:
+            rows.append(buf[r * c:r * c + (y1 - y0)])
+    return rows[0] if len(rows) == 1 else torch.cat(rows, dim=0)
+
+
+def render_sharded(dist, torch, buf, plan, rank, width, render_band):
+    """render_band((ty0, ty1), full_frame_base_ptr) must render this rank's tile rows; then the
+    bands are exchanged and the contiguous image is returned."""
+    render_band(plan.bands[rank], band_target_ptr(buf, plan, rank, width))
+    gather_bands(dist, buf, plan, rank)
+    return assemble(torch, buf, plan)
+
+
+def row_costs_from_ranges(ranges, tiles_x, tiles_y, fixed=64.0):
+    """Cost per tile row from a frame's per-tile [start, end) ranges (gs_renderer_download_ranges):
+    pairs in the row plus a constant per tile for the fixed work."""
+    r = np.asarray(ranges, dtype=np.int64).reshape(tiles_y, tiles_x, 2)
+    return (r[..., 1] - r[..., 0]).sum(axis=1).astype(np.float64) + fixed * tiles_x
