@@ -145,13 +145,36 @@ def test_fullsize_4k_frame_matches_oracle_hash(gs, device, stream):
     buf.destroy()
 
 
+class _HostTorch:
+    """the two torch entry points parallel.assemble / allocate_gather use, on numpy arrays (the GPU
+    suite must not initialise torch's own HIP runtime next to the product library's)"""
+    float32 = np.float32
+
+    @staticmethod
+    def cat(rows, dim=0):
+        return np.concatenate(rows, axis=dim)
+
+
+class _DeviceGather:
+    """device memory with the shape of parallel.allocate_gather's tensor"""
+
+    def __init__(self, gs, device, plan, width):
+        self.shape = (plan.world_size * plan.chunk_rows, width, 4)
+        self.buf = gs.Buffer(device, size=self.shape[0] * width * 16)
+
+    def data_ptr(self):
+        return self.buf.device_ptr()
+
+    def host(self, stream):
+        return self.buf.download(stream, np.float32).reshape(self.shape)
+
+
 def test_sharded_path_single_gpu_4k(gs, device, stream):
     """The 8-GPU decomposition of the 4K frame (BASELINE config 4), driven through the SAME code
     path bench.py uses for N > 1 — BandPlan, band_target_ptr into the gather buffer, assemble — with
     the 8 "ranks" played one after the other on this GPU (the all-gather is what is left out: every
     rank's chunk is simply already there).  Default floor(g R / G) bands and a cost-balanced plan
     must both reproduce the oracle's frame hash."""
-    import torch
     from importlib import import_module
     par = import_module("wgpu_3dgs_core_amd.parallel")
     g = GOLD["10m-4k"]
@@ -161,27 +184,27 @@ def test_sharded_path_single_gpu_4k(gs, device, stream):
     cam = helpers.default_camera(gs, W, H)
     gt, mt = gs.gaussian_transform_pod(sh_deg=g["sh_deg"]), gs.model_transform_pod()
     key = "frame_sha256" if buf.spatial_order() else "frame_sha256_index_order"
-    tstream = device.wrap_stream(torch.cuda.current_stream().cuda_stream)
     r = gs.Renderer(device)
     plan = par.BandPlan(H, 8)
     assert [b - a for a, b in plan.bands] == [16, 17, 17, 17, 17, 17, 17, 17]
     row_pairs = np.zeros(plan.tiles_y)
     tiles_x = (W + 15) // 16
     for attempt in range(2):
-        gbuf = par.allocate_gather(torch, plan, W, "cuda")
+        gbuf = _DeviceGather(gs, device, plan, W)
         pairs = 0
         for rank in range(8):
-            r.render(tstream, buf, gt, mt, cam, par.band_target_ptr(gbuf, plan, rank, W), band=plan.bands[rank])
+            r.render(stream, buf, gt, mt, cam, par.band_target_ptr(gbuf, plan, rank, W), band=plan.bands[rank])
             pairs += r.stats().pairs
             if attempt == 0:
                 a, b = plan.bands[rank]
                 rows = par.row_costs_from_ranges(r.download_ranges(tiles_x * plan.tiles_y), tiles_x, plan.tiles_y, fixed=0.0)
                 row_pairs[a:b] = rows[a:b]
-        torch.cuda.synchronize()
-        img = par.assemble(torch, gbuf, plan).cpu().numpy()
+        img = par.assemble(_HostTorch, gbuf.host(stream), plan)
+        gbuf.buf.release()
         assert img.shape == (H, W, 4)
         assert pairs == g["pairs"]
-        assert hashlib.sha256(img.tobytes()).hexdigest() == g[key], "sharded frame differs (plan %s)" % (plan.bands,)
+        assert hashlib.sha256(np.ascontiguousarray(img).tobytes()).hexdigest() == g[key], \
+            "sharded frame differs (plan %s)" % (plan.bands,)
         # second round: bands re-cut to equal pairs
         cost = lambda pl: max(row_pairs[a:b].sum() for a, b in pl.bands)
         new = plan.rebalanced(row_pairs + 64.0 * tiles_x)

@@ -1258,6 +1258,7 @@ struct gs_renderer {
     bool wide_tiles;  // tile keys are u32 (more than 65536 tiles) instead of u16
     uint32_t launches;                    // kernel launches of the last frame (diagnostic)
     hipStream_t last_stream;
+    bool have_frame;                      // last_stream is meaningful (the null stream is a valid stream)
     gs_buffer *last_order;   // mirror order of the last frame's buffer (null = index order), for the taps
     // timing
     bool timing;
@@ -1299,6 +1300,7 @@ extern "C" gs_status gs_renderer_create(gs_device *dev, gs_renderer **out) {
     r->wide_tiles = false;
     r->launches = 0;
     r->last_stream = nullptr;
+    r->have_frame = false;
     r->last_order = nullptr;
     r->timing = false;
     r->ev_valid = false;
@@ -1312,7 +1314,7 @@ extern "C" gs_status gs_renderer_create(gs_device *dev, gs_renderer **out) {
 extern "C" void gs_renderer_destroy(gs_renderer *r) {
     if (!r) return;
     (void)hipSetDevice(r->dev->ordinal);
-    if (r->last_stream) (void)hipStreamSynchronize(r->last_stream);   // kernels of the last frame write pinned memory
+    if (r->have_frame) (void)hipStreamSynchronize(r->last_stream);   // kernels of the last frame write pinned memory
     DevArray *arrs[] = {&r->recs, &r->depth, &r->rect, &r->sorted_rect, &r->exp_sums, &r->chunk_tiles, &r->chunk_vis,
                         &r->state, &r->zero_region, &r->scan_tmp, &r->dkeys[0], &r->dkeys[1], &r->dvals[0],
                         &r->dvals[1], &r->tkeys[0], &r->tkeys[1], &r->tvals[0], &r->tvals[1], &r->ghist,
@@ -1371,7 +1373,7 @@ extern "C" gs_status gs_renderer_wait_frame(gs_renderer *r, gs_frame_result *out
     if (!r) return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "null renderer");
     GS_TRY(use_device(r->dev));
     if (out) std::memset(out, 0, sizeof(*out));
-    if (!r->last_stream) return GS_OK;      // no frame yet
+    if (!r->have_frame) return GS_OK;       // no frame yet
     GS_HIP(hipStreamSynchronize(r->last_stream));
     const gs::FrameResult &fr = last_result(r);
     if (out) {
@@ -1399,13 +1401,13 @@ extern "C" gs_status gs_renderer_wait_frame(gs_renderer *r, gs_frame_result *out
 extern "C" gs_status gs_renderer_stats(gs_renderer *r, gs_frame_stats *out) {
     if (!r || !out) return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "null argument");
     GS_TRY(use_device(r->dev));
-    if (r->last_stream) GS_HIP(hipStreamSynchronize(r->last_stream));
+    if (r->have_frame) GS_HIP(hipStreamSynchronize(r->last_stream));
     GS_TRY(collect_timing(r));
     std::memset(out, 0, sizeof(*out));
     const gs::FrameResult &fr = last_result(r);
     out->gaussians = r->n;
-    out->visible = r->last_stream ? fr.visible : 0;
-    out->pairs = r->last_stream ? fr.pairs_total : 0;
+    out->visible = r->have_frame ? fr.visible : 0;
+    out->pairs = r->have_frame ? fr.pairs_total : 0;
     out->tiles_x = r->tiles_x;
     out->tiles_y = r->tiles_y;
     out->sort_passes = r->sort_passes;
@@ -1843,6 +1845,7 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
     r->tiles_x = fc.tiles_x;
     r->tiles_y = fc.tiles_y;
     r->last_stream = st;
+    r->have_frame = true;
     r->launches = 0;
 
     // depth keys = bits of the (positive) view depth minus the bits of the near plane: every visible
@@ -2044,7 +2047,7 @@ static gs_status download_sync(gs_renderer *r, void *dst, const void *src, size_
 // preprocess plus the key bias; chunks without visible Gaussians may be block-culled and stale
 static gs_status download_slot_depths(gs_renderer *r, std::vector<uint32_t> &depth) {
     depth.assign(r->n, 0xffffffffu);
-    if (!r->last_stream || !r->n) return GS_OK;
+    if (!r->have_frame || !r->n) return GS_OK;
     const size_t nchunks = (r->n + gs::PP_CHUNK - 1) / gs::PP_CHUNK;
     std::vector<uint32_t> chunk_vis(nchunks);
     GS_TRY(download_sync(r, depth.data(), r->depth.ptr, r->n * 4));
@@ -2107,8 +2110,8 @@ extern "C" gs_status gs_renderer_download_sorted(gs_renderer *r, uint64_t *keys_
                                                  uint64_t capacity, uint64_t *pairs_out) {
     if (!r) return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "null renderer");
     GS_TRY(use_device(r->dev));
-    if (r->last_stream) GS_HIP(hipStreamSynchronize(r->last_stream));
-    uint64_t d = r->last_stream ? last_result(r).pairs_total : 0;
+    if (r->have_frame) GS_HIP(hipStreamSynchronize(r->last_stream));
+    uint64_t d = r->have_frame ? last_result(r).pairs_total : 0;
     if (d > r->pair_capacity) d = r->pair_capacity;     // an overflowed frame only holds this many
     if (pairs_out) *pairs_out = d;
     uint64_t m = d < capacity ? d : capacity;
