@@ -55,6 +55,7 @@ pub const GS_KERNEL_COUNT_: u32 = 5;
 #[repr(C)] pub struct gs_device { _private: [u8; 0] }
 #[repr(C)] pub struct gs_stream { _private: [u8; 0] }
 #[repr(C)] pub struct gs_buffer { _private: [u8; 0] }
+#[repr(C)] pub struct gs_download { _private: [u8; 0] }
 #[repr(C)] pub struct gs_gaussians_buffer { _private: [u8; 0] }
 #[repr(C)] pub struct gs_bundle { _private: [u8; 0] }
 #[repr(C)] pub struct gs_renderer { _private: [u8; 0] }
@@ -279,8 +280,13 @@ extern "C" {
     pub fn gs_buffer_device_ptr(b: *const gs_buffer) -> *mut c_void;
     pub fn gs_buffer_write(b: *mut gs_buffer, s: *mut gs_stream, offset: usize, src: *const c_void, bytes: usize) -> gs_status;
     pub fn gs_buffer_download(b: *mut gs_buffer, s: *mut gs_stream, dst: *mut c_void, bytes: usize) -> gs_status;
+    pub fn gs_buffer_prepare_download(b: *mut gs_buffer, s: *mut gs_stream, out: *mut *mut gs_download) -> gs_status;
+    pub fn gs_download_ready(d: *mut gs_download) -> i32;
+    pub fn gs_download_map(d: *mut gs_download, data_out: *mut *const c_void, bytes_out: *mut usize) -> gs_status;
+    pub fn gs_download_release(d: *mut gs_download);
     pub fn gs_gaussians_buffer_create(dev: *mut gs_device, sh: u32, cov: u32, pods_or_null: *const c_void, len: usize, out: *mut *mut gs_gaussians_buffer) -> gs_status;
     pub fn gs_gaussians_buffer_create_from_gaussians(dev: *mut gs_device, sh: u32, cov: u32, gaussians: *const gs_gaussian, len: usize, out: *mut *mut gs_gaussians_buffer) -> gs_status;
+    pub fn gs_pack_device(dev: *mut gs_device, s: *mut gs_stream, sh: u32, cov: u32, gaussians_device: *const gs_gaussian, n: usize, pods_device: *mut c_void) -> gs_status;
     pub fn gs_gaussians_buffer_from_buffer(buffer: *mut gs_buffer, sh: u32, cov: u32, out: *mut *mut gs_gaussians_buffer) -> gs_status;
     pub fn gs_gaussians_buffer_destroy(g: *mut gs_gaussians_buffer);
     pub fn gs_gaussians_buffer_len(g: *const gs_gaussians_buffer) -> usize;

@@ -274,6 +274,18 @@ void *gs_buffer_device_ptr(const gs_buffer *b);
 gs_status gs_buffer_write(gs_buffer *b, gs_stream *s, size_t offset, const void *src, size_t bytes);
 /* BufferWrapper::download — src/buffer/mod.rs:27-42 (blocking: prepare_download + map + poll) */
 gs_status gs_buffer_download(gs_buffer *b, gs_stream *s, void *dst, size_t bytes);
+/* BufferWrapper::prepare_download — src/buffer/mod.rs:48-78: enqueues the copy of the whole buffer
+ * into a host-visible staging buffer on `s` and returns at once (the wgpu original records
+ * copy_buffer_to_buffer into the caller's encoder).
+ * BufferWrapper::map_download — :80-101: gs_download_map blocks until the copy has landed (the
+ * map_async + device.poll(wait) of the original) and exposes the bytes, valid until
+ * gs_download_release; gs_download_ready polls without blocking.
+ * Errors: GS_ERR_DOWNLOAD (DownloadBufferError). */
+typedef struct gs_download gs_download;
+gs_status gs_buffer_prepare_download(gs_buffer *b, gs_stream *s, gs_download **out);
+int32_t gs_download_ready(gs_download *d);
+gs_status gs_download_map(gs_download *d, const void **data_out, size_t *bytes_out);
+void gs_download_release(gs_download *d);
 
 /* GaussiansBuffer<G> — src/buffer/gaussian.rs:17-229 */
 typedef struct gs_gaussians_buffer gs_gaussians_buffer;
@@ -282,11 +294,17 @@ typedef struct gs_gaussians_buffer gs_gaussians_buffer;
 gs_status gs_gaussians_buffer_create(gs_device *dev, gs_sh_config sh, gs_cov3d_config cov,
                                      const void *pods_or_null, size_t len,
                                      gs_gaussians_buffer **out);
-/* new(device, gaussians): pack on the host then upload — :21-30 */
+/* new(device, gaussians): upload the source records, pack on the device (gs_pack_device) — :21-30 */
 gs_status gs_gaussians_buffer_create_from_gaussians(gs_device *dev, gs_sh_config sh,
                                                     gs_cov3d_config cov, const gs_gaussian *gaussians,
                                                     size_t len, gs_gaussians_buffer **out);
 /* TryFrom<wgpu::Buffer> — :213-229; the wrapper retains `buffer` */
+/* G::from_gaussian on the device (src/buffer/gaussian.rs:314-339 for all 12 PODs): `n` source
+ * records (struct Gaussian, 224 bytes each) already in device memory -> PODs in device memory, bit-equal
+ * to gs_pack.  GaussiansBuffer::new / update / update_range with Gaussians go through this: the
+ * source records cross PCIe once and are packed on the device. */
+gs_status gs_pack_device(gs_device *dev, gs_stream *s, gs_sh_config sh, gs_cov3d_config cov,
+                         const gs_gaussian *gaussians_device, size_t n, void *pods_device);
 gs_status gs_gaussians_buffer_from_buffer(gs_buffer *buffer, gs_sh_config sh, gs_cov3d_config cov,
                                           gs_gaussians_buffer **out);
 void gs_gaussians_buffer_destroy(gs_gaussians_buffer *g);

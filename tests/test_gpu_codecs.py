@@ -1,0 +1,136 @@
+"""GPU tests of the load path end to end through the PRODUCT's own code: file bytes ->
+gs_ply_read / gs_spz_decode (csrc/gs_ply.cpp, gs_spz.cpp) -> Gaussian::from_ply / from_spz ->
+GaussiansBuffer::new (source records uploaded once, packed on the device by gs_pack_device) ->
+one frame, compared with the CPU oracle fed by the ORACLE's own readers of the same reference data
+files (examples/model.ply, examples/model.spz; /root/reference/tests/e2e/ply.rs:203-231,
+tests/e2e/spz.rs).  Plus: device pack == host pack for all 12 PODs, and the prepare_download /
+map_download pair (src/buffer/mod.rs:48-101)."""
+import os
+
+import numpy as np
+import pytest
+
+import helpers
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _oracle_ply(ob, path):
+    raw = np.fromfile(path, dtype=np.uint8)
+    n = ob.lib().gso_read_inria_ply(raw.ctypes.data, raw.size, None, 0)
+    ply = np.zeros(n, dtype=ob.PLY_DTYPE)
+    assert ob.lib().gso_read_inria_ply(raw.ctypes.data, raw.size, ply.ctypes.data, n) == n
+    g = np.zeros(n, dtype=ob.GAUSSIAN_DTYPE)
+    for i in range(n):
+        ob.lib().gso_gaussian_from_ply(ply[i:i + 1].ctypes.data, g[i:i + 1].ctypes.data)
+    return g
+
+
+def _frame_pair(gs, ob, device, stream, pod, g_product, g_oracle, W, H, cam_kw, sh_deg=3):
+    """product Gaussians through the HIP path, oracle Gaussians through the oracle; same uniforms"""
+    ocam = helpers.default_camera(ob, W, H, **cam_kw)
+    cam = helpers.copy_camera(ocam, gs.Camera)
+    buf = gs.GaussiansBuffer.new(device, pod, g_product)                  # upload + device pack
+    opods = ob.pack(pod.sh, pod.cov, g_oracle)
+    assert np.array_equal(buf.download(stream), opods), "device-packed PODs differ from the oracle's pack"
+    img = gs.Buffer(device, size=W * H * 16)
+    r = gs.Renderer(device)
+    r.render(stream, buf, gs.gaussian_transform_pod(sh_deg=sh_deg), gs.model_transform_pod(), cam, img.device_ptr())
+    rgba = img.download(stream, np.float32).reshape(H, W, 4)
+    order = buf.download_order(stream)
+    ref, d, vis, _ = ob.render(pod.sh, pod.cov, opods, ob.gaussian_transform(sh_deg=sh_deg), ob.model_transform(), ocam,
+                               order=order)
+    st = r.stats()
+    r.destroy(); img.release(); buf.destroy()
+    assert (st.visible, st.pairs) == (vis, d)
+    return rgba, ref, st
+
+
+@pytest.mark.parametrize("pod_idx", [0, 5, 7, 11])
+def test_model_ply_file_to_frame(gs, ob, device, stream, pod_idx):
+    """BASELINE config #1 input through the product's PLY reader"""
+    path = os.path.join(GOLD, "model.ply")
+    ply = gs.PlyGaussians.read_from_file(path)
+    assert len(ply) == 9
+    g = gs.gaussian_from_ply(ply.pods)
+    go = _oracle_ply(ob, path)
+    for f in ("pos", "color", "sh", "scale", "rot"):
+        assert np.array_equal(g[f], go[f]), "product from_ply differs from the oracle's in %s" % f
+    pod = gs.ALL_PODS[pod_idx]
+    rgba, ref, st = _frame_pair(gs, ob, device, stream, pod, g, go, 640, 480,
+                                dict(eye=(4.0, 4.0, 22.0), target=(4.0, 4.0, 4.0)))
+    assert st.visible == 9
+    assert np.abs(rgba - ref).max() <= 1e-4
+    assert np.array_equal(rgba.view(np.uint32), ref.view(np.uint32))
+    assert rgba[..., 3].max() > 0.5
+
+
+def test_model_spz_file_to_frame(gs, ob, device, stream):
+    """the reference's examples/model.spz through the product's gunzip + column decode"""
+    path = os.path.join(GOLD, "model.spz")
+    spz = gs.SpzGaussians.read_from_file(path)
+    g = np.ascontiguousarray(spz.iter_gaussian(), dtype=gs.GAUSSIAN_DTYPE)
+    import gzip
+    go = ob.spz_decode_raw(gzip.decompress(open(path, "rb").read()))
+    assert len(g) == len(go) and len(g) > 0
+    for f in ("pos", "color", "sh", "scale", "rot"):
+        assert np.array_equal(g[f], go[f]), "product from_spz differs from the oracle's in %s" % f
+    center = g["pos"].astype(np.float64).mean(axis=0)
+    extent = float(np.abs(g["pos"] - center).max()) + 1.0
+    cam_kw = dict(eye=(float(center[0]), float(center[1]), float(center[2]) + 3.0 * extent),
+                  target=tuple(float(x) for x in center))
+    rgba, ref, st = _frame_pair(gs, ob, device, stream, gs.GaussianPod(gs.SH_SINGLE, gs.COV3D_ROT_SCALE), g, go,
+                                512, 384, cam_kw)
+    assert st.visible >= 1
+    assert np.array_equal(rgba.view(np.uint32), ref.view(np.uint32))
+
+
+@pytest.mark.parametrize("sh", [0, 1, 2, 3])
+@pytest.mark.parametrize("cov", [0, 1, 2])
+def test_device_pack_equals_host_pack(gs, ob, device, stream, sh, cov):
+    """gs_pack_device == gs_pack == oracle pack, byte for byte, on random Gaussians that exercise f16
+    rounding ties / overflow / subnormals, snorm8 clamping and NaNs (gaussian_config.rs:49-117,219-233)."""
+    import synth
+    n = 3000          # not a multiple of the pack group: the tail group is partial
+    g = synth.scene(n, first=77)
+    rng = np.random.default_rng(5)
+    g["sh"] = rng.normal(0, 0.6, size=g["sh"].shape).astype(np.float32)
+    special = np.array([0.0, -0.0, 1.0, -1.0, 65504.0, 65520.0, 1e5, -1e5, 5.96e-8, 2.98e-8, 6.1e-5, 6.0e-5,
+                        1.0009765625, 1.00048828125, np.inf, -np.inf, np.nan, 1.0 / 127, 0.999, -1.001, 3.4e38],
+                       dtype=np.float32)
+    g["sh"].reshape(-1)[:len(special)] = special
+    g["scale"][:8] = [[1e-3, 2.0, 300.0]] * 8
+    pod = gs.GaussianPod(sh, cov)
+    host = pod.from_gaussian(g)
+    assert np.array_equal(host, ob.pack(sh, cov, g))
+    buf = gs.GaussiansBuffer.new(device, pod, g)
+    assert np.array_equal(buf.download(stream), host)
+    # update_range through the device pack, and the explicit entry point on caller-owned device memory
+    buf.update_range(stream, 100, g[:50])
+    exp = host.copy()
+    exp[100 * pod.size:150 * pod.size] = host[:50 * pod.size]
+    assert np.array_equal(buf.download(stream), exp)
+    src = gs.Buffer(device, data=g.view(np.uint8).reshape(-1))
+    dst = gs.Buffer(device, size=n * pod.size)
+    gs.pack_device(device, stream, pod, src, n, dst)
+    assert np.array_equal(dst.download(stream), host)
+    src.release(); dst.release(); buf.destroy()
+
+
+def test_prepare_download_map_download(gs, device, stream):
+    """BufferWrapper::prepare_download / map_download: the copy is enqueued, mapped later; the
+    mapped bytes are those of the buffer at the time the copy ran on the stream."""
+    data = np.arange(1 << 20, dtype=np.uint32)
+    buf = gs.Buffer(device, data=data.view(np.uint8))
+    d = buf.prepare_download(stream)
+    buf.write(stream, 0, np.zeros(16, dtype=np.uint8))       # ordered AFTER the download on the same stream
+    got = d.map(np.uint32)
+    assert d.ready()
+    assert np.array_equal(got, data)
+    d.release()
+    d2 = buf.prepare_download(stream)
+    got2 = d2.map(np.uint32)
+    assert not got2[:4].any() and np.array_equal(got2[4:], data[4:])
+    d2.release()
+    buf.release()

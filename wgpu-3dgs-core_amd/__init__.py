@@ -646,10 +646,44 @@ class Buffer:
         _check(_L.gs_buffer_download(self._h, stream._h, _ptr(out), out.nbytes))
         return out.view(dtype)
 
+    def prepare_download(self, stream):
+        """BufferWrapper::prepare_download: enqueue the copy into a staging buffer; returns a Download"""
+        h = C.c_void_p()
+        _check(_L.gs_buffer_prepare_download(self._h, stream._h if stream else None, C.byref(h)))
+        return Download(h)
+
     def release(self):
         if self._h:
             _L.gs_buffer_release(self._h)
             self._h = None
+
+
+class Download:
+    """A pending device-to-host copy (gs_download): map() = BufferWrapper::map_download"""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    def ready(self):
+        return bool(_L.gs_download_ready(self._h))
+
+    def map(self, dtype=np.uint8):
+        """blocks until the copy has landed; returns a numpy COPY of the staged bytes"""
+        data, n = C.c_void_p(), C.c_size_t()
+        _check(_L.gs_download_map(self._h, C.byref(data), C.byref(n)))
+        raw = (C.c_uint8 * n.value).from_address(data.value) if n.value else b""
+        return np.frombuffer(bytes(raw), dtype=np.uint8).view(dtype).copy()
+
+    def release(self):
+        if self._h:
+            _L.gs_download_release(self._h)
+            self._h = None
+
+
+def pack_device(device, stream, pod, gaussians_buffer, count, pods_buffer):
+    """gs_pack_device: Gaussians (struct Gaussian records in `gaussians_buffer`) -> PODs in `pods_buffer`"""
+    _check(_L.gs_pack_device(device._h, stream._h if stream else None, pod.sh, pod.cov,
+                             C.c_void_p(gaussians_buffer.device_ptr()), count, C.c_void_p(pods_buffer.device_ptr())))
 
 
 class GaussiansBuffer:

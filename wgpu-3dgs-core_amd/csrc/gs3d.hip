@@ -18,6 +18,7 @@
 
 #include "gs_bundle_kernels.h"
 #include "gs_render_kernels.h"
+#include "gs_pack_kernels.h"
 #include "_gen_kernel_lib_src.h"
 
 // ------------------------------------------------------------------------------------------------
@@ -112,29 +113,6 @@ extern "C" gs_status gs_pod_features(gs_sh_config sh, gs_cov3d_config cov, uint8
     return GS_OK;
 }
 
-// IEEE binary32 -> binary16, round to nearest even (half::f16::from_f32)
-static uint16_t f32_to_f16_rtne(float value) {
-    union { uint32_t u; float f; } f, magic;
-    f.f = value;
-    const uint32_t f32infty = 255u << 23, f16max = (127u + 16u) << 23;
-    magic.u = ((127u - 15u) + (23u - 10u) + 1u) << 23;
-    uint32_t sign = f.u & 0x80000000u;
-    f.u ^= sign;
-    uint16_t o;
-    if (f.u >= f16max) {
-        o = (f.u > f32infty) ? (uint16_t)(0x7e00u | ((f.u >> 13) & 0x1ffu)) : (uint16_t)0x7c00u;
-    } else if (f.u < (113u << 23)) {
-        f.f += magic.f;
-        o = (uint16_t)(f.u - magic.u);
-    } else {
-        uint32_t odd = (f.u >> 13) & 1u;
-        f.u += ((uint32_t)(15 - 127) << 23) + 0xfffu;
-        f.u += odd;
-        o = (uint16_t)(f.u >> 13);
-    }
-    return (uint16_t)(o | (sign >> 16));
-}
-
 static float f16_to_f32_host(uint16_t h) {
     union { uint32_t u; float f; } o;
     uint32_t sign = ((uint32_t)h & 0x8000u) << 16, e = (h >> 10) & 0x1fu, m = h & 0x3ffu;
@@ -147,24 +125,6 @@ static float f16_to_f32_host(uint16_t h) {
         o.u = sign | ((e + 112u) << 23) | (m << 13);
     }
     return o.f;
-}
-
-// glam Mat3::from_quat(rot) * Mat3::from_diagonal(scale), then m * m^T (gaussian_config.rs:195-208)
-static void cov3d_from_rot_scale(const float q[4], const float s[3], float out[6]) {
-    gs::ModelTransform mt{};
-    std::memcpy(mt.rot, q, 16);
-    std::memcpy(mt.scale, s, 12);
-    float m[9];
-    gs::model_scale_rot_mat(mt, m);  // same x2/xx/wz formulation, columns scaled by s
-    auto sig = [&](int r, int c) {
-        return (m[0 + r] * m[0 + c] + m[3 + r] * m[3 + c]) + m[6 + r] * m[6 + c];
-    };
-    out[0] = sig(0, 0);
-    out[1] = sig(1, 0);
-    out[2] = sig(2, 0);
-    out[3] = sig(1, 1);
-    out[4] = sig(2, 1);
-    out[5] = sig(2, 2);
 }
 
 template <class F>
@@ -185,45 +145,13 @@ static void parallel_for(size_t n, F fn) {
     for (auto &th : pool) th.join();
 }
 
+// G::from_gaussian on the host: the same encoders the device kernel uses (gs_pack_kernels.h)
 static void pack_one(int sh, int cov, const gs_gaussian &g, uint8_t *p, size_t stride) {
-    std::memset(p, 0, stride);
-    std::memcpy(p, g.pos, 12);
-    std::memcpy(p + 12, g.color, 4);
-    uint8_t *s = p + 16;
-    if (sh == GS_SH_SINGLE) {
-        std::memcpy(s, g.sh, 180);
-    } else if (sh == GS_SH_HALF) {
-        uint16_t h[46];
-        for (int k = 0; k < 45; k++) h[k] = f32_to_f16_rtne(g.sh[k]);
-        h[45] = 0;
-        std::memcpy(s, h, 92);
-    } else if (sh == GS_SH_NORM8) {
-        int8_t b[48];
-        for (int k = 0; k < 45; k++) {
-            float v = g.sh[k] * 127.0f;
-            if (v != v) v = 0.0f;             // Rust `as i8`: NaN -> 0
-            if (v < -127.0f) v = -127.0f;
-            if (v > 127.0f) v = 127.0f;
-            b[k] = (int8_t)v;                 // truncation toward zero
-        }
-        b[45] = b[46] = b[47] = 0;
-        std::memcpy(s, b, 48);
-    }
-    uint8_t *c = s + gs::sh_bytes(sh);
-    if (cov == GS_COV3D_ROT_SCALE) {
-        std::memcpy(c, g.rot, 16);
-        std::memcpy(c + 16, g.scale, 12);
-    } else {
-        float c6[6];
-        cov3d_from_rot_scale(g.rot, g.scale, c6);
-        if (cov == GS_COV3D_SINGLE) {
-            std::memcpy(c, c6, 24);
-        } else {
-            uint16_t h[6];
-            for (int k = 0; k < 6; k++) h[k] = f32_to_f16_rtne(c6[k]);
-            std::memcpy(c, h, 12);
-        }
-    }
+    static_assert(sizeof(gs_gaussian) == gs::GAUSSIAN_WORDS * 4, "gs_gaussian layout");
+    uint32_t gw[gs::GAUSSIAN_WORDS], pw[56];
+    std::memcpy(gw, &g, sizeof(gw));
+    gs::pack_words(sh, cov, gw, pw);
+    std::memcpy(p, pw, stride);
 }
 
 extern "C" gs_status gs_pack(gs_sh_config sh, gs_cov3d_config cov, const gs_gaussian *in, size_t n,
@@ -554,6 +482,67 @@ extern "C" gs_status gs_buffer_download(gs_buffer *b, gs_stream *s, void *dst, s
     return GS_OK;
 }
 
+// BufferWrapper::prepare_download / map_download (src/buffer/mod.rs:48-101): the copy into a
+// host-visible staging buffer is only ENQUEUED; the caller maps (waits for) it later.
+struct gs_download {
+    gs_device *dev;
+    void *pinned;
+    size_t bytes;
+    hipEvent_t done;
+};
+
+extern "C" gs_status gs_buffer_prepare_download(gs_buffer *b, gs_stream *s, gs_download **out) {
+    if (!b || !out) return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "null argument");
+    *out = nullptr;
+    GS_TRY(use_device(b->dev));
+    gs_download *d = new gs_download();
+    d->dev = b->dev;
+    d->bytes = b->bytes;
+    d->pinned = nullptr;
+    hipError_t e = hipHostMalloc(&d->pinned, b->bytes ? b->bytes : 1, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&d->done, hipEventDisableTiming);
+    else d->done = nullptr;
+    hipStream_t st = stream_of(b->dev, s);
+    if (e == hipSuccess && b->bytes) e = hipMemcpyAsync(d->pinned, b->ptr, b->bytes, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipEventRecord(d->done, st);
+    if (e != hipSuccess) {
+        if (d->pinned) (void)hipHostFree(d->pinned);
+        if (d->done) (void)hipEventDestroy(d->done);
+        delete d;
+        return fail(GS_ERR_DOWNLOAD, (uint64_t)e, 0, 0, "download failed: %s", hipGetErrorString(e));
+    }
+    *out = d;
+    return GS_OK;
+}
+
+extern "C" int32_t gs_download_ready(gs_download *d) {
+    if (!d) return 0;
+    (void)hipSetDevice(d->dev->ordinal);
+    const hipError_t e = hipEventQuery(d->done);
+    (void)hipGetLastError();
+    return e == hipSuccess ? 1 : 0;
+}
+
+extern "C" gs_status gs_download_map(gs_download *d, const void **data_out, size_t *bytes_out) {
+    if (!d || !data_out) return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "null argument");
+    GS_TRY(use_device(d->dev));
+    const hipError_t e = hipEventSynchronize(d->done);
+    if (e != hipSuccess)
+        return fail(GS_ERR_DOWNLOAD, (uint64_t)e, 0, 0, "download failed: %s", hipGetErrorString(e));
+    *data_out = d->pinned;
+    if (bytes_out) *bytes_out = d->bytes;
+    return GS_OK;
+}
+
+extern "C" void gs_download_release(gs_download *d) {
+    if (!d) return;
+    (void)hipSetDevice(d->dev->ordinal);
+    (void)hipEventSynchronize(d->done);     // the copy may still be writing the staging memory
+    (void)hipHostFree(d->pinned);
+    (void)hipEventDestroy(d->done);
+    delete d;
+}
+
 // ------------------------------------------------------------------------------------------------
 // GaussiansBuffer<G>
 // ------------------------------------------------------------------------------------------------
@@ -634,16 +623,78 @@ extern "C" gs_status gs_gaussians_buffer_create(gs_device *dev, gs_sh_config sh,
     return st;
 }
 
+#define GS_CFG_TABLE(kernel)                                                                     \
+    {                                                                                            \
+        {kernel<0, 0>, kernel<0, 1>, kernel<0, 2>}, {kernel<1, 0>, kernel<1, 1>, kernel<1, 2>},  \
+        {kernel<2, 0>, kernel<2, 1>, kernel<2, 2>}, {kernel<3, 0>, kernel<3, 1>, kernel<3, 2>},  \
+    }
+
+typedef void (*pack_fn)(const uint32_t *, uint64_t, uint32_t *);
+static pack_fn k_tbl_pack[4][3] = GS_CFG_TABLE(gs::k_pack_pods);
+
+extern "C" gs_status gs_pack_device(gs_device *dev, gs_stream *s, gs_sh_config sh, gs_cov3d_config cov,
+                                    const gs_gaussian *gaussians_device, size_t n, void *pods_device) {
+    if (!dev || !valid_cfg(sh, cov) || (n && (!gaussians_device || !pods_device)))
+        return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "gs_pack_device: bad argument");
+    if (((uintptr_t)gaussians_device | (uintptr_t)pods_device) & 3u)
+        return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "gs_pack_device: pointers must be 4-byte aligned");
+    GS_TRY(use_device(dev));
+    if (!n) return GS_OK;
+    const uint64_t groups = ((uint64_t)n + gs::PACK_GROUP - 1) / gs::PACK_GROUP;
+    if (groups > 0x7fffffffull) return fail(GS_ERR_INVALID_ARGUMENT, n, 0, 0, "too many Gaussians");
+    hipLaunchKernelGGL(k_tbl_pack[sh][cov], dim3((uint32_t)groups), dim3(256), 0, stream_of(dev, s),
+                       (const uint32_t *)gaussians_device, (uint64_t)n, (uint32_t *)pods_device);
+    GS_HIP(hipGetLastError());
+    return GS_OK;
+}
+
+// Gaussians on the host -> PODs in `g` at [start, start + count): the source records cross PCIe as
+// they are (one copy per slice of at most PACK_SLICE Gaussians through a staging buffer) and are
+// packed on the device.  The caller's memory may be reused when this returns.
+static gs_status upload_gaussians(gs_gaussians_buffer *g, gs_stream *s, size_t start, const gs_gaussian *gaussians,
+                                  size_t count) {
+    constexpr size_t PACK_SLICE = 4u << 20;     // 4 Mi Gaussians = 896 MiB of staging at most
+    gs_device *dev = g->buf->dev;
+    GS_TRY(use_device(dev));
+    if (!count) return GS_OK;
+    hipStream_t st = stream_of(dev, s);
+    const size_t slice = count < PACK_SLICE ? count : PACK_SLICE;
+    void *staging = nullptr;
+    hipError_t e = hipMalloc(&staging, slice * sizeof(gs_gaussian));
+    if (e != hipSuccess)
+        return fail(GS_ERR_OUT_OF_MEMORY, slice * sizeof(gs_gaussian), 0, 0, "hipMalloc failed: %s", hipGetErrorString(e));
+    gs_status rc = GS_OK;
+    const size_t stride = pod_stride(g);
+    for (size_t first = 0; first < count && rc == GS_OK; first += slice) {
+        const size_t cnt = count - first < slice ? count - first : slice;
+        e = hipMemcpyAsync(staging, gaussians + first, cnt * sizeof(gs_gaussian), hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) {
+            rc = fail(GS_ERR_HIP, (uint64_t)e, 0, 0, "upload failed: %s", hipGetErrorString(e));
+            break;
+        }
+        rc = gs_pack_device(dev, s, (gs_sh_config)g->sh, (gs_cov3d_config)g->cov, (const gs_gaussian *)staging, cnt,
+                            (uint8_t *)g->buf->ptr + (start + first) * stride);
+        // the staging buffer is reused by the next slice and freed below: wait for the kernel
+        if (rc == GS_OK && hipStreamSynchronize(st) != hipSuccess) rc = fail(GS_ERR_HIP, 0, 0, 0, "pack failed");
+    }
+    (void)hipFree(staging);
+    return rc;
+}
+
 extern "C" gs_status gs_gaussians_buffer_create_from_gaussians(gs_device *dev, gs_sh_config sh,
                                                                gs_cov3d_config cov,
                                                                const gs_gaussian *gaussians,
                                                                size_t len,
                                                                gs_gaussians_buffer **out) {
-    if (!valid_cfg(sh, cov) || (len && !gaussians))
+    if (!valid_cfg(sh, cov) || (len && !gaussians) || !out)
         return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "bad argument");
-    std::vector<uint8_t> pods(len * gs_pod_size(sh, cov));
-    GS_TRY(gs_pack(sh, cov, gaussians, len, pods.data()));
-    return gs_gaussians_buffer_create(dev, sh, cov, pods.data(), len, out);
+    GS_TRY(gs_gaussians_buffer_create(dev, sh, cov, nullptr, len, out));
+    gs_status rc = upload_gaussians(*out, nullptr, 0, gaussians, len);
+    if (rc != GS_OK) {
+        gs_gaussians_buffer_destroy(*out);
+        *out = nullptr;
+    }
+    return rc;
 }
 
 extern "C" void gs_gaussians_buffer_destroy(gs_gaussians_buffer *g) {
@@ -683,7 +734,7 @@ extern "C" gs_status gs_gaussians_buffer_update_range(gs_gaussians_buffer *g, gs
                                                       size_t count) {
     if (!g) return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "null buffer");
     size_t len = gs_gaussians_buffer_len(g);
-    if (start + count > len)
+    if (count > len || start > len - count)      // (start + count could wrap)
         return fail(GS_ERR_RANGE_COUNT_MISMATCH, count, start, len,
                     "Gaussians count mismatch: %zu + %zu > %zu", count, start, len);
     g->mark(start, start + count);
@@ -698,9 +749,9 @@ extern "C" gs_status gs_gaussians_buffer_update_gaussians(gs_gaussians_buffer *g
     if (count != len)
         return fail(GS_ERR_COUNT_MISMATCH, count, len, 0, "Gaussians count mismatch: %zu != %zu",
                     count, len);
-    std::vector<uint8_t> pods(count * pod_stride(g));
-    GS_TRY(gs_pack((gs_sh_config)g->sh, (gs_cov3d_config)g->cov, gaussians, count, pods.data()));
-    return gs_gaussians_buffer_update(g, s, pods.data(), count);
+    if (count && !gaussians) return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "null gaussians");
+    g->mark_all();
+    return upload_gaussians(g, s, 0, gaussians, count);
 }
 
 extern "C" gs_status gs_gaussians_buffer_update_range_gaussians(gs_gaussians_buffer *g, gs_stream *s,
@@ -709,12 +760,12 @@ extern "C" gs_status gs_gaussians_buffer_update_range_gaussians(gs_gaussians_buf
                                                                 size_t count) {
     if (!g) return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "null buffer");
     size_t len = gs_gaussians_buffer_len(g);
-    if (start + count > len)
+    if (count > len || start > len - count)
         return fail(GS_ERR_RANGE_COUNT_MISMATCH, count, start, len,
                     "Gaussians count mismatch: %zu + %zu > %zu", count, start, len);
-    std::vector<uint8_t> pods(count * pod_stride(g));
-    GS_TRY(gs_pack((gs_sh_config)g->sh, (gs_cov3d_config)g->cov, gaussians, count, pods.data()));
-    return gs_gaussians_buffer_update_range(g, s, start, pods.data(), count);
+    if (count && !gaussians) return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "null gaussians");
+    g->mark(start, start + count);
+    return upload_gaussians(g, s, start, gaussians, count);
 }
 
 extern "C" gs_status gs_gaussians_buffer_download(gs_gaussians_buffer *g, gs_stream *s,
@@ -783,12 +834,6 @@ extern "C" gs_status gs_model_transform_buffer_from_buffer(gs_buffer *b) {
 // ------------------------------------------------------------------------------------------------
 
 typedef void (*bundle_kernel_fn)(gs::BundleArgs, uint32_t);
-
-#define GS_CFG_TABLE(kernel)                                                                     \
-    {                                                                                            \
-        {kernel<0, 0>, kernel<0, 1>, kernel<0, 2>}, {kernel<1, 0>, kernel<1, 1>, kernel<1, 2>},  \
-        {kernel<2, 0>, kernel<2, 1>, kernel<2, 2>}, {kernel<3, 0>, kernel<3, 1>, kernel<3, 2>},  \
-    }
 
 static bundle_kernel_fn k_tbl_test_gaussian[4][3] = GS_CFG_TABLE(gs::k_test_gaussian);
 static bundle_kernel_fn k_tbl_unpack_soa[4][3] = GS_CFG_TABLE(gs::k_unpack_soa);
