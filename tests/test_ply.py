@@ -132,3 +132,18 @@ def test_truncated_and_mixed_type_files(gs, ob):
         body += b"\x01" + p.tobytes() + np.float64(3.5).tobytes()
     got = gs.PlyGaussians.read_from(head.encode() + body)
     assert got.inria is False and got.pods.tobytes() == plys.tobytes()
+
+
+def test_vertex_count_larger_than_the_file_is_rejected_up_front(gs):
+    """The header's vertex count sizes the caller's allocation: a count the remaining bytes cannot
+    hold must fail as the reference's UnexpectedEof does, before anything is allocated."""
+    import os
+    raw = open(os.path.join(os.path.dirname(__file__), "golden", "model.ply"), "rb").read()
+    bad = raw.replace(b"element vertex 9", b"element vertex 4000000000", 1)
+    assert bad != raw
+    with pytest.raises(gs.PlyError):
+        gs.PlyGaussians.read_from(bad)
+    assert len(gs.PlyGaussians.read_from(raw)) == 9
+    ascii_hdr = b"ply\nformat ascii 1.0\nelement vertex 1000000\nproperty float x\nend_header\n1.0\n"
+    with pytest.raises(gs.PlyError):
+        gs.PlyGaussians.read_from(ascii_hdr)

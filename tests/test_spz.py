@@ -255,3 +255,22 @@ def test_spz_to_device_buffer(gs, ob):
     pod = gs.GaussianPod(0, 0)   # GaussianPodWithShSingleCov3dRotScaleConfigs
     packed = pod.from_gaussian(got.gaussians)
     assert packed.tobytes() == ob.pack(0, 0, got.gaussians).tobytes()
+
+
+def test_gzip_bomb_and_truncation_are_rejected(gs):
+    """A gzip member that inflates far past the size its own SPZ header declares must be refused
+    before it eats memory, and a truncated member must not be accepted (the inflate
+    buffer used to double without bound and lengths were cast to 32 bits)."""
+    import gzip
+    import struct
+    hdr = struct.pack("<IIIBBBB", 0x5053474E, 2, 0, 0, 12, 0, 0)        # version 2, zero points
+    bomb = gzip.compress(hdr + b"\0" * (64 << 20), compresslevel=9)     # 64 MiB of zeros behind an empty scene
+    assert len(bomb) < 1 << 20
+    with pytest.raises(gs.SpzError):
+        gs.SpzGaussians.read_from(bomb)
+    ok = gzip.compress(hdr)
+    assert len(gs.SpzGaussians.read_from(ok)) == 0
+    with pytest.raises(gs.SpzError):
+        gs.SpzGaussians.read_from(ok[:-6])
+    with pytest.raises(gs.SpzError):
+        gs.SpzGaussians.read_from(b"not a gzip stream at all")

@@ -254,6 +254,16 @@ extern "C" gs_status gs_ply_read(const void *bytes, size_t len, gs_ply_gaussian_
     bool inria = h.enc == LE && vertex->props.size() == 62 && vi == 0;
     for (size_t k = 0; inria && k < 62; k++)
         inria = !vertex->props[k].is_list && vertex->props[k].type == T_F32 && vertex->props[k].field == (int)k;
+    {   // The header's vertex count is untrusted and callers size their allocation from it: a count the
+        // remaining bytes cannot possibly hold is the reference's UnexpectedEof, reported up front.
+        size_t min_bytes = 0;
+        for (const Prop &p : vertex->props)
+            min_bytes += h.enc == ASCII ? 2 : (size_t)type_size(p.is_list ? p.count_type : p.type);
+        if (min_bytes == 0) min_bytes = h.enc == ASCII ? 1 : 0;
+        const size_t avail = len > h.body ? len - h.body : 0;
+        if (min_bytes && vertex->count > avail / min_bytes + (h.enc == ASCII ? 1 : 0))
+            return gs_fail(GS_ERR_PLY, vertex->count, avail, min_bytes, "%s", k_eof);
+    }
     *count_out = vertex->count;
     if (is_inria_out) *is_inria_out = inria ? 1 : 0;
     if (!out) return GS_OK;

@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <new>
 #include <vector>
 
 #include "gs_internal.h"
@@ -259,22 +260,54 @@ extern "C" gs_status gs_spz_encode_decompressed(const gs_gaussian *in, size_t n,
 }
 
 // ---- gzip framing (flate2 GzDecoder / GzEncoder, spz.rs:945-959) ---------------------------------
+// Inputs of any size are fed to zlib in chunks (avail_in is 32-bit).  The output is bounded: once
+// the 16-byte SPZ header has been inflated the payload size is known (payload_bytes), and a stream
+// that inflates past it (plus slack) is rejected instead of growing without limit; a stream whose
+// first bytes are not an SPZ header is capped at 1 GiB.
 static gs_status gunzip(const void *bytes, size_t len, std::vector<uint8_t> &out) {
+    constexpr size_t CHUNK = (size_t)1 << 30;
     z_stream zs;
     std::memset(&zs, 0, sizeof(zs));
     if (inflateInit2(&zs, 16 + MAX_WBITS) != Z_OK) return gs_fail(GS_ERR_SPZ, 0, 0, 0, "zlib init failed");
-    zs.next_in = (Bytef *)bytes;
-    zs.avail_in = (uInt)len;
-    out.resize(len * 4 + 1024);
-    int rc;
-    do {
-        if (zs.total_out == out.size()) out.resize(out.size() * 2);
-        size_t room = out.size() - zs.total_out;
-        zs.next_out = out.data() + zs.total_out;
-        zs.avail_out = (uInt)(room > 0x40000000u ? 0x40000000u : room);
-        rc = inflate(&zs, Z_NO_FLUSH);
-    } while (rc == Z_OK);
-    size_t total = zs.total_out;
+    const uint8_t *in = (const uint8_t *)bytes;
+    size_t in_left = len, total = 0, limit = CHUNK;
+    bool limit_from_header = false;
+    int rc = Z_OK;
+    try {
+        out.resize(len < ((size_t)1 << 26) ? len * 4 + 1024 : len + (len >> 1));
+        do {
+            if (zs.avail_in == 0 && in_left) {
+                const size_t take = in_left < CHUNK ? in_left : CHUNK;
+                zs.next_in = (Bytef *)in;
+                zs.avail_in = (uInt)take;
+                in += take;
+                in_left -= take;
+            }
+            if (total == out.size()) out.resize(out.size() < limit ? (out.size() * 2 < limit ? out.size() * 2 : limit + 1) : out.size() + 1);
+            size_t room = out.size() - total;
+            if (room > CHUNK) room = CHUNK;
+            zs.next_out = out.data() + total;
+            zs.avail_out = (uInt)room;
+            rc = inflate(&zs, Z_NO_FLUSH);
+            total += room - zs.avail_out;
+            if (!limit_from_header && total >= 16) {
+                gs_spz_header h;
+                std::memcpy(&h, out.data(), 16);
+                if (h.magic == k_magic && h.version >= 1 && h.version <= 3 && h.sh_degree <= 3) {
+                    limit = payload_bytes(h) + 65536;
+                    limit_from_header = true;
+                }
+            }
+            if (total > limit) {
+                inflateEnd(&zs);
+                return gs_fail(GS_ERR_SPZ, total, limit, 0, "gzip stream inflates past the size its SPZ header declares");
+            }
+            if (rc == Z_BUF_ERROR && zs.avail_in == 0 && in_left == 0) break;    // truncated input
+        } while (rc == Z_OK || (rc == Z_BUF_ERROR && (zs.avail_out == 0 || in_left)));
+    } catch (const std::bad_alloc &) {
+        inflateEnd(&zs);
+        return gs_fail(GS_ERR_OUT_OF_MEMORY, out.size(), 0, 0, "out of memory inflating SPZ data");
+    }
     inflateEnd(&zs);
     if (rc != Z_STREAM_END) return gs_fail(GS_ERR_SPZ, (uint64_t)rc, 0, 0, "invalid gzip header");
     out.resize(total);
@@ -282,17 +315,42 @@ static gs_status gunzip(const void *bytes, size_t len, std::vector<uint8_t> &out
 }
 
 static gs_status gzip_member(const void *bytes, size_t len, std::vector<uint8_t> &z) {
+    constexpr size_t CHUNK = (size_t)1 << 30;
     z_stream zs;
     std::memset(&zs, 0, sizeof(zs));
     if (deflateInit2(&zs, Z_DEFAULT_COMPRESSION, Z_DEFLATED, 16 + MAX_WBITS, 8, Z_DEFAULT_STRATEGY) != Z_OK)
         return gs_fail(GS_ERR_SPZ, 0, 0, 0, "zlib init failed");
-    z.resize(deflateBound(&zs, (uLong)len) + 64);
-    zs.next_in = (Bytef *)bytes;
-    zs.avail_in = (uInt)len;
-    zs.next_out = z.data();
-    zs.avail_out = (uInt)z.size();
-    int zr = deflate(&zs, Z_FINISH);
-    size_t total = zs.total_out;
+    int zr = Z_OK;
+    size_t total = 0;
+    try {
+        // deflateBound takes a uLong; bound the whole input chunk by chunk
+        size_t bound = 64;
+        for (size_t left = len; ; left -= CHUNK) {
+            bound += deflateBound(&zs, (uLong)(left < CHUNK ? left : CHUNK));
+            if (left <= CHUNK) break;
+        }
+        z.resize(bound);
+        const uint8_t *in = (const uint8_t *)bytes;
+        size_t in_left = len;
+        do {
+            if (zs.avail_in == 0 && in_left) {
+                const size_t take = in_left < CHUNK ? in_left : CHUNK;
+                zs.next_in = (Bytef *)in;
+                zs.avail_in = (uInt)take;
+                in += take;
+                in_left -= take;
+            }
+            size_t room = z.size() - total;
+            if (room > CHUNK) room = CHUNK;
+            zs.next_out = z.data() + total;
+            zs.avail_out = (uInt)room;
+            zr = deflate(&zs, in_left ? Z_NO_FLUSH : Z_FINISH);
+            total += room - zs.avail_out;
+        } while (zr == Z_OK && total < z.size());
+    } catch (const std::bad_alloc &) {
+        deflateEnd(&zs);
+        return gs_fail(GS_ERR_OUT_OF_MEMORY, len, 0, 0, "out of memory compressing SPZ data");
+    }
     deflateEnd(&zs);
     if (zr != Z_STREAM_END) return gs_fail(GS_ERR_SPZ, (uint64_t)zr, 0, 0, "gzip compression failed");
     z.resize(total);
@@ -311,7 +369,6 @@ static gs_status copy_out(const std::vector<uint8_t> &v, void *out, size_t capac
 // write_to = write_decompressed + compress (spz.rs:945-959)
 extern "C" gs_status gs_spz_decompress(const void *bytes, size_t len, void *out, size_t capacity, size_t *bytes_out) {
     if (!bytes || !bytes_out) return gs_fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "null argument");
-    if (len > 0xffffffffull) return gs_fail(GS_ERR_INVALID_ARGUMENT, len, 0, 0, "input larger than 4 GiB");
     std::vector<uint8_t> raw;
     gs_status rc = gunzip(bytes, len, raw);
     if (rc != GS_OK) return rc;
@@ -320,7 +377,6 @@ extern "C" gs_status gs_spz_decompress(const void *bytes, size_t len, void *out,
 
 extern "C" gs_status gs_spz_compress(const void *bytes, size_t len, void *out, size_t capacity, size_t *bytes_out) {
     if ((len && !bytes) || !bytes_out) return gs_fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "null argument");
-    if (len > 0xffffffffull) return gs_fail(GS_ERR_INVALID_ARGUMENT, len, 0, 0, "input larger than 4 GiB");
     std::vector<uint8_t> z;
     gs_status rc = gzip_member(bytes, len, z);
     if (rc != GS_OK) return rc;
@@ -342,7 +398,12 @@ extern "C" gs_status gs_spz_encode(const gs_gaussian *in, size_t n, const gs_spz
     size_t raw_size = 0;
     gs_status rc = gs_spz_encode_decompressed(in, n, opt, nullptr, 0, &raw_size);
     if (rc != GS_OK) return rc;
-    std::vector<uint8_t> raw(raw_size);
+    std::vector<uint8_t> raw;
+    try {
+        raw.resize(raw_size);
+    } catch (const std::bad_alloc &) {
+        return gs_fail(GS_ERR_OUT_OF_MEMORY, raw_size, 0, 0, "out of memory encoding SPZ data");
+    }
     rc = gs_spz_encode_decompressed(in, n, opt, raw.data(), raw.size(), &raw_size);
     if (rc != GS_OK) return rc;
     std::vector<uint8_t> z;
