@@ -445,7 +445,8 @@ def main():
             "config": {"workload": wl["label"], "gaussians": wl["n"], "visible": res["visible"],
                        "pairs": res["pairs"], "sort_passes": res["sort_passes"],
                        "launches_per_frame": res["launches"],
-                       "parallelism": "tile-row bands x%d + one RCCL all-gather (%s)" % (world, res["band_plan"])
+                       "parallelism": "tile-row bands x%d + one %s all-gather (%s)" % (
+                           world, "RCCL" if backend == "nccl" else "%s (rehearsal, host-staged)" % backend, res["band_plan"])
                        if world > 1 else "single GPU", "image_checksum": res["checksum"]},
             "frame_ms": res.get("frame_ms"),
             "stages_ms": res["stages_ms"],

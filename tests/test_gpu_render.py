@@ -589,3 +589,46 @@ def test_radix_sort_skewed_digits(gs, device, stream):
     k, v = gs.sort_pairs_u64(device, stream, keys, vals, 45)
     order = np.argsort(keys, kind="stable")
     assert np.array_equal(k, keys[order]) and np.array_equal(v, vals[order])
+
+
+def test_pair_capacity_overflow_is_flagged_and_recovered(gs, ob, device, stream):
+    """Steady-state frames size the pair buffers from earlier frames (no read-back inside a frame).
+    When the camera moves so that a frame needs far more pairs than that, the frame drops its
+    farthest pairs and says so (gs_renderer_wait_frame -> PairCapacityError with the true D); the
+    next frame has the larger buffers.  render(check=True) does the wait + re-render itself and must
+    return the exact frame."""
+    import synth
+    g = synth.scene(60000, first=5)
+    pod = gs.GaussianPod(gs.SH_NONE, gs.COV3D_ROT_SCALE)
+    pods = pod.from_gaussian(g)
+    buf = gs.GaussiansBuffer.new_with_pods(device, pod, pods)
+    W, H = 960, 540
+    img = gs.Buffer(device, size=W * H * 16)
+    r = gs.Renderer(device)
+    gt, mt = gs.gaussian_transform_pod(sh_deg=0), gs.model_transform_pod()
+    gt_big = gs.gaussian_transform_pod(size=4.0, sh_deg=0)      # 4x larger splats: ~10x the pairs, same "shape"
+    far_cam = helpers.default_camera(gs, W, H, eye=(0.0, 0.0, 60.0), target=(0.0, 0.0, 0.0))   # tiny splats: few pairs
+    near_cam = helpers.default_camera(gs, W, H)                                                 # inside the scene
+    order = buf.download_order(stream)
+    ogt, omt = ob.gaussian_transform(size=4.0, sh_deg=0), ob.model_transform()
+
+    fr_far = r.render(stream, buf, gt, mt, far_cam, img.device_ptr())        # sizing frame
+    assert fr_far.flags == 0
+    # same shape (N, image size, band), very different view: pipelined frame with the old capacity
+    r.render(stream, buf, gt_big, mt, near_cam, img.device_ptr(), check=False)
+    with pytest.raises(gs.PairCapacityError) as e:
+        r.wait_frame()
+    assert e.value.pairs > e.value.capacity >= fr_far.pairs
+    d_true = e.value.pairs
+    # the flagged frame still rendered its nearest pairs; the retry is exact
+    fr = r.render(stream, buf, gt_big, mt, near_cam, img.device_ptr())       # check=True: grows, re-renders if needed
+    assert fr.flags == 0 and fr.pairs == d_true and fr.pair_capacity >= d_true
+    rgba = img.download(stream, np.float32).reshape(H, W, 4)
+    ref, d, vis, _ = ob.render(pod.sh, pod.cov, pods, ogt, omt, helpers.copy_camera(near_cam, ob.Camera), order=order)
+    assert d == d_true and fr.visible == vis
+    assert np.array_equal(rgba.view(np.uint32), ref.view(np.uint32))
+    # and back: the larger buffers stay, nothing is flagged
+    fr2 = r.render(stream, buf, gt, mt, far_cam, img.device_ptr(), check=False)
+    assert fr2 is None
+    assert r.wait_frame().flags == 0
+    r.destroy(); img.release(); buf.destroy()

@@ -1553,12 +1553,12 @@ struct SortCompact {
 // holding the result is returned.  `sc` = host bound of the count (sizes the grid) and, optionally,
 // the device word holding the real count.  With `compact`, pass 0 reads keys[0] as the dense key
 // array of preprocess and ignores vals[0].
-template <typename K, int RB>
-static gs_status run_sort_rb(const gs_device *dev, void *const keys[2], void *const vals[2], DevArray &ghist,
+template <typename K, int RB, int ITEMS>
+static gs_status run_sort_items(const gs_device *dev, void *const keys[2], void *const vals[2], DevArray &ghist,
                              DevArray &digit_totals, gs::SortCount sc, uint32_t end_bit, const SortCompact *compact,
                              hipStream_t st, int &result_side, uint32_t &passes_out, uint32_t &launches) {
     constexpr uint32_t R = 1u << RB;
-    constexpr uint32_t TILE = (uint32_t)gs::sort_tile<K>();
+    constexpr uint32_t TILE = (uint32_t)(gs::SORT_THREADS * ITEMS);
     uint32_t passes = (end_bit + RB - 1) / RB;
     if (compact && passes == 0) passes = 1;      // the compaction (and V) must happen even for a 0-bit key range
     passes_out = passes;
@@ -1585,16 +1585,16 @@ static gs_status run_sort_rb(const gs_device *dev, void *const keys[2], void *co
         uint32_t *vo = first ? compact->visible_out : nullptr;
 #define GS_SORT_PASS(COMPACT)                                                                                     \
     do {                                                                                                          \
-        hipLaunchKernelGGL((gs::k_sort_hist<K, RB, COMPACT>), dim3(pnb), dim3(gs::SORT_THREADS), 0, st, kin, psc, \
+        hipLaunchKernelGGL((gs::k_sort_hist<K, RB, COMPACT, ITEMS>), dim3(pnb), dim3(gs::SORT_THREADS), 0, st, kin, psc, \
                            shift, digit_mask, (uint32_t *)ghist.ptr, cv);                                         \
         hipLaunchKernelGGL((gs::k_sort_scan_rows<(int)TILE>), dim3(R), dim3(256), 0, st, (uint32_t *)ghist.ptr,   \
                            pnb, psc, (uint32_t *)digit_totals.ptr);                                               \
         if (dev->lds_atomic_ordered)                                                                              \
-            hipLaunchKernelGGL((gs::k_sort_scatter<K, true, RB, COMPACT>), dim3(pnb), dim3(gs::SORT_THREADS), 0,  \
+            hipLaunchKernelGGL((gs::k_sort_scatter<K, true, RB, COMPACT, ITEMS>), dim3(pnb), dim3(gs::SORT_THREADS), 0,  \
                                st, kin, vin, kout, vout, psc, shift, digit_mask, (const uint32_t *)ghist.ptr,     \
                                (const uint32_t *)digit_totals.ptr, cv, vo);                                       \
         else                                                                                                      \
-            hipLaunchKernelGGL((gs::k_sort_scatter<K, false, RB, COMPACT>), dim3(pnb), dim3(gs::SORT_THREADS), 0, \
+            hipLaunchKernelGGL((gs::k_sort_scatter<K, false, RB, COMPACT, ITEMS>), dim3(pnb), dim3(gs::SORT_THREADS), 0, \
                                st, kin, vin, kout, vout, psc, shift, digit_mask, (const uint32_t *)ghist.ptr,     \
                                (const uint32_t *)digit_totals.ptr, cv, vo);                                       \
     } while (0)
@@ -1611,6 +1611,21 @@ static gs_status run_sort_rb(const gs_device *dev, void *const keys[2], void *co
     GS_HIP(hipGetLastError());
     result_side = side;
     return GS_OK;
+}
+
+// tile size from the host-side bound of the element count (see SortCfg)
+template <typename K, int RB>
+static gs_status run_sort_rb(const gs_device *dev, void *const keys[2], void *const vals[2], DevArray &ghist,
+                             DevArray &digit_totals, gs::SortCount sc, uint32_t end_bit, const SortCompact *compact,
+                             hipStream_t st, int &result_side, uint32_t &passes_out, uint32_t &launches) {
+    const uint64_t bound = compact ? compact->dense_count : sc.count;
+    if constexpr (gs::SortCfg<K>::ITEMS_LARGE != gs::SortCfg<K>::ITEMS) {
+        if (bound >= (4u << 20))
+            return run_sort_items<K, RB, gs::SortCfg<K>::ITEMS_LARGE>(dev, keys, vals, ghist, digit_totals, sc, end_bit,
+                                                                    compact, st, result_side, passes_out, launches);
+    }
+    return run_sort_items<K, RB, gs::SortCfg<K>::ITEMS>(dev, keys, vals, ghist, digit_totals, sc, end_bit, compact, st,
+                                                       result_side, passes_out, launches);
 }
 
 // host-known count (spatial order build, stand-alone sort)

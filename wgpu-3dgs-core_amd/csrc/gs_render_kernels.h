@@ -1092,10 +1092,14 @@ constexpr int RADIX_BITS = 8;          // default digit width; the depth sort ma
 constexpr int RADIX = 1 << RADIX_BITS;
 constexpr int RADIX_BITS_MAX = 9;
 
+// Keys per thread (tile = 256 x ITEMS keys per workgroup).  Larger tiles write longer digit runs and
+// amortise the per-block histogram rows; smaller tiles give a small sort more workgroups than CUs.
+// Measured (round 2, depth sort of V = 0.71 N): 16 -> 32 keys per thread is 0.212 -> 0.180 ms at
+// N = 10 M but 50 -> 68 us at N = 1 M; 16-bit tile keys: 32 per thread beats 16 at both sizes.
 template <typename K> struct SortCfg;
-template <> struct SortCfg<uint64_t> { static constexpr int ITEMS = 8; };
-template <> struct SortCfg<uint32_t> { static constexpr int ITEMS = 16; };
-template <> struct SortCfg<uint16_t> { static constexpr int ITEMS = 32; };
+template <> struct SortCfg<uint64_t> { static constexpr int ITEMS = 8, ITEMS_LARGE = 8; };
+template <> struct SortCfg<uint32_t> { static constexpr int ITEMS = 16, ITEMS_LARGE = 32; };
+template <> struct SortCfg<uint16_t> { static constexpr int ITEMS = 32, ITEMS_LARGE = 32; };
 template <typename K> constexpr int sort_tile() { return SORT_THREADS * SortCfg<K>::ITEMS; }
 
 // Where a sort's element count comes from: a host value, or (count_dev != null) a device word
@@ -1122,12 +1126,11 @@ constexpr uint32_t SORT_INVALID_KEY = 0xffffffffu;
 // contiguous memory.  Tile ids and depth exponents are highly repetitive, so neighbouring lanes
 // often hit the same bin; the private copies (lane & (COPIES-1)) cut the same-address LDS atomic
 // serialisation.
-template <typename K, int RB, bool COMPACT>
+template <typename K, int RB, bool COMPACT, int ITEMS>
 __global__ __launch_bounds__(SORT_THREADS) void k_sort_hist(const K *__restrict__ keys, SortCount sc,
                                                             uint32_t shift, uint32_t digit_mask,
                                                             uint32_t *__restrict__ ghist,
                                                             const uint32_t *__restrict__ chunk_vis) {
-    constexpr int ITEMS = SortCfg<K>::ITEMS;
     constexpr uint32_t TILE = SORT_THREADS * ITEMS;
     constexpr int R = 1 << RB;
     constexpr int COPIES = 2048 / R;   // 8 KiB of private copies: 8 x 256 or 4 x 512 bins
@@ -1222,13 +1225,12 @@ __global__ __launch_bounds__(256) void k_sort_scan_rows(uint32_t *__restrict__ g
 // with this kernel's own access pattern for both digit widths and with partially masked waves
 // (k_probe_lds_atomic_order<RB>) and the host falls back to the ballot-based ranking if the probe
 // ever fails.
-template <typename K, bool FAST_RANK, int RB, bool COMPACT>
+template <typename K, bool FAST_RANK, int RB, bool COMPACT, int ITEMS>
 __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
     const K *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, K *__restrict__ keys_out,
     uint32_t *__restrict__ vals_out, SortCount sc, uint32_t shift, uint32_t digit_mask,
     const uint32_t *__restrict__ ghist, const uint32_t *__restrict__ digit_totals,
     const uint32_t *__restrict__ chunk_vis, uint32_t *__restrict__ visible_out) {
-    constexpr int ITEMS = SortCfg<K>::ITEMS;
     constexpr int TILE = SORT_THREADS * ITEMS;
     constexpr int R = 1 << RB;
     constexpr int DPT = R / SORT_THREADS;        // digits per thread: thread t owns digits [t*DPT, t*DPT+DPT)
@@ -1252,16 +1254,21 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
     const uint32_t tile_base = blockIdx.x * TILE;
     const uint32_t in_tile = count - tile_base < (uint32_t)TILE ? count - tile_base : (uint32_t)TILE;
     const uint32_t wave_off = wid * (ITEMS * WAVE);
-    // COMPACT: a wave's ITEMS*64 = 1024 elements are exactly one preprocess chunk
-    bool chunk_ok = true;
-    if constexpr (COMPACT) chunk_ok = wave_off < in_tile && chunk_vis[(tile_base + wave_off) >> 10] != 0u;
+    // COMPACT: 16 rounds of a wave (1024 elements) are exactly one preprocess chunk
+    static_assert(!COMPACT || ITEMS % 16 == 0, "compacting pass: whole chunks per wave");
+    bool chunk_ok[COMPACT ? ITEMS / 16 : 1];
+    if constexpr (COMPACT) {
+#pragma unroll
+        for (int c = 0; c < ITEMS / 16; c++)
+            chunk_ok[c] = wave_off + c * 1024u < in_tile && chunk_vis[(tile_base + wave_off + c * 1024u) >> 10] != 0u;
+    }
     K key[ITEMS];
     uint32_t val[ITEMS];
     uint32_t rank[ITEMS];
 #pragma unroll
     for (int k = 0; k < ITEMS; k++) {
         const uint32_t e = wave_off + k * WAVE + lane;     // element of the tile (no 32-bit wrap near 2^32)
-        const bool ok = e < in_tile && chunk_ok;
+        const bool ok = e < in_tile && (!COMPACT || chunk_ok[COMPACT ? k / 16 : 0]);
         key[k] = ok ? keys_in[tile_base + e] : (K)~(K)0;
         if constexpr (COMPACT) val[k] = tile_base + e;
         else val[k] = ok ? vals_in[tile_base + e] : 0u;

@@ -98,13 +98,16 @@ def gather_bands(dist, buf, plan, rank):
     mine = buf[rank * c:(rank + 1) * c]
     if dist.get_backend() == "nccl":        # RCCL: fused form, output aliases the input chunk
         dist.all_gather_into_tensor(buf, mine)
-    else:                                   # gloo (CPU rehearsals): list form on chunk views
-        parts = [buf[r * c:(r + 1) * c] for r in range(g)]
-        recv = [p if r != rank else p.clone() for r, p in enumerate(parts)]
-        dist.all_gather(recv, mine.contiguous())
-        for r, p in enumerate(parts):
-            if r != rank:
-                p.copy_(recv[r])
+        return
+    # gloo (rehearsals only): list form; gloo has no all-gather on device tensors, so a device
+    # buffer is staged through the host (this is NOT the product path: RCCL above is)
+    on_device = buf.device.type != "cpu"
+    src = mine.cpu() if on_device else mine.contiguous()
+    recv = [src.new_empty(src.shape) for _ in range(g)]
+    dist.all_gather(recv, src)
+    for r in range(g):
+        if r != rank:
+            buf[r * c:(r + 1) * c].copy_(recv[r])
 
 
 def assemble(torch, buf, plan):
