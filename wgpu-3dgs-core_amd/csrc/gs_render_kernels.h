@@ -1095,7 +1095,8 @@ constexpr int RADIX_BITS_MAX = 9;
 // Keys per thread (tile = 256 x ITEMS keys per workgroup).  Larger tiles write longer digit runs and
 // amortise the per-block histogram rows; smaller tiles give a small sort more workgroups than CUs.
 // Measured (round 2, depth sort of V = 0.71 N): 16 -> 32 keys per thread is 0.212 -> 0.180 ms at
-// N = 10 M but 50 -> 68 us at N = 1 M; 16-bit tile keys: 32 per thread beats 16 at both sizes.
+// N = 10 M but 50 -> 68 us at N = 1 M; 16-bit tile keys: 32 per thread beats 16 at both sizes, and
+// 64 per thread (96 KiB of LDS, one workgroup per CU) is slower (10 M: 0.30 -> 0.39 ms).
 template <typename K> struct SortCfg;
 template <> struct SortCfg<uint64_t> { static constexpr int ITEMS = 8, ITEMS_LARGE = 8; };
 template <> struct SortCfg<uint32_t> { static constexpr int ITEMS = 16, ITEMS_LARGE = 32; };
