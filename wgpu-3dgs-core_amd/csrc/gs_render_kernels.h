@@ -1236,8 +1236,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
     constexpr int R = 1 << RB;
     constexpr int DPT = R / SORT_THREADS;        // digits per thread: thread t owns digits [t*DPT, t*DPT+DPT)
     __shared__ uint32_t s_wave_hist[4][R];       // per-wave digit counters
-    __shared__ uint32_t s_bin_start[R];          // exclusive scan of block digit counts
-    __shared__ uint32_t s_global[R];             // global offset of this block's digit run
+    __shared__ uint32_t s_delta[R];              // (global offset of this block's digit run) - (its start in the LDS tile)
     __shared__ uint32_t s_scan[4];
     __shared__ K s_keys[TILE];
     __shared__ uint32_t s_vals[TILE];
@@ -1304,6 +1303,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
 
     // per digit: offsets of each wave inside the digit run, block digit count
     uint32_t live_total;      // elements this block scatters
+    uint32_t bin0[DPT];       // start of my digits' runs in the LDS tile
     {
         uint32_t c[DPT][4], dc[DPT], mine = 0;
 #pragma unroll
@@ -1318,7 +1318,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
 #pragma unroll
         for (int q = 0; q < DPT; q++) {
             const uint32_t digit = tid * DPT + q;
-            s_bin_start[digit] = bin_start;
+            bin0[q] = bin_start;
             s_wave_hist[0][digit] = bin_start;
             s_wave_hist[1][digit] = bin_start + c[q][0];
             s_wave_hist[2][digit] = bin_start + c[q][0] + c[q][1];
@@ -1339,7 +1339,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
 #pragma unroll
         for (int q = 0; q < DPT; q++) {
             const uint32_t digit = tid * DPT + q;
-            s_global[digit] = digit_base + ghist[(uint64_t)digit * num_blocks + blockIdx.x];
+            s_delta[digit] = digit_base + ghist[(uint64_t)digit * num_blocks + blockIdx.x] - bin0[q];
             digit_base += tot[q];
         }
         if constexpr (COMPACT)
@@ -1365,7 +1365,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
         if (pos < live) {
             K kk = s_keys[pos];
             uint32_t d = (uint32_t)(kk >> shift) & digit_mask;
-            uint32_t dst = s_global[d] + (pos - s_bin_start[d]);
+            uint32_t dst = s_delta[d] + pos;
             keys_out[dst] = kk;
             vals_out[dst] = s_vals[pos];
         }
