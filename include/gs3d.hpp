@@ -35,6 +35,8 @@ struct LossyConfigError : Error { using Error::Error; };   // where the referenc
 struct NoDeviceError : Error { using Error::Error; };
 struct PlyError : Error { using Error::Error; };   // std::io::Error of the PLY reader
 struct SpzError : Error { using Error::Error; };   // std::io::Error of the SPZ reader
+// gs_renderer_wait_frame: the frame exceeded the pair capacity sized from earlier frames (render again)
+struct PairCapacityError : Error { using Error::Error; uint64_t pairs() const { return a; } uint64_t capacity() const { return b; } };
 
 inline void check(gs_status s) {
     if (s == GS_OK) return;
@@ -53,6 +55,7 @@ inline void check(gs_status s) {
     case GS_ERR_NO_DEVICE: throw NoDeviceError(i);
     case GS_ERR_PLY: throw PlyError(i);
     case GS_ERR_SPZ: throw SpzError(i);
+    case GS_ERR_PAIR_CAPACITY: throw PairCapacityError(i);
     default: throw Error(i);
     }
 }
@@ -224,6 +227,26 @@ class Buffer {   // wgpu::Buffer + BufferWrapper (src/buffer/mod.rs:17-102); Clo
         check(gs_buffer_download(h_, s.raw(), out.data(), out.size() * sizeof(T)));
         return out;
     }
+    // BufferWrapper::prepare_download / map_download (src/buffer/mod.rs:48-101): the copy is
+    // enqueued now and mapped (waited for) later
+    class Download {
+      public:
+        explicit Download(gs_download *d) : d_(d) {}
+        Download(Download &&o) noexcept : d_(o.d_) { o.d_ = nullptr; }
+        Download(const Download &) = delete;
+        ~Download() { gs_download_release(d_); }
+        bool ready() const { return gs_download_ready(d_) != 0; }
+        template <class T> std::vector<T> map() {
+            const void *p = nullptr;
+            size_t n = 0;
+            check(gs_download_map(d_, &p, &n));
+            const T *t = static_cast<const T *>(p);
+            return std::vector<T>(t, t + n / sizeof(T));
+        }
+      private:
+        gs_download *d_;
+    };
+    Download prepare_download(Stream &s) const { gs_download *d = nullptr; check(gs_buffer_prepare_download(h_, s.raw(), &d)); return Download(d); }
     gs_buffer *raw() const { return h_; }
   private:
     gs_buffer *h_ = nullptr;
@@ -386,9 +409,19 @@ class Renderer {
                 const gs_camera &cam, float *rgba_device, uint32_t band_ty0 = 0, uint32_t band_ty1 = 0xffffffffu) {
         check(gs_render_frame(h_, s.raw(), g.raw(), &gt, &mt, &cam, band_ty0, band_ty1, rgba_device));
     }
+    // render() only enqueues; wait_frame() blocks until the frame is complete and throws
+    // PairCapacityError when it exceeded the pair capacity (the next frame has larger buffers)
+    gs_frame_result wait_frame() { gs_frame_result fr; check(gs_renderer_wait_frame(h_, &fr)); return fr; }
     gs_frame_stats stats() { gs_frame_stats st; check(gs_renderer_stats(h_, &st)); return st; }
   private:
     gs_renderer *h_ = nullptr;
 };
+
+// G::from_gaussian on the device: `count` struct Gaussian records in `gaussians` -> PODs in `pods`
+template <class G>
+inline void pack_device(Device &d, Stream &s, const Buffer &gaussians, size_t count, Buffer &pods) {
+    check(gs_pack_device(d.raw(), s.raw(), G::sh, G::cov3d, static_cast<const gs_gaussian *>(gaussians.device_ptr()), count,
+                         pods.device_ptr()));
+}
 
 }  // namespace gs3d

@@ -122,8 +122,19 @@ int main() {
     Buffer img(dev, 320 * 200 * 16);
     Renderer r(dev);
     r.render(s, rbuf, gt, mt, cam, (float *)img.device_ptr());
+    auto fr = r.wait_frame();                       // render() only enqueued the frame
+    REQUIRE(fr.gaussians == 15 && fr.flags == 0 && fr.pairs <= fr.pair_capacity && fr.launches > 0);
     auto st = r.stats();
+    REQUIRE(st.visible == fr.visible && st.pairs == fr.pairs);
+    auto pending = img.prepare_download(s);         // prepare_download ... map_download
+    auto mapped = pending.map<float>();
     auto px = img.download<float>(s);
+    REQUIRE(mapped == px);
+    {   // device pack == host pack
+        Buffer src(dev, gs.size() * sizeof(Gaussian), gs.data()), dst(dev, gs.size() * G::size());
+        pack_device<G>(dev, s, src, gs.size(), dst);
+        REQUIRE(dst.download<uint8_t>(s) == G::from_gaussians(gs));
+    }
     double sum = 0; for (float v : px) sum += v;
     REQUIRE(st.gaussians == 15 && std::isfinite(sum));
     std::printf("cpp mirror OK: visible %llu pairs %llu checksum %.6f\n", (unsigned long long)st.visible, (unsigned long long)st.pairs, sum);
