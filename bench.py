@@ -297,7 +297,7 @@ def blend_valu_object(res):
                    lds_insts_per_launch=pmc.get("SQ_INSTS_LDS"),
                    valu_active_cycles=pmc["SQ_ACTIVE_INST_VALU"] * 4,      # the counter is in quad-cycles
                    valu_busy_frac=pmc["SQ_ACTIVE_INST_VALU"] * 4 / cycles,
-                   valu_insts_per_pair=pmc["SQ_INSTS_VALU"] * 64 / max(res["pairs"], 1),
+                   valu_wave_insts_per_pair=pmc["SQ_INSTS_VALU"] / max(res["pairs"], 1),
                    note="fraction of the %d SIMDs' issue cycles at %.1f GHz spent issuing VALU instructions; "
                         "fp32 vector peak 157.3 TFLOP/s is 64 FLOP/clk/SIMD" % (SIMDS, CLOCK_GHZ))
     else:

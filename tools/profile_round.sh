@@ -62,13 +62,20 @@ python3 - "$OUT" "$TAG" <<'PY'
 import csv, json, sys
 out, tag = sys.argv[1], sys.argv[2]
 b = json.loads([l for l in open("%s/%s_bench_default_line.json" % (out, tag)) if l.startswith("{")][-1])
+pmc = json.load(open("%s/pmc_traffic.json" % out))
 rows = list(csv.DictReader(open("%s/%s_bench_default_kernel_stats.csv" % (out, tag))))
 with open("%s/%s_bench_default_agreement.txt" % (out, tag), "w") as f:
-    f.write("bench roofline.avg_launch_ms = %.4f ms (HIP events in the same process)\n" % b["roofline"]["avg_launch_ms"])
+    f.write("roofline kernel, average launch duration: bench.py (HIP events on the launch stream, default command) vs rocprofv3\n")
+    f.write("(--kernel-trace --stats of `bench.py --workload <wl> --no-roofline`, %s_<wl>_summary.md)\n" % tag)
+    for key, wl in (("roofline", "10m"), ("roofline_nocull", "10m-nocull")):
+        if key in b and ("preprocess_%s" % wl) in pmc:
+            f.write("  %-11s bench %.4f ms   rocprofv3 %.4f ms   (%s)\n" % (wl, b[key]["avg_launch_ms"],
+                    pmc["preprocess_%s" % wl]["avg_us"] / 1e3, pmc["preprocess_%s" % wl]["kernel"]))
+    f.write("kernel stats of the traced default command itself (one kernel name serves 10m, 10m-nocull and 10m-4k launches):\n")
     for r in rows:
         if "k_preprocess" in r["Name"]:
-            f.write("rocprofv3 %s: calls %s avg %.4f ms\n" % (r["Name"][:70], r["Calls"], float(r["AverageNs"]) / 1e6))
-    f.write(json.dumps({k: b[k] for k in ("metric", "value", "unit", "ms_per_step", "roofline", "roofline_nocull") if k in b}) + "\n")
+            f.write("  rocprofv3 %s: calls %s avg %.4f ms\n" % (r["Name"][:70], r["Calls"], float(r["AverageNs"]) / 1e6))
+    f.write(json.dumps({k: b[k] for k in ("metric", "value", "unit", "ms_per_step", "frame_ms", "roofline", "roofline_nocull", "blend") if k in b}) + "\n")
 print(open("%s/%s_bench_default_agreement.txt" % (out, tag)).read())
 PY
 find "$OUT" -name "*.csv" -size +2M -delete
