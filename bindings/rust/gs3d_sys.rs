@@ -44,6 +44,11 @@ pub const GS_DISPLAY_SPLAT: u32 = 0;
 pub const GS_DISPLAY_ELLIPSE: u32 = 1;
 pub const GS_DISPLAY_POINT: u32 = 2;
 
+// enum gs_gaussians_source (passed as u32)
+pub const GS_SOURCE_INTERNAL: u32 = 0;
+pub const GS_SOURCE_PLY: u32 = 1;
+pub const GS_SOURCE_SPZ: u32 = 2;
+
 // enum gs_kernel_id (passed as u32)
 pub const GS_KERNEL_ARRAY_MAP_ADD: u32 = 0;
 pub const GS_KERNEL_TEST_GAUSSIAN: u32 = 1;
@@ -263,6 +268,8 @@ extern "C" {
     pub fn gs_spz_encode_decompressed(r#in: *const gs_gaussian, n: usize, options: *const gs_spz_options, out: *mut c_void, capacity: usize, bytes_out: *mut usize) -> gs_status;
     pub fn gs_spz_decompress(bytes: *const c_void, len: usize, out: *mut c_void, capacity: usize, bytes_out: *mut usize) -> gs_status;
     pub fn gs_spz_compress(bytes: *const c_void, len: usize, out: *mut c_void, capacity: usize, bytes_out: *mut usize) -> gs_status;
+    pub fn gs_gaussians_read(bytes: *const c_void, len: usize, source: gs_gaussians_source, out: *mut gs_gaussian, capacity: usize, count_out: *mut usize) -> gs_status;
+    pub fn gs_gaussians_write(r#in: *const gs_gaussian, n: usize, source: gs_gaussians_source, out: *mut c_void, capacity: usize, bytes_out: *mut usize) -> gs_status;
     pub fn gs_device_create(hip_ordinal: i32, out: *mut *mut gs_device) -> gs_status;
     pub fn gs_device_destroy(dev: *mut gs_device);
     pub fn gs_device_limits(dev: *const gs_device, out: *mut gs_limits) -> gs_status;

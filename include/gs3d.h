@@ -229,6 +229,20 @@ gs_status gs_spz_encode_decompressed(const gs_gaussian *in, size_t n, const gs_s
 gs_status gs_spz_decompress(const void *bytes, size_t len, void *out, size_t capacity, size_t *bytes_out);
 gs_status gs_spz_compress(const void *bytes, size_t len, void *out, size_t capacity, size_t *bytes_out);
 
+/* GaussiansSource / Gaussians — src/gaussian.rs:394-548: the unified representation, reduced to
+ * what crosses an FFI: read a source format into Gaussians, write Gaussians as a source format.
+ *   gs_gaussians_read  = Gaussians::read_from(reader, source)?.iter_gaussian()   (:478-497)
+ *   gs_gaussians_write = Gaussians::from_gaussians_iter(iter, source).write_to(writer)   (:426-436, 513-524;
+ *                        SPZ with the default options, as `iter.collect::<SpzGaussians>()` does)
+ * GS_SOURCE_INTERNAL fails with the reference's InvalidInput messages ("cannot read Internal
+ * Gaussians from buffer" / "cannot write Internal Gaussians to buffer") as GS_ERR_INVALID_ARGUMENT.
+ * Call with out == NULL for the count / size. */
+typedef enum { GS_SOURCE_INTERNAL = 0, GS_SOURCE_PLY = 1, GS_SOURCE_SPZ = 2 } gs_gaussians_source;
+gs_status gs_gaussians_read(const void *bytes, size_t len, gs_gaussians_source source, gs_gaussian *out,
+                            size_t capacity, size_t *count_out);
+gs_status gs_gaussians_write(const gs_gaussian *in, size_t n, gs_gaussians_source source, void *out,
+                             size_t capacity, size_t *bytes_out);
+
 /* ------------------------------------------------------------------------------------------ */
 /* Device, streams                                                                             */
 /* ------------------------------------------------------------------------------------------ */

@@ -74,3 +74,40 @@ def test_spz_read_write_preserves_reference_file_columns(gs):
     assert s.write_decompressed() == raw
     assert gzip.decompress(s.write_to()) == raw
     assert gs.SpzGaussians.read_from(s.write_to()) == s
+
+
+def test_c_abi_gaussians_read_write(gs):
+    """gs_gaussians_read / gs_gaussians_write (GaussiansSource behind the C ABI, src/gaussian.rs:394-548):
+    same bytes / Gaussians as the per-format entry points, Internal refused with the reference's messages."""
+    import ctypes as C
+    import os
+    L = gs._capi.load()
+    gold = os.path.join(os.path.dirname(__file__), "golden")
+    for name, src, ref in (("model.ply", 1, lambda b: gs.gaussian_from_ply(gs.PlyGaussians.read_from(b).pods)),
+                           ("model.spz", 2, lambda b: gs.SpzGaussians.read_from(b).iter_gaussian())):
+        raw = open(os.path.join(gold, name), "rb").read()
+        buf = np.frombuffer(raw, dtype=np.uint8)
+        n = C.c_size_t()
+        assert L.gs_gaussians_read(buf.ctypes.data, buf.size, src, None, 0, C.byref(n)) == 0
+        out = np.zeros(n.value, dtype=gs.GAUSSIAN_DTYPE)
+        assert L.gs_gaussians_read(buf.ctypes.data, buf.size, src, out.ctypes.data, n.value, C.byref(n)) == 0
+        exp = np.ascontiguousarray(ref(raw), dtype=gs.GAUSSIAN_DTYPE)
+        assert out.tobytes() == exp.tobytes()
+        # write -> read round trip through the same pair of entry points
+        size = C.c_size_t()
+        assert L.gs_gaussians_write(out.ctypes.data, len(out), src, None, 0, C.byref(size)) == 0
+        enc = np.zeros(size.value, dtype=np.uint8)
+        assert L.gs_gaussians_write(out.ctypes.data, len(out), src, enc.ctypes.data, enc.size, C.byref(size)) == 0
+        if src == 1:
+            assert enc.tobytes() == gs.PlyGaussians.from_gaussians(out).write_to()
+        else:
+            assert enc.tobytes() == gs.SpzGaussians.write_gaussians(out)
+        assert L.gs_gaussians_read(enc.ctypes.data, enc.size, src, None, 0, C.byref(n)) == 0 and n.value == len(out)
+    info = gs._capi.ErrorInfo()
+    n = C.c_size_t()
+    assert L.gs_gaussians_read(buf.ctypes.data, buf.size, 0, None, 0, C.byref(n)) == -1
+    L.gs_last_error(C.byref(info))
+    assert info.message == b"cannot read Internal Gaussians from buffer"
+    assert L.gs_gaussians_write(out.ctypes.data, len(out), 0, None, 0, C.byref(n)) == -1
+    L.gs_last_error(C.byref(info))
+    assert info.message == b"cannot write Internal Gaussians to buffer"

@@ -154,6 +154,8 @@ SIGNATURES = {
     "gs_bundle_dispatch_with_bind_groups": (i32, [vp, vp, u32, vp, vp, u32]),
     "gs_bundle_last_workgroup_count": (u32, [vp]),
     "gs_camera_look_at": (None, [vp, vp, vp, f32, u32, u32, f32, f32, vp]),
+    "gs_gaussians_read": (i32, [vp, sz, i32, vp, sz, vp]),
+    "gs_gaussians_write": (i32, [vp, sz, i32, vp, sz, vp]),
     "gs_buffer_prepare_download": (i32, [vp, vp, vp]),
     "gs_download_ready": (i32, [vp]),
     "gs_download_map": (i32, [vp, vp, vp]),

@@ -411,3 +411,54 @@ extern "C" gs_status gs_spz_encode(const gs_gaussian *in, size_t n, const gs_spz
     if (rc != GS_OK) return rc;
     return copy_out(z, out, capacity, bytes_out);
 }
+
+// ---- Gaussians / GaussiansSource (gaussian.rs:394-548) over the two codecs -----------------------
+extern "C" gs_status gs_gaussians_read(const void *bytes, size_t len, gs_gaussians_source source, gs_gaussian *out,
+                                       size_t capacity, size_t *count_out) {
+    if (!bytes || !count_out) return gs_fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "null argument");
+    switch (source) {
+    case GS_SOURCE_PLY: {
+        size_t n = 0;
+        gs_status rc = gs_ply_read(bytes, len, nullptr, 0, &n, nullptr);
+        if (rc != GS_OK) return rc;
+        *count_out = n;
+        if (!out) return GS_OK;
+        const size_t m = n < capacity ? n : capacity;
+        std::vector<gs_ply_gaussian_pod> pods;
+        try {
+            pods.resize(m);
+        } catch (const std::bad_alloc &) {
+            return gs_fail(GS_ERR_OUT_OF_MEMORY, m * sizeof(gs_ply_gaussian_pod), 0, 0, "out of memory reading PLY data");
+        }
+        rc = gs_ply_read(bytes, len, pods.data(), m, &n, nullptr);
+        if (rc != GS_OK) return rc;
+        gs_gaussian_from_ply(pods.data(), m, out);
+        return GS_OK;
+    }
+    case GS_SOURCE_SPZ: return gs_spz_decode(bytes, len, nullptr, out, capacity, count_out);
+    default: return gs_fail(GS_ERR_INVALID_ARGUMENT, (uint64_t)source, 0, 0, "cannot read Internal Gaussians from buffer");
+    }
+}
+
+extern "C" gs_status gs_gaussians_write(const gs_gaussian *in, size_t n, gs_gaussians_source source, void *out,
+                                        size_t capacity, size_t *bytes_out) {
+    if ((n && !in) || !bytes_out) return gs_fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "null argument");
+    switch (source) {
+    case GS_SOURCE_PLY: {
+        std::vector<gs_ply_gaussian_pod> pods;
+        try {
+            pods.resize(n);
+        } catch (const std::bad_alloc &) {
+            return gs_fail(GS_ERR_OUT_OF_MEMORY, n * sizeof(gs_ply_gaussian_pod), 0, 0, "out of memory writing PLY data");
+        }
+        gs_gaussian_to_ply(in, n, pods.data());
+        return gs_ply_write(pods.data(), n, out, capacity, bytes_out);
+    }
+    case GS_SOURCE_SPZ: {
+        gs_spz_options o;
+        gs_spz_options_default(&o);
+        return gs_spz_encode(in, n, &o, out, capacity, bytes_out);
+    }
+    default: return gs_fail(GS_ERR_INVALID_ARGUMENT, (uint64_t)source, 0, 0, "cannot write Internal Gaussians to buffer");
+    }
+}
