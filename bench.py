@@ -212,10 +212,12 @@ def stage_models(wl, res):
         "depth_sort": (n * 4 * 2 + v * 8 + (dpasses - 1) * v * 8 * 3,
                        "first pass reads the N dense keys twice (hist, scatter) and writes V x 8 B; "
                        "each further pass reads V x 8 B twice and writes it once"),
-        "expand": (v * (4 + 8) + v * 8 + v * (4 + 8) + d * (tkey + 4),
-                   "count: V x (4-B slot + 8-B rect gather) -> V x 8 B; emit: V x 12 B in, D x (key + 4 B) out"),
-        "tile_sort": (tpasses * d * (tkey + (tkey + 4) * 2),
-                      "per pass: D keys (hist) + D x (key + 4 B) read and written (scatter)"),
+        "expand": (v * (4 + 8) + v * 8,
+                   "k_expand_count: V x (4-B slot + 8-B rect gather) -> V x 8 B (the pairs themselves are produced "
+                   "by the first kernel of the tile sort)"),
+        "tile_sort": (v * (4 + 8) + d * (tkey + 4) + d * (tkey + 4) * 2 + (tpasses - 1) * d * (tkey + (tkey + 4) * 2),
+                      "k_pairs_emit: V x 12 B in, D x (key + 4 B) out, first histogram fused; first scatter: D x (key + "
+                      "4 B) read and written; each further pass: D keys (hist) + D x (key + 4 B) read and written"),
         "ranges": (d * tkey + tiles * 8, "D keys read, tile ranges written"),
     }
     out = {}

@@ -6,7 +6,7 @@
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 constexpr int NC = 14;
 
-template <int MODE>
+template <int MODE, bool NTL = false, bool NTS = false>
 __global__ __launch_bounds__(256) void k_rw(const uint4* __restrict__ planar, uint32_t n, uint4* __restrict__ out,
                                              uint32_t* __restrict__ out4, uint2* __restrict__ out8, uint32_t* __restrict__ sums) {
     __shared__ uint4 s_out[MODE == 4 ? 3 * 1024 : 1];
@@ -17,7 +17,11 @@ __global__ __launch_bounds__(256) void k_rw(const uint4* __restrict__ planar, ui
         uint32_t il = i < n ? i : n - 1;
         uint4 v[NC];
 #pragma unroll
-        for (int c = 0; c < NC; c++) v[c] = planar[(((uint64_t)(il >> 10) * NC + c) << 10) | (il & 1023u)];
+        for (int c = 0; c < NC; c++) {
+            const uint4* p = planar + ((((uint64_t)(il >> 10) * NC + c) << 10) | (il & 1023u));
+            if (NTL) { typedef uint32_t u4 __attribute__((ext_vector_type(4))); u4 t = __builtin_nontemporal_load((const u4*)p); v[c] = make_uint4(t.x, t.y, t.z, t.w); }
+            else v[c] = *p;
+        }
         uint4 r0 = v[0], r1 = v[1], r2 = v[2];
 #pragma unroll
         for (int c = 3; c < NC; c++) { r0.x ^= v[c].x; r1.y += v[c].y; r2.z ^= v[c].z; r0.w += v[c].w; }
@@ -34,8 +38,14 @@ __global__ __launch_bounds__(256) void k_rw(const uint4* __restrict__ planar, ui
             if (MODE == 5) {
                 uint32_t* o = (uint32_t*)out + (uint64_t)i * 9;
                 typedef uint32_t u4a __attribute__((ext_vector_type(4), aligned(4)));
+                if (NTS) {
+                    __builtin_nontemporal_store(u4a{r0.x, r0.y, r0.z, r0.w}, (u4a*)o); __builtin_nontemporal_store(u4a{r1.x, r1.y, r1.z, r1.w}, (u4a*)(o + 4));
+                    __builtin_nontemporal_store(r2.x, o + 8); __builtin_nontemporal_store(r2.y, out4 + i);
+                    typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+                    __builtin_nontemporal_store(u2{r2.z, r2.w}, (u2*)(out8 + i));
+                } else {
                 *(u4a*)o = u4a{r0.x, r0.y, r0.z, r0.w}; *(u4a*)(o + 4) = u4a{r1.x, r1.y, r1.z, r1.w}; o[8] = r2.x;
-                out4[i] = r2.y; out8[i] = make_uint2(r2.z, r2.w);
+                out4[i] = r2.y; out8[i] = make_uint2(r2.z, r2.w); }
             }
             if (MODE == 6) {   // block-planar output: [block][3][1024] uint4, one contiguous 48 KiB span per WG
                 uint64_t b = (uint64_t)blockIdx.x * 3 * 1024 + (k * 256 + threadIdx.x);
@@ -52,13 +62,13 @@ __global__ __launch_bounds__(256) void k_rw(const uint4* __restrict__ planar, ui
     if (acc_all == 0x12345u) sums[blockIdx.x] = acc_all;
 }
 
-template <int MODE>
+template <int MODE, bool NTL = false, bool NTS = false>
 static void run(const char* name, double wbytes_per, const uint4* planar, uint32_t n, uint4* out, uint32_t* out4, uint2* out8, uint32_t* sums) {
     uint32_t nb = (n + 1023) / 1024;
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
-    for (int w = 0; w < 2; w++) hipLaunchKernelGGL(k_rw<MODE>, dim3(nb), dim3(256), 0, 0, planar, n, out, out4, out8, sums);
+    for (int w = 0; w < 2; w++) hipLaunchKernelGGL((k_rw<MODE, NTL, NTS>), dim3(nb), dim3(256), 0, 0, planar, n, out, out4, out8, sums);
     CK(hipEventRecord(a));
-    for (int r = 0; r < 10; r++) hipLaunchKernelGGL(k_rw<MODE>, dim3(nb), dim3(256), 0, 0, planar, n, out, out4, out8, sums);
+    for (int r = 0; r < 10; r++) hipLaunchKernelGGL((k_rw<MODE, NTL, NTS>), dim3(nb), dim3(256), 0, 0, planar, n, out, out4, out8, sums);
     CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
     float ms; CK(hipEventElapsedTime(&ms, a, b)); ms /= 10;
     printf("%-44s %7.3f ms  read %.2f TB/s  total %.2f TB/s\n", name, ms, n * 224.0 / ms / 1e9, n * (224.0 + wbytes_per) / ms / 1e9);
@@ -78,6 +88,11 @@ int main() {
     run<6>("W6 48 B block-planar (48 KiB span per WG)", 48, planar, n, out, out4, out8, sums);
     run<4>("W4 48 B via LDS, burst at WG end", 48, planar, n, out, out4, out8, sums);
     run<5>("W5 36 B AoS + 4 B + 8 B (current)", 48, planar, n, out, out4, out8, sums);
+    run<0, true>("W0 no writes, nt loads", 0, planar, n, out, out4, out8, sums);
+    run<5, true, false>("W5 nt loads", 48, planar, n, out, out4, out8, sums);
+    run<5, false, true>("W5 nt stores", 48, planar, n, out, out4, out8, sums);
+    run<5, true, true>("W5 nt loads + nt stores", 48, planar, n, out, out4, out8, sums);
+    run<7, true, false>("W7 nt loads", 12, planar, n, out, out4, out8, sums);
     run<0>("W0 no writes (again)", 0, planar, n, out, out4, out8, sums);
     return 0;
 }

@@ -1556,11 +1556,12 @@ struct SortCompact {
 template <typename K, int RB, int ITEMS>
 static gs_status run_sort_items(const gs_device *dev, void *const keys[2], void *const vals[2], DevArray &ghist,
                              DevArray &digit_totals, gs::SortCount sc, uint32_t end_bit, const SortCompact *compact,
-                             hipStream_t st, int &result_side, uint32_t &passes_out, uint32_t &launches) {
+                             hipStream_t st, int &result_side, uint32_t &passes_out, uint32_t &launches,
+                             const gs::ExpandIO *source = nullptr) {
     constexpr uint32_t R = 1u << RB;
     constexpr uint32_t TILE = (uint32_t)(gs::SORT_THREADS * ITEMS);
     uint32_t passes = (end_bit + RB - 1) / RB;
-    if (compact && passes == 0) passes = 1;      // the compaction (and V) must happen even for a 0-bit key range
+    if ((compact || source) && passes == 0) passes = 1;   // the compaction (and V) / the generation (and D) must happen even for a 0-bit key range
     passes_out = passes;
     result_side = 0;
     if (sc.count == 0 || passes == 0) return GS_OK;
@@ -1598,7 +1599,26 @@ static gs_status run_sort_items(const gs_device *dev, void *const keys[2], void 
                                st, kin, vin, kout, vout, psc, shift, digit_mask, (const uint32_t *)ghist.ptr,     \
                                (const uint32_t *)digit_totals.ptr, cv, vo);                                       \
     } while (0)
-        if constexpr (sizeof(K) == 4) {
+        if (source && p == 0) {
+            // the pairs come from the depth-ordered rects: k_pairs_emit writes this pass's input
+            // (keys[side] / vals[side]) and its histogram at once
+            if constexpr (sizeof(K) <= 4) {
+                gs::ExpandIO src = *source;
+                src.tvals = (uint32_t *)vals[side];
+                hipLaunchKernelGGL((gs::k_pairs_emit<K, RB, ITEMS>), dim3(pnb), dim3(gs::SORT_THREADS), 0, st, src,
+                                   digit_mask, (uint32_t *)ghist.ptr, (K *)keys[side]);
+                hipLaunchKernelGGL((gs::k_sort_scan_rows<(int)TILE>), dim3(R), dim3(256), 0, st, (uint32_t *)ghist.ptr,
+                                   pnb, psc, (uint32_t *)digit_totals.ptr);
+                if (dev->lds_atomic_ordered)
+                    hipLaunchKernelGGL((gs::k_sort_scatter<K, true, RB, false, ITEMS>), dim3(pnb), dim3(gs::SORT_THREADS),
+                                       0, st, kin, vin, kout, vout, psc, shift, digit_mask, (const uint32_t *)ghist.ptr,
+                                       (const uint32_t *)digit_totals.ptr, cv, vo);
+                else
+                    hipLaunchKernelGGL((gs::k_sort_scatter<K, false, RB, false, ITEMS>), dim3(pnb), dim3(gs::SORT_THREADS),
+                                       0, st, kin, vin, kout, vout, psc, shift, digit_mask, (const uint32_t *)ghist.ptr,
+                                       (const uint32_t *)digit_totals.ptr, cv, vo);
+            }
+        } else if constexpr (sizeof(K) == 4) {
             if (first) GS_SORT_PASS(true); else GS_SORT_PASS(false);
         } else {
             GS_SORT_PASS(false);
@@ -1617,15 +1637,16 @@ static gs_status run_sort_items(const gs_device *dev, void *const keys[2], void 
 template <typename K, int RB>
 static gs_status run_sort_rb(const gs_device *dev, void *const keys[2], void *const vals[2], DevArray &ghist,
                              DevArray &digit_totals, gs::SortCount sc, uint32_t end_bit, const SortCompact *compact,
-                             hipStream_t st, int &result_side, uint32_t &passes_out, uint32_t &launches) {
+                             hipStream_t st, int &result_side, uint32_t &passes_out, uint32_t &launches,
+                             const gs::ExpandIO *source = nullptr) {
     const uint64_t bound = compact ? compact->dense_count : sc.count;
     if constexpr (gs::SortCfg<K>::ITEMS_LARGE != gs::SortCfg<K>::ITEMS) {
         if (bound >= (4u << 20))
             return run_sort_items<K, RB, gs::SortCfg<K>::ITEMS_LARGE>(dev, keys, vals, ghist, digit_totals, sc, end_bit,
-                                                                    compact, st, result_side, passes_out, launches);
+                                                                    compact, st, result_side, passes_out, launches, source);
     }
     return run_sort_items<K, RB, gs::SortCfg<K>::ITEMS>(dev, keys, vals, ghist, digit_totals, sc, end_bit, compact, st,
-                                                       result_side, passes_out, launches);
+                                                       result_side, passes_out, launches, source);
 }
 
 // host-known count (spatial order build, stand-alone sort)
@@ -1946,13 +1967,13 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
     GS_TRY(dev_reserve(r->recs, nn * 4 * gs::REC_WORDS + 16));
     GS_TRY(dev_reserve(r->depth, nn * 4));
     GS_TRY(dev_reserve(r->rect, nn * 8));
-    GS_TRY(dev_reserve(r->sorted_rect, nn * 8));
+    GS_TRY(dev_reserve(r->sorted_rect, (nn + 1024) * 8));   // padded: k_pairs_emit reads whole batches
     GS_TRY(dev_reserve(r->chunk_tiles, nc * 4));
     GS_TRY(dev_reserve(r->chunk_vis, nc * 4));
     GS_TRY(dev_reserve(r->scan_tmp, nc * 4));
     for (int i = 0; i < 2; i++) {
         GS_TRY(dev_reserve(r->dkeys[i], nn * 4));
-        GS_TRY(dev_reserve(r->dvals[i], nn * 4));
+        GS_TRY(dev_reserve(r->dvals[i], (nn + 1024) * 4));
     }
     const uint32_t exp_grid = (n + gs::EXP_CHUNK - 1) / gs::EXP_CHUNK;   // V <= N
     GS_TRY(dev_reserve(r->exp_sums, (size_t)(exp_grid ? exp_grid : 1) * 4));
@@ -2086,31 +2107,27 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
         eo.capacity = capacity;
         eo.tiles_x = fc.tiles_x;
         eo.gen = gen;
+        eo.sb_bound = exp_grid / gs::EXP_SB + 1;
         hipLaunchKernelGGL(gs::k_expand_count, dim3((exp_grid + gs::EXP_COUNT_CHUNKS - 1) / gs::EXP_COUNT_CHUNKS),
                            dim3(gs::EXP_CHUNK), 0, st, eo);
-        if (wide)
-            hipLaunchKernelGGL(gs::k_expand_emit<uint32_t>, dim3(exp_grid), dim3(gs::EXP_CHUNK), 0, st, eo,
-                               (uint32_t *)r->tkeys[0].ptr);
-        else
-            hipLaunchKernelGGL(gs::k_expand_emit<uint16_t>, dim3(exp_grid), dim3(gs::EXP_CHUNK), 0, st, eo,
-                               (uint16_t *)r->tkeys[0].ptr);
         GS_HIP(hipGetLastError());
-        r->launches += 2;
+        r->launches++;
         mark(ST_TSORT);
 
-        // ---- stable sort on the tile id alone (pairs are already in depth order) ----
+        // ---- stable sort on the tile id alone (pairs are generated in depth order by its first pass) ----
         int tside = 0;
         uint32_t tpasses = 0;
         const gs::SortCount tc{capacity, &state->pairs};
         {
             void *k2[2] = {r->tkeys[0].ptr, r->tkeys[1].ptr};
             void *v2[2] = {r->tvals[0].ptr, r->tvals[1].ptr};
+            const gs::ExpandIO *src = &eo;
             if (wide)
                 GS_TRY((run_sort_rb<uint32_t, gs::RADIX_BITS>(r->dev, k2, v2, r->ghist, r->digit_totals, tc, tile_bits, nullptr,
-                                                              st, tside, tpasses, r->launches)));
+                                                              st, tside, tpasses, r->launches, src)));
             else
                 GS_TRY((run_sort_rb<uint16_t, gs::RADIX_BITS>(r->dev, k2, v2, r->ghist, r->digit_totals, tc, tile_bits, nullptr,
-                                                              st, tside, tpasses, r->launches)));
+                                                              st, tside, tpasses, r->launches, src)));
         }
         mark(ST_RANGES);
         if (capacity) {

@@ -1,19 +1,24 @@
 // gs_render_kernels.h — hand-written gfx950 kernels of the render hot path:
-//   repack      AoS PODs -> block-planar mirror (16-byte chunks, one plane per chunk index and block)
+//   repack      AoS PODs -> block-planar mirror (16-byte chunks, one plane per chunk index and block),
+//               optionally in spatial (Morton) order
 //   preprocess  unpack + model/view transform + SH evaluation + 3D->2D covariance projection
-//               + cull + tile rect (HBM-read bound: the roofline kernel), fused with the ordered
-//               compaction of the visible Gaussians (decoupled look-back over the workgroups)
-//   depth sort  stable LSD radix sort of the V visible Gaussians on the bits of their view depth
-//   expand      (tile id, Gaussian) pairs in depth order, one per overlapped tile: gather of the
-//               tile rects, scan (decoupled look-back) and wave-cooperative emission in one kernel
+//               + cull + tile rect (HBM-read bound: the roofline kernel); writes dense per-slot
+//               arrays: 36-byte blend record, depth key (all-ones = culled), tile rect
+//   depth sort  stable LSD radix sort of the visible Gaussians on the bits of their view depth;
+//               its first pass reads the dense keys and compacts (k_sort_* with COMPACT)
+//   expand      k_expand_count: gather of the tile rects into depth order + per-chunk pair counts;
+//               k_pairs_emit: the (tile id, Gaussian) pairs in depth order, cut by output slots,
+//               with the histogram of the tile sort's first pass fused in
 //   tile sort   stable LSD radix sort of the D pairs on the tile id alone (u16 keys up to 65536 tiles)
 //   ranges      per-tile [start, end) from key boundaries
-//   blend       one 128-thread workgroup per 16x16 tile, sorted splats staged through LDS,
-//               wave64 ballot compaction of non-contributing splats, packed-f32 front-to-back blend
+//   blend       one 128-thread workgroup per 16x16 tile (k_blend_grouped): sorted splats staged
+//               through LDS, per-8x4-block index lists by wave64 ballot, front-to-back blend
 // All counts that only the device knows (V, D) stay on the device: grids are sized from host-side
 // upper bounds and surplus workgroups exit.  No MFMA anywhere: nothing here is a dense contraction.
 // wave = 64 lanes throughout.
 #pragma once
+
+#include <type_traits>
 
 #include "gs_kernel_lib.h"
 
@@ -142,7 +147,7 @@ struct FrameState {
 };
 constexpr uint32_t FRAME_FLAG_PAIR_OVERFLOW = 1u;   // D exceeded the pair capacity: farthest pairs dropped
 
-// pinned host memory, one per frame parity; written by workgroup 0 of k_expand_emit
+// pinned host memory, one per frame parity; written by workgroup 0 of k_pairs_emit
 struct FrameResult {
     uint32_t visible;
     uint32_t flags;
@@ -922,6 +927,7 @@ struct ExpandIO {
     uint32_t capacity;               // pair capacity (pairs beyond it are dropped and flagged)
     uint32_t tiles_x;
     uint32_t gen;
+    uint32_t sb_bound;               // host bound of the number of super-chunks (entries past the real one are zero)
 };
 
 // Expansion, part 1: gather the tile rects into depth order (the only random access of the key
@@ -965,116 +971,6 @@ __global__ __launch_bounds__(EXP_CHUNK) void k_expand_count(ExpandIO io) {
 #pragma unroll
         for (int d = 1; d < (int)EXP_COUNT_CHUNKS; d <<= 1) all += __shfl_xor((unsigned long long)all, d, WAVE);
         if (c == 0 && all) atomicAdd(io.sb_sums + first_chunk / EXP_SB, (unsigned long long)all);
-    }
-}
-
-// Expansion, part 2.  A workgroup owns EXP_CHUNK consecutive Gaussians of the depth order.  The
-// offset of its first pair is the sum of the super-chunks in front of its own plus the chunks of
-// its super-chunk in front of it (a few hundred values read cooperatively: no scan kernel, no
-// serial chain).  Pairs are emitted cooperatively at wave granularity: a wave produces its output
-// slots 64 at a time; every Gaussian whose first slot falls in the current 64-slot window drops a
-// marker there (LDS), an inclusive max-scan over the lanes turns the markers into "owner of this
-// slot", and each lane fetches its owner's (first slot, id, rect origin, width) with one 16-byte
-// LDS read.  Windows that lie entirely inside one large splat (no marker) skip the scan.
-// Consecutive lanes write consecutive slots, so stores are coalesced whatever the splat sizes.
-// (The depth order puts the nearest = largest splats first, so the first workgroups are the
-// heaviest; small workgroups keep that critical path short.)  Workgroup 0 also publishes D.
-template <typename TK>
-__global__ __launch_bounds__(EXP_CHUNK) void k_expand_emit(ExpandIO io, TK *__restrict__ tkeys) {
-    __shared__ uint32_t s_scan[4];
-    __shared__ uint32_t s_mark[4][WAVE];
-    __shared__ uint4 s_tab[4][WAVE];   // per lane: first slot, Gaussian id, rect origin, rect width
-    __shared__ unsigned long long s_part[4];
-    const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
-    const uint32_t chunk = blockIdx.x;
-    const uint32_t v_count = io.state->visible;
-    if ((uint64_t)chunk * EXP_CHUNK >= v_count && chunk != 0u) return;
-    const uint32_t nchunks = (uint32_t)(((uint64_t)v_count + EXP_CHUNK - 1) / EXP_CHUNK);
-    const uint32_t nsb = (nchunks + EXP_SB - 1) / EXP_SB, my_sb = chunk / EXP_SB;
-
-    // offset of this chunk's first pair (and, in workgroup 0, the frame's D)
-    uint64_t part = 0, all = 0;
-    for (uint32_t q = threadIdx.x; q < nsb; q += EXP_CHUNK) {
-        const uint64_t v = io.sb_sums[q];
-        if (q < my_sb) part += v;
-        all += v;
-    }
-    for (uint32_t c = my_sb * EXP_SB + threadIdx.x; c < chunk; c += EXP_CHUNK) part += io.sums[c];
-    part = wave_reduce_add64(part);
-    if (lane == 0) s_part[wid] = part;
-    __syncthreads();
-    const uint64_t base64 = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
-    if (chunk == 0u) {
-        __syncthreads();
-        all = wave_reduce_add64(all);
-        if (lane == 0) s_part[wid] = all;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const uint64_t d = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
-            const uint32_t over = d > (uint64_t)io.capacity ? FRAME_FLAG_PAIR_OVERFLOW : 0u;
-            io.state->pairs = over ? io.capacity : (uint32_t)d;
-            io.result->visible = v_count;
-            io.result->pairs_total = d;
-            io.result->flags = over;
-            io.result->gen = io.gen;
-        }
-        if (v_count == 0u) return;
-    }
-    if (base64 >= (uint64_t)io.capacity) return;            // everything of this chunk is past the capacity
-
-    const uint32_t j = chunk * EXP_CHUNK + threadIdx.x;
-    uint32_t g = 0, cnt = 0, origin = 0, width = 1;
-    if (j < v_count) {
-        g = io.order[j];
-        const uint2 r = io.sorted_rect[j];
-        const uint32_t w = (r.y & 0xffffu) - (r.x & 0xffffu), h = (r.y >> 16) - (r.x >> 16);
-        origin = r.x;
-        width = w ? w : 1u;
-        cnt = w * h;
-    }
-    const uint32_t incl = wave_inclusive_scan(cnt, lane);
-    const uint32_t excl = incl - cnt;
-    const uint32_t wave_total = __shfl(incl, 63, WAVE);
-    if (lane == 63u) s_scan[wid] = incl;
-    s_tab[wid][lane] = make_uint4(excl, g, origin, width);
-    __syncthreads();
-    const uint32_t w0 = s_scan[0], w1 = s_scan[1], w2 = s_scan[2];
-    const uint32_t wave_off = wid == 0 ? 0u : wid == 1 ? w0 : wid == 2 ? w0 + w1 : w0 + w1 + w2;
-    const uint64_t out0 = base64 + wave_off;
-    uint32_t carry = 0;
-    for (uint32_t win = 0; win < wave_total; win += WAVE) {
-        const bool starts_here = cnt != 0u && excl >= win && excl < win + WAVE;
-        uint32_t owner = carry;
-        if (__any(starts_here)) {
-            s_mark[wid][lane] = 0u;
-            __builtin_amdgcn_wave_barrier();
-            if (starts_here) s_mark[wid][excl - win] = lane + 1u;
-            __builtin_amdgcn_wave_barrier();
-            uint32_t m = wave_inclusive_max(s_mark[wid][lane]);
-            owner = m ? m - 1u : carry;
-            carry = __shfl(owner, 63, WAVE);
-        }
-        const uint4 ot = s_tab[wid][owner];   // one 16-byte LDS read instead of four cross-lane permutes
-        const uint32_t o_excl = ot.x, o_g = ot.y, o_org = ot.z, o_w = ot.w;
-        const uint32_t e = win + lane;
-        const uint32_t local = e - o_excl;
-        // local / o_w without the 35-instruction integer division: local < 2^22 (<= 2^22 tiles) and
-        // o_w < 2^16 are exact in f32, the reciprocal estimate is off by at most one, fixed up exactly
-        uint32_t row = (uint32_t)((float)local * __builtin_amdgcn_rcpf((float)o_w));
-        uint32_t col = local - row * o_w;
-        if ((int32_t)col < 0) {
-            row--;
-            col += o_w;
-        } else if (col >= o_w) {
-            row++;
-            col -= o_w;
-        }
-        const uint32_t tile = ((o_org >> 16) + row) * io.tiles_x + (o_org & 0xffffu) + col;
-        const uint64_t o = out0 + e;
-        if (e < wave_total && o < (uint64_t)io.capacity) {
-            tkeys[o] = (TK)tile;
-            io.tvals[o] = o_g;
-        }
     }
 }
 
@@ -1226,53 +1122,47 @@ __global__ __launch_bounds__(256) void k_sort_scan_rows(uint32_t *__restrict__ g
 // with this kernel's own access pattern for both digit widths and with partially masked waves
 // (k_probe_lds_atomic_order<RB>) and the host falls back to the ballot-based ranking if the probe
 // ever fails.
-template <typename K, bool FAST_RANK, int RB, bool COMPACT, int ITEMS>
-__global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
-    const K *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, K *__restrict__ keys_out,
-    uint32_t *__restrict__ vals_out, SortCount sc, uint32_t shift, uint32_t digit_mask,
-    const uint32_t *__restrict__ ghist, const uint32_t *__restrict__ digit_totals,
-    const uint32_t *__restrict__ chunk_vis, uint32_t *__restrict__ visible_out) {
-    constexpr int TILE = SORT_THREADS * ITEMS;
-    constexpr int R = 1 << RB;
-    constexpr int DPT = R / SORT_THREADS;        // digits per thread: thread t owns digits [t*DPT, t*DPT+DPT)
-    __shared__ uint32_t s_wave_hist[4][R];       // per-wave digit counters
-    __shared__ uint32_t s_delta[R];              // (global offset of this block's digit run) - (its start in the LDS tile)
-    __shared__ uint32_t s_scan[4];
-    __shared__ K s_keys[TILE];
-    __shared__ uint32_t s_vals[TILE];
 
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
-    const uint32_t count = sc.get();
-    const uint32_t num_blocks = gridDim.x;                 // row stride of ghist
-    if ((uint64_t)blockIdx.x * TILE >= count) return;      // grid sized from an upper bound of the count
+// LDS of a scatter workgroup
+template <typename K, int RB, int ITEMS>
+struct ScatterShared {
+    static constexpr int TILE = SORT_THREADS * ITEMS;
+    static constexpr int R = 1 << RB;
+    uint32_t wave_hist[4][R];      // per-wave digit counters
+    uint32_t delta[R];             // (global offset of this block's digit run) - (its start in the LDS tile)
+    uint32_t scan[4];
+    K keys[TILE];
+    uint32_t vals[TILE];
+};
+
+template <typename K, int RB, int ITEMS>
+__device__ __forceinline__ void scatter_clear(ScatterShared<K, RB, ITEMS> &sh) {
+    constexpr int DPT = (1 << RB) / SORT_THREADS;
 #pragma unroll
     for (int w = 0; w < 4; w++)
 #pragma unroll
-        for (int q = 0; q < DPT; q++) s_wave_hist[w][tid + q * SORT_THREADS] = 0;
+        for (int q = 0; q < DPT; q++) sh.wave_hist[w][threadIdx.x + q * SORT_THREADS] = 0;
     __syncthreads();
+}
 
-    const uint32_t tile_base = blockIdx.x * TILE;
-    const uint32_t in_tile = count - tile_base < (uint32_t)TILE ? count - tile_base : (uint32_t)TILE;
-    const uint32_t wave_off = wid * (ITEMS * WAVE);
-    // COMPACT: 16 rounds of a wave (1024 elements) are exactly one preprocess chunk
-    static_assert(!COMPACT || ITEMS % 16 == 0, "compacting pass: whole chunks per wave");
-    bool chunk_ok[COMPACT ? ITEMS / 16 : 1];
-    if constexpr (COMPACT) {
-#pragma unroll
-        for (int c = 0; c < ITEMS / 16; c++)
-            chunk_ok[c] = wave_off + c * 1024u < in_tile && chunk_vis[(tile_base + wave_off + c * 1024u) >> 10] != 0u;
-    }
-    K key[ITEMS];
-    uint32_t val[ITEMS];
+// Everything after a workgroup holds its tile in registers (key[k], val[k] = element
+// wave_off + k * 64 + lane of the tile; padding = all-ones key): rank, local reorder, coalesced store.
+template <typename K, bool FAST_RANK, int RB, bool COMPACT, int ITEMS>
+__device__ __forceinline__ void scatter_ranked(ScatterShared<K, RB, ITEMS> &sh, K (&key)[ITEMS], uint32_t (&val)[ITEMS],
+                                               uint32_t in_tile, uint32_t num_blocks, K *__restrict__ keys_out,
+                                               uint32_t *__restrict__ vals_out, uint32_t shift, uint32_t digit_mask,
+                                               const uint32_t *__restrict__ ghist,
+                                               const uint32_t *__restrict__ digit_totals,
+                                               uint32_t *__restrict__ visible_out) {
+    constexpr int R = 1 << RB;
+    constexpr int DPT = R / SORT_THREADS;        // digits per thread: thread t owns digits [t*DPT, t*DPT+DPT)
+    auto &s_wave_hist = sh.wave_hist;
+    auto &s_delta = sh.delta;
+    auto &s_scan = sh.scan;
+    auto &s_keys = sh.keys;
+    auto &s_vals = sh.vals;
+    const uint32_t tid = threadIdx.x, wid = tid >> 6;
     uint32_t rank[ITEMS];
-#pragma unroll
-    for (int k = 0; k < ITEMS; k++) {
-        const uint32_t e = wave_off + k * WAVE + lane;     // element of the tile (no 32-bit wrap near 2^32)
-        const bool ok = e < in_tile && (!COMPACT || chunk_ok[COMPACT ? k / 16 : 0]);
-        key[k] = ok ? keys_in[tile_base + e] : (K)~(K)0;
-        if constexpr (COMPACT) val[k] = tile_base + e;
-        else val[k] = ok ? vals_in[tile_base + e] : 0u;
-    }
     if constexpr (FAST_RANK) {
 #pragma unroll
         for (int k = 0; k < ITEMS; k++) {
@@ -1369,6 +1259,358 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
             keys_out[dst] = kk;
             vals_out[dst] = s_vals[pos];
         }
+    }
+}
+
+template <typename K, bool FAST_RANK, int RB, bool COMPACT, int ITEMS>
+__global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
+    const K *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, K *__restrict__ keys_out,
+    uint32_t *__restrict__ vals_out, SortCount sc, uint32_t shift, uint32_t digit_mask,
+    const uint32_t *__restrict__ ghist, const uint32_t *__restrict__ digit_totals,
+    const uint32_t *__restrict__ chunk_vis, uint32_t *__restrict__ visible_out) {
+    constexpr int TILE = SORT_THREADS * ITEMS;
+    __shared__ ScatterShared<K, RB, ITEMS> sh;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
+    const uint32_t count = sc.get();
+    if ((uint64_t)blockIdx.x * TILE >= count) return;      // grid sized from an upper bound of the count
+    scatter_clear(sh);
+
+    const uint32_t tile_base = blockIdx.x * TILE;
+    const uint32_t in_tile = count - tile_base < (uint32_t)TILE ? count - tile_base : (uint32_t)TILE;
+    const uint32_t wave_off = wid * (ITEMS * WAVE);
+    // COMPACT: 16 rounds of a wave (1024 elements) are exactly one preprocess chunk
+    static_assert(!COMPACT || ITEMS % 16 == 0, "compacting pass: whole chunks per wave");
+    bool chunk_ok[COMPACT ? ITEMS / 16 : 1];
+    if constexpr (COMPACT) {
+#pragma unroll
+        for (int c = 0; c < ITEMS / 16; c++)
+            chunk_ok[c] = wave_off + c * 1024u < in_tile && chunk_vis[(tile_base + wave_off + c * 1024u) >> 10] != 0u;
+    }
+    K key[ITEMS];
+    uint32_t val[ITEMS];
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) {
+        const uint32_t e = wave_off + k * WAVE + lane;     // element of the tile (no 32-bit wrap near 2^32)
+        const bool ok = e < in_tile && (!COMPACT || chunk_ok[COMPACT ? k / 16 : 0]);
+        key[k] = ok ? keys_in[tile_base + e] : (K)~(K)0;
+        if constexpr (COMPACT) val[k] = tile_base + e;
+        else val[k] = ok ? vals_in[tile_base + e] : 0u;
+    }
+    scatter_ranked<K, FAST_RANK, RB, COMPACT, ITEMS>(sh, key, val, in_tile, gridDim.x, keys_out, vals_out, shift,
+                                                     digit_mask, ghist, digit_totals, visible_out);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Expansion, part 2: the (tile id, Gaussian) pairs in depth order, cut by OUTPUT slots.  Pair p
+// belongs to the Gaussian j with prefix(j) <= p < prefix(j + 1) and is tile (p - prefix(j)) of its
+// rect, row-major.  A workgroup of k_pairs_emit produces exactly the pairs of one tile of the tile
+// sort's first pass (a wave owns ITEMS * 64 consecutive slots), so
+//   * the work is balanced whatever the splat sizes: the few hundred nearest splats that cover
+//     hundreds of tiles each no longer form a critical path (Gaussian-cut workgroups: 25 us at 1 M
+//     for 3.5 M pairs, of which 5 us are average work);
+//   * the digit histogram of the sort's first pass is counted while the pairs are written, which
+//     removes that pass's histogram kernel (one read of all keys).
+// A wave finds its starting point with two cooperative steps over k_expand_count's sums (super-chunk
+// sums, then the chunk sums of one super-chunk) and then walks the Gaussians 64 at a time (next
+// batch prefetched).  Inside a batch every Gaussian drops ONE marker at its first slot; the owner
+// of each slot is then an inclusive max-scan over the 64 lanes of a window, and the tile id follows
+// from the owner's table entry without a per-pair integer division.
+// ---------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ uint64_t wave_inclusive_scan64(uint64_t v, uint32_t lane) {
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+        const uint64_t o = __shfl_up((unsigned long long)v, d, WAVE);
+        if (lane >= (uint32_t)d) v += o;
+    }
+    return v;
+}
+
+struct PairCursor {
+    uint32_t chunk;      // first chunk (of EXP_CHUNK Gaussians in depth order) holding pairs at or after slot o0
+    uint64_t prefix;     // pairs in front of that chunk
+    uint64_t total;      // D: all pairs of the frame
+};
+
+// One level of the search: PER consecutive values per lane starting at element `first` (limit `n`),
+// `run` = pairs in front of `first`.  Returns true and (index, prefix in front of it) of the element
+// whose range holds slot o0; else adds the level's total to run.  Wave-uniform.
+template <int PER, bool ALWAYS_TOTAL = false, typename T>
+__device__ __forceinline__ bool cursor_level(const T *__restrict__ vals, uint32_t first, uint32_t n, uint64_t o0,
+                                             uint32_t lane, uint64_t &run, uint32_t &index, uint64_t &prefix) {
+    uint64_t v[PER], mine = 0;
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        const uint32_t q = first + lane * PER + k;
+        v[k] = q < n ? (uint64_t)vals[q] : 0ull;
+        mine += v[k];
+    }
+    const uint64_t incl = wave_inclusive_scan64(mine, lane);
+    const uint64_t hit = __ballot(run + incl > o0);
+    const uint64_t level_total = __shfl((unsigned long long)incl, WAVE - 1, WAVE);
+    if (hit) {
+        const uint32_t l = (uint32_t)__builtin_ctzll(hit);
+        uint64_t before = run + __shfl((unsigned long long)(incl - mine), l, WAVE);
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+            const uint64_t x = __shfl((unsigned long long)v[k], l, WAVE);
+            if (k == PER - 1 || before + x > o0) {
+                index = first + l * PER + k;
+                prefix = before;
+                break;
+            }
+            before += x;
+        }
+        if (ALWAYS_TOTAL) run += level_total;
+        return true;
+    }
+    run += level_total;
+    return false;
+}
+
+// wave-uniform; every lane of the wave must call it
+__device__ __forceinline__ PairCursor pair_cursor(const ExpandIO &io, uint32_t v_count, uint64_t o0, uint32_t lane) {
+    constexpr int SB_PER = 4, CH_PER = (int)(EXP_SB / WAVE);
+    static_assert(EXP_SB % WAVE == 0, "one chunk-level step per super-chunk");
+    const uint32_t nchunks = (uint32_t)(((uint64_t)v_count + EXP_CHUNK - 1) / EXP_CHUNK);
+    PairCursor cur;
+    uint64_t run = 0, sb_prefix = 0;
+    uint32_t sb = 0;
+    bool found = false;
+    // (the loop bound comes from the host, so these loads do not wait for V; entries past the real
+    // number of super-chunks are zero)
+    for (uint32_t q0 = 0; q0 < io.sb_bound; q0 += WAVE * SB_PER) {
+        // one pass serves both the search and D: after the hit only the totals are still needed
+        uint64_t r = run;
+        uint32_t i = 0;
+        uint64_t p = 0;
+        const bool hit = cursor_level<SB_PER, true>(io.sb_sums, q0, io.sb_bound, o0, lane, r, i, p);
+        if (hit && !found) {
+            found = true;
+            sb = i;
+            sb_prefix = p;
+        }
+        run = r;
+    }
+    cur.total = run;
+    cur.chunk = nchunks;
+    cur.prefix = run;
+    if (!found) return cur;                // o0 >= D
+    run = sb_prefix;
+    const uint32_t c_end = nchunks < (sb + 1u) * EXP_SB ? nchunks : (sb + 1u) * EXP_SB;
+    cursor_level<CH_PER>(io.sums, sb * EXP_SB, c_end, o0, lane, run, cur.chunk, cur.prefix);
+    return cur;
+}
+
+constexpr int GEN_PER = 4;                    // Gaussians per lane per batch (consecutive: vector loads)
+constexpr int GEN_BATCH = WAVE * GEN_PER;     // = EXP_CHUNK: a batch is one chunk of the count kernel
+static_assert(GEN_BATCH == EXP_CHUNK, "the cursor hands out chunk starts");
+
+template <typename K, int NSLOTS>
+struct PairGenShared {                 // LDS private to one wave
+    uint32_t vals[NSLOTS + GEN_BATCH]; // output staging (Gaussian id per slot); until a slot is produced it holds
+                                       // the marker: 1 + batch index of the Gaussian whose first pair it is, 0 = none
+    K keys[NSLOTS];                    // output staging (tile id per slot)
+    uint4 tab[GEN_BATCH];              // per Gaussian of the batch: first slot (signed, relative to the wave's
+                                       // first), id, tile id of the rect origin, rect width
+};
+
+// The wave produces its output slots [0, n_slots) (absolute: o0 + slot) into sh.keys / sh.vals and
+// calls count(tile) once per pair.  Nothing is stored to global memory in here: stores retire
+// through the same in-order counter as the loads of the next batch, and waiting for that load would
+// wait for every store issued after it (measured: 25 us instead of 10 at 1 M).
+// A lane owns GEN_PER consecutive slots of a 256-slot group, so one max-scan over the lanes serves
+// 256 pairs.  Every iteration of the outer loop advances j (bounded by v_count): the wave always
+// terminates.
+template <typename K, int NSLOTS, typename Count>
+__device__ __forceinline__ void pair_generate(const ExpandIO &io, uint32_t v_count, uint64_t o0, uint32_t n_slots,
+                                              const PairCursor &cur, uint32_t lane, PairGenShared<K, NSLOTS> &sh,
+                                              Count count) {
+    static_assert(sizeof(K) == 2 || sizeof(K) == 4, "tile keys are u16 or u32");
+    {
+        uint4 *z = (uint4 *)sh.vals;
+#pragma unroll
+        for (uint32_t q = lane; q < (NSLOTS + GEN_BATCH) / 4; q += WAVE) z[q] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    // slots relative to o0 from here on: the chunk in front of o0 holds < 2^30 pairs, a batch < 2^30
+    int32_t rel = (int32_t)(int64_t)(cur.prefix - o0);      // <= 0: first slot of the batch
+    const int32_t n = (int32_t)n_slots;
+    uint32_t j = cur.chunk * EXP_CHUNK;
+    // the next batch's 48 bytes per lane are requested before the current batch is worked on (the
+    // arrays are padded: reading past v_count is in bounds, the values are masked below)
+    const uint4 *order4 = (const uint4 *)io.order;
+    const uint4 *rect4 = (const uint4 *)io.sorted_rect;
+    uint4 g_next = order4[(j >> 2) + lane];
+    uint4 ra_next = rect4[(j >> 1) + 2 * lane], rb_next = rect4[(j >> 1) + 2 * lane + 1];
+    __builtin_amdgcn_wave_barrier();
+    while (rel < n && j < v_count) {
+        const uint32_t g[GEN_PER] = {g_next.x, g_next.y, g_next.z, g_next.w};
+        const uint32_t r0[GEN_PER] = {ra_next.x, ra_next.z, rb_next.x, rb_next.z};
+        const uint32_t r1[GEN_PER] = {ra_next.y, ra_next.w, rb_next.y, rb_next.w};
+        if (j + GEN_BATCH < v_count) {
+            g_next = order4[((j + GEN_BATCH) >> 2) + lane];
+            ra_next = rect4[((j + GEN_BATCH) >> 1) + 2 * lane];
+            rb_next = rect4[((j + GEN_BATCH) >> 1) + 2 * lane + 1];
+        }
+        uint32_t w[GEN_PER], cnt[GEN_PER], mine = 0;
+#pragma unroll
+        for (int k = 0; k < GEN_PER; k++) {
+            const bool live = j + GEN_PER * lane + k < v_count;
+            w[k] = (r1[k] & 0xffffu) - (r0[k] & 0xffffu);
+            cnt[k] = live ? __umul24(w[k], (r1[k] >> 16) - (r0[k] >> 16)) : 0u;
+            mine += cnt[k];
+        }
+        const uint32_t incl = wave_inclusive_scan(mine, lane);
+        const int32_t bend = rel + (int32_t)__builtin_amdgcn_readlane(incl, WAVE - 1);
+        const int32_t lo = rel > 0 ? rel : 0, hi = bend < n ? bend : n;
+        if (hi > lo) {
+            int32_t start = rel + (int32_t)(incl - mine);
+            uint32_t last = 0;        // 1 + batch index of the last Gaussian (with pairs) starting at or before lo
+#pragma unroll
+            for (int k = 0; k < GEN_PER; k++) {
+                const uint32_t idx = GEN_PER * lane + k;
+                sh.tab[idx] = make_uint4((uint32_t)start, g[k], __umul24(r0[k] >> 16, io.tiles_x) + (r0[k] & 0xffffu),
+                                         w[k] ? w[k] : 1u);
+                if (cnt[k] != 0u) {
+                    if (start <= lo) last = idx + 1u;
+                    else if (start < hi) sh.vals[start] = idx + 1u;
+                }
+                start += (int32_t)cnt[k];
+            }
+            uint32_t carry = wave_reduce_max(last);       // >= 1: the batch reaches past lo
+            __builtin_amdgcn_wave_barrier();
+            // one group = 256 consecutive slots, 4 per lane.  FULL: the whole group belongs to this batch
+            // (no per-slot range tests, vector stores)
+            auto group = [&](int32_t wb, auto full_tag) {
+                constexpr bool FULL = decltype(full_tag)::value;
+                const int32_t s0 = wb + GEN_PER * (int32_t)lane;
+                const uint4 mraw = *(const uint4 *)&sh.vals[s0];
+                const uint32_t raw[GEN_PER] = {mraw.x, mraw.y, mraw.z, mraw.w};
+                bool act[GEN_PER];
+                uint32_t m[GEN_PER], lane_max = 0;
+#pragma unroll
+                for (int k = 0; k < GEN_PER; k++) {
+                    act[k] = FULL || (s0 + k >= lo && s0 + k < hi);
+                    m[k] = act[k] ? raw[k] : 0u;       // slots below lo already hold their output
+                    lane_max = m[k] > lane_max ? m[k] : lane_max;
+                }
+                const uint32_t incl_max = wave_inclusive_max(lane_max);
+                uint32_t own = __shfl_up(incl_max, 1, WAVE);      // markers of the lanes below me
+                own = lane == 0u ? carry : (own > carry ? own : carry);
+                const uint32_t top = __builtin_amdgcn_readlane(incl_max, WAVE - 1);
+                carry = top > carry ? top : carry;
+                // owners first, then the four table reads back to back, then the arithmetic, then the
+                // histogram adds: LDS atomics in between would serialise the reads behind them
+                uint32_t tile[GEN_PER], gid[GEN_PER];
+                uint4 ot[GEN_PER];
+#pragma unroll
+                for (int k = 0; k < GEN_PER; k++) {
+                    own = m[k] > own ? m[k] : own;
+                    ot[k] = sh.tab[own - 1u];
+                }
+#pragma unroll
+                for (int k = 0; k < GEN_PER; k++) {
+                    const uint32_t local = (uint32_t)(s0 + k - (int32_t)ot[k].x);
+                    // row = local / width without the integer division: local < 2^22 and width < 2^16 are
+                    // exact in f32, the estimate is off by at most one either way, fixed up exactly
+                    uint32_t row = (uint32_t)((float)local * __builtin_amdgcn_rcpf((float)ot[k].w));
+                    const uint32_t rem = local - __umul24(row, ot[k].w);
+                    if ((int32_t)rem < 0) row--;
+                    else if (rem >= ot[k].w) row++;
+                    // tile = origin + row * tiles_x + col, col = local - row * width
+                    tile[k] = ot[k].z + local + __umul24(row, io.tiles_x - ot[k].w);
+                    gid[k] = ot[k].y;
+                }
+#pragma unroll
+                for (int k = 0; k < GEN_PER; k++)
+                    if (act[k]) count(tile[k]);
+                if constexpr (FULL) {
+                    *(uint4 *)&sh.vals[s0] = make_uint4(gid[0], gid[1], gid[2], gid[3]);
+                    if constexpr (sizeof(K) == 2)
+                        *(uint2 *)&sh.keys[s0] = make_uint2(tile[0] | (tile[1] << 16), tile[2] | (tile[3] << 16));
+                    else
+                        *(uint4 *)&sh.keys[s0] = make_uint4(tile[0], tile[1], tile[2], tile[3]);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < GEN_PER; k++)
+                        if (act[k]) {
+                            sh.vals[s0 + k] = gid[k];
+                            sh.keys[s0 + k] = (K)tile[k];
+                        }
+                }
+            };
+            for (int32_t wb = lo & ~(GEN_BATCH - 1); wb < hi; wb += GEN_BATCH) {
+                if (wb >= lo && wb + GEN_BATCH <= hi) group(wb, std::true_type());
+                else group(wb, std::false_type());
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        rel = bend;
+        j += GEN_BATCH;
+    }
+}
+
+// Pairs of one sort tile + the histogram of their first digit; workgroup 0 also publishes D (clamped
+// to the pair capacity), the overflow flag and the frame result.  Grid: capacity / TILE workgroups.
+template <typename K, int RB, int ITEMS>
+__global__ __launch_bounds__(SORT_THREADS) void k_pairs_emit(ExpandIO io, uint32_t digit_mask,
+                                                             uint32_t *__restrict__ ghist, K *__restrict__ tkeys) {
+    constexpr uint32_t TILE = SORT_THREADS * ITEMS;
+    constexpr uint32_t NSLOTS = ITEMS * WAVE;
+    constexpr int R = 1 << RB;
+    constexpr int COPIES = 2048 / R;
+    constexpr int DPT = R / SORT_THREADS;
+    __shared__ uint32_t s_hist[COPIES][R];
+    __shared__ PairGenShared<K, NSLOTS> s_gen[4];
+    const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+    const uint32_t v_count = io.state->visible;
+    const uint64_t o0 = (uint64_t)blockIdx.x * TILE + wid * NSLOTS;
+    const PairCursor cur = pair_cursor(io, v_count, o0, lane);
+    const uint64_t d = cur.total;
+    const uint32_t count = d > (uint64_t)io.capacity ? io.capacity : (uint32_t)d;
+    if (blockIdx.x == 0u && threadIdx.x == 0u) {
+        const uint32_t over = d > (uint64_t)io.capacity ? FRAME_FLAG_PAIR_OVERFLOW : 0u;
+        io.state->pairs = count;
+        io.result->visible = v_count;
+        io.result->pairs_total = d;
+        io.result->flags = over;
+        io.result->gen = io.gen;
+    }
+    if ((uint64_t)blockIdx.x * TILE >= count) return;      // the same D in every wave: block-uniform
+#pragma unroll
+    for (int c = 0; c < COPIES; c++)
+#pragma unroll
+        for (int q = 0; q < DPT; q++) s_hist[c][threadIdx.x + q * SORT_THREADS] = 0;
+    __syncthreads();
+    if (o0 < count) {
+        const uint32_t n_slots = count - o0 < (uint64_t)NSLOTS ? (uint32_t)(count - o0) : NSLOTS;
+        uint32_t *hist = s_hist[threadIdx.x & (uint32_t)(COPIES - 1)];
+        PairGenShared<K, NSLOTS> &sh = s_gen[wid];
+        pair_generate<K>(io, v_count, o0, n_slots, cur, lane, sh,
+                         [&](uint32_t tile) { atomicAdd(&hist[tile & digit_mask], 1u); });
+        // the wave's slots leave in whole 16-byte vectors (o0 is a multiple of NSLOTS: aligned)
+        uint32_t *vout = io.tvals + o0;
+        K *kout = tkeys + o0;
+        if (n_slots == NSLOTS) {
+#pragma unroll
+            for (uint32_t q = lane; q < NSLOTS / 4; q += WAVE) ((uint4 *)vout)[q] = ((const uint4 *)sh.vals)[q];
+#pragma unroll
+            for (uint32_t q = lane; q < NSLOTS * sizeof(K) / 16; q += WAVE) ((uint4 *)kout)[q] = ((const uint4 *)sh.keys)[q];
+        } else {
+            for (uint32_t q = lane; q < n_slots; q += WAVE) {
+                vout[q] = sh.vals[q];
+                kout[q] = sh.keys[q];
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < DPT; q++) {
+        const uint32_t digit = threadIdx.x + q * SORT_THREADS;
+        uint32_t sum = 0;
+#pragma unroll
+        for (int c = 0; c < COPIES; c++) sum += s_hist[c][digit];
+        ghist[(uint64_t)digit * gridDim.x + blockIdx.x] = sum;
     }
 }
 
