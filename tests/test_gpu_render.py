@@ -413,6 +413,39 @@ def test_edge_cases(gs, ob, device, stream):
     assert st.pairs >= 40 * 30
 
 
+@pytest.mark.parametrize("case", ["one_tile", "screen_fillers", "single_tile_splats", "ragged_counts"])
+def test_pair_emission_regimes(gs, ob, device, stream, case):
+    """k_pairs_emit cuts the pairs by output slots: a wave owns 2048 consecutive pairs wherever the
+    Gaussian boundaries fall.  Regimes: an image of one tile (0 tile-key bits, the sort still has to
+    run its generating pass), splats whose rect is the whole 1080p screen (8160 pairs each: one
+    Gaussian spans several waves and workgroups), splats of one tile each (2048 Gaussians per wave),
+    and visible counts that are not multiples of the 256-Gaussian batch."""
+    import synth
+    pod = gs.GaussianPod(gs.SH_NONE, gs.COV3D_ROT_SCALE)
+    if case == "one_tile":
+        g = synth.scene(500, first=77)
+        st = _compare_frame(gs, ob, device, stream, pod.sh, pod.cov, g, 16, 16, gt_kw=dict(sh_deg=0))
+        assert st.tiles_x * st.tiles_y == 1 and st.pairs == st.visible > 0
+    elif case == "screen_fillers":
+        g = synth.scene(300, first=5)
+        for k in range(5):
+            g["pos"][7 * k] = (0.05 * k, -0.03 * k, -0.4 - 0.1 * k)
+            g["scale"][7 * k] = (2.0, 1.5, 1.0)
+            g["color"][7 * k, 3] = 30
+        st = _compare_frame(gs, ob, device, stream, pod.sh, pod.cov, g, 1920, 1080, gt_kw=dict(sh_deg=0))
+        assert st.pairs >= 5 * 120 * 68
+    elif case == "single_tile_splats":
+        g = synth.scene(30000, first=1234)
+        g["scale"] *= 0.02
+        st = _compare_frame(gs, ob, device, stream, pod.sh, pod.cov, g, 640, 480, gt_kw=dict(sh_deg=0))
+        assert st.pairs < 2 * st.visible
+    else:
+        for n in (255, 257, 1021, 4099):
+            g = synth.scene(n, first=n)
+            g["pos"][:, 2] = -np.abs(g["pos"][:, 2]) - 3.0       # all in front: V is close to n
+            _compare_frame(gs, ob, device, stream, pod.sh, pod.cov, g, 333, 211, gt_kw=dict(sh_deg=0))
+
+
 def test_pair_overflow_is_reported_not_wrapped(gs, ob, device, stream):
     """150k screen-filling splats at 4K need 150k x 32400 > 2^32 pairs: the frame must fail with
     GS_ERR_PAIR_OVERFLOW instead of wrapping the 32-bit pair count (and must stay usable after)."""
