@@ -1553,6 +1553,13 @@ struct SortCompact {
 // holding the result is returned.  `sc` = host bound of the count (sizes the grid) and, optionally,
 // the device word holding the real count.  With `compact`, pass 0 reads keys[0] as the dense key
 // array of preprocess and ignores vals[0].
+template <int TILE>
+static void launch_scan_rows(uint32_t rows, hipStream_t st, uint32_t *ghist, uint32_t stride, gs::SortCount sc,
+                             uint32_t *totals) {
+    hipLaunchKernelGGL((gs::k_sort_scan_rows<TILE>), dim3(rows), dim3(gs::SCAN_ROWS_THREADS), 0, st, ghist, stride, sc,
+                       totals);
+}
+
 template <typename K, int RB, int ITEMS>
 static gs_status run_sort_items(const gs_device *dev, void *const keys[2], void *const vals[2], DevArray &ghist,
                              DevArray &digit_totals, gs::SortCount sc, uint32_t end_bit, const SortCompact *compact,
@@ -1588,8 +1595,7 @@ static gs_status run_sort_items(const gs_device *dev, void *const keys[2], void 
     do {                                                                                                          \
         hipLaunchKernelGGL((gs::k_sort_hist<K, RB, COMPACT, ITEMS>), dim3(pnb), dim3(gs::SORT_THREADS), 0, st, kin, psc, \
                            shift, digit_mask, (uint32_t *)ghist.ptr, cv);                                         \
-        hipLaunchKernelGGL((gs::k_sort_scan_rows<(int)TILE>), dim3(R), dim3(256), 0, st, (uint32_t *)ghist.ptr,   \
-                           pnb, psc, (uint32_t *)digit_totals.ptr);                                               \
+        launch_scan_rows<(int)TILE>(R, st, (uint32_t *)ghist.ptr, pnb, psc, (uint32_t *)digit_totals.ptr);        \
         if (dev->lds_atomic_ordered)                                                                              \
             hipLaunchKernelGGL((gs::k_sort_scatter<K, true, RB, COMPACT, ITEMS>), dim3(pnb), dim3(gs::SORT_THREADS), 0,  \
                                st, kin, vin, kout, vout, psc, shift, digit_mask, (const uint32_t *)ghist.ptr,     \
@@ -1607,8 +1613,7 @@ static gs_status run_sort_items(const gs_device *dev, void *const keys[2], void 
                 src.tvals = (uint32_t *)vals[side];
                 hipLaunchKernelGGL((gs::k_pairs_emit<K, RB, ITEMS>), dim3(pnb), dim3(gs::SORT_THREADS), 0, st, src,
                                    digit_mask, (uint32_t *)ghist.ptr, (K *)keys[side]);
-                hipLaunchKernelGGL((gs::k_sort_scan_rows<(int)TILE>), dim3(R), dim3(256), 0, st, (uint32_t *)ghist.ptr,
-                                   pnb, psc, (uint32_t *)digit_totals.ptr);
+                launch_scan_rows<(int)TILE>(R, st, (uint32_t *)ghist.ptr, pnb, psc, (uint32_t *)digit_totals.ptr);
                 if (dev->lds_atomic_ordered)
                     hipLaunchKernelGGL((gs::k_sort_scatter<K, true, RB, false, ITEMS>), dim3(pnb), dim3(gs::SORT_THREADS),
                                        0, st, kin, vin, kout, vout, psc, shift, digit_mask, (const uint32_t *)ghist.ptr,

@@ -1092,22 +1092,47 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_hist(const K *__restrict_
 }
 
 // One workgroup per digit: exclusive scan of its row (over the blocks that hold data) in place; row
-// total out.
+// total out.  1024 threads x 4 consecutive values = 4096 blocks per step: the rows of every frame
+// size of the bench (up to 50 M Gaussians: 27 k blocks) take a few dependent steps — with 256 values
+// per step the 10 M tile sort's rows took 21 (A/B on one box: 10 M frame -0.5 %, 1 M unchanged).
+constexpr int SCAN_ROWS_THREADS = 1024;
 template <int TILE>
-__global__ __launch_bounds__(256) void k_sort_scan_rows(uint32_t *__restrict__ ghist, uint32_t row_stride,
-                                                        SortCount sc, uint32_t *__restrict__ digit_totals) {
-    __shared__ uint32_t s_scan[4];
+__global__ __launch_bounds__(SCAN_ROWS_THREADS) void k_sort_scan_rows(uint32_t *__restrict__ ghist, uint32_t row_stride,
+                                                                      SortCount sc,
+                                                                      uint32_t *__restrict__ digit_totals) {
+    constexpr uint32_t PER = 4;
+    __shared__ uint32_t s_wave[SCAN_ROWS_THREADS / WAVE];
     const uint32_t count = sc.get();
     const uint32_t num_blocks = (uint32_t)(((uint64_t)count + TILE - 1) / TILE);
+    const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
     uint32_t *row = ghist + (uint64_t)blockIdx.x * row_stride;
     uint32_t carry = 0;
-    for (uint32_t base = 0; base < num_blocks; base += 256u) {
-        uint32_t i = base + threadIdx.x;
-        uint32_t v = i < num_blocks ? row[i] : 0u;
-        uint32_t total;
-        uint32_t ex = block_exclusive_scan_256(v, s_scan, total);
-        if (i < num_blocks) row[i] = carry + ex;
-        carry += total;
+    for (uint32_t base = 0; base < num_blocks; base += SCAN_ROWS_THREADS * PER) {
+        const uint32_t i0 = base + threadIdx.x * PER;
+        uint32_t v[PER], sum = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < PER; k++) {
+            v[k] = i0 + k < num_blocks ? row[i0 + k] : 0u;
+            sum += v[k];
+        }
+        const uint32_t inc = wave_inclusive_scan(sum, lane);
+        if (lane == 63u) s_wave[wid] = inc;
+        __syncthreads();
+        uint32_t wave_off = 0, tot = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < SCAN_ROWS_THREADS / WAVE; k++) {
+            const uint32_t x = s_wave[k];
+            if (k < wid) wave_off += x;
+            tot += x;
+        }
+        uint32_t run = carry + wave_off + inc - sum;
+#pragma unroll
+        for (uint32_t k = 0; k < PER; k++) {
+            if (i0 + k < num_blocks) row[i0 + k] = run;
+            run += v[k];
+        }
+        carry += tot;
+        __syncthreads();
     }
     if (threadIdx.x == 0) digit_totals[blockIdx.x] = carry;
 }
