@@ -532,7 +532,10 @@ gs_status gs_renderer_stats(gs_renderer *r, gs_frame_stats *out);
  * size the pair buffers (GS_ERR_PAIR_OVERFLOW if D would exceed 2^32).  Later frames take the
  * capacity from the measured D of earlier frames (25 % head room, grown lazily: buffer growth calls
  * hipFree, which synchronises the device).  If a frame nevertheless produces more pairs than fit,
- * its farthest pairs are dropped and gs_renderer_wait_frame reports GS_ERR_PAIR_CAPACITY. */
+ * its farthest pairs are dropped and gs_renderer_wait_frame reports GS_ERR_PAIR_CAPACITY.
+ *
+ * Limits (GS_ERR_INVALID_ARGUMENT beyond them): at most 2^22 tiles of 16 x 16 pixels and 65535 tiles
+ * along either axis; at most 2^32 - 16 Gaussians. */
 gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_buffer *gaussians,
                           const gs_gaussian_transform_pod *gaussian_transform,
                           const gs_model_transform_pod *model_transform, const gs_camera *camera,

@@ -446,6 +446,22 @@ def test_pair_emission_regimes(gs, ob, device, stream, case):
             _compare_frame(gs, ob, device, stream, pod.sh, pod.cov, g, 333, 211, gt_kw=dict(sh_deg=0))
 
 
+def test_image_size_limits_are_rejected(gs, device, stream):
+    """more than 2^22 tiles, or more than 65535 tiles along one axis (tile rects are packed as 16-bit
+    coordinates): GS_ERR_INVALID_ARGUMENT before anything is launched"""
+    import synth
+    pod = gs.GaussianPod(gs.SH_NONE, gs.COV3D_ROT_SCALE)
+    buf = gs.GaussiansBuffer.new_with_pods(device, pod, pod.from_gaussian(synth.scene(10)))
+    img = gs.Buffer(device, size=1024)
+    r = gs.Renderer(device)
+    gt, mt = gs.gaussian_transform_pod(sh_deg=0), gs.model_transform_pod()
+    for (w, h) in ((16 * 70000, 16), (16, 16 * 70000), (16 * 4096, 16 * 2048)):
+        cam = helpers.default_camera(gs, w, h)
+        with pytest.raises(gs.InvalidArgumentError):
+            r.render(stream, buf, gt, mt, cam, img.device_ptr())
+    buf.destroy(); img.release(); r.destroy()
+
+
 def test_pair_overflow_is_reported_not_wrapped(gs, ob, device, stream):
     """150k screen-filling splats at 4K need 150k x 32400 > 2^32 pairs: the frame must fail with
     GS_ERR_PAIR_OVERFLOW instead of wrapping the 32-bit pair count (and must stay usable after)."""

@@ -1288,7 +1288,7 @@ struct FrameShape {
 
 struct gs_renderer {
     gs_device *dev;
-    DevArray recs, depth, rect, sorted_rect, exp_sums, chunk_tiles, chunk_vis, state, zero_region, scan_tmp;
+    DevArray recs, depth, rect, sorted_rect, exp_sums, cursors, chunk_tiles, chunk_vis, state, zero_region, scan_tmp;
     DevArray dkeys[2], dvals[2];          // (depth bits - bias, mirror slot), capacity N
     DevArray tkeys[2], tvals[2];          // (tile id, mirror slot), capacity pair_capacity
     DevArray ghist, digit_totals;
@@ -1365,7 +1365,7 @@ extern "C" void gs_renderer_destroy(gs_renderer *r) {
     if (!r) return;
     (void)hipSetDevice(r->dev->ordinal);
     if (r->have_frame) (void)hipStreamSynchronize(r->last_stream);   // kernels of the last frame write pinned memory
-    DevArray *arrs[] = {&r->recs, &r->depth, &r->rect, &r->sorted_rect, &r->exp_sums, &r->chunk_tiles, &r->chunk_vis,
+    DevArray *arrs[] = {&r->recs, &r->depth, &r->rect, &r->sorted_rect, &r->exp_sums, &r->cursors, &r->chunk_tiles, &r->chunk_vis,
                         &r->state, &r->zero_region, &r->scan_tmp, &r->dkeys[0], &r->dkeys[1], &r->dvals[0],
                         &r->dvals[1], &r->tkeys[0], &r->tkeys[1], &r->tvals[0], &r->tvals[1], &r->ghist,
                         &r->digit_totals};
@@ -1874,6 +1874,7 @@ static gs_status reserve_pairs(gs_renderer *r, uint64_t pairs, bool wide) {
         GS_TRY(dev_reserve(r->tkeys[i], cap * (wide ? 4 : 2) + 64));
         GS_TRY(dev_reserve(r->tvals[i], cap * 4 + 64));
     }
+    GS_TRY(dev_reserve(r->cursors, (size_t)(cap / gs::CURSOR_SLOTS + 2) * sizeof(gs::PairCursorRec)));
     r->pair_capacity = cap;
     r->wide_tiles = wide;
     return GS_OK;
@@ -1939,6 +1940,9 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
     // one 256-Gaussian expansion chunk may touch at most 256 * num_tiles pairs: keep that inside 32 bits
     if ((uint64_t)fc.tiles_x * fc.tiles_y > (1ull << 22))
         return fail(GS_ERR_INVALID_ARGUMENT, cam->width, cam->height, 0, "more than 2^22 tiles");
+    // tile rects are packed as 16-bit tile coordinates
+    if (fc.tiles_x > 0xffffu || fc.tiles_y > 0xffffu)
+        return fail(GS_ERR_INVALID_ARGUMENT, cam->width, cam->height, 0, "more than 65535 tiles along one axis");
     const bool wide = num_tiles > 65536u;
     const size_t nn = n ? n : 1, nc = nchunks ? nchunks : 1;
 
@@ -2113,10 +2117,21 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
         eo.tiles_x = fc.tiles_x;
         eo.gen = gen;
         eo.sb_bound = exp_grid / gs::EXP_SB + 1;
+        // Where a wave of k_pairs_emit starts: found by the wave itself (a search over the super-chunk
+        // sums: one step per 256 of them) or looked up in a table that k_pairs_cursors writes first.
+        // The table costs a launch and wins once the search needs more than one step (A/B on one box:
+        // 1 M 0.369 vs 0.366 ms, 10 M 1.227 vs 1.226, 50 M 4.60 vs 4.80).  GS3D_CURSOR_KERNEL=0/1 forces.
+        static const int cursor_env = std::getenv("GS3D_CURSOR_KERNEL") ? std::atoi(std::getenv("GS3D_CURSOR_KERNEL")) : -1;
+        const bool cursor_kernel = cursor_env >= 0 ? cursor_env != 0 : eo.sb_bound > 256u;
+        eo.cursors = cursor_kernel ? (gs::PairCursorRec *)r->cursors.ptr : nullptr;
         hipLaunchKernelGGL(gs::k_expand_count, dim3((exp_grid + gs::EXP_COUNT_CHUNKS - 1) / gs::EXP_COUNT_CHUNKS),
                            dim3(gs::EXP_CHUNK), 0, st, eo);
-        GS_HIP(hipGetLastError());
         r->launches++;
+        if (cursor_kernel) {
+            hipLaunchKernelGGL(gs::k_pairs_cursors, dim3(eo.sb_bound), dim3(gs::EXP_SB), 0, st, eo);
+            r->launches++;
+        }
+        GS_HIP(hipGetLastError());
         mark(ST_TSORT);
 
         // ---- stable sort on the tile id alone (pairs are generated in depth order by its first pass) ----

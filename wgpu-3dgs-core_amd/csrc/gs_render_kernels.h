@@ -915,6 +915,7 @@ __global__ __launch_bounds__(1024) void k_scan_chunks(ScanJob j0, ScanJob j1) {
 constexpr int EXP_CHUNK = 256;   // Gaussians per workgroup in the expansion kernels
 constexpr uint32_t EXP_SB = 128;   // chunks per super-chunk of the expansion's offset sums
 
+struct PairCursorRec;
 struct ExpandIO {
     const uint32_t *order;           // [V] mirror slots in depth order (values of the depth sort)
     const uint2 *rect;               // [N] tile rects by slot
@@ -928,6 +929,7 @@ struct ExpandIO {
     uint32_t tiles_x;
     uint32_t gen;
     uint32_t sb_bound;               // host bound of the number of super-chunks (entries past the real one are zero)
+    struct PairCursorRec *cursors;   // [capacity / CURSOR_SLOTS + 1] where the pairs of every 1024-slot span start
 };
 
 // Expansion, part 1: gather the tile rects into depth order (the only random access of the key
@@ -1427,6 +1429,62 @@ __device__ __forceinline__ PairCursor pair_cursor(const ExpandIO &io, uint32_t v
     return cur;
 }
 
+// Where the pairs of every CURSOR_SLOTS-slot span of the output start: chunk (of EXP_CHUNK Gaussians
+// in depth order) whose pairs hold the span's first slot, and the number of pairs in front of that
+// chunk.  Written by k_pairs_cursors, one workgroup per super-chunk, one thread per chunk: O(chunks)
+// work in all, instead of a search over the sums in every wave of k_pairs_emit.
+constexpr uint32_t CURSOR_SLOTS = 1024;
+struct PairCursorRec {
+    uint32_t chunk;
+    uint32_t pad;
+    unsigned long long prefix;
+};
+
+// Grid: sb_bound workgroups of EXP_SB threads.  Workgroup 0 also publishes D (clamped to the pair
+// capacity), the overflow flag and the frame result.
+__global__ __launch_bounds__(EXP_SB) void k_pairs_cursors(ExpandIO io) {
+    static_assert(EXP_SB == 2 * WAVE, "two waves per super-chunk");
+    __shared__ unsigned long long s_before[2], s_all[2], s_wave0;
+    const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+    const uint32_t sb = blockIdx.x;
+    const uint32_t v_count = io.state->visible;
+    const uint32_t nchunks = (uint32_t)(((uint64_t)v_count + EXP_CHUNK - 1) / EXP_CHUNK);
+    uint64_t before = 0, all = 0;
+    for (uint32_t q = threadIdx.x; q < io.sb_bound; q += EXP_SB) {
+        const uint64_t v = io.sb_sums[q];
+        if (q < sb) before += v;
+        all += v;
+    }
+    before = wave_reduce_add64(before);
+    all = wave_reduce_add64(all);
+    const uint32_t c = sb * EXP_SB + threadIdx.x;
+    const uint64_t v = c < nchunks ? (uint64_t)io.sums[c] : 0ull;
+    const uint64_t incl = wave_inclusive_scan64(v, lane);
+    if (lane == 63u) {
+        s_before[wid] = before;
+        s_all[wid] = all;
+        if (wid == 0u) s_wave0 = incl;
+    }
+    __syncthreads();
+    const uint64_t d = s_all[0] + s_all[1];
+    if (sb == 0u && threadIdx.x == 0u) {
+        const uint32_t over = d > (uint64_t)io.capacity ? FRAME_FLAG_PAIR_OVERFLOW : 0u;
+        io.state->pairs = over ? io.capacity : (uint32_t)d;
+        io.result->visible = v_count;
+        io.result->pairs_total = d;
+        io.result->flags = over;
+        io.result->gen = io.gen;
+    }
+    if (v == 0ull) return;
+    const uint64_t p = s_before[0] + s_before[1] + (wid ? s_wave0 : 0ull) + incl - v;   // pairs in front of chunk c
+    const uint64_t end = p + v < (uint64_t)io.capacity ? p + v : (uint64_t)io.capacity;
+    // spans whose first slot lies in [p, end): bounded by capacity / CURSOR_SLOTS, ends for every thread
+    for (uint64_t k = (p + CURSOR_SLOTS - 1) / CURSOR_SLOTS; k * CURSOR_SLOTS < end; k++) {
+        io.cursors[k].chunk = c;
+        io.cursors[k].prefix = p;
+    }
+}
+
 constexpr int GEN_PER = 4;                    // Gaussians per lane per batch (consecutive: vector loads)
 constexpr int GEN_BATCH = WAVE * GEN_PER;     // = EXP_CHUNK: a batch is one chunk of the count kernel
 static_assert(GEN_BATCH == EXP_CHUNK, "the cursor hands out chunk starts");
@@ -1590,16 +1648,30 @@ __global__ __launch_bounds__(SORT_THREADS) void k_pairs_emit(ExpandIO io, uint32
     const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
     const uint32_t v_count = io.state->visible;
     const uint64_t o0 = (uint64_t)blockIdx.x * TILE + wid * NSLOTS;
-    const PairCursor cur = pair_cursor(io, v_count, o0, lane);
-    const uint64_t d = cur.total;
-    const uint32_t count = d > (uint64_t)io.capacity ? io.capacity : (uint32_t)d;
-    if (blockIdx.x == 0u && threadIdx.x == 0u) {
-        const uint32_t over = d > (uint64_t)io.capacity ? FRAME_FLAG_PAIR_OVERFLOW : 0u;
-        io.state->pairs = count;
-        io.result->visible = v_count;
-        io.result->pairs_total = d;
-        io.result->flags = over;
-        io.result->gen = io.gen;
+    PairCursor cur;
+    uint32_t count;
+    if (io.cursors) {
+        static_assert(NSLOTS % CURSOR_SLOTS == 0, "a wave starts on a cursor");
+        count = io.state->pairs < io.capacity ? io.state->pairs : io.capacity;   // published by k_pairs_cursors
+        cur.chunk = 0;
+        cur.prefix = 0;
+        if (o0 < count) {
+            const PairCursorRec rec = io.cursors[o0 / CURSOR_SLOTS];
+            cur.chunk = rec.chunk;
+            cur.prefix = rec.prefix;
+        }
+    } else {
+        cur = pair_cursor(io, v_count, o0, lane);
+        const uint64_t d = cur.total;
+        count = d > (uint64_t)io.capacity ? io.capacity : (uint32_t)d;
+        if (blockIdx.x == 0u && threadIdx.x == 0u) {
+            const uint32_t over = d > (uint64_t)io.capacity ? FRAME_FLAG_PAIR_OVERFLOW : 0u;
+            io.state->pairs = count;
+            io.result->visible = v_count;
+            io.result->pairs_total = d;
+            io.result->flags = over;
+            io.result->gen = io.gen;
+        }
     }
     if ((uint64_t)blockIdx.x * TILE >= count) return;      // the same D in every wave: block-uniform
 #pragma unroll
