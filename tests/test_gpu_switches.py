@@ -1,0 +1,28 @@
+"""The debug switches of DESIGN.md §4.4 are read once per process, so the alternative code paths they
+select (the pair-emission start table at small sizes, the ballot-based rank of the radix scatter) are
+exercised by running a subset of the parity tests in a child process per setting — one child at a
+time."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SUBSET = "synthetic_small or emission or capacity_overflow or edge_cases or wide_tile_keys or radix_sort_skewed"
+
+
+@pytest.mark.parametrize("env", [{"GS3D_CURSOR_KERNEL": "1"}, {"GS3D_DISABLE_FAST_RANK": "1"},
+                                 {"GS3D_BLEND_GROUPS": "1"}], ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
+def test_parity_subset_under_switch(env):
+    if any(os.environ.get(k) == v for k, v in env.items()):
+        pytest.skip("already running under this switch")
+    child_env = dict(os.environ)
+    child_env.update(env)
+    res = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_render.py"), "-x", "-q",
+                          "-m", "gpu", "-k", SUBSET, "-p", "no:cacheprovider"],
+                         cwd=ROOT, env=child_env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-3000:]
+    assert " passed" in res.stdout and "deselected" in res.stdout, res.stdout[-1000:]
