@@ -1176,7 +1176,8 @@ __device__ __forceinline__ void scatter_clear(ScatterShared<K, RB, ITEMS> &sh) {
 // wave_off + k * 64 + lane of the tile; padding = all-ones key): rank, local reorder, coalesced store.
 template <typename K, bool FAST_RANK, int RB, bool COMPACT, int ITEMS>
 __device__ __forceinline__ void scatter_ranked(ScatterShared<K, RB, ITEMS> &sh, K (&key)[ITEMS], uint32_t (&val)[ITEMS],
-                                               uint32_t in_tile, uint32_t num_blocks, K *__restrict__ keys_out,
+                                               uint32_t in_tile, uint32_t block, uint32_t num_blocks,
+                                               K *__restrict__ keys_out,
                                                uint32_t *__restrict__ vals_out, uint32_t shift, uint32_t digit_mask,
                                                const uint32_t *__restrict__ ghist,
                                                const uint32_t *__restrict__ digit_totals,
@@ -1256,11 +1257,11 @@ __device__ __forceinline__ void scatter_ranked(ScatterShared<K, RB, ITEMS> &sh, 
 #pragma unroll
         for (int q = 0; q < DPT; q++) {
             const uint32_t digit = tid * DPT + q;
-            s_delta[digit] = digit_base + ghist[(uint64_t)digit * num_blocks + blockIdx.x] - bin0[q];
+            s_delta[digit] = digit_base + ghist[(uint64_t)digit * num_blocks + block] - bin0[q];
             digit_base += tot[q];
         }
         if constexpr (COMPACT)
-            if (blockIdx.x == 0 && tid == 0) *visible_out = all;     // V = everything the pass ranked
+            if (block == 0 && tid == 0) *visible_out = all;     // V = everything the pass ranked
     }
     __syncthreads();
 
@@ -1289,20 +1290,36 @@ __device__ __forceinline__ void scatter_ranked(ScatterShared<K, RB, ITEMS> &sh, 
     }
 }
 
+// Workgroup -> tile of the pass.  The hardware deals consecutive workgroup ids round-robin to the 8
+// XCDs, each with its own L2.  Tile b's run of a digit is followed in memory by tile b + 1's, and the
+// runs are short (16-64 elements): with tiles dealt in order, the two halves of almost every 128-byte
+// line are written through two different L2s and reach HBM as partial lines.  With `xcd_remap` XCD x
+// gets the contiguous tile range [x * per, (x + 1) * per): neighbouring runs meet in one L2.
+__device__ __forceinline__ uint32_t scatter_tile_of(uint32_t wg, uint32_t num_tiles, uint32_t xcd_remap) {
+    if (!xcd_remap) return wg;
+    const uint32_t per = (num_tiles + 7u) / 8u;
+    return (wg & 7u) * per + (wg >> 3);     // may be >= num_tiles: the caller's count test rejects it
+}
+
 template <typename K, bool FAST_RANK, int RB, bool COMPACT, int ITEMS>
 __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
     const K *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, K *__restrict__ keys_out,
     uint32_t *__restrict__ vals_out, SortCount sc, uint32_t shift, uint32_t digit_mask,
     const uint32_t *__restrict__ ghist, const uint32_t *__restrict__ digit_totals,
-    const uint32_t *__restrict__ chunk_vis, uint32_t *__restrict__ visible_out) {
+    const uint32_t *__restrict__ chunk_vis, uint32_t *__restrict__ visible_out, uint32_t num_tiles,
+    uint32_t xcd_remap) {
     constexpr int TILE = SORT_THREADS * ITEMS;
     __shared__ ScatterShared<K, RB, ITEMS> sh;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
     const uint32_t count = sc.get();
-    if ((uint64_t)blockIdx.x * TILE >= count) return;      // grid sized from an upper bound of the count
+    // tiles that hold data (the grid comes from an upper bound of the count: dealing THAT range to the
+    // XCDs would leave the last ones idle)
+    const uint32_t live_tiles = (uint32_t)(((uint64_t)count + TILE - 1) / TILE);
+    const uint32_t block = scatter_tile_of(blockIdx.x, live_tiles, xcd_remap);
+    if (block >= live_tiles) return;
     scatter_clear(sh);
 
-    const uint32_t tile_base = blockIdx.x * TILE;
+    const uint32_t tile_base = block * TILE;
     const uint32_t in_tile = count - tile_base < (uint32_t)TILE ? count - tile_base : (uint32_t)TILE;
     const uint32_t wave_off = wid * (ITEMS * WAVE);
     // COMPACT: 16 rounds of a wave (1024 elements) are exactly one preprocess chunk
@@ -1323,7 +1340,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
         if constexpr (COMPACT) val[k] = tile_base + e;
         else val[k] = ok ? vals_in[tile_base + e] : 0u;
     }
-    scatter_ranked<K, FAST_RANK, RB, COMPACT, ITEMS>(sh, key, val, in_tile, gridDim.x, keys_out, vals_out, shift,
+    scatter_ranked<K, FAST_RANK, RB, COMPACT, ITEMS>(sh, key, val, in_tile, block, num_tiles, keys_out, vals_out, shift,
                                                      digit_mask, ghist, digit_totals, visible_out);
 }
 
