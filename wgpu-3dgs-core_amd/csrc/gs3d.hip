@@ -1591,14 +1591,18 @@ static gs_status run_sort_items(const gs_device *dev, void *const keys[2], void 
         if (first) GS_TRY(dev_reserve(ghist, (size_t)pnb * R * 4));
         const uint32_t *cv = first ? compact->chunk_vis : nullptr;
         uint32_t *vo = first ? compact->visible_out : nullptr;
-        // XCD-aware tile order in the scatter (see scatter_tile_of).  Measured per pass at 10 M (remap vs
-        // plain): compacting depth pass 37.8 vs 46.1 us, second depth pass 41.8 vs 43.2, 4K tile pass of 8
-        // bits 329 vs 370 — but the last depth pass (clustered top digit) 39.4 vs 29.2 and the 1080p tile
-        // passes of 7 / 6 bits 130 vs 120 / 127 vs 106: it pays where a tile's digit runs are shorter than
-        // a few cache lines (<= 32 elements) and costs where they are long.  GS3D_XCD_REMAP=0 disables.
+        // XCD-aware tile order in the scatter (see scatter_tile_of): XCD x takes `xr` consecutive tiles
+        // of every group of 8 * xr.  xr grows with the number of tiles (a group must stay a small part
+        // of the pass) between 4 and 64.  GS3D_XCD_REMAP=0 disables, GS3D_XCD_REMAP_C=<n> forces a size.
         static const bool remap_on = !(std::getenv("GS3D_XCD_REMAP") && std::getenv("GS3D_XCD_REMAP")[0] == '0');
-        const uint32_t xcd_remap = remap_on && pnb >= 256u && (TILE >> bits) <= 32u && !(passes > 1 && p == passes - 1) ? 1u : 0u;
-        const uint32_t sgrid = xcd_remap ? 8u * ((pnb + 7u) / 8u) : pnb;
+        static const int remap_c = std::getenv("GS3D_XCD_REMAP_C") ? std::atoi(std::getenv("GS3D_XCD_REMAP_C")) : 0;
+        uint32_t xr = 0;
+        if (remap_on && pnb >= 256u) {
+            xr = 4u;
+            while (xr < 64u && xr * 2u * 256u <= pnb) xr *= 2u;
+            if (remap_c > 1) xr = (uint32_t)remap_c;
+        }
+        const uint32_t sgrid = xr ? 8u * xr * ((pnb + 8u * xr - 1u) / (8u * xr)) : pnb;
 #define GS_SORT_PASS(COMPACT)                                                                                     \
     do {                                                                                                          \
         hipLaunchKernelGGL((gs::k_sort_hist<K, RB, COMPACT, ITEMS>), dim3(pnb), dim3(gs::SORT_THREADS), 0, st, kin, psc, \
@@ -1607,11 +1611,11 @@ static gs_status run_sort_items(const gs_device *dev, void *const keys[2], void 
         if (dev->lds_atomic_ordered)                                                                              \
             hipLaunchKernelGGL((gs::k_sort_scatter<K, true, RB, COMPACT, ITEMS>), dim3(sgrid), dim3(gs::SORT_THREADS), 0,  \
                                st, kin, vin, kout, vout, psc, shift, digit_mask, (const uint32_t *)ghist.ptr,     \
-                               (const uint32_t *)digit_totals.ptr, cv, vo, pnb, xcd_remap);                       \
+                               (const uint32_t *)digit_totals.ptr, cv, vo, pnb, xr);                       \
         else                                                                                                      \
             hipLaunchKernelGGL((gs::k_sort_scatter<K, false, RB, COMPACT, ITEMS>), dim3(sgrid), dim3(gs::SORT_THREADS), 0, \
                                st, kin, vin, kout, vout, psc, shift, digit_mask, (const uint32_t *)ghist.ptr,     \
-                               (const uint32_t *)digit_totals.ptr, cv, vo, pnb, xcd_remap);                       \
+                               (const uint32_t *)digit_totals.ptr, cv, vo, pnb, xr);                       \
     } while (0)
         if (source && p == 0) {
             // the pairs come from the depth-ordered rects: k_pairs_emit writes this pass's input
@@ -1625,11 +1629,11 @@ static gs_status run_sort_items(const gs_device *dev, void *const keys[2], void 
                 if (dev->lds_atomic_ordered)
                     hipLaunchKernelGGL((gs::k_sort_scatter<K, true, RB, false, ITEMS>), dim3(sgrid), dim3(gs::SORT_THREADS),
                                        0, st, kin, vin, kout, vout, psc, shift, digit_mask, (const uint32_t *)ghist.ptr,
-                                       (const uint32_t *)digit_totals.ptr, cv, vo, pnb, xcd_remap);
+                                       (const uint32_t *)digit_totals.ptr, cv, vo, pnb, xr);
                 else
                     hipLaunchKernelGGL((gs::k_sort_scatter<K, false, RB, false, ITEMS>), dim3(sgrid), dim3(gs::SORT_THREADS),
                                        0, st, kin, vin, kout, vout, psc, shift, digit_mask, (const uint32_t *)ghist.ptr,
-                                       (const uint32_t *)digit_totals.ptr, cv, vo, pnb, xcd_remap);
+                                       (const uint32_t *)digit_totals.ptr, cv, vo, pnb, xr);
             }
         } else if constexpr (sizeof(K) == 4) {
             if (first) GS_SORT_PASS(true); else GS_SORT_PASS(false);

@@ -1292,13 +1292,15 @@ __device__ __forceinline__ void scatter_ranked(ScatterShared<K, RB, ITEMS> &sh, 
 
 // Workgroup -> tile of the pass.  The hardware deals consecutive workgroup ids round-robin to the 8
 // XCDs, each with its own L2.  Tile b's run of a digit is followed in memory by tile b + 1's, and the
-// runs are short (16-64 elements): with tiles dealt in order, the two halves of almost every 128-byte
-// line are written through two different L2s and reach HBM as partial lines.  With `xcd_remap` XCD x
-// gets the contiguous tile range [x * per, (x + 1) * per): neighbouring runs meet in one L2.
-__device__ __forceinline__ uint32_t scatter_tile_of(uint32_t wg, uint32_t num_tiles, uint32_t xcd_remap) {
-    if (!xcd_remap) return wg;
-    const uint32_t per = (num_tiles + 7u) / 8u;
-    return (wg & 7u) * per + (wg >> 3);     // may be >= num_tiles: the caller's count test rejects it
+// runs are short (16-128 elements): with tiles dealt in order, the two halves of almost every
+// 128-byte line are written through two different L2s and reach HBM as partial lines.  With
+// xcd_chunk = C, XCD x takes C consecutive tiles of every group of 8 C tiles: neighbouring runs meet
+// in one L2, while all XCDs still work on the same region of the output at any time (giving each
+// XCD one contiguous eighth of the pass instead lost more on DRAM page locality than it gained).
+__device__ __forceinline__ uint32_t scatter_tile_of(uint32_t wg, uint32_t xcd_chunk) {
+    if (!xcd_chunk) return wg;
+    const uint32_t slot = wg >> 3;
+    return (slot / xcd_chunk) * 8u * xcd_chunk + (wg & 7u) * xcd_chunk + slot % xcd_chunk;   // may be past the live tiles
 }
 
 template <typename K, bool FAST_RANK, int RB, bool COMPACT, int ITEMS>
@@ -1307,15 +1309,13 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
     uint32_t *__restrict__ vals_out, SortCount sc, uint32_t shift, uint32_t digit_mask,
     const uint32_t *__restrict__ ghist, const uint32_t *__restrict__ digit_totals,
     const uint32_t *__restrict__ chunk_vis, uint32_t *__restrict__ visible_out, uint32_t num_tiles,
-    uint32_t xcd_remap) {
+    uint32_t xcd_chunk) {
     constexpr int TILE = SORT_THREADS * ITEMS;
     __shared__ ScatterShared<K, RB, ITEMS> sh;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
     const uint32_t count = sc.get();
-    // tiles that hold data (the grid comes from an upper bound of the count: dealing THAT range to the
-    // XCDs would leave the last ones idle)
-    const uint32_t live_tiles = (uint32_t)(((uint64_t)count + TILE - 1) / TILE);
-    const uint32_t block = scatter_tile_of(blockIdx.x, live_tiles, xcd_remap);
+    const uint32_t live_tiles = (uint32_t)(((uint64_t)count + TILE - 1) / TILE);   // the grid comes from an upper bound
+    const uint32_t block = scatter_tile_of(blockIdx.x, xcd_chunk);
     if (block >= live_tiles) return;
     scatter_clear(sh);
 
