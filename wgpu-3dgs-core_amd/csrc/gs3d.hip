@@ -1605,8 +1605,8 @@ static gs_status run_sort_items(const gs_device *dev, void *const keys[2], void 
         const uint32_t sgrid = xr ? 8u * xr * ((pnb + 8u * xr - 1u) / (8u * xr)) : pnb;
 #define GS_SORT_PASS(COMPACT)                                                                                     \
     do {                                                                                                          \
-        hipLaunchKernelGGL((gs::k_sort_hist<K, RB, COMPACT, ITEMS>), dim3(pnb), dim3(gs::SORT_THREADS), 0, st, kin, psc, \
-                           shift, digit_mask, (uint32_t *)ghist.ptr, cv);                                         \
+        hipLaunchKernelGGL((gs::k_sort_hist<K, RB, COMPACT, ITEMS>), dim3(sgrid), dim3(gs::SORT_THREADS), 0, st, kin, psc, \
+                           shift, digit_mask, (uint32_t *)ghist.ptr, cv, pnb, xr);                                \
         launch_scan_rows<(int)TILE>(R, st, (uint32_t *)ghist.ptr, pnb, psc, (uint32_t *)digit_totals.ptr);        \
         if (dev->lds_atomic_ordered)                                                                              \
             hipLaunchKernelGGL((gs::k_sort_scatter<K, true, RB, COMPACT, ITEMS>), dim3(sgrid), dim3(gs::SORT_THREADS), 0,  \
@@ -1623,8 +1623,8 @@ static gs_status run_sort_items(const gs_device *dev, void *const keys[2], void 
             if constexpr (sizeof(K) <= 4) {
                 gs::ExpandIO src = *source;
                 src.tvals = (uint32_t *)vals[side];
-                hipLaunchKernelGGL((gs::k_pairs_emit<K, RB, ITEMS>), dim3(pnb), dim3(gs::SORT_THREADS), 0, st, src,
-                                   digit_mask, (uint32_t *)ghist.ptr, (K *)keys[side]);
+                hipLaunchKernelGGL((gs::k_pairs_emit<K, RB, ITEMS>), dim3(sgrid), dim3(gs::SORT_THREADS), 0, st, src,
+                                   digit_mask, (uint32_t *)ghist.ptr, (K *)keys[side], pnb, xr);
                 launch_scan_rows<(int)TILE>(R, st, (uint32_t *)ghist.ptr, pnb, psc, (uint32_t *)digit_totals.ptr);
                 if (dev->lds_atomic_ordered)
                     hipLaunchKernelGGL((gs::k_sort_scatter<K, true, RB, false, ITEMS>), dim3(sgrid), dim3(gs::SORT_THREADS),

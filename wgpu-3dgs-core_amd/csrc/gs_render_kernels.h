@@ -1021,6 +1021,19 @@ struct SortCount {
 // partitioned (key, slot) list of the V visible ones, and workgroup 0 publishes V.
 constexpr uint32_t SORT_INVALID_KEY = 0xffffffffu;
 
+// Workgroup -> tile of the pass.  The hardware deals consecutive workgroup ids round-robin to the 8
+// XCDs, each with its own L2.  Tile b's run of a digit is followed in memory by tile b + 1's, and the
+// runs are short (16-128 elements): with tiles dealt in order, the two halves of almost every
+// 128-byte line are written through two different L2s and reach HBM as partial lines.  With
+// xcd_chunk = C, XCD x takes C consecutive tiles of every group of 8 C tiles: neighbouring runs meet
+// in one L2, while all XCDs still work on the same region of the output at any time (giving each
+// XCD one contiguous eighth of the pass instead lost more on DRAM page locality than it gained).
+__device__ __forceinline__ uint32_t scatter_tile_of(uint32_t wg, uint32_t xcd_chunk) {
+    if (!xcd_chunk) return wg;
+    const uint32_t slot = wg >> 3;
+    return (slot / xcd_chunk) * 8u * xcd_chunk + (wg & 7u) * xcd_chunk + slot % xcd_chunk;   // may be past the live tiles
+}
+
 // ghist layout: [digit][block] (digit-major, row stride = the grid size) so that the row scan reads
 // contiguous memory.  Tile ids and depth exponents are highly repetitive, so neighbouring lanes
 // often hit the same bin; the private copies (lane & (COPIES-1)) cut the same-address LDS atomic
@@ -1029,22 +1042,25 @@ template <typename K, int RB, bool COMPACT, int ITEMS>
 __global__ __launch_bounds__(SORT_THREADS) void k_sort_hist(const K *__restrict__ keys, SortCount sc,
                                                             uint32_t shift, uint32_t digit_mask,
                                                             uint32_t *__restrict__ ghist,
-                                                            const uint32_t *__restrict__ chunk_vis) {
+                                                            const uint32_t *__restrict__ chunk_vis, uint32_t num_blocks,
+                                                            uint32_t xcd_chunk) {
     constexpr uint32_t TILE = SORT_THREADS * ITEMS;
     constexpr int R = 1 << RB;
     constexpr int COPIES = 2048 / R;   // 8 KiB of private copies: 8 x 256 or 4 x 512 bins
     constexpr int DPT = R / SORT_THREADS;
     static_assert(!COMPACT || (sizeof(K) == 4 && TILE % PP_CHUNK == 0), "compacting pass: u32 keys, whole chunks per tile");
     const uint32_t count = sc.get();
-    const uint32_t num_blocks = gridDim.x;
-    if ((uint64_t)blockIdx.x * TILE >= count) return;   // past the real count: the row entries are never read
+    // same workgroup -> tile order as the scatter: the row entries of neighbouring tiles (4 bytes each,
+    // adjacent in ghist) are then written through one L2
+    const uint32_t block = scatter_tile_of(blockIdx.x, xcd_chunk);
+    if ((uint64_t)block * TILE >= count) return;   // past the real count: the row entries are never read
     __shared__ uint32_t s_hist[COPIES][R];
 #pragma unroll
     for (int c = 0; c < COPIES; c++)
 #pragma unroll
         for (int q = 0; q < DPT; q++) s_hist[c][threadIdx.x + q * SORT_THREADS] = 0;
     __syncthreads();
-    const uint32_t base = blockIdx.x * TILE;
+    const uint32_t base = block * TILE;
     const uint32_t copy = threadIdx.x & (uint32_t)(COPIES - 1);
     // 16-byte loads: the order of the keys does not matter for a histogram
     constexpr int PER_VEC = 16 / sizeof(K);
@@ -1089,7 +1105,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_hist(const K *__restrict_
         uint32_t sum = 0;
 #pragma unroll
         for (int c = 0; c < COPIES; c++) sum += s_hist[c][digit];
-        ghist[(uint64_t)digit * num_blocks + blockIdx.x] = sum;
+        ghist[(uint64_t)digit * num_blocks + block] = sum;
     }
 }
 
@@ -1288,19 +1304,6 @@ __device__ __forceinline__ void scatter_ranked(ScatterShared<K, RB, ITEMS> &sh, 
             vals_out[dst] = s_vals[pos];
         }
     }
-}
-
-// Workgroup -> tile of the pass.  The hardware deals consecutive workgroup ids round-robin to the 8
-// XCDs, each with its own L2.  Tile b's run of a digit is followed in memory by tile b + 1's, and the
-// runs are short (16-128 elements): with tiles dealt in order, the two halves of almost every
-// 128-byte line are written through two different L2s and reach HBM as partial lines.  With
-// xcd_chunk = C, XCD x takes C consecutive tiles of every group of 8 C tiles: neighbouring runs meet
-// in one L2, while all XCDs still work on the same region of the output at any time (giving each
-// XCD one contiguous eighth of the pass instead lost more on DRAM page locality than it gained).
-__device__ __forceinline__ uint32_t scatter_tile_of(uint32_t wg, uint32_t xcd_chunk) {
-    if (!xcd_chunk) return wg;
-    const uint32_t slot = wg >> 3;
-    return (slot / xcd_chunk) * 8u * xcd_chunk + (wg & 7u) * xcd_chunk + slot % xcd_chunk;   // may be past the live tiles
 }
 
 template <typename K, bool FAST_RANK, int RB, bool COMPACT, int ITEMS>
@@ -1654,7 +1657,8 @@ __device__ __forceinline__ void pair_generate(const ExpandIO &io, uint32_t v_cou
 // to the pair capacity), the overflow flag and the frame result.  Grid: capacity / TILE workgroups.
 template <typename K, int RB, int ITEMS>
 __global__ __launch_bounds__(SORT_THREADS) void k_pairs_emit(ExpandIO io, uint32_t digit_mask,
-                                                             uint32_t *__restrict__ ghist, K *__restrict__ tkeys) {
+                                                             uint32_t *__restrict__ ghist, K *__restrict__ tkeys,
+                                                             uint32_t num_blocks, uint32_t xcd_chunk) {
     constexpr uint32_t TILE = SORT_THREADS * ITEMS;
     constexpr uint32_t NSLOTS = ITEMS * WAVE;
     constexpr int R = 1 << RB;
@@ -1664,7 +1668,8 @@ __global__ __launch_bounds__(SORT_THREADS) void k_pairs_emit(ExpandIO io, uint32
     __shared__ PairGenShared<K, NSLOTS> s_gen[4];
     const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
     const uint32_t v_count = io.state->visible;
-    const uint64_t o0 = (uint64_t)blockIdx.x * TILE + wid * NSLOTS;
+    const uint32_t block = scatter_tile_of(blockIdx.x, xcd_chunk);   // as the scatter and the histograms
+    const uint64_t o0 = (uint64_t)block * TILE + wid * NSLOTS;
     PairCursor cur;
     uint32_t count;
     if (io.cursors) {
@@ -1681,7 +1686,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_pairs_emit(ExpandIO io, uint32
         cur = pair_cursor(io, v_count, o0, lane);
         const uint64_t d = cur.total;
         count = d > (uint64_t)io.capacity ? io.capacity : (uint32_t)d;
-        if (blockIdx.x == 0u && threadIdx.x == 0u) {
+        if (block == 0u && threadIdx.x == 0u) {
             const uint32_t over = d > (uint64_t)io.capacity ? FRAME_FLAG_PAIR_OVERFLOW : 0u;
             io.state->pairs = count;
             io.result->visible = v_count;
@@ -1690,7 +1695,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_pairs_emit(ExpandIO io, uint32
             io.result->gen = io.gen;
         }
     }
-    if ((uint64_t)blockIdx.x * TILE >= count) return;      // the same D in every wave: block-uniform
+    if ((uint64_t)block * TILE >= count) return;      // the same D in every wave: block-uniform
 #pragma unroll
     for (int c = 0; c < COPIES; c++)
 #pragma unroll
@@ -1724,7 +1729,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_pairs_emit(ExpandIO io, uint32
         uint32_t sum = 0;
 #pragma unroll
         for (int c = 0; c < COPIES; c++) sum += s_hist[c][digit];
-        ghist[(uint64_t)digit * gridDim.x + blockIdx.x] = sum;
+        ghist[(uint64_t)digit * num_blocks + block] = sum;
     }
 }
 
