@@ -1658,7 +1658,16 @@ static gs_status run_sort_rb(const gs_device *dev, void *const keys[2], void *co
                              const gs::ExpandIO *source = nullptr) {
     const uint64_t bound = compact ? compact->dense_count : sc.count;
     if constexpr (gs::SortCfg<K>::ITEMS_LARGE != gs::SortCfg<K>::ITEMS) {
-        if (bound >= (4u << 20))
+        // u32 keys: larger tiles for larger sorts.  u16 tile keys: a tile's digit runs should hold >= 32
+        // elements — 4096-key tiles do for digits of up to 7 bits (1080p: 13 tile bits = 7 + 6) and fit
+        // twice as many workgroups per CU (10 M: emit + tile sort 376 -> 358 us); 8-bit digits (4K: 15
+        // bits = 8 + 7) keep 8192-key tiles (848 vs 875 us with the small ones).
+        bool large = bound >= (4u << 20);
+        if (sizeof(K) == 2) {
+            const uint32_t passes = (end_bit + RB - 1) / RB;
+            large = passes ? (end_bit + passes - 1) / passes > 7u : false;
+        }
+        if (large)
             return run_sort_items<K, RB, gs::SortCfg<K>::ITEMS_LARGE>(dev, keys, vals, ghist, digit_totals, sc, end_bit,
                                                                     compact, st, result_side, passes_out, launches, source);
     }

@@ -998,7 +998,7 @@ constexpr int RADIX_BITS_MAX = 9;
 template <typename K> struct SortCfg;
 template <> struct SortCfg<uint64_t> { static constexpr int ITEMS = 8, ITEMS_LARGE = 8; };
 template <> struct SortCfg<uint32_t> { static constexpr int ITEMS = 16, ITEMS_LARGE = 32; };
-template <> struct SortCfg<uint16_t> { static constexpr int ITEMS = 32, ITEMS_LARGE = 32; };
+template <> struct SortCfg<uint16_t> { static constexpr int ITEMS = 16, ITEMS_LARGE = 32; };
 template <typename K> constexpr int sort_tile() { return SORT_THREADS * SortCfg<K>::ITEMS; }
 
 // Where a sort's element count comes from: a host value, or (count_dev != null) a device word
