@@ -1514,6 +1514,7 @@ static void make_frame_consts(const gs_gaussian_transform_pod *gt, const gs_mode
     fc.band_ty1 = band_ty1 < fc.tiles_y ? band_ty1 : fc.tiles_y;
     if (fc.band_ty1 < fc.band_ty0) fc.band_ty1 = fc.band_ty0;
     fc.mask_culled_records = 0;
+    fc.nt_loads = 0;
     fc.ellipse_pmin = -0.5f * (fc.max_std_dev * fc.max_std_dev);
     // block culling gain (see block_is_culled): |W R_m S_m|_F^2 bounds the squared spectral norm of
     // the linear part whatever the caller's view matrix is; 0.1 % head room for the f32 arithmetic
@@ -2061,6 +2062,12 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
         const bool banded = g->sh != GS_SH_NONE && (force_banded >= 0 ? force_banded != 0 : true);
         static const int mask_env = std::getenv("GS3D_MASK_REC") ? std::atoi(std::getenv("GS3D_MASK_REC")) : -1;
         fc.mask_culled_records = mask_env >= 0 ? (uint32_t)mask_env : (g->order != nullptr ? 1u : 0u);
+        // Non-temporal loads of the mirror once it no longer fits the 256 MiB Infinity Cache: nothing of
+        // it survives until the next frame anyway (10 M x 224 B: preprocess 0.440 -> 0.421 ms); a mirror that
+        // does fit is re-read from the caches frame after frame and loses that with nt (1 M x 48 B:
+        // 22 -> 27 us).  GS3D_NT_LOADS=0/1 forces.
+        static const int nt_env = std::getenv("GS3D_NT_LOADS") ? std::atoi(std::getenv("GS3D_NT_LOADS")) : -1;
+        fc.nt_loads = nt_env >= 0 ? (uint32_t)nt_env : ((uint64_t)n * gs::pod_words(g->sh, g->cov) * 4u > (512ull << 20) ? 1u : 0u);
         static const bool block_cull_off = std::getenv("GS3D_BLOCK_CULL") && std::getenv("GS3D_BLOCK_CULL")[0] == '0';
         // SH-less records are 48 bytes: the block test (one more dependent load per workgroup)
         // costs more than skipping them saves (measured at 1 M: +4 us on a 20 us kernel)

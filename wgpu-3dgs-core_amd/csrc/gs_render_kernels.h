@@ -46,6 +46,7 @@ struct FrameConsts {
     uint32_t tiles_x, tiles_y;
     uint32_t band_ty0, band_ty1;   // already clamped to tiles_y
     uint32_t mask_culled_records;  // k_preprocess_banded: culled lanes skip their 36-byte record store
+    uint32_t nt_loads;             // preprocess reads the mirror with the non-temporal policy
     float cull_gain;               // block culling: size^2 * |R_m S_m|_F^2 * (fx^2 (1+limx^2) + fy^2 (1+limy^2)); 0 = off
     float ellipse_pmin;            // display mode Ellipse: -max_std_dev^2 / 2
 };
@@ -539,6 +540,16 @@ __device__ __forceinline__ void eval_sh(const uint32_t *w, uint32_t deg, bool no
     rgb[2] = fmaxf(acc[2], 0.0f);
 }
 
+// streaming read of the mirror: every byte is read once per frame.  nt = the non-temporal cache policy
+typedef uint32_t u32x4_nt __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 load_planar(const uint4 *__restrict__ p, bool nt) {
+    if (nt) {
+        const u32x4_nt t = __builtin_nontemporal_load((const u32x4_nt *)p);
+        return make_uint4(t.x, t.y, t.z, t.w);
+    }
+    return *p;
+}
+
 // One Gaussian: returns the number of tiles touched (0 = culled) and fills the 48-byte record.
 // Written without early exits: every cull test only clears `ok`, so all the record's loads are
 // unconditional and the compiler can issue them back to back at the top (memory-level
@@ -724,7 +735,7 @@ __global__ __launch_bounds__(PP_THREADS) void k_preprocess(const uint4 *__restri
             // uniform sh_deg branches), which serialises 4-5 HBM round trips per Gaussian.
             uint4 v[NC];
 #pragma unroll
-            for (int c = 0; c < NC; c++) v[c] = planar[planar_at(c, i, NC)];
+            for (int c = 0; c < NC; c++) v[c] = load_planar(planar + planar_at(c, i, NC), fc.nt_loads != 0u);
             uint32_t w[NW];
 #pragma unroll
             for (int c = 0; c < NC; c++) {
@@ -774,11 +785,11 @@ __global__ __launch_bounds__(PP_THREADS) void k_preprocess_banded(const uint4 *_
         const uint32_t i = base + k * PP_THREADS + threadIdx.x;
         if (i < n) {
             uint32_t w[NW];
-            uint4 v0 = planar[planar_at(0, i, NC)];
+            uint4 v0 = load_planar(planar + planar_at(0, i, NC), fc.nt_loads != 0u);
             uint4 vg[G1 - G0 + 1];
 #pragma unroll
             for (int c = G0; c <= G1; c++)
-                if (c != 0) vg[c - G0] = planar[planar_at(c, i, NC)];
+                if (c != 0) vg[c - G0] = load_planar(planar + planar_at(c, i, NC), fc.nt_loads != 0u);
             asm volatile("" : "+v"(v0.x), "+v"(v0.y), "+v"(v0.z), "+v"(v0.w));
             w[0] = v0.x; w[1] = v0.y; w[2] = v0.z; w[3] = v0.w;
 #pragma unroll
@@ -798,7 +809,7 @@ __global__ __launch_bounds__(PP_THREADS) void k_preprocess_banded(const uint4 *_
                 if constexpr (S1 >= S0) {
                     uint4 vs[S1 - S0 + 1];
 #pragma unroll
-                    for (int c = S0; c <= S1; c++) vs[c - S0] = planar[planar_at(c, i, NC)];
+                    for (int c = S0; c <= S1; c++) vs[c - S0] = load_planar(planar + planar_at(c, i, NC), fc.nt_loads != 0u);
 #pragma unroll
                     for (int c = S0; c <= S1; c++) {
                         asm volatile("" : "+v"(vs[c - S0].x), "+v"(vs[c - S0].y), "+v"(vs[c - S0].z), "+v"(vs[c - S0].w));
