@@ -1369,10 +1369,12 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
 //   * the digit histogram of the sort's first pass is counted while the pairs are written, which
 //     removes that pass's histogram kernel (one read of all keys).
 // A wave finds its starting point with two cooperative steps over k_expand_count's sums (super-chunk
-// sums, then the chunk sums of one super-chunk) and then walks the Gaussians 64 at a time (next
-// batch prefetched).  Inside a batch every Gaussian drops ONE marker at its first slot; the owner
-// of each slot is then an inclusive max-scan over the 64 lanes of a window, and the tile id follows
-// from the owner's table entry without a per-pair integer division.
+// sums, then the chunk sums of one super-chunk; above 8.4 M Gaussians from the table that
+// k_pairs_cursors writes instead) and then walks the Gaussians one chunk of 256 at a time, 4 per lane
+// (next batch prefetched).  Inside a batch every Gaussian drops ONE marker at its first slot; slots
+// are produced 256 at a time, 4 consecutive per lane: the owner of each slot comes from one
+// inclusive max-scan over the lanes, and the tile id follows from the owner's table entry without a
+// per-pair integer division.
 // ---------------------------------------------------------------------------------------------
 
 __device__ __forceinline__ uint64_t wave_inclusive_scan64(uint64_t v, uint32_t lane) {
