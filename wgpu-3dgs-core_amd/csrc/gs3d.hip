@@ -1585,7 +1585,9 @@ static gs_status run_sort_items(const gs_device *dev, void *const keys[2], void 
         const bool first = compact && p == 0;
         const K *kin = first ? (const K *)compact->dense_keys : (const K *)keys[side];
         const uint32_t *vin = (const uint32_t *)vals[side];
-        K *kout = (K *)keys[side ^ 1];
+        // the sorted depth keys themselves are never read (compact = the frame's depth sort): its last pass
+        // writes the order only
+        K *kout = compact && p == passes - 1 ? (K *)nullptr : (K *)keys[side ^ 1];
         uint32_t *vout = (uint32_t *)vals[side ^ 1];
         const gs::SortCount psc = first ? gs::SortCount{compact->dense_count, nullptr} : sc;
         const uint32_t pnb = first ? (uint32_t)(((uint64_t)compact->dense_count + TILE - 1) / TILE) : nb;

@@ -1311,7 +1311,7 @@ __device__ __forceinline__ void scatter_ranked(ScatterShared<K, RB, ITEMS> &sh, 
             K kk = s_keys[pos];
             uint32_t d = (uint32_t)(kk >> shift) & digit_mask;
             uint32_t dst = s_delta[d] + pos;
-            keys_out[dst] = kk;
+            if (keys_out) keys_out[dst] = kk;      // null: nobody reads the keys of this pass (last depth pass)
             vals_out[dst] = s_vals[pos];
         }
     }
