@@ -822,13 +822,14 @@ __global__ __launch_bounds__(PP_THREADS) void k_preprocess_banded(const uint4 *_
                 shade_one<SH>(w, fc, d, rec);
             }
             if (cnt || !fc.mask_culled_records) {
+                // (the rect of a culled Gaussian is never read: its key says "culled")
                 uint32_t *o = io.recs + (uint64_t)i * REC_WORDS;
                 *(u32x4_a4 *)(o) = u32x4_a4{rec[0].x, rec[0].y, rec[0].z, rec[0].w};
                 *(u32x4_a4 *)(o + 4) = u32x4_a4{rec[1].x, rec[1].y, rec[1].z, rec[1].w};
                 o[8] = rec[2].x;
+                io.rect[i] = make_uint2(rec[2].z, rec[2].w);
             }
             io.depth[i] = cnt ? rec[2].y - io.key_bias : 0xffffffffu;
-            io.rect[i] = cnt ? make_uint2(rec[2].z, rec[2].w) : make_uint2(0u, 0u);
             local += cnt;
             local_vis += cnt ? 1u : 0u;
         }
