@@ -90,13 +90,25 @@ def run_workload(gs, synth, torch, dist, dev, stream, rank, world, wl, steps, wa
         return r.render(stream, buf, gt, mt, cam, par.band_target_ptr(gbuf, plan, rank, W), band=plan.bands[rank],
                         check=check)
 
+    # N > 1: frames go through a two-buffer pipeline — the all-gather of frame i (on RCCL's stream)
+    # overlaps the rendering of frame i + 1; every frame is exchanged and assembled inside the timed region
+    pipe = [None]
+    count = [0]
+
     def step():
-        render()
-        par.gather_bands(dist, gbuf, plan, rank)
-        return par.assemble(torch, gbuf, plan) if world > 1 else gbuf
+        if world == 1:
+            render()
+            return gbuf
+        i = count[0]
+        count[0] += 1
+        r.render(stream, buf, gt, mt, cam, pipe[0].begin(i), band=plan.bands[rank], check=False)
+        pipe[0].submit(i)
+        return pipe[0].finish(i - 1) if i else None
 
     def sync_all():
         if world > 1:
+            if pipe[0] is not None and count[0]:
+                pipe[0].finish(count[0] - 1)       # the last frame's exchange belongs to the region that ends here
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -112,6 +124,8 @@ def run_workload(gs, synth, torch, dist, dev, stream, rank, world, wl, steps, wa
         gbuf = par.allocate_gather(torch, plan, W, "cuda")
         plan_kind = "tile rows re-cut to equal pairs (one calibration frame)"
     fr = render(check=True)          # sizes the pair buffers for this band (blocking once)
+    if world > 1:
+        pipe[0] = par.FramePipeline(torch, dist, plan, rank, W, "cuda")
     for _ in range(warmup):
         step()
     sync_all()
@@ -171,6 +185,8 @@ def run_workload(gs, synth, torch, dist, dev, stream, rank, world, wl, steps, wa
         st = r.stats()
         stages = {name: st.stage_ms[i] / max(st.timed_frames, 1) for i, name in enumerate(gs.STAGE_NAMES)}
     img = step()
+    if world > 1:
+        img = pipe[0].finish(count[0] - 1)       # the frame just submitted, exchanged and assembled
     sync_all()
     checksum = float(img[:H].double().sum().item())
     visible, pairs = int(st.visible), int(st.pairs)

@@ -122,3 +122,48 @@ def test_sharded_frame_equals_single_rank(tmp_path, world, balanced):
         assert got.shape == full.shape
         assert np.array_equal(got.view(np.uint32), full.view(np.uint32)), "rank %d" % r
         assert np.array_equal(np.load(os.path.join(str(tmp_path), "bands%d.npy" % r)), bands0)   # same plan everywhere
+
+
+def _pipeline_worker(rank, world, port, height, width, out_dir):
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "tools")]
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    par = _par()
+    plan = par.BandPlan(height, world)
+    pipe = par.FramePipeline(torch, dist, plan, rank, width, "cpu")
+    y0, y1 = plan.pixel_rows(rank)
+    images = []
+    frames = 5
+    for i in range(frames):
+        base = pipe.begin(i)
+        buf = pipe.bufs[i % 2]
+        off = (base - buf.data_ptr()) // 4
+        flat = buf.view(-1)
+        for y in range(y0, y1):          # frame i, row y: value 1000 i + y in every channel
+            flat[off + y * width * 4:off + (y + 1) * width * 4] = float(1000 * i + y)
+        pipe.submit(i)
+        if i:
+            images.append(pipe.finish(i - 1).clone())
+    images.append(pipe.finish(frames - 1).clone())
+    pipe.drain()
+    np.save(os.path.join(out_dir, "pipe%d.npy" % rank), torch.stack(images).numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_frame_pipeline_keeps_frames_apart(tmp_path, world):
+    """FramePipeline: frame i + 1 is written into the other buffer while frame i is exchanged; every
+    finished frame must hold exactly its own rows from every rank."""
+    import torch.multiprocessing as mp
+    height, width = 100, 7
+    port = _free_port()
+    mp.spawn(_pipeline_worker, args=(world, port, height, width, str(tmp_path)), nprocs=world, join=True)
+    for rank in range(world):
+        got = np.load(os.path.join(str(tmp_path), "pipe%d.npy" % rank))
+        assert got.shape == (5, height, width, 4)
+        for i in range(5):
+            want = (1000 * i + np.arange(height, dtype=np.float32))[:, None, None] * np.ones((1, width, 4), np.float32)
+            assert np.array_equal(got[i], want), (rank, i)

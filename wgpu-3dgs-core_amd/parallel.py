@@ -87,18 +87,20 @@ def band_target_ptr(buf, plan, rank, width):
     return buf.data_ptr() + (rank * plan.chunk_rows - y0) * width * 16
 
 
-def gather_bands(dist, buf, plan, rank):
+def gather_bands(dist, buf, plan, rank, async_op=False):
     """One all-gather, in place: every rank contributes its chunk of `buf`.  The form of the
     collective is chosen once from the backend (never by catching an error from a collective: ranks
-    that disagree about which collective they are in deadlock)."""
+    that disagree about which collective they are in deadlock).  async_op=True (RCCL only) returns
+    the work handle: the collective runs on its own stream behind the render already enqueued, and
+    the caller's stream goes on without waiting for it until handle.wait()."""
     g = plan.world_size
     if g == 1:
-        return
+        return None
     c = plan.chunk_rows
     mine = buf[rank * c:(rank + 1) * c]
     if dist.get_backend() == "nccl":        # RCCL: fused form, output aliases the input chunk
-        dist.all_gather_into_tensor(buf, mine)
-        return
+        return dist.all_gather_into_tensor(buf, mine, async_op=async_op) if async_op else \
+            dist.all_gather_into_tensor(buf, mine)
     # gloo (rehearsals only): list form; gloo has no all-gather on device tensors, so a device
     # buffer is staged through the host (this is NOT the product path: RCCL above is)
     on_device = buf.device.type != "cpu"
@@ -119,6 +121,54 @@ def assemble(torch, buf, plan):
         if y1 > y0:
             rows.append(buf[r * c:r * c + (y1 - y0)])
     return rows[0] if len(rows) == 1 else torch.cat(rows, dim=0)
+
+
+class FramePipeline:
+    """Frames in flight on `depth` gather buffers used in turn: the all-gather of frame i runs on the
+    collective's stream while frame i + 1 is rendered into the next buffer (xGMI transfer hidden
+    behind compute; a frame costs max(render, gather) instead of their sum).
+
+        buf_ptr = pipe.begin(i)        # base pointer for the renderer (waits for the frame that last used the buffer)
+        ... render frame i's band into buf_ptr ...
+        pipe.submit(i)                 # start the exchange of frame i
+        image = pipe.finish(i - 1)     # the complete previous frame (orders the caller's stream behind its exchange)
+    """
+
+    def __init__(self, torch, dist, plan, rank, width, device, depth=2):
+        assert depth >= 2
+        self.torch, self.dist, self.plan, self.rank, self.width = torch, dist, plan, rank, width
+        self.bufs = [allocate_gather(torch, plan, width, device) for _ in range(depth)]
+        self.work = [None] * depth          # exchange in flight on each buffer
+        self.frame = [None] * depth         # frame number each buffer holds
+
+    def _slot(self, i):
+        return i % len(self.bufs)
+
+    def _wait(self, k):
+        if self.work[k] is not None:
+            self.work[k].wait()             # stream-level: the current stream waits, the host does not
+            self.work[k] = None
+
+    def begin(self, i):
+        k = self._slot(i)
+        self._wait(k)                       # the buffer's previous exchange must have read and written it
+        self.frame[k] = i
+        return band_target_ptr(self.bufs[k], self.plan, self.rank, self.width)
+
+    def submit(self, i):
+        k = self._slot(i)
+        assert self.frame[k] == i
+        self.work[k] = gather_bands(self.dist, self.bufs[k], self.plan, self.rank, async_op=True)
+
+    def finish(self, i):
+        k = self._slot(i)
+        assert self.frame[k] == i, "frame %d is no longer in the pipeline" % i
+        self._wait(k)
+        return assemble(self.torch, self.bufs[k], self.plan)
+
+    def drain(self):
+        for k in range(len(self.bufs)):
+            self._wait(k)
 
 
 def render_sharded(dist, torch, buf, plan, rank, width, render_band):
