@@ -1547,7 +1547,7 @@ __device__ __forceinline__ void pair_generate(const ExpandIO &io, uint32_t v_cou
     {
         uint4 *z = (uint4 *)sh.vals;
 #pragma unroll
-        for (uint32_t q = lane; q < (NSLOTS + GEN_BATCH) / 4; q += WAVE) z[q] = make_uint4(0u, 0u, 0u, 0u);
+        for (uint32_t q0 = 0; q0 < (NSLOTS + GEN_BATCH) / 4; q0 += WAVE) z[q0 + lane] = make_uint4(0u, 0u, 0u, 0u);
     }
     // slots relative to o0 from here on: the chunk in front of o0 holds < 2^30 pairs, a batch < 2^30
     int32_t rel = (int32_t)(int64_t)(cur.prefix - o0);      // <= 0: first slot of the batch
@@ -1726,9 +1726,10 @@ __global__ __launch_bounds__(SORT_THREADS) void k_pairs_emit(ExpandIO io, uint32
         K *kout = tkeys + o0;
         if (n_slots == NSLOTS) {
 #pragma unroll
-            for (uint32_t q = lane; q < NSLOTS / 4; q += WAVE) ((uint4 *)vout)[q] = ((const uint4 *)sh.vals)[q];
+            for (uint32_t q0 = 0; q0 < NSLOTS / 4; q0 += WAVE) ((uint4 *)vout)[q0 + lane] = ((const uint4 *)sh.vals)[q0 + lane];
 #pragma unroll
-            for (uint32_t q = lane; q < NSLOTS * sizeof(K) / 16; q += WAVE) ((uint4 *)kout)[q] = ((const uint4 *)sh.keys)[q];
+            for (uint32_t q0 = 0; q0 < NSLOTS * sizeof(K) / 16; q0 += WAVE)
+                ((uint4 *)kout)[q0 + lane] = ((const uint4 *)sh.keys)[q0 + lane];
         } else {
             for (uint32_t q = lane; q < n_slots; q += WAVE) {
                 vout[q] = sh.vals[q];
