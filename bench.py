@@ -247,6 +247,30 @@ def stage_models(wl, res):
     return out
 
 
+def frame_bytes_object(wl, res):
+    """Whole-frame byte models over the frame time (SURVEY.md §8d asks for B_frame / t_frame beside
+    Msplats/s).  Two models: the survey's textbook pipeline (64-bit keys, six 8-bit passes over
+    12-byte pairs) — quoted as an EQUIVALENT rate, not as a fraction of peak, because this
+    implementation does not move those bytes (two-level sort: depth keys of the V visible Gaussians,
+    then 2-byte tile keys) — and the sum of the bytes this implementation's stages move
+    (stage_models), whose rate is a real fraction of the 8 TB/s peak."""
+    n, d, v = wl["n"], res["pairs"], res["visible"]
+    px = wl["width"] * wl["height"]
+    tiles = ((wl["width"] + 15) // 16) * ((wl["height"] + 15) // 16)
+    passes = -(-(32 + max(tiles - 1, 1).bit_length()) // 8)
+    survey = n * wl["payload"] + (v * 48 + n * 4) + d * 12 + passes * d * 12 * 2 + d * (4 + 48) + px * 16
+    t = res["ms_per_frame"] * 1e-3
+    out = dict(survey_model_bytes=survey, survey_model="N x payload + V x 48 + N x 4 + D x 12 + %d passes x D x 24 + D x 52 + W x H x 16"
+               % passes, survey_equivalent_gbs=survey / t / 1e9)
+    sm = stage_models(wl, res)
+    if sm:
+        mine = sum(x["model_bytes"] for x in sm.values() if x.get("bound") == "hbm") + d * (4 + 36) + px * 16
+        out.update(implementation_model_bytes=mine, implementation_gbs=mine / t / 1e9,
+                   implementation_frac=mine / t / 1e9 / HBM_PEAK_GBS,
+                   implementation_model="sum of stage_models + blend (D x (4-B index + 36-B record) + W x H x 16)")
+    return out
+
+
 def kernel_source_stamp():
     h = hashlib.sha256()
     for f in ("gs_render_kernels.h", "gs_kernel_lib.h"):
@@ -436,7 +460,7 @@ def main():
             d = {"workload": w["label"], "value": w["n"] / (rr["ms_per_frame"] * 1e-3) / 1e6, "unit": "Msplats/s",
                  "ms_per_step": rr["ms_per_frame"], "frame_ms": rr.get("frame_ms"), "visible": rr["visible"],
                  "pairs": rr["pairs"], "launches_per_frame": rr["launches"], "stages_ms": rr["stages_ms"],
-                 "stage_models": stage_models(w, rr)}
+                 "stage_models": stage_models(w, rr), "frame_bytes": frame_bytes_object(w, rr)}
             if rr["stages_ms"]:
                 pre = rr["stages_ms"]["preprocess"]
                 d["preprocess_read_frac"] = w["n"] * w["payload"] / (pre * 1e-3) / 1e9 / HBM_PEAK_GBS
@@ -469,6 +493,7 @@ def main():
             "frame_ms": res.get("frame_ms"),
             "stages_ms": res["stages_ms"],
             "stage_models": stage_models(wl, res),
+            "frame_bytes": frame_bytes_object(wl, res),
             "blend": blend_valu_object(res) if args.workload == "1m" and world == 1 else None,
         }
         if world > 1:
