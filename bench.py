@@ -70,7 +70,7 @@ def _camera(gs, wl):
 
 
 def run_workload(gs, synth, torch, dist, dev, stream, rank, world, wl, steps, warmup, timing_steps,
-                 frame_samples, rebalance=True):
+                 frame_samples, rebalance=True, two_in_flight=False):
     """Times `steps` pipelined frames between barriers (max over ranks), then `frame_samples`
     individually event-timed frames (median / min / p95), then a short run with HIP-event stage
     timing.  Returns a dict (rank-0 view; per-rank numbers where world > 1)."""
@@ -194,7 +194,39 @@ def run_workload(gs, synth, torch, dist, dev, stream, rank, world, wl, steps, wa
         t = torch.tensor([pairs], dtype=torch.float64, device="cuda")
         dist.all_reduce(t)
         pairs = int(t.item())
+    # Throughput with TWO frames in flight (single GPU): a second renderer (its own scratch buffers) on a
+    # second stream takes every other frame, so the latency-bound sort chain of frame i + 1 fills the gaps
+    # of frame i's VALU-bound blend.  Reported beside `value`, never as `value`: a frame's latency does
+    # not change.  Both images are checked against the single-stream frame.
+    in_flight = None
+    if world == 1 and two_in_flight:
+        # two streams of their own (torch's current stream may be the legacy default stream, which
+        # serialises with every other stream)
+        torch.cuda.synchronize()
+        r.set_timing(False)          # no stage events in this run
+        s1, s2 = dev.create_stream(), dev.create_stream()
+        r2 = gs.Renderer(dev)
+        img2 = gs.Buffer(dev, size=W * H * 16)
+        lanes = [(r, s1, par.band_target_ptr(gbuf, plan, rank, W)), (r2, s2, img2.device_ptr())]
+        r2.render(s2, buf, gt, mt, cam, img2.device_ptr(), check=True)      # sizing frame of the second renderer
+        for i in range(2 * warmup):
+            rr, ss, pp = lanes[i & 1]
+            rr.render(ss, buf, gt, mt, cam, pp, check=False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            rr, ss, pp = lanes[i & 1]
+            rr.render(ss, buf, gt, mt, cam, pp, check=False)
+        torch.cuda.synchronize()
+        dt2 = time.perf_counter() - t0
+        sum2 = float(img2.download(s2, np.float32).astype(np.float64).sum())
+        in_flight = dict(frames_in_flight=2, ms_per_step=dt2 * 1e3 / steps, value=wl["n"] / (dt2 / steps) / 1e6,
+                         unit="Msplats/s", image_checksums_equal=bool(abs(sum2 - checksum) <= 1e-6 * max(1.0, abs(checksum))),
+                         note="two renderers on two streams take the frames alternately; per-frame latency unchanged")
+        r2.destroy()
+        img2.release()
     out = dict(ms_per_frame=dt * 1e3 / steps, visible=visible, pairs=pairs, sort_passes=int(st.sort_passes),
+               two_frames_in_flight=in_flight,
                stages_ms=stages, checksum=checksum, launches=int(fr.launches), pair_capacity=int(fr.pair_capacity),
                per_rank_ms=per_rank, render_ms_per_rank=render_ms, gather_ms_per_rank=gather_ms,
                bands=plan.bands, band_plan=plan_kind)
@@ -401,6 +433,7 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=3)
     ap.add_argument("--timing-steps", type=int, default=20)
     ap.add_argument("--frame-samples", type=int, default=100)
+    ap.add_argument("--no-in-flight", action="store_true", help="skip the two-frames-in-flight measurement")
     ap.add_argument("--no-rebalance", action="store_true", help="N > 1: keep the floor(g*R/G) band plan")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--force-device", type=int, default=-1, help="rehearsal: put every rank on this GPU")
@@ -437,12 +470,12 @@ def main():
     # launch on torch's current stream so the RCCL all-gather is ordered behind the blend kernel
     stream = dev.wrap_stream(torch.cuda.current_stream().cuda_stream)
 
-    def run(name, steps, warmup, samples):
+    def run(name, steps, warmup, samples, two_in_flight=False):
         return run_workload(gs, synth, torch, dist, dev, stream, rank, world, WORKLOADS[name], steps, warmup,
-                            args.timing_steps, samples, rebalance=not args.no_rebalance)
+                            args.timing_steps, samples, rebalance=not args.no_rebalance, two_in_flight=two_in_flight)
 
     wl = WORKLOADS[args.workload]
-    res = run(args.workload, args.steps, args.warmup, args.frame_samples)
+    res = run(args.workload, args.steps, args.warmup, args.frame_samples, two_in_flight=not args.no_in_flight)
     rsteps, rwarm = max(5, min(args.steps, 20)), max(2, min(args.warmup, 5))
     roof = nocull = None
     if not args.no_roofline:
@@ -494,6 +527,7 @@ def main():
             "stages_ms": res["stages_ms"],
             "stage_models": stage_models(wl, res),
             "frame_bytes": frame_bytes_object(wl, res),
+            "two_frames_in_flight": res.get("two_frames_in_flight"),
             "blend": blend_valu_object(res) if args.workload == "1m" and world == 1 else None,
         }
         if world > 1:
