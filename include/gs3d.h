@@ -534,6 +534,14 @@ gs_status gs_renderer_stats(gs_renderer *r, gs_frame_stats *out);
  * hipFree, which synchronises the device).  If a frame nevertheless produces more pairs than fit,
  * its farthest pairs are dropped and gs_renderer_wait_frame reports GS_ERR_PAIR_CAPACITY.
  *
+ * Frames in flight: a renderer owns the scratch buffers of ONE frame, so consecutive frames on one
+ * renderer run one after the other.  To overlap frames (the sort chain of frame i + 1 fills the gaps
+ * of frame i's blend: +20 % frames per second at 1 M Gaussians), use one gs_renderer per frame slot,
+ * each on its own gs_stream, and hand them the frames in turn; the Gaussian buffer is shared (the
+ * renderer-internal mirror of the buffer is built on the stream of the first frame that needs it and
+ * frames on other streams wait for that build; UPDATING a buffer that frames on other streams may
+ * still be reading is the caller's to order, as with any buffer used across streams).
+ *
  * Limits (GS_ERR_INVALID_ARGUMENT beyond them): at most 2^22 tiles of 16 x 16 pixels and 65535 tiles
  * along either axis; at most 2^32 - 16 Gaussians. */
 gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_buffer *gaussians,

@@ -446,6 +446,35 @@ def test_pair_emission_regimes(gs, ob, device, stream, case):
             _compare_frame(gs, ob, device, stream, pod.sh, pod.cov, g, 333, 211, gt_kw=dict(sh_deg=0))
 
 
+def test_two_renderers_keep_frames_in_flight_on_one_buffer(gs, ob, device, stream):
+    """One Gaussian buffer, two renderers on two streams taking frames alternately with nothing but
+    the final synchronisation between them: the mirror is built on the first frame's stream and the
+    other stream must wait for it; every frame equals the oracle's."""
+    import synth
+    g = synth.scene(30000, first=99)
+    pod = gs.GaussianPod(gs.SH_HALF, gs.COV3D_ROT_SCALE)
+    pods = pod.from_gaussian(g)
+    buf = gs.GaussiansBuffer.new_with_pods(device, pod, pods)
+    cams = [helpers.default_camera(gs, 640, 480), helpers.default_camera(gs, 640, 480, eye=(0.5, 0.2, 1.0), target=(0.4, 0.1, -1.0))]
+    gt, mt = gs.gaussian_transform_pod(sh_deg=2), gs.model_transform_pod()
+    streams = [device.create_stream(), device.create_stream()]
+    rs = [gs.Renderer(device), gs.Renderer(device)]
+    imgs = [gs.Buffer(device, size=640 * 480 * 16) for _ in range(2)]
+    for i in range(6):                    # first frames are sizing frames of each renderer, then pipelined ones
+        k = i & 1
+        rs[k].render(streams[k], buf, gt, mt, cams[k], imgs[k].device_ptr(), check=False)
+    for s in streams:
+        s.synchronize()
+    order = _mirror_order(ob, buf, stream, pod.sh, pod.cov, pods)
+    for k in range(2):
+        rgba = imgs[k].download(streams[k], np.float32).reshape(480, 640, 4)
+        ocam = helpers.copy_camera(cams[k], ob.Camera)
+        o = ob.render(pod.sh, pod.cov, pods, ob.gaussian_transform(sh_deg=2), ob.model_transform(), ocam, order=order)[0]
+        assert np.array_equal(rgba.view(np.uint32), o.view(np.uint32)), k
+        rs[k].destroy(); imgs[k].release()
+    buf.destroy()
+
+
 def test_image_size_limits_are_rejected(gs, device, stream):
     """more than 2^22 tiles, or more than 65535 tiles along one axis (tile rects are packed as 16-bit
     coordinates): GS_ERR_INVALID_ARGUMENT before anything is launched"""

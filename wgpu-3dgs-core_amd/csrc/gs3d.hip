@@ -567,6 +567,10 @@ struct gs_gaussians_buffer {
     void *inv;
     void *block_bounds;      // 8 floats per 1024-slot block (k_block_bounds); null = not available
     size_t partial_since_order;   // Gaussians rewritten by partial updates since the order was built
+    // The mirror is (re)built on the stream of whichever frame first needs it; frames on OTHER streams
+    // (several renderers keeping frames in flight on one buffer) wait for this event before reading it.
+    hipEvent_t mirror_ready = nullptr;
+    hipStream_t mirror_stream = nullptr;
     void mark(size_t lo, size_t hi) {
         if (lo >= hi) return;
         partial_since_order += hi - lo;
@@ -708,6 +712,7 @@ extern "C" void gs_gaussians_buffer_destroy(gs_gaussians_buffer *g) {
     if (g->planar) (void)hipFree(g->planar);
     if (g->inv) (void)hipFree(g->inv);
     if (g->block_bounds) (void)hipFree(g->block_bounds);
+    if (g->mirror_ready) (void)hipEventDestroy(g->mirror_ready);
     if (g->order) gs_buffer_release(g->order);
     gs_buffer_release(g->buf);
     delete g;
@@ -1812,6 +1817,12 @@ static gs_status ensure_planar(gs_gaussians_buffer *g, hipStream_t st) {
         hipLaunchKernelGGL(k_tbl_block_bounds[g->sh][g->cov], dim3(nblocks), dim3(gs::PP_THREADS), 0, st,
                            (const uint4 *)g->planar, (uint32_t)len, (float *)g->block_bounds);
         GS_HIP(hipGetLastError());
+        if (!g->mirror_ready) GS_HIP(hipEventCreateWithFlags(&g->mirror_ready, hipEventDisableTiming));
+        GS_HIP(hipEventRecord(g->mirror_ready, st));
+        g->mirror_stream = st;
+    } else if (g->mirror_ready && st != g->mirror_stream) {
+        // the mirror was built on another stream: order this stream behind that build
+        GS_HIP(hipStreamWaitEvent(st, g->mirror_ready, 0));
     }
     g->dirty_lo = g->dirty_hi = 0;
     return GS_OK;
