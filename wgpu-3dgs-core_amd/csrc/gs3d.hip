@@ -1924,8 +1924,7 @@ static uint32_t float_bits(float f) {
     return u;
 }
 
-// device memory that must start out as zeros (look-back words carry a generation tag instead of
-// being cleared every frame; tickets only ever count up)
+// device memory that must start out as zeros (the frame state: V and D live there between kernels)
 static gs_status reserve_zeroed(DevArray &a, size_t bytes, hipStream_t st) {
     if (a.bytes >= bytes && a.ptr) return GS_OK;
     GS_TRY(dev_reserve(a, bytes));
