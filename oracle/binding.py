@@ -127,8 +127,21 @@ def lib():
     L.gso_last_stage_seconds.argtypes = [vp]
     L.gso_set_threads.argtypes = [i32]
     L.gso_get_max_threads.restype = i32
+    L.gso_set_rect_version.argtypes = [i32]
+    L.gso_rect_version.restype = i32
+    # the product's A/B switch GS3D_RECT_V1=1 (spec version 1 of the tile rect) selects the matching oracle
+    L.gso_set_rect_version(1 if os.environ.get("GS3D_RECT_V1") == "1" else 2)
     _lib = L
     return L
+
+
+def set_rect_version(v):
+    """1 = radius square, 2 = clipped to the splat's visible box (default)"""
+    lib().gso_set_rect_version(int(v))
+
+
+def rect_version():
+    return int(lib().gso_rect_version())
 
 
 def _p(a):

@@ -709,6 +709,51 @@ static void eval_sh(int sh, const void *pod, uint32_t deg, int no_sh0, const flo
 
 static inline float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
 
+/* version of the tile-rect definition.  1 = the radius square; 2 (default) = the
+ * radius square clipped, in display mode Splat, to the bounding box of the region where the splat can
+ * reach alpha >= 1/255.  Both versions produce the same image: version 2 only drops (tile, Gaussian)
+ * pairs that contribute to no pixel.  Version 1 is kept so that the version-1 goldens stay checkable. */
+static int g_rect_version = 2;
+void gso_set_rect_version(int v) { g_rect_version = v; }
+int gso_rect_version(void) { return g_rect_version; }
+
+/* ln k correctly rounded to binary32 for the opacity byte k (alpha = (k / 255) exp(power) reaches
+ * 1/255 only where power >= -ln k); entry 0 unused */
+static const float LN_OPACITY_BYTE[256] = {
+    0.0f, 0.0f, 0.693147182f, 1.09861231f, 1.38629436f, 1.60943794f, 1.79175949f, 1.9459101f,
+    2.07944155f, 2.19722462f, 2.30258512f, 2.39789534f, 2.48490667f, 2.56494927f, 2.6390574f, 2.70805025f,
+    2.77258873f, 2.83321333f, 2.8903718f, 2.94443893f, 2.99573231f, 3.04452252f, 3.09104252f, 3.13549423f,
+    3.17805386f, 3.21887589f, 3.25809646f, 3.29583693f, 3.33220458f, 3.36729574f, 3.40119743f, 3.43398714f,
+    3.46573591f, 3.49650764f, 3.52636051f, 3.55534816f, 3.58351898f, 3.61091781f, 3.63758612f, 3.66356158f,
+    3.68887949f, 3.71357203f, 3.73766971f, 3.76120019f, 3.7841897f, 3.80666256f, 3.82864141f, 3.85014749f,
+    3.87120104f, 3.89182019f, 3.91202307f, 3.93182564f, 3.95124364f, 3.97029185f, 3.98898411f, 4.00733328f,
+    4.02535152f, 4.04305124f, 4.06044292f, 4.07753754f, 4.09434462f, 4.1108737f, 4.12713432f, 4.14313459f,
+    4.15888309f, 4.17438745f, 4.18965483f, 4.20469284f, 4.21950769f, 4.23410654f, 4.2484951f, 4.26268005f,
+    4.27666616f, 4.29045963f, 4.30406523f, 4.31748819f, 4.3307333f, 4.34380531f, 4.356709f, 4.36944771f,
+    4.38202667f, 4.39444923f, 4.40671921f, 4.41884041f, 4.43081665f, 4.44265127f, 4.45434713f, 4.46590805f,
+    4.47733688f, 4.48863649f, 4.49980974f, 4.51085949f, 4.5217886f, 4.53259945f, 4.54329491f, 4.55387688f,
+    4.56434822f, 4.57471085f, 4.58496761f, 4.59511995f, 4.60517025f, 4.61512041f, 4.62497282f, 4.63472891f,
+    4.64439106f, 4.65396023f, 4.66343927f, 4.67282867f, 4.68213129f, 4.69134808f, 4.70048046f, 4.70953035f,
+    4.71849871f, 4.72738791f, 4.73619843f, 4.74493217f, 4.75359011f, 4.76217413f, 4.77068472f, 4.77912331f,
+    4.7874918f, 4.79579067f, 4.80402088f, 4.81218433f, 4.82028151f, 4.82831383f, 4.83628178f, 4.84418726f,
+    4.85203028f, 4.85981226f, 4.86753464f, 4.87519741f, 4.88280201f, 4.89034891f, 4.89784002f, 4.90527487f,
+    4.91265488f, 4.919981f, 4.92725372f, 4.93447399f, 4.94164228f, 4.94876003f, 4.95582724f, 4.96284485f,
+    4.96981335f, 4.97673368f, 4.98360682f, 4.99043274f, 4.99721241f, 5.0039463f, 5.01063538f, 5.01727962f,
+    5.02388048f, 5.03043795f, 5.0369525f, 5.04342508f, 5.04985619f, 5.0562458f, 5.06259489f, 5.0689044f,
+    5.07517385f, 5.08140421f, 5.08759642f, 5.09375f, 5.09986639f, 5.10594559f, 5.11198759f, 5.11799383f,
+    5.12396383f, 5.12989855f, 5.13579845f, 5.14166355f, 5.14749432f, 5.1532917f, 5.15905523f, 5.16478586f,
+    5.17048407f, 5.17614985f, 5.18178368f, 5.18738604f, 5.19295692f, 5.19849682f, 5.20400667f, 5.20948601f,
+    5.21493578f, 5.22035599f, 5.22574663f, 5.23110867f, 5.23644209f, 5.2417469f, 5.24702406f, 5.25227356f,
+    5.2574954f, 5.26269007f, 5.26785803f, 5.27299976f, 5.2781148f, 5.2832036f, 5.28826714f, 5.29330492f,
+    5.29831743f, 5.30330467f, 5.30826759f, 5.3132062f, 5.31812f, 5.32300997f, 5.32787609f, 5.33271885f,
+    5.33753824f, 5.34233427f, 5.34710741f, 5.35185814f, 5.35658646f, 5.36129236f, 5.36597586f, 5.37063789f,
+    5.37527847f, 5.37989712f, 5.38449526f, 5.38907194f, 5.39362764f, 5.39816284f, 5.40267754f, 5.40717173f,
+    5.41164589f, 5.4161005f, 5.42053509f, 5.42495012f, 5.42934561f, 5.43372202f, 5.43807936f, 5.44241762f,
+    5.44673729f, 5.45103836f, 5.45532131f, 5.45958567f, 5.4638319f, 5.46806002f, 5.47227049f, 5.47646332f,
+    5.48063898f, 5.484797f, 5.48893785f, 5.49306154f, 5.49716806f, 5.50125837f, 5.50533152f, 5.50938845f,
+    5.51342869f, 5.51745272f, 5.52146101f, 5.52545309f, 5.52942896f, 5.53338957f, 5.53733444f, 5.54126358f,
+};
+
 /* Frame constants derived from the uniforms, evaluated once per frame. */
 typedef struct {
     float M[16];   /* model_transform_mat */
@@ -720,6 +765,7 @@ typedef struct {
     float max_std_dev;
     uint32_t sh_deg;
     int no_sh0;
+    int clip_rect; /* DESIGN.md §3.3, second step of the rect (display mode Splat only) */
 } frame_consts;
 
 static void make_frame_consts(const gso_gaussian_transform *gt, const gso_model_transform *mt,
@@ -745,6 +791,7 @@ static void make_frame_consts(const gso_gaussian_transform *gt, const gso_model_
     fc->max_std_dev = gso_transform_max_std_dev(flags);
     fc->sh_deg = gso_transform_sh_deg(flags);
     fc->no_sh0 = (int)gso_transform_no_sh0(flags);
+    fc->clip_rect = gso_transform_display_mode(flags) == 0u && g_rect_version >= 2;
 }
 
 /* DESIGN.md §3.3. Returns tiles touched (0 = culled). */
@@ -797,6 +844,21 @@ static uint32_t project_one(int sh, int cov, const uint8_t *pod, const frame_con
     float fx1 = clampf(floorf((mx + radius) * 0.0625f) + 1.0f, 0.0f, (float)tiles_x);
     float fy0 = clampf(floorf((my - radius) * 0.0625f), lo_y, hi_y);
     float fy1 = clampf(floorf((my + radius) * 0.0625f) + 1.0f, lo_y, hi_y);
+    /* the record's quadratic form: power(dx, dy) = qa dx^2 + qb dx dy + qc dy^2 */
+    float qa = -0.5f * (cc * inv), qb = cb * inv, qc = -0.5f * (ca * inv);
+    if (fc->clip_rect) {
+        /* DESIGN.md §3.3, second step: bounding box of {power >= -(ln k + 0.1)}; tile t holds the
+         * pixel centres 16 t + 0.5 ... 16 t + 15.5; a NaN extent leaves the rect as it is */
+        uint32_t kop = ld_u32(pod + 12) >> 24; /* opacity byte of the colour word */
+        if (kop == 0u) return 0;
+        float lim = LN_OPACITY_BYTE[kop] + 0.1f;
+        float ex = sqrtf(lim / -(qa - (qb * qb) / (4.0f * qc)));
+        float ey = sqrtf(lim / -(qc - (qb * qb) / (4.0f * qa)));
+        fx0 = fmaxf(fx0, floorf(((mx - ex) - 15.5f) * 0.0625f) + 1.0f);
+        fx1 = fminf(fx1, floorf(((mx + ex) - 0.5f) * 0.0625f) + 1.0f);
+        fy0 = fmaxf(fy0, floorf(((my - ey) - 15.5f) * 0.0625f) + 1.0f);
+        fy1 = fminf(fy1, floorf(((my + ey) - 0.5f) * 0.0625f) + 1.0f);
+    }
     if (!(fx1 > fx0) || !(fy1 > fy0)) return 0;
     uint32_t tx0 = (uint32_t)fx0, tx1 = (uint32_t)fx1, ty0 = (uint32_t)fy0, ty1 = (uint32_t)fy1;
 
@@ -814,9 +876,9 @@ static uint32_t project_one(int sh, int cov, const uint8_t *pod, const frame_con
 
     out->mx = mx;
     out->my = my;
-    out->ca = -0.5f * (cc * inv);
-    out->cb = (cb * inv); /* = -B of the conic, B = -cb*inv */
-    out->cc = -0.5f * (ca * inv);
+    out->ca = qa;
+    out->cb = qb; /* = -B of the conic, B = -cb*inv */
+    out->cc = qc;
     out->opacity = col[3];
     out->r = rgb[0];
     out->g = rgb[1];

@@ -190,6 +190,10 @@ uint64_t gso_render_ordered(int sh, int cov, const void *pods, size_t n, const g
  * preprocess, keys, sort, ranges, blend */
 void gso_last_stage_seconds(double out[5]);
 void gso_set_threads(int n);
+/* tile-rect definition of DESIGN.md §3.3: 1 = radius square, 2 (default) = clipped to the splat's
+ * visible box in display mode Splat (same images, fewer pairs) */
+void gso_set_rect_version(int v);
+int gso_rect_version(void);
 int gso_get_max_threads(void);
 
 #ifdef __cplusplus

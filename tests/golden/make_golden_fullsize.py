@@ -5,8 +5,13 @@ Per workload it records N, the visible count V, the pair count D, the sha256 of 
 (so a differing generator is told apart from a differing renderer), of the spatial mirror order and
 of the f32 RGBA frame (in that order, and in plain index order for buffers with the spatial order
 switched off).  The HIP path is bit-exact against the oracle, so tests/test_gpu_fullsize.py compares hashes.
-Output: tests/golden/fullsize_v1.json.   Run:  python tests/golden/make_golden_fullsize.py [workload ...]
-(1m takes seconds, 10m a few minutes on 8 cores, 50m needs ~25 GB of RAM.)"""
+Output: tests/golden/fullsize_v2.json.   Run:  python tests/golden/make_golden_fullsize.py [workload ...]
+(1m takes seconds, 10m a few minutes on 8 cores, 50m needs ~25 GB of RAM.)
+
+fullsize_v1.json (round 1 / 2, kept) was made with version 1 of the tile rect (the
+radius square).  Version 2 clips the rect to the splat's visible box: fewer pairs, fewer visible
+Gaussians, THE SAME IMAGE.  This generator renders every workload with both versions, refuses to
+write anything unless the two frames are bit-identical, and records the counts of both."""
 import hashlib
 import json
 import os
@@ -41,12 +46,18 @@ def run(name):
     t0 = time.time()
     # the buffer's default mirror order: pairs of bit-identical depth follow it
     order = ob.spatial_order(wl["sh"], wl["cov"], pods)
+    ob.set_rect_version(1)
+    rgba1, d1, v1, _ = ob.render(wl["sh"], wl["cov"], pods, gt, mt, cam, want_image=True, order=order)
+    ob.set_rect_version(2)
     rgba, d, v, _ = ob.render(wl["sh"], wl["cov"], pods, gt, mt, cam, want_image=True, order=order)
     dt = time.time() - t0
+    if not np.array_equal(rgba.view(np.uint32), rgba1.view(np.uint32)):
+        raise SystemExit("%s: rect versions 1 and 2 give different frames" % name)
+    del rgba1
     rgba_index_order = ob.render(wl["sh"], wl["cov"], pods, gt, mt, cam, want_image=True)[0]
     alpha = rgba[..., 3]
     return dict(n=wl["n"], sh=wl["sh"], cov=wl["cov"], sh_deg=wl["sh_deg"], width=wl["width"], height=wl["height"],
-                visible=v, pairs=d, scene_sha256=pods_hash.hexdigest(),
+                visible=v, pairs=d, visible_rect_v1=v1, pairs_rect_v1=d1, scene_sha256=pods_hash.hexdigest(),
                 frame_sha256=hashlib.sha256(rgba.tobytes()).hexdigest(),
                 order_sha256=hashlib.sha256(order.tobytes()).hexdigest(),
                 frame_sha256_index_order=hashlib.sha256(rgba_index_order.tobytes()).hexdigest(),
@@ -57,7 +68,7 @@ def run(name):
 
 def main():
     names = sys.argv[1:] or ["100k", "1m", "10m", "10m-4k"]
-    path = os.path.join(HERE, "fullsize_v1.json")
+    path = os.path.join(HERE, "fullsize_v2.json")
     out = json.load(open(path)) if os.path.exists(path) else {}
     ob.build()
     for name in names:

@@ -19,7 +19,7 @@ rasteriser's documented conventions) — NOT from gs_oracle.c:
 It narrows common-mode risk; it does NOT pin the rows to the reference (they stay "parity
 unpinned").
 
-Output: tests/golden/witness_v1.npz — inputs (Gaussians, uniforms) and expected projected
+Output: tests/golden/witness_v2.npz — inputs (Gaussians, uniforms) and expected projected
 records / images for three views, plus margins that tell the test which discontinuous decisions
 (ceil of the radius, cull tests, tile-rect floors) are too close to call in float32.
 Run:  python tests/golden/make_witness.py
@@ -165,7 +165,21 @@ def project(g, view):
     tx1 = np.clip(np.floor((mx + radius) / 16.0) + 1, 0, tiles_x)
     ty0 = np.clip(np.floor((my - radius) / 16.0), b0, b1)
     ty1 = np.clip(np.floor((my + radius) / 16.0) + 1, b0, b1)
-    visible = in_depth & ok_det & (radius > 0) & (tx1 > tx0) & (ty1 > ty0)
+    # DESIGN.md §3.3, second step of the rect (display mode Splat, which is all this witness renders):
+    # alpha = (k / 255) exp(power) reaches 1/255 only where power >= -ln k, k the opacity byte.  The set
+    # {power >= -(ln k + 0.1)} is the ellipse d^T cov2d^-1 d <= 2 (ln k + 0.1), whose bounding box has the
+    # half-extents sqrt(2 (ln k + 0.1) cov2d_xx) and sqrt(2 (ln k + 0.1) cov2d_yy) — derived here from the
+    # covariance, where the implementations work from the inverted (conic) form.  Tile t holds the pixel
+    # centres 16 t + 0.5 ... 16 t + 15.5; tiles the box does not reach are dropped; k = 0 is never visible.
+    kop = g["color"][:, 3].astype(np.int64)
+    lim = np.log(np.maximum(kop, 1).astype(np.float64)) + 0.1
+    ex = np.sqrt(2.0 * lim * cov2d[:, 0, 0])
+    ey = np.sqrt(2.0 * lim * cov2d[:, 1, 1])
+    cx0, cx1 = np.floor((mx - ex - 15.5) / 16.0) + 1, np.floor((mx + ex - 0.5) / 16.0) + 1
+    cy0, cy1 = np.floor((my - ey - 15.5) / 16.0) + 1, np.floor((my + ey - 0.5) / 16.0) + 1
+    tx0, tx1 = np.maximum(tx0, cx0), np.minimum(tx1, cx1)
+    ty0, ty1 = np.maximum(ty0, cy0), np.minimum(ty1, cy1)
+    visible = in_depth & ok_det & (radius > 0) & (tx1 > tx0) & (ty1 > ty0) & (kop > 0)
 
     # colour: view direction camera -> Gaussian, taken to model space with S^-1 R^T, renormalised
     dw = pw - np.asarray(view["eye"], dtype=np.float64)
@@ -187,7 +201,10 @@ def project(g, view):
     frac = rad_real - np.floor(rad_real)
     m_radius = np.minimum(frac, 1.0 - frac)
     edges = np.stack([(mx - radius) / 16.0, (mx + radius) / 16.0, (my - radius) / 16.0, (my + radius) / 16.0], 1)
-    m_rect = np.abs(edges - np.round(edges)).min(axis=1) * 16.0
+    clip_edges = np.stack([(mx - ex - 15.5) / 16.0, (mx + ex - 0.5) / 16.0, (my - ey - 15.5) / 16.0,
+                           (my + ey - 0.5) / 16.0], 1)
+    m_rect = np.minimum(np.abs(edges - np.round(edges)).min(axis=1),
+                        np.abs(clip_edges - np.round(clip_edges)).min(axis=1)) * 16.0
     m_depth = np.minimum(np.abs(z - view["near"]), np.abs(z - view["far"]))
     return dict(visible=visible, mx=mx, my=my, conic=conic, cov2d=cov2d, det=det, rgb=rgb, opacity=opacity,
                 depth=z, radius=radius, rect=np.stack([tx0, ty0, tx1, ty1], 1).astype(np.int64),
@@ -301,7 +318,7 @@ def main():
         print(n, "visible", int(p["visible"].sum()), "pairs", pairs, "covered", int((img[..., 3] > 0).sum()),
               "alpha max", img[..., 3].max())
     out["views"] = np.array([v["name"] for v in views()])
-    np.savez_compressed(os.path.join(HERE, "witness_v1.npz"), **out)
+    np.savez_compressed(os.path.join(HERE, "witness_v2.npz"), **out)
 
 
 if __name__ == "__main__":

@@ -1,6 +1,6 @@
 """GPU parity at BASELINE.json's full sizes.  The oracle is too slow to run inside the GPU suite
 at 10 M Gaussians, so these tests use (1) frame / scene hashes the oracle produced offline
-(tests/golden/fullsize_v1.json, generator: tests/golden/make_golden_fullsize.py) — the HIP path is
+(tests/golden/fullsize_v2.json, generator: tests/golden/make_golden_fullsize.py) — the HIP path is
 specified bit-exact, so equal sha256 == equal frames — and (2) size-independent properties of the
 intermediate results: sortedness and stability (in mirror order) of the (tile, depth) pairs, the pair multiset being
 exactly the rect expansion of the projected records, tile ranges partitioning [0, D), idempotence,
@@ -17,7 +17,11 @@ import helpers
 pytestmark = pytest.mark.gpu
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-GOLD = json.load(open(os.path.join(HERE, "golden", "fullsize_v1.json")))
+GOLD = json.load(open(os.path.join(HERE, "golden", "fullsize_v2.json")))
+if os.environ.get("GS3D_RECT_V1") == "1":
+    # the A/B switch of DESIGN.md §3.3: version 1 of the tile rect — same frames, the version-1 counts
+    for _g in GOLD.values():
+        _g["visible"], _g["pairs"] = _g["visible_rect_v1"], _g["pairs_rect_v1"]
 
 
 def _upload(gs, device, stream, g, step=1_000_000):

@@ -1,5 +1,6 @@
 """The debug switches of DESIGN.md §4.4 are read once per process, so the alternative code paths they
-select (the pair-emission start table at small sizes, the ballot-based rank of the radix scatter) are
+select (the pair-emission start table at small sizes, the ballot-based rank of the radix scatter,
+version 1 of the tile rect — for which the oracle binding switches to version 1 as well) are
 exercised by running a subset of the parity tests in a child process per setting — one child at a
 time."""
 import os
@@ -15,7 +16,8 @@ SUBSET = "synthetic_small or emission or capacity_overflow or edge_cases or wide
 
 
 @pytest.mark.parametrize("env", [{"GS3D_CURSOR_KERNEL": "1"}, {"GS3D_DISABLE_FAST_RANK": "1"},
-                                 {"GS3D_BLEND_GROUPS": "1"}], ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
+                                 {"GS3D_BLEND_GROUPS": "1"}, {"GS3D_RECT_V1": "1"}],
+                         ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
 def test_parity_subset_under_switch(env):
     if any(os.environ.get(k) == v for k, v in env.items()):
         pytest.skip("already running under this switch")

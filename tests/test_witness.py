@@ -1,6 +1,6 @@
 """The render stages x1-x5 against an INDEPENDENT float64 witness and closed-form cases.
 
-tests/golden/witness_v1.npz is produced by tests/golden/make_witness.py: a numpy/float64
+tests/golden/witness_v2.npz is produced by tests/golden/make_witness.py: a numpy/float64
 restatement of DESIGN.md §3 written from the text and from Kerbl et al. 2023, not from
 oracle/gs_oracle.c (different loop structure, matrix algebra instead of expanded terms, np.exp,
 np.linalg.inv / eigvalsh).  These tests narrow the common-mode risk that the oracle and the HIP
@@ -21,7 +21,7 @@ import pytest
 import helpers
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-WIT = np.load(os.path.join(HERE, "golden", "witness_v1.npz"))
+WIT = np.load(os.path.join(HERE, "golden", "witness_v2.npz"))
 VIEWS = [str(v) for v in WIT["views"]]
 IMAGE_TOL = 1e-4
 
@@ -164,9 +164,17 @@ def test_closed_form_axis_aligned_gaussian_at_image_centre(ob):
     assert abs(p["depth"] - z) < 1e-6
     assert abs(-2 * p["ca"] - 1 / a) <= 1e-6 / a and abs(-2 * p["cc"] - 1 / c) <= 1e-6 / c
     assert abs(p["cb"]) <= 1e-9
+    # rect: the radius square, clipped to the box the splat can colour: with the axes
+    # aligned the region {alpha >= 1/255} (opacity byte 255) extends sqrt(2 (ln 255 + 0.1) Sigma'_xx) along
+    # x and sqrt(2 (ln 255 + 0.1) Sigma'_yy) along y; tile t holds the pixel centres 16 t + 0.5 ... 16 t + 15.5
     r = np.ceil(3.0 * np.sqrt(max(a, c)))
-    assert p["tx0"] == int((W / 2 - r) // 16) and p["tx1"] == int((W / 2 + r) // 16) + 1
-    assert p["ty0"] == int((H / 2 - r) // 16) and p["ty1"] == int((H / 2 + r) // 16) + 1
+    ex, ey = np.sqrt(2 * (np.log(255.0) + 0.1) * a), np.sqrt(2 * (np.log(255.0) + 0.1) * c)
+    assert ey < r < ex + 1      # this Gaussian is 4:1: the box is clearly narrower than the square along y
+    assert p["tx0"] == max(int((W / 2 - r) // 16), int(np.floor((W / 2 - ex - 15.5) / 16)) + 1)
+    assert p["tx1"] == min(int((W / 2 + r) // 16) + 1, int(np.floor((W / 2 + ex - 0.5) / 16)) + 1)
+    assert p["ty0"] == max(int((H / 2 - r) // 16), int(np.floor((H / 2 - ey - 15.5) / 16)) + 1)
+    assert p["ty1"] == min(int((H / 2 + r) // 16) + 1, int(np.floor((H / 2 + ey - 0.5) / 16)) + 1)
+    assert (p["ty1"] - p["ty0"]) < (int((H / 2 + r) // 16) + 1 - int((H / 2 - r) // 16))   # and it does drop tile rows
     # size scales the covariance by size^2 before the 0.3 dilation
     proj2, _ = ob.preprocess(ob.SH_SINGLE, ob.COV_ROT_SCALE, pods, ob.gaussian_transform(size=2.0, sh_deg=0),
                              ob.model_transform(), cam)

@@ -1520,6 +1520,13 @@ static void make_frame_consts(const gs_gaussian_transform_pod *gt, const gs_mode
     if (fc.band_ty1 < fc.band_ty0) fc.band_ty1 = fc.band_ty0;
     fc.mask_culled_records = 0;
     fc.nt_loads = 0;
+    // in display mode Splat the tile rect is clipped to the splat's visible box.
+    // GS3D_RECT_V1=1 keeps the unclipped rect of spec version 1 (same images, more pairs) for A/B runs
+    // and for the parity tests against the version-1 goldens.
+    {
+        static const bool rect_v1 = std::getenv("GS3D_RECT_V1") && std::getenv("GS3D_RECT_V1")[0] == '1';
+        fc.clip_rect = gt->flags[0] == GS_DISPLAY_SPLAT && !rect_v1 ? 1u : 0u;
+    }
     fc.ellipse_pmin = -0.5f * (fc.max_std_dev * fc.max_std_dev);
     // block culling gain (see block_is_culled): |W R_m S_m|_F^2 bounds the squared spectral norm of
     // the linear part whatever the caller's view matrix is; 0.1 % head room for the f32 arithmetic
