@@ -2,7 +2,7 @@
 """One-off soak of the whole frame against the oracle on randomly drawn scenes: Gaussian count, image
 size, splat scale (from sub-pixel to screen-filling), depth range, POD layout, SH degree, band.
 Every stage is compared bit for bit (tests/test_gpu_render.py::_compare_frame).
-usage (GPU box): python tools/soak_frames.py <first seed> <last seed>"""
+usage (GPU box): python tools/soak_frames.py <first seed> <last seed> [big]"""
 import os
 import sys
 
@@ -20,6 +20,7 @@ import test_gpu_render as t  # noqa: E402
 
 def main():
     lo, hi = int(sys.argv[1]), int(sys.argv[2])
+    big = len(sys.argv) > 3 and sys.argv[3] == "big"
     ob.build()
     dev = gs.Device(0)
     stream = dev.create_stream()
@@ -29,6 +30,9 @@ def main():
         w, h = int(rng.integers(1, 700)), int(rng.integers(1, 500))
         if rng.random() < 0.2:
             w, h = int(rng.choice([16, 1920, 33])), int(rng.choice([16, 1080, 31]))
+        if big:                                     # several sort tiles per pass, several emit workgroups
+            n = int(rng.choice([150_000, 300_000, 500_000]))
+            w, h = int(rng.choice([1920, 1280, 3840])), int(rng.choice([1080, 720, 2160]))
         g = synth.scene(n, first=int(rng.integers(0, 1 << 30)))
         g["scale"] *= np.float32(rng.choice([0.02, 0.3, 1.0, 3.0, 12.0]))
         if rng.random() < 0.3:                      # a few screen-fillers right in front of the camera
