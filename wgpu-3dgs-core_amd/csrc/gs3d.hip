@@ -1335,7 +1335,10 @@ extern "C" gs_status gs_renderer_create(gs_device *dev, gs_renderer **out) {
     if (e == hipSuccess)
         e = hipHostMalloc((void **)&r->results, 2 * sizeof(gs::FrameResult), hipHostMallocMapped | hipHostMallocCoherent);
     for (int i = 0; i < 2 && e == hipSuccess; i++) {
-        e = hipEventCreateWithFlags(&r->done[i], hipEventDisableTiming);
+        // no system-scope fence at the event: what the host reads after it (the frame result) lives in
+        // coherent pinned memory, and images are fetched with copies that synchronise by themselves
+        static const bool fence = std::getenv("GS3D_EVENT_FENCE") && std::getenv("GS3D_EVENT_FENCE")[0] == '1';
+        e = hipEventCreateWithFlags(&r->done[i], hipEventDisableTiming | (fence ? 0u : hipEventDisableSystemFence));
         r->done_valid[i] = false;
         r->done_gen[i] = 0;
     }
