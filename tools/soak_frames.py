@@ -51,7 +51,16 @@ def main():
         if rng.random() < 0.3 and tiles_y > 1:
             a = int(rng.integers(0, tiles_y))
             band = (a, int(rng.integers(a + 1, tiles_y + 1)))
-        st = t._compare_frame(gs, ob, dev, stream, sh, cov, g, w, h, gt_kw=dict(sh_deg=deg), band=band)
+        gt_kw = dict(sh_deg=deg)
+        mt_kw = {}
+        if rng.random() < 0.5:                      # transform uniforms: size, max_std_dev, display mode, model transform
+            gt_kw.update(size=float(rng.choice([0.5, 1.0, 2.0])), max_std_dev=float(rng.choice([1.0, 1.5, 2.5, 3.0])),
+                         mode=int(rng.choice([0, 0, 1, 2])), no_sh0=bool(rng.random() < 0.3))
+            q = rng.normal(size=4)
+            q /= np.linalg.norm(q)
+            mt_kw = dict(pos=tuple(float(x) for x in rng.uniform(-1, 1, 3)), rot=tuple(float(x) for x in q),
+                         scale=tuple(float(x) for x in rng.uniform(0.5, 2.0, 3)))
+        st = t._compare_frame(gs, ob, dev, stream, sh, cov, g, w, h, gt_kw=gt_kw, mt_kw=mt_kw, band=band)
         print("seed %d ok: n %d %dx%d sh %d cov %d deg %d band %s -> V %d D %d" % (
             seed, n, w, h, sh, cov, deg, band, st.visible, st.pairs), flush=True)
 
