@@ -81,3 +81,24 @@ def test_clipped_rect_drops_only_pairs_without_any_visible_pixel(both_versions, 
                 worst = max(worst, float(alpha.max()))
     assert worst < 1.0 / 255.0, "a dropped pair would have coloured a pixel (alpha %g)" % worst
     assert worst < 0.93 / 255.0      # and with the head room the definition asks for (exp(-0.1) = 0.905)
+
+
+def _table_after(path, marker):
+    import re
+    text = open(path).read()
+    body = text[text.index(marker):]
+    body = body[body.index("{") + 1:body.index("};")]
+    vals = [float(x.rstrip("f")) for x in re.findall(r"[-+]?[0-9]*\.?[0-9]+(?:[eE][-+]?[0-9]+)?f", body)]
+    return np.asarray(vals, dtype=np.float32)
+
+
+def test_ln_tables_of_product_and_oracle_are_ln_k_correctly_rounded():
+    """L(k) = ln k rounded to binary32, entry 0 unused (0).  The product's table
+    (device constant) and the oracle's are separate texts: both must be the same 256 numbers."""
+    root = os.path.dirname(HERE)
+    want = np.concatenate([[np.float32(0.0)], np.log(np.arange(1, 256, dtype=np.float64)).astype(np.float32)])
+    prod = _table_after(os.path.join(root, "wgpu-3dgs-core_amd", "csrc", "gs_render_kernels.h"), "k_ln_opacity_byte[256]")
+    orac = _table_after(os.path.join(root, "oracle", "gs_oracle.c"), "LN_OPACITY_BYTE[256]")
+    assert prod.shape == orac.shape == (256,)
+    assert np.array_equal(prod.view(np.uint32), want.view(np.uint32))
+    assert np.array_equal(orac.view(np.uint32), want.view(np.uint32))
