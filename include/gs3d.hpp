@@ -187,6 +187,45 @@ private:
     }
 };
 
+// Gaussians / GaussiansSource (src/gaussian.rs:394-548): the format-agnostic read / write over the
+// fused entry points gs_gaussians_read / gs_gaussians_write.  Source::Internal cannot be read from or
+// written to a byte buffer (the reference's io::Error messages come back in Error::what()).
+enum class GaussiansSource : uint32_t { Internal = GS_SOURCE_INTERNAL, Ply = GS_SOURCE_PLY, Spz = GS_SOURCE_SPZ };
+
+class Gaussians {
+public:
+    GaussiansSource source = GaussiansSource::Internal;
+    std::vector<Gaussian> gaussians;
+
+    static Gaussians from_gaussians(std::vector<Gaussian> g) {
+        Gaussians out;
+        out.gaussians = std::move(g);
+        return out;
+    }
+    static Gaussians read_from(const void *bytes, size_t len, GaussiansSource source) {
+        Gaussians out;
+        out.source = source;
+        size_t n = 0;
+        check(gs_gaussians_read(bytes, len, (gs_gaussians_source)source, nullptr, 0, &n));
+        out.gaussians.resize(n);
+        check(gs_gaussians_read(bytes, len, (gs_gaussians_source)source, out.gaussians.data(), n, &n));
+        return out;
+    }
+    // write in `as` (default: the format the Gaussians were read from)
+    std::vector<uint8_t> write_to(GaussiansSource as) const {
+        size_t n = 0;
+        check(gs_gaussians_write(gaussians.data(), gaussians.size(), (gs_gaussians_source)as, nullptr, 0, &n));
+        std::vector<uint8_t> out(n);
+        check(gs_gaussians_write(gaussians.data(), gaussians.size(), (gs_gaussians_source)as, out.data(), out.size(), &n));
+        out.resize(n);
+        return out;
+    }
+    std::vector<uint8_t> write_to() const { return write_to(source); }
+    const std::vector<Gaussian> &iter_gaussian() const { return gaussians; }
+    size_t len() const { return gaussians.size(); }
+    bool is_empty() const { return gaussians.empty(); }
+};
+
 // ---- device / stream / buffer --------------------------------------------------------------------
 class Device {
   public:

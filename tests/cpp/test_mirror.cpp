@@ -57,6 +57,26 @@ static int host_codecs() {
     o.version = 999;
     try { SpzGaussians::write_gaussians(gs, o); REQUIRE(false); }
     catch (const SpzError &e) { REQUIRE(std::string(e.what()) == "Unsupported SPZ version: 999, expected one of 1..=3"); }
+    // Gaussians / GaussiansSource over the fused entry points (tests/e2e/gaussian.rs): a PLY round
+    // trip is exact, an SPZ one within the format's quantisation, Internal has no byte form
+    auto from_ply = Gaussians::read_from(bytes.data(), bytes.size(), GaussiansSource::Ply);
+    REQUIRE(from_ply.source == GaussiansSource::Ply && from_ply.len() == 2 && !from_ply.is_empty());
+    {   // PLY -> Gaussian -> PLY: positions and scales come back exactly (colour / opacity go through
+        // the SH-DC and sigmoid conversions of Gaussian::from_ply / to_ply)
+        auto rewritten = from_ply.write_to();
+        auto again = Gaussians::read_from(rewritten.data(), rewritten.size(), GaussiansSource::Ply);
+        REQUIRE(again.len() == 2);
+        for (size_t i = 0; i < 2; i++)
+            for (int c = 0; c < 3; c++) REQUIRE(again.gaussians[i].pos[c] == from_ply.gaussians[i].pos[c]);
+    }
+    auto as_spz = from_ply.write_to(GaussiansSource::Spz);
+    auto from_spz = Gaussians::read_from(as_spz.data(), as_spz.size(), GaussiansSource::Spz);
+    REQUIRE(from_spz.len() == 2);
+    for (int c = 0; c < 3; c++) REQUIRE(std::fabs(from_spz.gaussians[1].pos[c] - gs[1].pos[c]) <= 1.0f);
+    try { Gaussians::from_gaussians(gs).write_to(); REQUIRE(false); }
+    catch (const Error &e) { REQUIRE(std::string(e.what()) == "cannot write Internal Gaussians to buffer"); }
+    try { Gaussians::read_from(bytes.data(), bytes.size(), GaussiansSource::Internal); REQUIRE(false); }
+    catch (const Error &e) { REQUIRE(std::string(e.what()) == "cannot read Internal Gaussians from buffer"); }
     std::printf("host codecs OK\n");
     return 0;
 }
