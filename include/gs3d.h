@@ -535,7 +535,9 @@ gs_status gs_renderer_stats(gs_renderer *r, gs_frame_stats *out);
  * its farthest pairs are dropped and gs_renderer_wait_frame reports GS_ERR_PAIR_CAPACITY.
  *
  * Frames in flight: a renderer owns the scratch buffers of ONE frame, so consecutive frames on one
- * renderer run one after the other.  To overlap frames (the sort chain of frame i + 1 fills the gaps
+ * renderer run one after the other: in stream order on one stream, and when a frame is submitted on a
+ * different stream than the renderer's previous frame it is ordered behind that frame's end-of-frame
+ * event (a device-side wait, the call does not block).  To overlap frames (the sort chain of frame i + 1 fills the gaps
  * of frame i's blend: +20 % frames per second at 1 M Gaussians), use one gs_renderer per frame slot,
  * each on its own gs_stream, and hand them the frames in turn; the Gaussian buffer is shared (the
  * renderer-internal mirror of the buffer is built on the stream of the first frame that needs it and

@@ -475,6 +475,58 @@ def test_two_renderers_keep_frames_in_flight_on_one_buffer(gs, ob, device, strea
     buf.destroy()
 
 
+def test_one_renderer_alternating_streams_is_ordered(gs, ob, device, stream):
+    """ONE renderer handed frames on two streams in turn with no host synchronisation in between: the
+    frames share the renderer's scratch buffers, so gs_render_frame orders each frame behind the
+    previous one's end-of-frame event when the stream changes (round-2 advisor finding: a silent data
+    race before).  Frames of two cameras and an empty buffer (whose result block is published in
+    stream order) must all equal the oracle's; the empty frame in between must report V = D = 0."""
+    import synth
+    g = synth.scene(60000, first=7)
+    pod = gs.GaussianPod(gs.SH_HALF, gs.COV3D_ROT_SCALE)
+    pods = pod.from_gaussian(g)
+    buf = gs.GaussiansBuffer.new_with_pods(device, pod, pods)
+    empty = gs.GaussiansBuffer.new_with_pods(device, pod, pods[:0])
+    W, H = 800, 600
+    cams = [helpers.default_camera(gs, W, H), helpers.default_camera(gs, W, H, eye=(0.5, 0.2, 1.0), target=(0.4, 0.1, -1.0))]
+    gt, mt = gs.gaussian_transform_pod(sh_deg=2), gs.model_transform_pod()
+    streams = [device.create_stream(), device.create_stream()]
+    r = gs.Renderer(device)
+    for k in range(2):       # sizing frames (blocking), so that the loop below only enqueues
+        tmp = gs.Buffer(device, size=W * H * 16)
+        r.render(streams[k], buf, gt, mt, cams[k], tmp.device_ptr())
+        tmp.release()
+    imgs = [gs.Buffer(device, size=W * H * 16) for _ in range(8)]
+    for i in range(8):
+        r.render(streams[i & 1], buf, gt, mt, cams[(i >> 1) & 1], imgs[i].device_ptr(), check=False)
+    fr = r.wait_frame()
+    assert fr.pairs > 0
+    # an empty frame between two full ones, on alternating streams
+    e_img = gs.Buffer(device, size=W * H * 16)
+    r.render(streams[0], buf, gt, mt, cams[0], imgs[0].device_ptr(), check=False)
+    r.render(streams[1], empty, gt, mt, cams[0], e_img.device_ptr(), check=False)
+    fe = r.wait_frame()
+    assert (fe.visible, fe.pairs, fe.flags) == (0, 0, 0)
+    r.render(streams[0], buf, gt, mt, cams[1], imgs[1].device_ptr(), check=False)
+    r.wait_frame()
+    for s in streams:
+        s.synchronize()
+    order = _mirror_order(ob, buf, stream, pod.sh, pod.cov, pods)
+    want = [ob.render(pod.sh, pod.cov, pods, ob.gaussian_transform(sh_deg=2), ob.model_transform(),
+                      helpers.copy_camera(c, ob.Camera), order=order)[0] for c in cams]
+    for i in range(8):
+        k = (i >> 1) & 1 if i > 1 else i      # imgs[0] / imgs[1] were re-rendered with cams[0] / cams[1] above
+        rgba = imgs[i].download(stream, np.float32).reshape(H, W, 4)
+        assert np.array_equal(rgba.view(np.uint32), want[k].view(np.uint32)), i
+        imgs[i].release()
+    bg = e_img.download(stream, np.float32).reshape(H, W, 4)
+    assert not bg.any()          # background 0, alpha 0
+    e_img.release()
+    r.destroy()
+    buf.destroy()
+    empty.destroy()
+
+
 def test_image_size_limits_are_rejected(gs, device, stream):
     """more than 2^22 tiles, or more than 65535 tiles along one axis (tile rects are packed as 16-bit
     coordinates): GS_ERR_INVALID_ARGUMENT before anything is launched"""

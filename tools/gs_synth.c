@@ -14,6 +14,9 @@
 #include <math.h>
 #include <stddef.h>
 #include <stdint.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 typedef struct {
     float rot[4];
@@ -32,6 +35,15 @@ static inline uint64_t splitmix64(uint64_t x) {
 
 static inline double uni(uint64_t seed, uint64_t i, uint64_t k) {
     return (double)(splitmix64(seed ^ (i * 64u + k)) >> 40) * (1.0 / 16777216.0);
+}
+
+/* OpenMP threads of gs_synth_scene (a launcher may have exported OMP_NUM_THREADS=1) */
+void gs_synth_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
 }
 
 void gs_synth_scene(uint64_t seed, uint64_t first, uint64_t count, synth_gaussian *out) {

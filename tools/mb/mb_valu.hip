@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -56,8 +57,34 @@ static void run(const char *name, int instr_per_item) {
     printf("\n");
 }
 
-int main() {
+// --pmc: only what the counter calibration needs (tools/calibrate_valu.sh runs this under
+// rocprofv3 --pmc): the saturating v_fma_f32 and v_pk_fma_f32 streams at 8 waves per SIMD, a few
+// launches each, wall time per launch printed beside them.  A pure stream of independent VALU
+// instructions at 8 waves per SIMD keeps the SIMD's vector issue busy all the time: its counters
+// per SIMD-cycle are what "VALU busy = 1.0" looks like on this part.
+template <int KIND>
+static void run_pmc(const char *name) {
+    float *out; CK(hipMalloc(&out, 4096));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const int iters = 16384, wps = 8, blocks = 256 * wps;
+    for (int rep = 0; rep < 4; rep++) {
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(256), 0, 0, out, iters, 1.0f);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        const double inst = (double)wps * iters * UNROLL;     // loop-body VALU wave-instructions per SIMD
+        printf("CAL %s kind=%d launch=%d ms=%.4f body_insts_per_simd=%.0f ns_per_inst=%.4f\n", name, KIND, rep, ms, inst,
+               ms * 1e6 / inst);
+    }
+}
+
+int main(int argc, char **argv) {
     setvbuf(stdout, NULL, _IONBF, 0);
+    if (argc > 1 && !strcmp(argv[1], "--pmc")) {
+        run_pmc<0>("v_fma_f32");
+        run_pmc<1>("v_pk_fma_f32");
+        return 0;
+    }
     run<0>("v_fma_f32", 1);
     run<1>("v_pk_fma_f32", 1);
     run<2>("v_mul_f32", 1);

@@ -31,6 +31,15 @@ def build(force=False):
 
 
 _lib = None
+_threads = None
+
+
+def set_threads(n):
+    """OpenMP threads of the generator (torchrun exports OMP_NUM_THREADS=1 to every rank)."""
+    global _threads
+    _threads = int(n)
+    if _lib is not None:
+        _lib.gs_synth_set_threads(_threads)
 
 
 def scene(count, first=0, seed=SEED):
@@ -40,6 +49,9 @@ def scene(count, first=0, seed=SEED):
         build()
         _lib = C.CDLL(_LIB)
         _lib.gs_synth_scene.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p]
+        _lib.gs_synth_set_threads.argtypes = [C.c_int]
+        if _threads is not None:
+            _lib.gs_synth_set_threads(_threads)
     out = np.zeros(count, dtype=GAUSSIAN_DTYPE)
     _lib.gs_synth_scene(seed, first, count, out.ctypes.data_as(C.c_void_p))
     return out

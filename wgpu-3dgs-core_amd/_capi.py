@@ -3,6 +3,7 @@ library is missing or cannot be built: there is no pure-Python / CPU path behind
 import ctypes as C
 import os
 
+from . import _hiprt
 from . import build as _build
 
 vp, sz, u8, u32, i32, u64, f32 = (C.c_void_p, C.c_size_t, C.c_uint8, C.c_uint32, C.c_int32,
@@ -195,7 +196,10 @@ def load():
                 raise ImportError(
                     "libgs3d_hip.so is missing and could not be built (%s); this package has no "
                     "CPU fallback" % exc) from exc
+    # one HIP runtime per process whatever the import order of torch and this package (_hiprt.py)
+    _hiprt.prepare()
     lib = C.CDLL(_build.LIB_PATH)
+    _hiprt.check()
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch: fail loudly
         fn.restype = res

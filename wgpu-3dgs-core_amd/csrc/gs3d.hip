@@ -1963,6 +1963,12 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
     GS_TRY(use_device(r->dev));
     hipStream_t st = s->s;
     GS_TRY(collect_timing(r));
+    // Frames of one renderer share its scratch buffers and result blocks, so they must run one after
+    // the other.  On one stream that is stream order; a caller that moves the renderer to ANOTHER
+    // stream gets the same guarantee from the previous frame's end-of-frame event (a device-side wait,
+    // the host does not block).
+    if (r->have_frame && st != r->last_stream && r->done_valid[r->gen & 1u])
+        GS_HIP(hipStreamWaitEvent(st, r->done[r->gen & 1u], 0));
     const bool timing = r->timing && r->ev_valid;
     static const char *const k_stage_names[ST_COUNT] = {"gs3d:repack", "gs3d:preprocess", "gs3d:sizing", "gs3d:depth_sort",
                                                         "gs3d:expand", "gs3d:tile_sort", "gs3d:ranges", "gs3d:blend",
@@ -1995,7 +2001,8 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
     for (int i = 0; i < 2; i++) {
         if (!r->done_valid[i] || hipEventQuery(r->done[i]) != hipSuccess) continue;
         const gs::FrameResult &fr = r->results[i];
-        if (fr.gen != r->done_gen[i] || fr.pairs_total > 0xfffffff0ull) continue;
+        // gen is published last with a system-scope release (publish_result): read it first
+        if (__atomic_load_n(&fr.gen, __ATOMIC_ACQUIRE) != r->done_gen[i] || fr.pairs_total > 0xfffffff0ull) continue;
         // grow when the last measured D leaves less than 1/8 of head room
         if (fr.pairs_total + fr.pairs_total / 8 > r->pair_capacity && capacity_for(fr.pairs_total) > want_capacity)
             want_capacity = capacity_for(fr.pairs_total);
@@ -2057,10 +2064,9 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
         GS_TRY(dev_reserve(r->zero_region, (size_t)num_tiles * 8));
         GS_HIP(hipMemsetAsync(r->zero_region.ptr, 0, (size_t)num_tiles * 8, st));
         GS_TRY(reserve_pairs(r, 1, wide));
-        result->visible = 0;
-        result->pairs_total = 0;
-        result->flags = 0;
-        result->gen = gen;
+        hipLaunchKernelGGL(gs::k_publish_result, dim3(1), dim3(64), 0, st, result, state, gen);
+        GS_HIP(hipGetLastError());
+        r->launches++;
         mark(ST_SCAN); mark(ST_DSORT); mark(ST_EXPAND); mark(ST_TSORT); mark(ST_RANGES);
         r->sort_passes = 0;
         r->dsorted_side = r->tsorted_side = 0;

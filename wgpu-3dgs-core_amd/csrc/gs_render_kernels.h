@@ -158,6 +158,28 @@ struct FrameResult {
     uint32_t pad[3];
 };
 
+// One thread publishes a frame's result to pinned host memory.  `gen` goes LAST, behind a
+// system-scope release: a host that polls the block without a fencing event (hipEventQuery on an
+// event created with hipEventDisableSystemFence, then a read) and finds the expected generation
+// also finds that generation's counts.
+__device__ __forceinline__ void publish_result(FrameResult *r, uint32_t visible, uint64_t pairs_total, uint32_t flags,
+                                               uint32_t gen) {
+    r->visible = visible;
+    r->pairs_total = pairs_total;
+    r->flags = flags;
+    __hip_atomic_store(&r->gen, gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// the frame without Gaussians: its (empty) result is published IN STREAM ORDER like every other
+// frame's, so an older frame still in flight on the same result block cannot overwrite it later
+__global__ void k_publish_result(FrameResult *r, FrameState *state, uint32_t gen) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        state->visible = 0;
+        state->pairs = 0;
+        publish_result(r, 0u, 0ull, 0u, gen);
+    }
+}
+
 // wave sum of a 64-bit value, uniform in every lane (all 64 lanes active)
 __device__ __forceinline__ uint64_t wave_reduce_add64(uint64_t v) {
 #pragma unroll
@@ -1559,10 +1581,7 @@ __global__ __launch_bounds__(EXP_SB) void k_pairs_cursors(ExpandIO io) {
     if (sb == 0u && threadIdx.x == 0u) {
         const uint32_t over = d > (uint64_t)io.capacity ? FRAME_FLAG_PAIR_OVERFLOW : 0u;
         io.state->pairs = over ? io.capacity : (uint32_t)d;
-        io.result->visible = v_count;
-        io.result->pairs_total = d;
-        io.result->flags = over;
-        io.result->gen = io.gen;
+        publish_result(io.result, v_count, d, over, io.gen);
     }
     if (v == 0ull) return;
     const uint64_t p = s_before[0] + s_before[1] + (wid ? s_wave0 : 0ull) + incl - v;   // pairs in front of chunk c
@@ -1758,10 +1777,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_pairs_emit(ExpandIO io, uint32
         if (block == 0u && threadIdx.x == 0u) {
             const uint32_t over = d > (uint64_t)io.capacity ? FRAME_FLAG_PAIR_OVERFLOW : 0u;
             io.state->pairs = count;
-            io.result->visible = v_count;
-            io.result->pairs_total = d;
-            io.result->flags = over;
-            io.result->gen = io.gen;
+            publish_result(io.result, v_count, d, over, io.gen);
         }
     }
     if ((uint64_t)block * TILE >= count) return;      // the same D in every wave: block-uniform

@@ -15,8 +15,23 @@ Exchange layout: every rank renders its band straight into ITS chunk of a gather
 G equal chunks (chunk = the tallest band, in pixel rows); one in-place all-gather fills the other
 chunks; `assemble` returns the contiguous image.  Equal chunks keep the exchange a single
 fixed-size collective whatever the plan.
+
+One HIP runtime: the torch wheel bundles its own libamdhip64 / libhsa-runtime64 and the product
+library must run on the SAME copy as torch and RCCL (two runtimes in one process: the second finds
+no GPU).  `_capi.load()` arranges that for either import order (`_hiprt.py`: torch's copy is mapped
+first whenever torch is installed); every entry point here that receives the torch module re-checks
+it (`_hiprt.check`) so that a process that forced GS3D_HIP_RUNTIME=system and then imported torch
+fails with a clear message instead of "No HIP GPUs are available".
+
+Streams: launch on a dedicated non-default stream (`torch.cuda.Stream()`, wrapped with
+`Device.wrap_stream(s.cuda_stream)` and made current with `torch.cuda.stream(s)` around the calls of
+this module): RCCL orders its own stream behind the CURRENT stream when a collective is issued and
+`work.wait()` makes the CURRENT stream wait for it; the legacy null stream would serialise with every
+other stream of the device and defeat the overlap `FramePipeline` exists for.
 """
 import numpy as np
+
+from . import _hiprt
 
 TILE = 16
 
@@ -76,6 +91,7 @@ def band_plan(height, world_size):
 def allocate_gather(torch, plan, width, device):
     """Gather buffer [G * chunk_rows, width, 4] f32: chunk g holds band g from its first row on;
     the rows of a chunk past its band's height are never written."""
+    _hiprt.check("torch")
     return torch.zeros((plan.world_size * plan.chunk_rows, width, 4), dtype=torch.float32, device=device)
 
 
@@ -87,14 +103,16 @@ def band_target_ptr(buf, plan, rank, width):
     return buf.data_ptr() + (rank * plan.chunk_rows - y0) * width * 16
 
 
-def gather_bands(dist, buf, plan, rank, async_op=False):
+def gather_bands(dist, buf, plan, rank, async_op=False, force=False):
     """One all-gather, in place: every rank contributes its chunk of `buf`.  The form of the
     collective is chosen once from the backend (never by catching an error from a collective: ranks
     that disagree about which collective they are in deadlock).  async_op=True (RCCL only) returns
     the work handle: the collective runs on its own stream behind the render already enqueued, and
-    the caller's stream goes on without waiting for it until handle.wait()."""
+    the caller's stream goes on without waiting for it until handle.wait().  A world of one has
+    nothing to exchange and returns at once unless force=True, which issues the collective anyway
+    (tests: the real RCCL call, its in-place aliasing and its stream semantics on ONE GPU)."""
     g = plan.world_size
-    if g == 1:
+    if g == 1 and not force:
         return None
     c = plan.chunk_rows
     mine = buf[rank * c:(rank + 1) * c]
@@ -134,9 +152,10 @@ class FramePipeline:
         image = pipe.finish(i - 1)     # the complete previous frame (orders the caller's stream behind its exchange)
     """
 
-    def __init__(self, torch, dist, plan, rank, width, device, depth=2):
+    def __init__(self, torch, dist, plan, rank, width, device, depth=2, force_collective=False):
         assert depth >= 2
         self.torch, self.dist, self.plan, self.rank, self.width = torch, dist, plan, rank, width
+        self.force = bool(force_collective)
         self.bufs = [allocate_gather(torch, plan, width, device) for _ in range(depth)]
         self.work = [None] * depth          # exchange in flight on each buffer
         self.frame = [None] * depth         # frame number each buffer holds
@@ -158,7 +177,7 @@ class FramePipeline:
     def submit(self, i):
         k = self._slot(i)
         assert self.frame[k] == i
-        self.work[k] = gather_bands(self.dist, self.bufs[k], self.plan, self.rank, async_op=True)
+        self.work[k] = gather_bands(self.dist, self.bufs[k], self.plan, self.rank, async_op=True, force=self.force)
 
     def finish(self, i):
         k = self._slot(i)
