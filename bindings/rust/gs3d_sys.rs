@@ -258,6 +258,7 @@ extern "C" {
     pub fn gs_model_transform_pod_default(out: *mut gs_model_transform_pod);
     pub fn gs_ply_property_name(index: u32) -> *const c_char;
     pub fn gs_gaussian_from_ply(r#in: *const gs_ply_gaussian_pod, n: usize, out: *mut gs_gaussian);
+    pub fn gs_expf(x: f32) -> f32;
     pub fn gs_gaussian_to_ply(r#in: *const gs_gaussian, n: usize, out: *mut gs_ply_gaussian_pod);
     pub fn gs_ply_read(bytes: *const c_void, len: usize, out: *mut gs_ply_gaussian_pod, capacity: usize, count_out: *mut usize, is_inria_out: *mut i32) -> gs_status;
     pub fn gs_ply_write(pods: *const gs_ply_gaussian_pod, n: usize, out: *mut c_void, capacity: usize, bytes_out: *mut usize) -> gs_status;
@@ -293,6 +294,9 @@ extern "C" {
     pub fn gs_download_release(d: *mut gs_download);
     pub fn gs_gaussians_buffer_create(dev: *mut gs_device, sh: u32, cov: u32, pods_or_null: *const c_void, len: usize, out: *mut *mut gs_gaussians_buffer) -> gs_status;
     pub fn gs_gaussians_buffer_create_from_gaussians(dev: *mut gs_device, sh: u32, cov: u32, gaussians: *const gs_gaussian, len: usize, out: *mut *mut gs_gaussians_buffer) -> gs_status;
+    pub fn gs_gaussians_buffer_create_from_ply(dev: *mut gs_device, sh: u32, cov: u32, ply: *const gs_ply_gaussian_pod, len: usize, out: *mut *mut gs_gaussians_buffer) -> gs_status;
+    pub fn gs_gaussians_buffer_update_range_ply(g: *mut gs_gaussians_buffer, s: *mut gs_stream, start: usize, ply: *const gs_ply_gaussian_pod, count: usize) -> gs_status;
+    pub fn gs_pack_device_from_ply(dev: *mut gs_device, s: *mut gs_stream, sh: u32, cov: u32, ply_device: *const gs_ply_gaussian_pod, n: usize, pods_device: *mut c_void) -> gs_status;
     pub fn gs_pack_device(dev: *mut gs_device, s: *mut gs_stream, sh: u32, cov: u32, gaussians_device: *const gs_gaussian, n: usize, pods_device: *mut c_void) -> gs_status;
     pub fn gs_gaussians_buffer_from_buffer(buffer: *mut gs_buffer, sh: u32, cov: u32, out: *mut *mut gs_gaussians_buffer) -> gs_status;
     pub fn gs_gaussians_buffer_destroy(g: *mut gs_gaussians_buffer);

@@ -171,6 +171,10 @@ typedef struct gs_ply_gaussian_pod {
 const char *gs_ply_property_name(uint32_t index);
 /* Gaussian::from_ply / Gaussian::to_ply — src/gaussian.rs:70-125 */
 void gs_gaussian_from_ply(const gs_ply_gaussian_pod *in, size_t n, gs_gaussian *out);
+/* The exp of Gaussian::from_ply (f32::exp in the reference, src/gaussian.rs:76,81): the double-based
+ * table algorithm glibc's expf uses, restated so that the host path above and the device path
+ * (gs_pack_device_from_ply) give the same bits (csrc/gs_convert.h). */
+float gs_expf(float x);
 void gs_gaussian_to_ply(const gs_gaussian *in, size_t n, gs_ply_gaussian_pod *out);
 /* PlyGaussians::read_from — ply.rs:292-408.  Call with out == NULL to get the vertex count, then
  * with a buffer.  Handles the Inria fast path (one memcpy) and custom property orders in ascii /
@@ -312,6 +316,20 @@ gs_status gs_gaussians_buffer_create(gs_device *dev, gs_sh_config sh, gs_cov3d_c
 gs_status gs_gaussians_buffer_create_from_gaussians(gs_device *dev, gs_sh_config sh,
                                                     gs_cov3d_config cov, const gs_gaussian *gaussians,
                                                     size_t len, gs_gaussians_buffer **out);
+/* PlyGaussians -> GaussiansBuffer in one step: the 248-byte vertex records cross PCIe as they are (one
+ * copy per slice) and ONE kernel does Gaussian::from_ply (src/gaussian.rs:70-92) fused with
+ * G::from_gaussian (src/buffer/gaussian.rs:314-339) — what the reference does per vertex on the host
+ * (src/source_format/ply.rs:386-390 iter_gaussian + src/buffer/gaussian.rs:21-30 new).  The PODs are
+ * bit-equal to gs_gaussian_from_ply followed by gs_pack. */
+gs_status gs_gaussians_buffer_create_from_ply(gs_device *dev, gs_sh_config sh, gs_cov3d_config cov,
+                                              const gs_ply_gaussian_pod *ply, size_t len,
+                                              gs_gaussians_buffer **out);
+/* the same for [start, start + count) of an existing buffer (update_range semantics and errors) */
+gs_status gs_gaussians_buffer_update_range_ply(gs_gaussians_buffer *g, gs_stream *s, size_t start,
+                                               const gs_ply_gaussian_pod *ply, size_t count);
+/* the kernel itself: `n` PlyGaussianPod records in DEVICE memory -> PODs in device memory */
+gs_status gs_pack_device_from_ply(gs_device *dev, gs_stream *s, gs_sh_config sh, gs_cov3d_config cov,
+                                  const gs_ply_gaussian_pod *ply_device, size_t n, void *pods_device);
 /* TryFrom<wgpu::Buffer> — :213-229; the wrapper retains `buffer` */
 /* G::from_gaussian on the device (src/buffer/gaussian.rs:314-339 for all 12 PODs): `n` source
  * records (struct Gaussian, 224 bytes each) already in device memory -> PODs in device memory, bit-equal

@@ -105,6 +105,7 @@ def lib():
     L.gso_given_gaussian_with_seed.argtypes = [u32, vp]
     L.gso_gaussian_from_ply.argtypes = [vp, vp]
     L.gso_gaussian_to_ply.argtypes = [vp, vp]
+    L.gso_gaussians_from_ply.argtypes = [vp, sz, vp]
     L.gso_read_inria_ply.restype = C.c_long
     L.gso_read_inria_ply.argtypes = [vp, sz, vp, sz]
     L.gso_spz_decode_raw.restype = C.c_long
@@ -165,6 +166,14 @@ def unpack_to_gaussian(sh, cov, pods):
     out = np.zeros(n, dtype=GAUSSIAN_DTYPE)
     rc = lib().gso_unpack_to_gaussian(sh, cov, _p(pods), n, _p(out))
     return rc, out
+
+
+def gaussians_from_ply(ply):
+    """Gaussian::from_ply over an array of PlyGaussianPod (libm expf: the reference's f32::exp on Linux)"""
+    p = np.ascontiguousarray(np.atleast_1d(ply), dtype=PLY_DTYPE)
+    out = np.zeros(len(p), dtype=GAUSSIAN_DTYPE)
+    lib().gso_gaussians_from_ply(_p(p), len(p), _p(out))
+    return out
 
 
 def shader_test_gaussian(sh, cov, pod_bytes):

@@ -501,6 +501,12 @@ void gso_gaussian_from_ply(const gso_ply_pod *ply, gso_gaussian *out) {
     }
 }
 
+/* PlyGaussians::iter_gaussian — src/source_format/ply.rs:386-390 (from_ply over all vertices; libm expf) */
+void gso_gaussians_from_ply(const gso_ply_pod *ply, size_t n, gso_gaussian *out) {
+#pragma omp parallel for schedule(static)
+    for (long long i = 0; i < (long long)n; i++) gso_gaussian_from_ply(&ply[i], &out[i]);
+}
+
 /* src/gaussian.rs:95-125 */
 void gso_gaussian_to_ply(const gso_gaussian *g, gso_ply_pod *out) {
     memcpy(out->pos, g->pos, 12);

@@ -135,6 +135,7 @@ void gso_model_to_world(const gso_model_transform *m, const float p[3], float ou
 /* ---- fixtures ---- */
 void gso_given_gaussian_with_seed(uint32_t seed, gso_gaussian *out);
 void gso_gaussian_from_ply(const gso_ply_pod *ply, gso_gaussian *out);
+void gso_gaussians_from_ply(const gso_ply_pod *ply, size_t n, gso_gaussian *out);
 void gso_gaussian_to_ply(const gso_gaussian *g, gso_ply_pod *out);
 /* Inria fast-path reader: returns count (>=0) or negative error; out may be NULL to query count */
 long gso_read_inria_ply(const uint8_t *bytes, size_t len, gso_ply_pod *out, size_t cap);

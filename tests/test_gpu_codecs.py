@@ -134,3 +134,74 @@ def test_prepare_download_map_download(gs, device, stream):
     assert not got2[:4].any() and np.array_equal(got2[4:], data[4:])
     d2.release()
     buf.release()
+
+
+@pytest.mark.parametrize("pod_idx", range(12))
+def test_device_from_ply_equals_host_path(gs, ob, device, stream, pod_idx):
+    """PLY vertex records -> PODs in ONE device kernel (Gaussian::from_ply fused with G::from_gaussian,
+    gs_gaussians_buffer_create_from_ply) must be byte-equal to the host path gs_gaussian_from_ply +
+    gs_pack (same gs_convert.h arithmetic on both sides, incl. the specified exp): the reference's
+    data file, 300 k synthetic vertices with hostile values (inf / NaN / overflowing and subnormal exp
+    results / zero quaternions), and a ranged update."""
+    from test_ply import _synthetic_ply
+    pod = gs.ALL_PODS[pod_idx]
+    for name, ply in (("model.ply", gs.PlyGaussians.read_from_file(os.path.join(GOLD, "model.ply")).pods),
+                      ("synthetic", _synthetic_ply(300_000, seed=pod_idx))):
+        want = pod.from_gaussian(gs.gaussian_from_ply(ply))
+        buf = gs.GaussiansBuffer.new_from_ply(device, pod, ply)
+        assert len(buf) == len(ply)
+        got = buf.download(stream)
+        assert np.array_equal(got, want.reshape(-1)), "%s: device from_ply differs from the host path (%s)" % (name, pod)
+        # a ranged update through the same kernel
+        if len(ply) > 1000:
+            part = _synthetic_ply(777, seed=100 + pod_idx)
+            buf.update_range_from_ply(stream, 123, part)
+            w2 = want.reshape(len(ply), -1).copy()
+            w2[123:123 + 777] = pod.from_gaussian(gs.gaussian_from_ply(part)).reshape(777, -1)
+            assert np.array_equal(buf.download(stream), w2.reshape(-1))
+            with pytest.raises(gs.GaussiansBufferUpdateRangeError):
+                buf.update_range_from_ply(stream, len(ply) - 5, part)
+        buf.destroy()
+    empty = gs.GaussiansBuffer.new_from_ply(device, pod, np.zeros(0, dtype=gs.PLY_GAUSSIAN_DTYPE))
+    assert empty.is_empty()
+    empty.destroy()
+
+
+def test_device_from_ply_frame_and_load_time(gs, ob, device, stream):
+    """file -> gs_ply_read -> device from_ply + pack -> frame == the oracle's frame of the oracle's own
+    from_ply (libm), on a 1 M-vertex PLY written by the product's writer; also records the load time
+    split (host from_ply vs device path) for DESIGN.md §7."""
+    import time
+    from test_ply import _synthetic_ply
+    n = 1_000_000
+    ply = _synthetic_ply(n, seed=77)
+    ply["pos"][:, 2] = -np.abs(ply["pos"][:, 2]) - 2.0
+    ply["scale"] = np.clip(ply["scale"], -7.0, -2.5)
+    ply["rot"][25:28] = (1.0, 0.1, 0.2, 0.3)
+    data = gs.PlyGaussians(ply).write_to()
+    back = gs.PlyGaussians.read_from(data)
+    assert np.array_equal(back.pods.view(np.uint32), ply.view(np.uint32))
+    pod = gs.GaussianPodWithShHalfCov3dRotScaleConfigs
+    t0 = time.perf_counter()
+    buf = gs.GaussiansBuffer.new_from_ply(device, pod, back)
+    t_dev = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    g_host = gs.gaussian_from_ply(back.pods)
+    t_host = time.perf_counter() - t0
+    go = ob.gaussians_from_ply(ply)
+    opods = ob.pack(pod.sh, pod.cov, go)
+    assert np.array_equal(buf.download(stream), opods), "device from_ply + pack differs from oracle from_ply + pack"
+    assert np.array_equal(pod.from_gaussian(g_host).reshape(-1), opods)
+    W, H = 1280, 720
+    ocam = helpers.default_camera(ob, W, H)
+    cam = helpers.copy_camera(ocam, gs.Camera)
+    img = gs.Buffer(device, size=W * H * 16)
+    r = gs.Renderer(device)
+    r.render(stream, buf, gs.gaussian_transform_pod(sh_deg=3), gs.model_transform_pod(), cam, img.device_ptr())
+    rgba = img.download(stream, np.float32).reshape(H, W, 4)
+    ref = ob.render(pod.sh, pod.cov, opods, ob.gaussian_transform(sh_deg=3), ob.model_transform(), ocam,
+                    order=buf.download_order(stream))[0]
+    assert np.array_equal(rgba.view(np.uint32), ref.view(np.uint32))
+    print("\nLOAD 1M-vertex PLY: device path (H2D 248 MB + k_from_ply_pods) %.3f s = %.2f GB/s of PLY bytes; "
+          "threaded host from_ply alone %.3f s" % (t_dev, n * 248 / t_dev / 1e9, t_host))
+    r.destroy(); img.release(); buf.destroy()

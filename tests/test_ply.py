@@ -147,3 +147,70 @@ def test_vertex_count_larger_than_the_file_is_rejected_up_front(gs):
     ascii_hdr = b"ply\nformat ascii 1.0\nelement vertex 1000000\nproperty float x\nend_header\n1.0\n"
     with pytest.raises(gs.PlyError):
         gs.PlyGaussians.read_from(ascii_hdr)
+
+
+def _synthetic_ply(n, seed=5):
+    """PlyGaussianPod records with trained-scene statistics (log-scales around -4, logit opacities,
+    unnormalised wxyz quaternions, f_dc / f_rest), plus hostile values in the first records."""
+    import wgpu_3dgs_core_amd as gs
+    rng = np.random.default_rng(seed)
+    p = np.zeros(n, dtype=gs.PLY_GAUSSIAN_DTYPE)
+    p["pos"] = rng.uniform(-10, 10, (n, 3)).astype(np.float32)
+    p["normal"] = rng.standard_normal((n, 3)).astype(np.float32)
+    p["color"] = (rng.standard_normal((n, 3)) * 1.2).astype(np.float32)
+    p["sh"] = (rng.standard_normal((n, 45)) * 0.1).astype(np.float32)
+    p["alpha"] = (rng.standard_normal(n) * 4.0).astype(np.float32)
+    p["scale"] = (rng.standard_normal((n, 3)) * 1.5 - 4.0).astype(np.float32)
+    p["rot"] = rng.standard_normal((n, 4)).astype(np.float32)
+    hostile = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 88.72283, 88.72284, 89.0, -103.97207, -103.97208, -104.5,
+                        -87.4, -95.0, -100.0, -103.28, 1e-30, -1e-30, 50.0, -50.0, 1e30, -1e30], dtype=np.float32)
+    k = min(n, len(hostile))
+    p["scale"][:k, 0] = hostile[:k]
+    p["alpha"][:k] = hostile[:k]
+    p["color"][:k, 1] = hostile[:k]
+    if n > 30:
+        p["rot"][25] = 0.0            # zero quaternion: 0 / 0 -> NaN on both sides
+        p["rot"][26] = (np.inf, 1, 2, 3)
+        p["rot"][27] = 1e-30          # squares underflow
+    return p
+
+
+def test_gs_expf_is_glibc_expf(gs):
+    """gs_expf (csrc/gs_convert.h, used by host AND device from_ply) restates the algorithm of glibc's
+    expf: same bits as libm on edge cases and on random arguments over the whole range."""
+    import ctypes as C
+    libm = C.CDLL("libm.so.6")
+    libm.expf.restype, libm.expf.argtypes = C.c_float, [C.c_float]
+    rng = np.random.default_rng(11)
+    xs = np.concatenate([np.array([0.0, -0.0, np.inf, -np.inf, 88.72283, 88.72284, -103.97207, -103.97208, -87.5, -100.0,
+                                   1e-30, -1e-30, -103.28, 1.0, -1.0], dtype=np.float32),
+                         rng.uniform(-104.5, 89.5, 20000).astype(np.float32),
+                         (rng.standard_normal(20000) * 3).astype(np.float32)])
+    for x in xs:
+        a, b = np.float32(gs.expf(x)), np.float32(libm.expf(float(x)))
+        assert a.tobytes() == b.tobytes(), (x, a, b)
+    assert np.isnan(gs.expf(float("nan")))
+
+
+def test_from_ply_one_million_matches_oracle_libm(gs, ob):
+    """The product's from_ply (threaded host loop over gs_convert.h — the code the device kernel runs
+    too) against the oracle's (libm expf, the reference's f32::exp) on 1 M synthetic vertices: every
+    field bit-equal.  gs_expf and libm can only differ where the double-precision result lies within
+    ~1e-9 ulp of a binary32 rounding boundary, so a handful of last-bit differences in `scale` (and the
+    alpha byte they feed) would not be an error — the reference's own tolerance is 1e-4
+    (tests/common/assert.rs:4) — but none occurs on this input."""
+    n = 1_000_000
+    p = _synthetic_ply(n)
+    g = gs.gaussian_from_ply(p)
+    o = ob.gaussians_from_ply(p)
+    for f in ("pos", "sh", "rot"):
+        assert np.array_equal(g[f].view(np.uint32), o[f].view(np.uint32)), f
+    ds = g["scale"].view(np.uint32).astype(np.int64) - o["scale"].view(np.uint32).astype(np.int64)
+    nan_both = np.isnan(g["scale"]) & np.isnan(o["scale"])
+    ds[nan_both] = 0
+    assert np.abs(ds).max() <= 1 and int((ds != 0).sum()) <= 4, (np.abs(ds).max(), int((ds != 0).sum()))
+    dc = g["color"].astype(np.int32) - o["color"].astype(np.int32)
+    assert np.abs(dc).max() <= 1 and int((dc != 0).sum()) <= 4
+    # and within the reference's tolerance in any case
+    fin = np.isfinite(o["scale"]) & (o["scale"] < 1e3)
+    assert np.abs(g["scale"][fin] - o["scale"][fin]).max() <= 1e-4

@@ -298,6 +298,11 @@ def gaussian_from_ply(ply):
     return out
 
 
+def expf(x):
+    """gs_expf: the exp of Gaussian::from_ply on host and device (csrc/gs_convert.h)"""
+    return float(_L.gs_expf(float(x)))
+
+
 def gaussian_to_ply(gaussians):
     """Gaussian::to_ply"""
     g = np.ascontiguousarray(np.atleast_1d(gaussians), dtype=GAUSSIAN_DTYPE)
@@ -701,6 +706,16 @@ class GaussiansBuffer:
         return GaussiansBuffer(device, pod, h)
 
     @staticmethod
+    def new_from_ply(device, pod, ply):
+        """PlyGaussians (or an array of PlyGaussianPod) -> buffer: the vertex records are uploaded as
+        they are and ONE device kernel does Gaussian::from_ply + G::from_gaussian
+        (gs_gaussians_buffer_create_from_ply) — bit-equal to new(device, pod, gaussian_from_ply(ply))."""
+        p = np.ascontiguousarray(np.atleast_1d(getattr(ply, "pods", ply)), dtype=PLY_GAUSSIAN_DTYPE)
+        h = C.c_void_p()
+        _check(_L.gs_gaussians_buffer_create_from_ply(device._h, pod.sh, pod.cov, _ptr(p), len(p), C.byref(h)))
+        return GaussiansBuffer(device, pod, h)
+
+    @staticmethod
     def new_with_pods(device, pod, pods):
         pods = np.ascontiguousarray(pods, dtype=np.uint8)
         assert pods.nbytes % pod.size == 0
@@ -747,6 +762,10 @@ class GaussiansBuffer:
     def update_range(self, stream, start, gaussians):
         g = np.ascontiguousarray(np.atleast_1d(gaussians), dtype=GAUSSIAN_DTYPE)
         _check(_L.gs_gaussians_buffer_update_range_gaussians(self._h, stream._h, start, _ptr(g), len(g)))
+
+    def update_range_from_ply(self, stream, start, ply):
+        p = np.ascontiguousarray(np.atleast_1d(getattr(ply, "pods", ply)), dtype=PLY_GAUSSIAN_DTYPE)
+        _check(_L.gs_gaussians_buffer_update_range_ply(self._h, stream._h, start, _ptr(p), len(p)))
 
     def update_range_with_pod(self, stream, start, pods):
         pods = np.ascontiguousarray(pods, dtype=np.uint8)

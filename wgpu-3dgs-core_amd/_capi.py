@@ -91,6 +91,7 @@ SIGNATURES = {
     "gs_ply_property_name": (C.c_char_p, [u32]),
     "gs_gaussian_from_ply": (None, [vp, sz, vp]),
     "gs_gaussian_to_ply": (None, [vp, sz, vp]),
+    "gs_expf": (f32, [f32]),
     "gs_ply_read": (i32, [vp, sz, vp, sz, vp, vp]),
     "gs_ply_write": (i32, [vp, sz, vp, sz, vp]),
     "gs_spz_options_default": (None, [vp]),
@@ -119,6 +120,9 @@ SIGNATURES = {
     "gs_buffer_download": (i32, [vp, vp, vp, sz]),
     "gs_gaussians_buffer_create": (i32, [vp, i32, i32, vp, sz, vp]),
     "gs_gaussians_buffer_create_from_gaussians": (i32, [vp, i32, i32, vp, sz, vp]),
+    "gs_gaussians_buffer_create_from_ply": (i32, [vp, i32, i32, vp, sz, vp]),
+    "gs_gaussians_buffer_update_range_ply": (i32, [vp, vp, sz, vp, sz]),
+    "gs_pack_device_from_ply": (i32, [vp, vp, i32, i32, vp, sz, vp]),
     "gs_gaussians_buffer_from_buffer": (i32, [vp, i32, i32, vp]),
     "gs_gaussians_buffer_destroy": (None, [vp]),
     "gs_gaussians_buffer_len": (sz, [vp]),

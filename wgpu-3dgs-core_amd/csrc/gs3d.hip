@@ -657,37 +657,106 @@ extern "C" gs_status gs_pack_device(gs_device *dev, gs_stream *s, gs_sh_config s
     return GS_OK;
 }
 
-// Gaussians on the host -> PODs in `g` at [start, start + count): the source records cross PCIe as
-// they are (one copy per slice of at most PACK_SLICE Gaussians through a staging buffer) and are
-// packed on the device.  The caller's memory may be reused when this returns.
-static gs_status upload_gaussians(gs_gaussians_buffer *g, gs_stream *s, size_t start, const gs_gaussian *gaussians,
-                                  size_t count) {
-    constexpr size_t PACK_SLICE = 4u << 20;     // 4 Mi Gaussians = 896 MiB of staging at most
+static pack_fn k_tbl_from_ply[4][3] = GS_CFG_TABLE(gs::k_from_ply_pods);
+
+extern "C" gs_status gs_pack_device_from_ply(gs_device *dev, gs_stream *s, gs_sh_config sh, gs_cov3d_config cov,
+                                             const gs_ply_gaussian_pod *ply_device, size_t n, void *pods_device) {
+    if (!dev || !valid_cfg(sh, cov) || (n && (!ply_device || !pods_device)))
+        return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "gs_pack_device_from_ply: bad argument");
+    if (((uintptr_t)ply_device | (uintptr_t)pods_device) & 3u)
+        return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "gs_pack_device_from_ply: pointers must be 4-byte aligned");
+    GS_TRY(use_device(dev));
+    if (!n) return GS_OK;
+    const uint64_t groups = ((uint64_t)n + gs::PACK_GROUP - 1) / gs::PACK_GROUP;
+    if (groups > 0x7fffffffull) return fail(GS_ERR_INVALID_ARGUMENT, n, 0, 0, "too many Gaussians");
+    hipLaunchKernelGGL(k_tbl_from_ply[sh][cov], dim3((uint32_t)groups), dim3(256), 0, stream_of(dev, s),
+                       (const uint32_t *)ply_device, (uint64_t)n, (uint32_t *)pods_device);
+    GS_HIP(hipGetLastError());
+    return GS_OK;
+}
+
+// Source records on the host (struct Gaussian, or PlyGaussianPod when `from_ply`) -> PODs in `g` at
+// [start, start + count): the records cross PCIe as they are, slice by slice through TWO staging
+// buffers (the copy of slice i + 1 overlaps the kernel of slice i), and are converted on the device.
+// The caller's memory may be reused when this returns.
+static gs_status upload_records(gs_gaussians_buffer *g, gs_stream *s, size_t start, const void *records, size_t count,
+                                bool from_ply) {
+    constexpr size_t PACK_SLICE = 2u << 20;     // 2 Mi records: 2 x 496 MiB of staging at most
     gs_device *dev = g->buf->dev;
     GS_TRY(use_device(dev));
     if (!count) return GS_OK;
     hipStream_t st = stream_of(dev, s);
+    const size_t rec = from_ply ? sizeof(gs_ply_gaussian_pod) : sizeof(gs_gaussian);
     const size_t slice = count < PACK_SLICE ? count : PACK_SLICE;
-    void *staging = nullptr;
-    hipError_t e = hipMalloc(&staging, slice * sizeof(gs_gaussian));
-    if (e != hipSuccess)
-        return fail(GS_ERR_OUT_OF_MEMORY, slice * sizeof(gs_gaussian), 0, 0, "hipMalloc failed: %s", hipGetErrorString(e));
+    const int nbuf = count > slice ? 2 : 1;
+    void *staging[2] = {nullptr, nullptr};
+    hipEvent_t used[2] = {nullptr, nullptr};
     gs_status rc = GS_OK;
+    for (int i = 0; i < nbuf && rc == GS_OK; i++) {
+        hipError_t e = hipMalloc(&staging[i], slice * rec);
+        if (e != hipSuccess) rc = fail(GS_ERR_OUT_OF_MEMORY, slice * rec, 0, 0, "hipMalloc failed: %s", hipGetErrorString(e));
+        else if ((e = hipEventCreateWithFlags(&used[i], hipEventDisableTiming)) != hipSuccess)
+            rc = fail(GS_ERR_HIP, (uint64_t)e, 0, 0, "hipEventCreate failed: %s", hipGetErrorString(e));
+    }
     const size_t stride = pod_stride(g);
-    for (size_t first = 0; first < count && rc == GS_OK; first += slice) {
+    int k = 0;
+    for (size_t first = 0; first < count && rc == GS_OK; first += slice, k ^= (nbuf - 1)) {
         const size_t cnt = count - first < slice ? count - first : slice;
-        e = hipMemcpyAsync(staging, gaussians + first, cnt * sizeof(gs_gaussian), hipMemcpyHostToDevice, st);
+        // the staging buffer's previous kernel must have read it before the next copy overwrites it
+        if (first >= (size_t)nbuf * slice && hipEventSynchronize(used[k]) != hipSuccess) {
+            rc = fail(GS_ERR_HIP, 0, 0, 0, "upload failed");
+            break;
+        }
+        hipError_t e = hipMemcpyAsync(staging[k], (const uint8_t *)records + first * rec, cnt * rec, hipMemcpyHostToDevice, st);
         if (e != hipSuccess) {
             rc = fail(GS_ERR_HIP, (uint64_t)e, 0, 0, "upload failed: %s", hipGetErrorString(e));
             break;
         }
-        rc = gs_pack_device(dev, s, (gs_sh_config)g->sh, (gs_cov3d_config)g->cov, (const gs_gaussian *)staging, cnt,
-                            (uint8_t *)g->buf->ptr + (start + first) * stride);
-        // the staging buffer is reused by the next slice and freed below: wait for the kernel
-        if (rc == GS_OK && hipStreamSynchronize(st) != hipSuccess) rc = fail(GS_ERR_HIP, 0, 0, 0, "pack failed");
+        void *dst = (uint8_t *)g->buf->ptr + (start + first) * stride;
+        rc = from_ply ? gs_pack_device_from_ply(dev, s, (gs_sh_config)g->sh, (gs_cov3d_config)g->cov,
+                                                (const gs_ply_gaussian_pod *)staging[k], cnt, dst)
+                      : gs_pack_device(dev, s, (gs_sh_config)g->sh, (gs_cov3d_config)g->cov, (const gs_gaussian *)staging[k],
+                                       cnt, dst);
+        if (rc == GS_OK && hipEventRecord(used[k], st) != hipSuccess) rc = fail(GS_ERR_HIP, 0, 0, 0, "upload failed");
     }
-    (void)hipFree(staging);
+    // the staging buffers are freed below and the caller's memory may be reused: wait for everything
+    if (hipStreamSynchronize(st) != hipSuccess && rc == GS_OK) rc = fail(GS_ERR_HIP, 0, 0, 0, "pack failed");
+    for (int i = 0; i < 2; i++) {
+        if (used[i]) (void)hipEventDestroy(used[i]);
+        if (staging[i]) (void)hipFree(staging[i]);
+    }
     return rc;
+}
+
+static gs_status upload_gaussians(gs_gaussians_buffer *g, gs_stream *s, size_t start, const gs_gaussian *gaussians,
+                                  size_t count) {
+    return upload_records(g, s, start, gaussians, count, false);
+}
+
+extern "C" gs_status gs_gaussians_buffer_create_from_ply(gs_device *dev, gs_sh_config sh, gs_cov3d_config cov,
+                                                         const gs_ply_gaussian_pod *ply, size_t len,
+                                                         gs_gaussians_buffer **out) {
+    if (!valid_cfg(sh, cov) || (len && !ply) || !out)
+        return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "bad argument");
+    GS_TRY(gs_gaussians_buffer_create(dev, sh, cov, nullptr, len, out));
+    gs_status rc = upload_records(*out, nullptr, 0, ply, len, true);
+    if (rc != GS_OK) {
+        gs_gaussians_buffer_destroy(*out);
+        *out = nullptr;
+    }
+    return rc;
+}
+
+extern "C" gs_status gs_gaussians_buffer_update_range_ply(gs_gaussians_buffer *g, gs_stream *s, size_t start,
+                                                          const gs_ply_gaussian_pod *ply, size_t count) {
+    if (!g) return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "null buffer");
+    size_t len = gs_gaussians_buffer_len(g);
+    if (count > len || start > len - count)
+        return fail(GS_ERR_RANGE_COUNT_MISMATCH, count, start, len,
+                    "Gaussians count mismatch: %zu + %zu > %zu", count, start, len);
+    if (count && !ply) return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "null ply records");
+    g->mark(start, start + count);
+    return upload_records(g, s, start, ply, count, true);
 }
 
 extern "C" gs_status gs_gaussians_buffer_create_from_gaussians(gs_device *dev, gs_sh_config sh,

@@ -1,0 +1,139 @@
+// gs_convert.h — source-format record -> struct Gaussian conversions as ONE set of host + device
+// functions: Gaussian::from_ply (src/gaussian.rs:70-92).  The host entry point
+// (gs_gaussian_from_ply, gs_ply.cpp) and the device kernel (k_from_ply_pods, gs3d.hip) both call
+// ply_to_gaussian_words below, so a scene loaded on the device is bit-identical to one converted on
+// the host by construction.
+//
+// exp: the reference calls f32::exp, which on Linux is glibc's expf.  A device `expf` (ocml) is a
+// different algorithm and differs from it in the last bit, so BOTH sides use gs_expf below: the
+// published algorithm glibc (>= 2.27), musl, newlib and bionic share — Szabolcs Nagy's expf from
+// ARM optimized-routines (math/expf.c, math/exp2f_data.c; EXP2F_TABLE_BITS = 5): the argument is
+// reduced in DOUBLE to k/32 + r, 2^(k/32) comes from a 32-entry table, a cubic in r finishes, and the
+// double result is rounded to binary32 once (worst-case error 0.502 ulp).  Every operation is an IEEE
+// double +, *, or a conversion, written without contraction, so host and device agree bit for bit,
+// and both agree with libm wherever the double result is not within ~1e-9 ulp of a binary32 rounding
+// boundary (tests/test_ply.py: 0 differences in 4 M samples; reference tolerance 1e-4,
+// tests/common/assert.rs:4).
+#pragma once
+#include <stdint.h>
+#include <string.h>
+
+#if defined(__HIP__) || defined(__HIPCC_RTC__)
+#define GS_HD __host__ __device__
+#else
+#define GS_HD
+#endif
+
+namespace gs {
+
+GS_HD inline uint32_t cv_f2u(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    return u;
+}
+GS_HD inline float cv_u2f(uint32_t u) {
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+GS_HD inline uint64_t cv_d2u(double d) {
+    uint64_t u;
+    memcpy(&u, &d, 8);
+    return u;
+}
+GS_HD inline double cv_u2d(uint64_t u) {
+    double d;
+    memcpy(&d, &u, 8);
+    return d;
+}
+
+// T[i] = bits(2^(i/32)) - (i << 47), 2^(i/32) correctly rounded to binary64
+GS_HD inline uint64_t expf_table(uint32_t i) {
+    const uint64_t T[32] = {
+        0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull,
+        0x3fef72b83c7d517bull, 0x3fef54873168b9aaull, 0x3fef387a6e756238ull, 0x3fef1e9df51fdee1ull,
+        0x3fef06fe0a31b715ull, 0x3feef1a7373aa9cbull, 0x3feedea64c123422ull, 0x3feece086061892dull,
+        0x3feebfdad5362a27ull, 0x3feeb42b569d4f82ull, 0x3feeab07dd485429ull, 0x3feea47eb03a5585ull,
+        0x3feea09e667f3bcdull, 0x3fee9f75e8ec5f74ull, 0x3feea11473eb0187ull, 0x3feea589994cce13ull,
+        0x3feeace5422aa0dbull, 0x3feeb737b0cdc5e5ull, 0x3feec49182a3f090ull, 0x3feed503b23e255dull,
+        0x3feee89f995ad3adull, 0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull,
+        0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full, 0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull};
+    return T[i & 31u];
+}
+
+// expf for every binary32 input (NaN -> NaN, +inf -> +inf, -inf -> 0, overflow -> +inf,
+// underflow -> 0 / subnormals rounded once)
+GS_HD inline float gs_expf(float x) {
+    const uint32_t ux = cv_f2u(x);
+    const uint32_t abstop = (ux >> 20) & 0x7ffu;
+    if (abstop >= 0x42bu) {                         // |x| >= 88 or NaN / inf
+        if (ux == 0xff800000u) return 0.0f;         // -inf
+        if (abstop >= 0x7f8u) return x + x;         // NaN, +inf
+        if (x > 88.72283172607421875f) return cv_u2f(0x7f800000u);   // x > log(2^128)
+        if (x < -103.972076416015625f) return 0.0f;                  // x < log(2^-150)
+    }
+    const double N = 32.0;
+    const double inv_ln2_n = 0x1.71547652b82fep+0 * N;
+    const double shift = 0x1.8p+52;
+    const double c0 = 0x1.c6af84b912394p-5 / N / N / N, c1 = 0x1.ebfce50fac4f3p-3 / N / N, c2 = 0x1.62e42ff0c52d6p-1 / N;
+    const double z = inv_ln2_n * (double)x;
+    double kd = z + shift;                          // round to nearest integer in the low bits
+    const uint64_t ki = cv_d2u(kd);
+    kd = kd - shift;
+    const double r = z - kd;
+    const uint64_t t = expf_table((uint32_t)ki) + (ki << 47);
+    const double s = cv_u2d(t);
+    const double p = c0 * r + c1;
+    const double r2 = r * r;
+    double y = c2 * r + 1.0;
+    y = p * r2 + y;
+    y = y * s;
+    return (float)y;
+}
+
+// Rust `as u8` of an f32: truncating, saturating, NaN -> 0
+GS_HD inline uint32_t cv_sat_u8(float v) {
+    if (!(v > 0.0f)) return 0u;
+    if (v >= 255.0f) return 255u;
+    return (uint32_t)(int)v;
+}
+GS_HD inline float cv_clamp_0_255(float v) {       // glam Vec4::clamp = max(lo).min(hi): NaN -> lo (sat_u8 maps it to 0 anyway)
+    float a = v > 0.0f ? v : 0.0f;
+    if (v != v) a = 0.0f;
+    return a < 255.0f ? a : 255.0f;
+}
+
+// struct Gaussian word offsets (include/gs3d.h gs_gaussian): rot xyzw @0, pos @4, color u8x4 @7,
+// sh[45] @8, scale @53; PlyGaussianPod (62 f32): pos @0, normal @3, f_dc @6, f_rest @9, opacity @54,
+// scale @55, rot wxyz @58
+constexpr int PLY_WORDS = 62;
+constexpr int CV_GAUSSIAN_WORDS = 56;
+
+// Gaussian::from_ply (src/gaussian.rs:70-92): p = 62 words of one PlyGaussianPod, g = 56 words out.
+// `sqrtf_cr` must be a correctly rounded binary32 square root (host sqrtf; device __fsqrt_rn).
+template <class Sqrt>
+GS_HD inline void ply_to_gaussian_words(const uint32_t *p, uint32_t *g, Sqrt sqrtf_cr) {
+    g[4] = p[0];
+    g[5] = p[1];
+    g[6] = p[2];
+    // Quat::from_xyzw(rot[1], rot[2], rot[3], rot[0]).normalize()
+    const float q[4] = {cv_u2f(p[59]), cv_u2f(p[60]), cv_u2f(p[61]), cv_u2f(p[58])};
+    const float len = sqrtf_cr(((q[0] * q[0] + q[1] * q[1]) + q[2] * q[2]) + q[3] * q[3]);
+    for (int k = 0; k < 4; k++) g[k] = cv_f2u(q[k] / len);
+    for (int k = 0; k < 3; k++) g[53 + k] = cv_f2u(gs_expf(cv_u2f(p[55 + k])));
+    uint32_t color = 0;
+    for (int k = 0; k < 3; k++) {
+        const float v = (cv_u2f(p[6 + k]) * 0.2820948f + 0.5f) * 255.0f;        // SH0_TO_LINEAR_FACTOR
+        color |= cv_sat_u8(cv_clamp_0_255(v)) << (8 * k);
+    }
+    const float a = (1.0f / (1.0f + gs_expf(-cv_u2f(p[54])))) * 255.0f;
+    color |= cv_sat_u8(cv_clamp_0_255(a)) << 24;
+    g[7] = color;
+    for (int k = 0; k < 15; k++) {       // channel-planar f_rest -> RGB-interleaved
+        g[8 + 3 * k + 0] = p[9 + k];
+        g[8 + 3 * k + 1] = p[9 + k + 15];
+        g[8 + 3 * k + 2] = p[9 + k + 30];
+    }
+}
+
+}  // namespace gs

@@ -5,6 +5,7 @@
 // bit manipulation for f16 / snorm8, float arithmetic in one written order, no contraction).
 #pragma once
 
+#include "gs_convert.h"
 #include "gs_kernel_lib.h"
 
 namespace gs {
@@ -125,6 +126,34 @@ __global__ __launch_bounds__(256) void k_pack_pods(const uint32_t *__restrict__ 
     for (uint32_t q = threadIdx.x; q < ng * GAUSSIAN_WORDS; q += 256) s_in[q] = src[q];
     __syncthreads();
     if (threadIdx.x < ng) pack_words(SH, COV, s_in + threadIdx.x * GAUSSIAN_WORDS, s_out + threadIdx.x * NW);
+    __syncthreads();
+    uint32_t *dst = pods + g0 * NW;
+    for (uint32_t q = threadIdx.x; q < ng * NW; q += 256) dst[q] = s_out[q];
+}
+
+// Device load path of a PLY scene: Gaussian::from_ply fused with G::from_gaussian.  Same structure as
+// k_pack_pods (contiguous span in, LDS, one record per thread LDS -> LDS, contiguous span out); the
+// per-record arithmetic is gs_convert.h's ply_to_gaussian_words, shared with the host path.
+struct DeviceSqrt {
+    __device__ float operator()(float v) const { return __fsqrt_rn(v); }
+};
+template <int SH, int COV>
+__global__ __launch_bounds__(256) void k_from_ply_pods(const uint32_t *__restrict__ ply, uint64_t count,
+                                                       uint32_t *__restrict__ pods) {
+    constexpr int NW = pod_words(SH, COV);
+    static_assert(CV_GAUSSIAN_WORDS == GAUSSIAN_WORDS, "one struct Gaussian layout");
+    __shared__ uint32_t s_in[PACK_GROUP * PLY_WORDS];         // 31 KiB
+    __shared__ uint32_t s_out[PACK_GROUP * NW];               // <= 28 KiB
+    const uint64_t g0 = (uint64_t)blockIdx.x * PACK_GROUP;
+    const uint32_t ng = (uint32_t)(count - g0 < PACK_GROUP ? count - g0 : PACK_GROUP);
+    const uint32_t *src = ply + g0 * PLY_WORDS;
+    for (uint32_t q = threadIdx.x; q < ng * PLY_WORDS; q += 256) s_in[q] = src[q];
+    __syncthreads();
+    if (threadIdx.x < ng) {
+        uint32_t gw[GAUSSIAN_WORDS];
+        ply_to_gaussian_words(s_in + threadIdx.x * PLY_WORDS, gw, DeviceSqrt());
+        pack_words(SH, COV, gw, s_out + threadIdx.x * NW);
+    }
     __syncthreads();
     uint32_t *dst = pods + g0 * NW;
     for (uint32_t q = threadIdx.x; q < ng * NW; q += 256) dst[q] = s_out[q];

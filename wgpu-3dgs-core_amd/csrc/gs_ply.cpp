@@ -10,8 +10,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
+#include "gs_convert.h"
 #include "gs_internal.h"
 
 static_assert(sizeof(gs_ply_gaussian_pod) == 248, "PlyGaussianPod is 62 f32");
@@ -31,34 +33,39 @@ extern "C" const char *gs_ply_property_name(uint32_t index) { return index < 62 
 
 // ---- Gaussian::from_ply / to_ply (src/gaussian.rs:70-125) ------------------------------------
 
-static uint8_t sat_u8(float v) {  // Rust `as u8`: truncating, saturating, NaN -> 0
-    if (!(v > 0.0f)) return 0;
-    if (v >= 255.0f) return 255;
-    return (uint8_t)v;
+// threaded over the records (50 M vertices took 80 s on one thread); the per-record arithmetic is
+// gs_convert.h's, shared with the device kernel
+template <class F>
+static void ply_parallel_for(size_t n, F fn) {
+    unsigned hw = std::thread::hardware_concurrency();
+    size_t threads = n < 32768 ? 1 : (hw ? (hw > 32 ? 32 : hw) : 4);
+    if (threads <= 1) {
+        fn((size_t)0, n);
+        return;
+    }
+    std::vector<std::thread> pool;
+    const size_t per = (n + threads - 1) / threads;
+    for (size_t t = 0; t < threads; t++) {
+        const size_t a = t * per, b = a + per < n ? a + per : n;
+        if (a >= b) break;
+        pool.emplace_back([=] { fn(a, b); });
+    }
+    for (auto &th : pool) th.join();
 }
 
 extern "C" void gs_gaussian_from_ply(const gs_ply_gaussian_pod *in, size_t n, gs_gaussian *out) {
-    for (size_t i = 0; i < n; i++) {
-        const gs_ply_gaussian_pod &p = in[i];
-        gs_gaussian &g = out[i];
-        std::memcpy(g.pos, p.pos, 12);
-        float q[4] = {p.rot[1], p.rot[2], p.rot[3], p.rot[0]};  // wxyz -> xyzw
-        float len = std::sqrt(((q[0] * q[0] + q[1] * q[1]) + q[2] * q[2]) + q[3] * q[3]);
-        for (int k = 0; k < 4; k++) g.rot[k] = q[k] / len;
-        for (int k = 0; k < 3; k++) g.scale[k] = std::exp(p.scale[k]);
-        for (int k = 0; k < 3; k++) {
-            float v = (p.color[k] * 0.2820948f + 0.5f) * 255.0f;   // SH0_TO_LINEAR_FACTOR
-            g.color[k] = sat_u8(std::fmin(std::fmax(v, 0.0f), 255.0f));
+    static_assert(sizeof(gs_gaussian) == gs::CV_GAUSSIAN_WORDS * 4, "gs_gaussian layout");
+    ply_parallel_for(n, [=](size_t a, size_t b) {
+        for (size_t i = a; i < b; i++) {
+            uint32_t pw[gs::PLY_WORDS], gw[gs::CV_GAUSSIAN_WORDS];
+            std::memcpy(pw, &in[i], sizeof(pw));
+            gs::ply_to_gaussian_words(pw, gw, [](float v) { return std::sqrt(v); });
+            std::memcpy(&out[i], gw, sizeof(gw));
         }
-        float a = (1.0f / (1.0f + std::exp(-p.alpha))) * 255.0f;
-        g.color[3] = sat_u8(std::fmin(std::fmax(a, 0.0f), 255.0f));
-        for (int k = 0; k < 15; k++) {   // channel-planar f_rest -> RGB-interleaved
-            g.sh[3 * k + 0] = p.sh[k];
-            g.sh[3 * k + 1] = p.sh[k + 15];
-            g.sh[3 * k + 2] = p.sh[k + 30];
-        }
-    }
+    });
 }
+
+extern "C" float gs_expf(float x) { return gs::gs_expf(x); }
 
 extern "C" void gs_gaussian_to_ply(const gs_gaussian *in, size_t n, gs_ply_gaussian_pod *out) {
     for (size_t i = 0; i < n; i++) {
