@@ -131,7 +131,7 @@ def lib():
     L.gso_set_rect_version.argtypes = [i32]
     L.gso_rect_version.restype = i32
     # the product's A/B switch GS3D_RECT_V1=1 (spec version 1 of the tile rect) selects the matching oracle
-    L.gso_set_rect_version(1 if os.environ.get("GS3D_RECT_V1") == "1" else 2)
+    L.gso_set_rect_version(1 if os.environ.get("GS3D_RECT_V1") == "1" else 3)
     _lib = L
     return L
 

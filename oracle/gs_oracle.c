@@ -719,7 +719,7 @@ static inline float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, 
  * radius square clipped, in display mode Splat, to the bounding box of the region where the splat can
  * reach alpha >= 1/255.  Both versions produce the same image: version 2 only drops (tile, Gaussian)
  * pairs that contribute to no pixel.  Version 1 is kept so that the version-1 goldens stay checkable. */
-static int g_rect_version = 2;
+static int g_rect_version = 3;
 void gso_set_rect_version(int v) { g_rect_version = v; }
 int gso_rect_version(void) { return g_rect_version; }
 
@@ -772,6 +772,7 @@ typedef struct {
     uint32_t sh_deg;
     int no_sh0;
     int clip_rect; /* DESIGN.md §3.3, second step of the rect (display mode Splat only) */
+    int clip_guard; /* version 3: no clip where the blend's own rounding error could exceed half the head room */
 } frame_consts;
 
 static void make_frame_consts(const gso_gaussian_transform *gt, const gso_model_transform *mt,
@@ -798,6 +799,7 @@ static void make_frame_consts(const gso_gaussian_transform *gt, const gso_model_
     fc->sh_deg = gso_transform_sh_deg(flags);
     fc->no_sh0 = (int)gso_transform_no_sh0(flags);
     fc->clip_rect = gso_transform_display_mode(flags) == 0u && g_rect_version >= 2;
+    fc->clip_guard = g_rect_version >= 3;
 }
 
 /* DESIGN.md §3.3. Returns tiles touched (0 = culled). */
@@ -857,13 +859,23 @@ static uint32_t project_one(int sh, int cov, const uint8_t *pod, const frame_con
          * pixel centres 16 t + 0.5 ... 16 t + 15.5; a NaN extent leaves the rect as it is */
         uint32_t kop = ld_u32(pod + 12) >> 24; /* opacity byte of the colour word */
         if (kop == 0u) return 0;
-        float lim = LN_OPACITY_BYTE[kop] + 0.1f;
-        float ex = sqrtf(lim / -(qa - (qb * qb) / (4.0f * qc)));
-        float ey = sqrtf(lim / -(qc - (qb * qb) / (4.0f * qa)));
-        fx0 = fmaxf(fx0, floorf(((mx - ex) - 15.5f) * 0.0625f) + 1.0f);
-        fx1 = fminf(fx1, floorf(((mx + ex) - 0.5f) * 0.0625f) + 1.0f);
-        fy0 = fmaxf(fy0, floorf(((my - ey) - 15.5f) * 0.0625f) + 1.0f);
-        fy1 = fminf(fy1, floorf(((my + ey) - 0.5f) * 0.0625f) + 1.0f);
+        /* version 3 (round 3): the blend evaluates `power` in binary32; over the pixels of the radius
+         * square (|dx|, |dy| <= radius + 16) its rounding error is at most
+         * E = 5 u (|qa| + |qb| + |qc|) (radius + 16)^2, 5 u = 3e-7.  Only where E <= 0.05 — half the
+         * head room; the other half covers the rounding of ex / ey themselves — can the clip be
+         * proven to drop no pixel the unclipped frame colours; elsewhere (needles hundreds of pixels
+         * long and thinner than a pixel) the radius square stays.  A NaN E keeps the square. */
+        float dd = radius + 16.0f;
+        float err = (3.0e-7f * ((fabsf(qa) + fabsf(qb)) + fabsf(qc))) * (dd * dd);
+        if (!fc->clip_guard || err <= 0.05f) {
+            float lim = LN_OPACITY_BYTE[kop] + 0.1f;
+            float ex = sqrtf(lim / -(qa - (qb * qb) / (4.0f * qc)));
+            float ey = sqrtf(lim / -(qc - (qb * qb) / (4.0f * qa)));
+            fx0 = fmaxf(fx0, floorf(((mx - ex) - 15.5f) * 0.0625f) + 1.0f);
+            fx1 = fminf(fx1, floorf(((mx + ex) - 0.5f) * 0.0625f) + 1.0f);
+            fy0 = fmaxf(fy0, floorf(((my - ey) - 15.5f) * 0.0625f) + 1.0f);
+            fy1 = fminf(fy1, floorf(((my + ey) - 0.5f) * 0.0625f) + 1.0f);
+        }
     }
     if (!(fx1 > fx0) || !(fy1 > fy0)) return 0;
     uint32_t tx0 = (uint32_t)fx0, tx1 = (uint32_t)fx1, ty0 = (uint32_t)fy0, ty1 = (uint32_t)fy1;

@@ -151,7 +151,15 @@ def test_device_from_ply_equals_host_path(gs, ob, device, stream, pod_idx):
         buf = gs.GaussiansBuffer.new_from_ply(device, pod, ply)
         assert len(buf) == len(ply)
         got = buf.download(stream)
-        assert np.array_equal(got, want.reshape(-1)), "%s: device from_ply differs from the host path (%s)" % (name, pod)
+        if not np.array_equal(got, want.reshape(-1)):
+            gw, ww = got.view(np.uint32).reshape(len(ply), -1), np.ascontiguousarray(want).view(np.uint32).reshape(len(ply), -1)
+            rec, word = np.nonzero(gw != ww)
+            msg = ["%s: device from_ply differs from the host path (%s) in %d words of %d records" % (
+                name, pod, len(rec), len(np.unique(rec)))]
+            for r, w in list(zip(rec, word))[:12]:
+                msg.append("record %d word %d: device %08x host %08x | ply scale %s alpha %r rot %s color %s" % (
+                    r, w, gw[r, w], ww[r, w], ply["scale"][r], ply["alpha"][r], ply["rot"][r], ply["color"][r]))
+            raise AssertionError("\n".join(msg))
         # a ranged update through the same kernel
         if len(ply) > 1000:
             part = _synthetic_ply(777, seed=100 + pod_idx)

@@ -1,8 +1,12 @@
 """DESIGN.md §3.3 defines the tile rect in two steps: the radius square (version 1, rounds 1-2) and,
 in display mode Splat, its clipping to the bounding box of the region where the splat can reach
-alpha >= 1/255 (version 2).  Version 2 must change no image: these tests pin that claim on the CPU
-side — the full-size goldens of both versions carry the same frame hashes, and on a small scene
-every pair that version 2 drops is checked pixel by pixel in float64."""
+alpha >= 1/255 (version 2, round 2; version 3, round 3 = version 2 guarded by a bound on the blend's
+own binary32 rounding error).  The clip must change no image: these tests pin that claim on the CPU
+side — the full-size goldens of both versions carry the same frame hashes, on a small scene every
+pair that the clip drops is checked pixel by pixel in float64, and ADVERSARIAL needles (hundreds of
+pixels long, thinner than a pixel, cond(cov2d) 1e5 - 1e7, tips on screen at 4K / 8K) are rendered with
+every version: the unguarded version 2 provably loses pixels there (the regime DESIGN §3.3 conceded
+in round 2), version 3 does not."""
 import json
 import os
 
@@ -102,3 +106,59 @@ def test_ln_tables_of_product_and_oracle_are_ln_k_correctly_rounded():
     assert prod.shape == orac.shape == (256,)
     assert np.array_equal(prod.view(np.uint32), want.view(np.uint32))
     assert np.array_equal(orac.view(np.uint32), want.view(np.uint32))
+
+
+# needles whose tips lie ON the screen, where the blend's binary32 `power` (three cancelling terms of
+# ~1e6) is noisy at the 0.1 level: (width, height, sigma_px, theta, opacity byte, centre)
+NEEDLES_UNGUARDED_V2_LOSES_PIXELS = [
+    (3840, 2160, 400.0, 45.0, 255, (1927.9, 1082.1)),
+    (7680, 4320, 800.0, 30.0, 255, (3840.25, 2160.25)),
+]
+
+
+def _needle_frames(ob, case, versions):
+    W, H, sigma, theta, op, c = case
+    g, cam = helpers.needle_gaussian(ob, theta, sigma, op, c, W, H)
+    pods = ob.pack(0, 0, g)
+    gt, mt = ob.gaussian_transform(sh_deg=0), ob.model_transform()
+    out = {}
+    for v in versions:
+        ob.set_rect_version(v)
+        proj, tiles = ob.preprocess(0, 0, pods, gt, mt, cam)
+        out[v] = (ob.render(0, 0, pods, gt, mt, cam)[0], int(tiles[0]), proj[0].copy())
+    return out
+
+
+@pytest.mark.parametrize("case", NEEDLES_UNGUARDED_V2_LOSES_PIXELS, ids=lambda c: "%dx%d-s%g-t%g" % c[:4])
+def test_adversarial_needles_unguarded_clip_loses_pixels_guarded_clip_does_not(both_versions, case):
+    """The finding behind version 3: on these inputs the version-2 clip drops tiles in which the
+    version-1 frame has pixels at alpha ~ 1/255 (the blend's f32 power is off by more than the 0.1 head
+    room there); with the guard the splat keeps its radius square and the frames are bit-identical."""
+    ob = both_versions
+    f = _needle_frames(ob, case, (1, 2, 3))
+    p = f[1][2]
+    q = np.array([[-2.0 * float(p["ca"]), -float(p["cb"])], [-float(p["cb"]), -2.0 * float(p["cc"])]])
+    ev = np.linalg.eigvalsh(q)
+    assert ev[1] / ev[0] > 1e5                                   # cond(cov2d)
+    assert f[2][1] < f[1][1]                                     # version 2 clips ...
+    d12 = np.abs(f[1][0] - f[2][0])
+    assert d12.max() > 0 and d12.max() < 2.0 / 255.0             # ... and loses threshold-level pixels
+    assert f[3][1] == f[1][1]                                    # version 3 refuses to clip this splat
+    assert np.array_equal(f[1][0].view(np.uint32), f[3][0].view(np.uint32))
+
+
+def test_adversarial_needle_scan_guarded_clip_changes_no_image(both_versions):
+    """cond(cov2d) 2e5 - 2e6, length up to the screen diagonal, opacity bytes 255 / 128 / 2, angles
+    across the range, sub-pixel offsets across tile borders: version 3 == version 1 bit for bit, and
+    the splats short enough for the guard (E <= 0.05) are still clipped."""
+    ob = both_versions
+    clipped = kept_square = 0
+    for sigma in (60.0, 120.0, 250.0, 440.0, 800.0):
+        for theta in (0.0, 7.0, 30.0, 45.0, 83.0, 135.0):
+            for op, c in ((255, (1920.25, 1080.25)), (128, (1913.3, 1077.8)), (2, (1927.97, 1072.03)), (255, (16.02, 2143.98))):
+                f = _needle_frames(ob, (3840, 2160, sigma, theta, op, c), (1, 3))
+                assert np.array_equal(f[1][0].view(np.uint32), f[3][0].view(np.uint32)), (sigma, theta, op, c)
+                assert f[3][1] <= f[1][1]
+                clipped += f[3][1] < f[1][1]
+                kept_square += f[3][1] == f[1][1]
+    assert clipped > 20 and kept_square > 20

@@ -671,14 +671,23 @@ __device__ __forceinline__ uint32_t project_geom(const uint32_t *w, const FrameC
         // own rounding) therefore holds every pixel the splat can colour; tiles outside it are dropped.
         const uint32_t kop = w[3] >> 24;
         ok = ok && (kop != 0u);
-        const float lim = k_ln_opacity_byte[kop] + 0.1f;
-        const float ex = sqrtf(lim / -(qa - (qb * qb) / (4.0f * qc)));
-        const float ey = sqrtf(lim / -(qc - (qb * qb) / (4.0f * qa)));
-        // tile t holds the pixel centres 16 t + 0.5 ... 16 t + 15.5; NaN extents change nothing
-        fx0 = fmaxf(fx0, floorf(((mx - ex) - 15.5f) * 0.0625f) + 1.0f);
-        fx1 = fminf(fx1, floorf(((mx + ex) - 0.5f) * 0.0625f) + 1.0f);
-        fy0 = fmaxf(fy0, floorf(((my - ey) - 15.5f) * 0.0625f) + 1.0f);
-        fy1 = fminf(fy1, floorf(((my + ey) - 0.5f) * 0.0625f) + 1.0f);
+        // Version 3 (round 3): the blend evaluates `power` in binary32; over the pixels of the radius
+        // square (|dx|, |dy| <= radius + 16) its rounding error is at most
+        // E = 5 u (|qa| + |qb| + |qc|) (radius + 16)^2 with 5 u = 3e-7.  Only where E <= 0.05 (half the head
+        // room; the other half covers the rounding of ex / ey) is the clip provably invisible; needles
+        // hundreds of pixels long and thinner than a pixel keep the radius square.  NaN E: no clip.
+        const float dd = radius + 16.0f;
+        const float err = (3.0e-7f * ((fabsf(qa) + fabsf(qb)) + fabsf(qc))) * (dd * dd);
+        if (err <= 0.05f) {
+            const float lim = k_ln_opacity_byte[kop] + 0.1f;
+            const float ex = sqrtf(lim / -(qa - (qb * qb) / (4.0f * qc)));
+            const float ey = sqrtf(lim / -(qc - (qb * qb) / (4.0f * qa)));
+            // tile t holds the pixel centres 16 t + 0.5 ... 16 t + 15.5; NaN extents change nothing
+            fx0 = fmaxf(fx0, floorf(((mx - ex) - 15.5f) * 0.0625f) + 1.0f);
+            fx1 = fminf(fx1, floorf(((mx + ex) - 0.5f) * 0.0625f) + 1.0f);
+            fy0 = fmaxf(fy0, floorf(((my - ey) - 15.5f) * 0.0625f) + 1.0f);
+            fy1 = fminf(fy1, floorf(((my + ey) - 0.5f) * 0.0625f) + 1.0f);
+        }
     }
     ok = ok && (fx1 > fx0) && (fy1 > fy0);
     // NaN-safe conversions: culled lanes may carry garbage; their values are never used
@@ -1019,6 +1028,7 @@ struct ExpandIO {
     uint32_t gen;
     uint32_t sb_bound;               // host bound of the number of super-chunks (entries past the real one are zero)
     struct PairCursorRec *cursors;   // [capacity / CURSOR_SLOTS + 1] where the pairs of every 1024-slot span start
+    uint32_t rect_presorted;         // sorted_rect was already written by the last depth-sort pass (GATHER)
 };
 
 // Expansion, part 1: gather the tile rects into depth order (the only random access of the key
@@ -1035,20 +1045,29 @@ __global__ __launch_bounds__(EXP_CHUNK) void k_expand_count(ExpandIO io) {
     const uint32_t v_count = io.state->visible;
     const uint32_t first_chunk = blockIdx.x * EXP_COUNT_CHUNKS;
     if ((uint64_t)first_chunk * EXP_CHUNK >= v_count) return;
-    uint32_t slot[EXP_COUNT_CHUNKS];
-#pragma unroll
-    for (uint32_t c = 0; c < EXP_COUNT_CHUNKS; c++) {
-        const uint64_t j = (uint64_t)(first_chunk + c) * EXP_CHUNK + threadIdx.x;
-        slot[c] = j < v_count ? io.order[j] : 0xffffffffu;
-    }
     uint2 r[EXP_COUNT_CHUNKS];
+    if (io.rect_presorted) {
+        // the last depth-sort pass gathered the rects while it scattered the slots: only the sums are left
 #pragma unroll
-    for (uint32_t c = 0; c < EXP_COUNT_CHUNKS; c++) r[c] = slot[c] != 0xffffffffu ? io.rect[slot[c]] : make_uint2(0u, 0u);
+        for (uint32_t c = 0; c < EXP_COUNT_CHUNKS; c++) {
+            const uint64_t j = (uint64_t)(first_chunk + c) * EXP_CHUNK + threadIdx.x;
+            r[c] = j < v_count ? io.sorted_rect[j] : make_uint2(0u, 0u);
+        }
+    } else {
+        uint32_t slot[EXP_COUNT_CHUNKS];
+#pragma unroll
+        for (uint32_t c = 0; c < EXP_COUNT_CHUNKS; c++) {
+            const uint64_t j = (uint64_t)(first_chunk + c) * EXP_CHUNK + threadIdx.x;
+            slot[c] = j < v_count ? io.order[j] : 0xffffffffu;
+        }
+#pragma unroll
+        for (uint32_t c = 0; c < EXP_COUNT_CHUNKS; c++) r[c] = slot[c] != 0xffffffffu ? io.rect[slot[c]] : make_uint2(0u, 0u);
+    }
     const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
 #pragma unroll
     for (uint32_t c = 0; c < EXP_COUNT_CHUNKS; c++) {
         const uint64_t j = (uint64_t)(first_chunk + c) * EXP_CHUNK + threadIdx.x;
-        if (j < v_count) io.sorted_rect[j] = r[c];
+        if (j < v_count && !io.rect_presorted) io.sorted_rect[j] = r[c];
         uint32_t v = ((r[c].y & 0xffffu) - (r[c].x & 0xffffu)) * ((r[c].y >> 16) - (r[c].x >> 16));
         v = wave_reduce_add(v);
         if (lane == 0) s_red[c][wid] = v;
@@ -1157,12 +1176,25 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_hist(const K *__restrict_
     static_assert(ITEMS % PER_VEC == 0, "tile must be a whole number of 16-byte vectors per thread");
     if (count - base >= TILE) {
         const uint4 *src = (const uint4 *)(keys + base);
+        // all loads of the tile are issued before the first LDS atomic (the per-chunk test of the
+        // compacting pass used to sit between them: a scalar load, a wait and a branch per vector)
+        bool ok[VECS];
+        uint4 qv[VECS];
 #pragma unroll
         for (int v = 0; v < VECS; v++) {
             // vector v of the tile covers elements [v * 1024, (v + 1) * 1024) for u32 keys = one preprocess chunk
-            if constexpr (COMPACT)
-                if (chunk_vis[(base >> 10) + v] == 0u) continue;
-            uint4 q = src[v * SORT_THREADS + threadIdx.x];
+            ok[v] = true;
+            if constexpr (COMPACT) ok[v] = chunk_vis[(base >> 10) + v] != 0u;
+        }
+#pragma unroll
+        for (int v = 0; v < VECS; v++) {
+            qv[v] = make_uint4(SORT_INVALID_KEY, SORT_INVALID_KEY, SORT_INVALID_KEY, SORT_INVALID_KEY);
+            if (ok[v]) qv[v] = src[v * SORT_THREADS + threadIdx.x];
+        }
+#pragma unroll
+        for (int v = 0; v < VECS; v++) {
+            if (COMPACT && !ok[v]) continue;
+            const uint4 q = qv[v];
             uint32_t w[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
             for (int e = 0; e < PER_VEC; e++) {
@@ -1279,14 +1311,23 @@ __device__ __forceinline__ void scatter_clear(ScatterShared<K, RB, ITEMS> &sh) {
 
 // Everything after a workgroup holds its tile in registers (key[k], val[k] = element
 // wave_off + k * 64 + lane of the tile; padding = all-ones key): rank, local reorder, coalesced store.
-template <typename K, bool FAST_RANK, int RB, bool COMPACT, int ITEMS>
+// GATHER (the LAST pass of the frame's depth sort): the values are mirror slots and the pass also
+// moves each slot's tile rect to the slot's final (depth-order) position — the random 8-byte gather
+// of the key path, issued here ITEMS deep per thread behind a kernel that otherwise waits on LDS,
+// instead of in a kernel of its own (k_expand_count) that re-reads the order it was just given.
+struct RectGather {
+    const uint2 *src;      // [N] tile rects by slot
+    uint2 *dst;            // [V] tile rects in depth order
+};
+
+template <typename K, bool FAST_RANK, int RB, bool COMPACT, int ITEMS, bool GATHER = false>
 __device__ __forceinline__ void scatter_ranked(ScatterShared<K, RB, ITEMS> &sh, K (&key)[ITEMS], uint32_t (&val)[ITEMS],
                                                uint32_t in_tile, uint32_t block, uint32_t num_blocks,
                                                K *__restrict__ keys_out,
                                                uint32_t *__restrict__ vals_out, uint32_t shift, uint32_t digit_mask,
                                                const uint32_t *__restrict__ ghist,
                                                const uint32_t *__restrict__ digit_totals,
-                                               uint32_t *__restrict__ visible_out) {
+                                               uint32_t *__restrict__ visible_out, RectGather rg = RectGather{nullptr, nullptr}) {
     constexpr int R = 1 << RB;
     constexpr int DPT = R / SORT_THREADS;        // digits per thread: thread t owns digits [t*DPT, t*DPT+DPT)
     auto &s_wave_hist = sh.wave_hist;
@@ -1382,6 +1423,31 @@ __device__ __forceinline__ void scatter_ranked(ScatterShared<K, RB, ITEMS> &sh, 
     __syncthreads();
     // without COMPACT the padding of a partial tile carries the all-ones key and sorts to the end
     const uint32_t live = COMPACT ? live_total : in_tile;
+    if constexpr (GATHER) {
+        uint32_t dstv[ITEMS], slotv[ITEMS];
+        uint2 rv[ITEMS];
+#pragma unroll
+        for (int k = 0; k < ITEMS; k++) {
+            const uint32_t pos = k * SORT_THREADS + tid;
+            dstv[k] = 0xffffffffu;
+            if (pos < live) {
+                const K kk = s_keys[pos];
+                dstv[k] = s_delta[(uint32_t)(kk >> shift) & digit_mask] + pos;
+                slotv[k] = s_vals[pos];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < ITEMS; k++)
+            if (dstv[k] != 0xffffffffu) rv[k] = rg.src[slotv[k]];      // ITEMS independent gathers in flight
+#pragma unroll
+        for (int k = 0; k < ITEMS; k++)
+            if (dstv[k] != 0xffffffffu) {
+                if (keys_out) keys_out[dstv[k]] = s_keys[k * SORT_THREADS + tid];
+                vals_out[dstv[k]] = slotv[k];
+                rg.dst[dstv[k]] = rv[k];
+            }
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < ITEMS; k++) {
         uint32_t pos = k * SORT_THREADS + tid;
@@ -1395,13 +1461,13 @@ __device__ __forceinline__ void scatter_ranked(ScatterShared<K, RB, ITEMS> &sh, 
     }
 }
 
-template <typename K, bool FAST_RANK, int RB, bool COMPACT, int ITEMS>
+template <typename K, bool FAST_RANK, int RB, bool COMPACT, int ITEMS, bool GATHER = false>
 __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
     const K *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, K *__restrict__ keys_out,
     uint32_t *__restrict__ vals_out, SortCount sc, uint32_t shift, uint32_t digit_mask,
     const uint32_t *__restrict__ ghist, const uint32_t *__restrict__ digit_totals,
     const uint32_t *__restrict__ chunk_vis, uint32_t *__restrict__ visible_out, uint32_t num_tiles,
-    uint32_t xcd_chunk) {
+    uint32_t xcd_chunk, RectGather rg) {
     constexpr int TILE = SORT_THREADS * ITEMS;
     __shared__ ScatterShared<K, RB, ITEMS> sh;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
@@ -1432,8 +1498,8 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
         if constexpr (COMPACT) val[k] = tile_base + e;
         else val[k] = ok ? vals_in[tile_base + e] : 0u;
     }
-    scatter_ranked<K, FAST_RANK, RB, COMPACT, ITEMS>(sh, key, val, in_tile, block, num_tiles, keys_out, vals_out, shift,
-                                                     digit_mask, ghist, digit_totals, visible_out);
+    scatter_ranked<K, FAST_RANK, RB, COMPACT, ITEMS, GATHER>(sh, key, val, in_tile, block, num_tiles, keys_out, vals_out,
+                                                             shift, digit_mask, ghist, digit_totals, visible_out, rg);
 }
 
 // ---------------------------------------------------------------------------------------------
