@@ -68,8 +68,9 @@ enum {
     /* std::io::Error of the SPZ reader / header validation; message = the Rust message */
     GS_ERR_SPZ = -25,
     /* gs_renderer_wait_frame: the frame produced more (tile, Gaussian) pairs than the renderer's pair
-     * buffers hold (a = pairs, b = capacity); its farthest pairs were dropped.  The next frame grows
-     * the buffers: render again. */
+     * buffers hold (a = pairs, b = capacity).  The frame was SKIPPED: the image was not written (it
+     * keeps what it held) rather than blended without its farthest pairs.  The next frame grows the
+     * buffers: render again. */
     GS_ERR_PAIR_CAPACITY = -26
 };
 
@@ -548,9 +549,13 @@ gs_status gs_renderer_stats(gs_renderer *r, gs_frame_stats *out);
  * The one exception is a SIZING frame — the first frame of a renderer, or the first after the
  * Gaussian count, image size or band changed — which blocks once in the middle to measure D and
  * size the pair buffers (GS_ERR_PAIR_OVERFLOW if D would exceed 2^32).  Later frames take the
- * capacity from the measured D of earlier frames (25 % head room, grown lazily: buffer growth calls
- * hipFree, which synchronises the device).  If a frame nevertheless produces more pairs than fit,
- * its farthest pairs are dropped and gs_renderer_wait_frame reports GS_ERR_PAIR_CAPACITY.
+ * capacity from the measured D of earlier frames (25 % head room over the last D, or over the last
+ * step extrapolated three frames ahead while D keeps growing; grown lazily: buffer growth calls
+ * hipFree, which synchronises the device).  If a frame nevertheless produces more pairs than fit, the
+ * device notices before the blend and the frame is SKIPPED — the RGBA target is left untouched, no
+ * image with missing splats is ever written — gs_renderer_wait_frame reports GS_ERR_PAIR_CAPACITY
+ * (flags bits 0 and 1) and the next gs_render_frame has the larger buffers: a viewer that presents a
+ * frame only after wait_frame / flags == 0 shows the previous frame once more, never a wrong one.
  *
  * Frames in flight: a renderer owns the scratch buffers of ONE frame, so consecutive frames on one
  * renderer run one after the other: in stream order on one stream, and when a frame is submitted on a
@@ -574,7 +579,7 @@ typedef struct gs_frame_result {
     uint64_t visible;         /* V */
     uint64_t pairs;           /* D (the true count, also when it exceeded the capacity) */
     uint64_t pair_capacity;   /* pairs the renderer's buffers hold */
-    uint32_t flags;           /* bit 0: pair capacity exceeded; bit 1: device-side wait timed out */
+    uint32_t flags;           /* bit 0: pair capacity exceeded; bit 1: the frame was skipped (image not written) */
     uint32_t launches;        /* kernel launches the frame enqueued (after the repack) */
 } gs_frame_result;
 

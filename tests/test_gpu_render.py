@@ -723,10 +723,11 @@ def test_radix_sort_skewed_digits(gs, device, stream):
 
 def test_pair_capacity_overflow_is_flagged_and_recovered(gs, ob, device, stream):
     """Steady-state frames size the pair buffers from earlier frames (no read-back inside a frame).
-    When the camera moves so that a frame needs far more pairs than that, the frame drops its
-    farthest pairs and says so (gs_renderer_wait_frame -> PairCapacityError with the true D); the
-    next frame has the larger buffers.  render(check=True) does the wait + re-render itself and must
-    return the exact frame."""
+    When the camera jumps so that a frame needs far more pairs than that, the device notices before the
+    blend and the frame is SKIPPED: the image keeps what it held (never a frame without its farthest
+    splats), the result carries FRAME_FLAG_PAIR_OVERFLOW | FRAME_FLAG_SKIPPED and wait_frame raises
+    PairCapacityError with the true D; the NEXT pipelined frame already has the larger buffers and is
+    exact.  render(check=True) does the wait + re-render itself."""
     import synth
     g = synth.scene(60000, first=5)
     pod = gs.GaussianPod(gs.SH_NONE, gs.COV3D_ROT_SCALE)
@@ -741,24 +742,111 @@ def test_pair_capacity_overflow_is_flagged_and_recovered(gs, ob, device, stream)
     near_cam = helpers.default_camera(gs, W, H)                                                 # inside the scene
     order = buf.download_order(stream)
     ogt, omt = ob.gaussian_transform(size=4.0, sh_deg=0), ob.model_transform()
+    ref, d, vis, _ = ob.render(pod.sh, pod.cov, pods, ogt, omt, helpers.copy_camera(near_cam, ob.Camera), order=order)
 
     fr_far = r.render(stream, buf, gt, mt, far_cam, img.device_ptr())        # sizing frame
     assert fr_far.flags == 0
+    far_img = img.download(stream, np.float32).copy()
     # same shape (N, image size, band), very different view: pipelined frame with the old capacity
     r.render(stream, buf, gt_big, mt, near_cam, img.device_ptr(), check=False)
     with pytest.raises(gs.PairCapacityError) as e:
         r.wait_frame()
     assert e.value.pairs > e.value.capacity >= fr_far.pairs
     d_true = e.value.pairs
-    # the flagged frame still rendered its nearest pairs; the retry is exact
-    fr = r.render(stream, buf, gt_big, mt, near_cam, img.device_ptr())       # check=True: grows, re-renders if needed
-    assert fr.flags == 0 and fr.pairs == d_true and fr.pair_capacity >= d_true
+    assert d_true == d
+    # the skipped frame wrote NOTHING: the target still holds the previous frame, bit for bit
+    assert np.array_equal(img.download(stream, np.float32).view(np.uint32), far_img.view(np.uint32)), \
+        "a frame that lost pairs must not reach the image"
+    # a viewer's loop: the next pipelined frame (check=False) already has the grown buffers and is exact
+    r.render(stream, buf, gt_big, mt, near_cam, img.device_ptr(), check=False)
+    fr = r.wait_frame()
+    assert fr.flags == 0 and fr.pairs == d_true and fr.pair_capacity >= d_true and fr.visible == vis
     rgba = img.download(stream, np.float32).reshape(H, W, 4)
-    ref, d, vis, _ = ob.render(pod.sh, pod.cov, pods, ogt, omt, helpers.copy_camera(near_cam, ob.Camera), order=order)
-    assert d == d_true and fr.visible == vis
     assert np.array_equal(rgba.view(np.uint32), ref.view(np.uint32))
+    # check=True on a fresh renderer: grows and re-renders by itself
+    r2 = gs.Renderer(device)
+    r2.render(stream, buf, gt, mt, far_cam, img.device_ptr())
+    fr = r2.render(stream, buf, gt_big, mt, near_cam, img.device_ptr())
+    assert fr.flags == 0 and fr.pairs == d_true
+    assert np.array_equal(img.download(stream, np.float32).reshape(H, W, 4).view(np.uint32), ref.view(np.uint32))
     # and back: the larger buffers stay, nothing is flagged
     fr2 = r.render(stream, buf, gt, mt, far_cam, img.device_ptr(), check=False)
     assert fr2 is None
     assert r.wait_frame().flags == 0
+    r.destroy(); r2.destroy(); img.release(); buf.destroy()
+
+
+def test_steady_zoom_never_reaches_the_skip_path(gs, ob, device, stream):
+    """A view whose D grows ~17 % per frame for 15 frames, enqueued in bursts of three with nothing
+    but the burst's last wait in between (so a frame is sized from results up to three frames old): the
+    trend-aware head room (last step extrapolated three frames ahead) must keep every frame inside its
+    capacity.  Every frame has its own target pre-filled with NaN: a skipped frame would leave its
+    target untouched.  The last frame is compared with the oracle."""
+    import synth
+    g = synth.scene(80000, first=11)
+    pod = gs.GaussianPod(gs.SH_NONE, gs.COV3D_ROT_SCALE)
+    pods = pod.from_gaussian(g)
+    buf = gs.GaussiansBuffer.new_with_pods(device, pod, pods)
+    W, H = 960, 540
+    nframes = 15
+    sentinel = np.full(W * H * 4, np.nan, dtype=np.float32)
+    imgs = [gs.Buffer(device, data=sentinel) for _ in range(nframes)]
+    r = gs.Renderer(device)
+    mt = gs.model_transform_pod()
+    sizes = [1.0 * 1.08 ** i for i in range(nframes)]     # pairs grow about with the splat size squared
+    gts = [gs.gaussian_transform_pod(size=float(sz), sh_deg=0) for sz in sizes]
+    cam = helpers.default_camera(gs, W, H)
+    fr0 = r.render(stream, buf, gts[0], mt, cam, imgs[0].device_ptr())    # sizing frame
+    pairs = [fr0.pairs]
+    for i in range(1, nframes):
+        r.render(stream, buf, gts[i], mt, cam, imgs[i].device_ptr(), check=False)
+        if i % 3 == 0 or i == nframes - 1:
+            try:
+                pairs.append(r.wait_frame().pairs)
+            except gs.PairCapacityError as e:
+                raise AssertionError("frame %d was skipped: D %d > capacity %d (history %s)" % (i, e.pairs, e.capacity, pairs))
+    assert pairs[-1] > 4 * pairs[0], pairs          # the sequence really grew (by ~1.17 per frame)
+    for i in range(nframes):
+        a = imgs[i].download(stream, np.float32)
+        assert not np.isnan(a).any(), "frame %d left its target untouched: it was skipped" % i
+    order = buf.download_order(stream)
+    ref = ob.render(pod.sh, pod.cov, pods, ob.gaussian_transform(size=float(sizes[-1]), sh_deg=0), ob.model_transform(),
+                    helpers.copy_camera(cam, ob.Camera), order=order)[0]
+    rgba = imgs[-1].download(stream, np.float32).reshape(H, W, 4)
+    assert np.array_equal(rgba.view(np.uint32), ref.view(np.uint32))
+    r.destroy(); buf.destroy()
+    for im in imgs:
+        im.release()
+
+
+@pytest.mark.parametrize("case", [(3840, 2160, 400.0, 45.0, 255, (1927.9, 1082.1)), (7680, 4320, 800.0, 30.0, 255, (3840.25, 2160.25)),
+                                  (3840, 2160, 250.0, 30.0, 2, (1913.3, 1077.8)), (3840, 2160, 60.0, 45.0, 255, (1920.25, 1080.25)),
+                                  (3840, 2160, 120.0, 83.0, 128, (16.02, 2143.98))],
+                         ids=lambda c: "%dx%d-s%g-t%g-k%d" % c[:5])
+def test_adversarial_needles_match_the_unclipped_frame(gs, ob, device, stream, case):
+    """DESIGN.md §3.3, version 3 of the tile rect: splats hundreds of pixels long and thinner than a
+    pixel (cond(cov2d) up to 2e6) with their tips on screen — where the round-2 clip lost threshold-level
+    pixels (tests/test_rect_versions.py) — render, on the HIP path with the default (clipping) rect,
+    bit-identically to the oracle with the same rect AND to the oracle with the unclipped version-1
+    rect; short needles are still clipped (fewer pairs than version 1)."""
+    W, H, sigma, theta, op, c = case
+    g, ocam = helpers.needle_gaussian(ob, theta, sigma, op, c, W, H)
+    pod = gs.GaussianPod(0, 0)
+    pods = pod.from_gaussian(g)
+    cam = helpers.copy_camera(ocam, gs.Camera)
+    gt, mt = gs.gaussian_transform_pod(sh_deg=0), gs.model_transform_pod()
+    r, buf, img, rgba = _render_gpu(gs, device, stream, pod, pods, gt, mt, cam)
+    st = r.stats()
+    old = ob.rect_version()
+    try:
+        same = ob.render(0, 0, pods, ob.gaussian_transform(sh_deg=0), ob.model_transform(), ocam)
+        ob.set_rect_version(1)
+        v1 = ob.render(0, 0, pods, ob.gaussian_transform(sh_deg=0), ob.model_transform(), ocam)
+    finally:
+        ob.set_rect_version(old)
+    assert st.pairs == same[1]
+    assert np.array_equal(rgba.view(np.uint32), same[0].view(np.uint32)), "HIP frame differs from the oracle's (same rect version)"
+    assert np.array_equal(rgba.view(np.uint32), v1[0].view(np.uint32)), "the clipped rect changed the image"
+    if old != 1:
+        assert (st.pairs < v1[1]) == (sigma <= 60.0), (st.pairs, v1[1])      # the guard keeps the square of the long thin ones
     r.destroy(); img.release(); buf.destroy()

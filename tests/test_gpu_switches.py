@@ -12,7 +12,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SUBSET = "synthetic_small or emission or capacity_overflow or edge_cases or wide_tile_keys or radix_sort_skewed"
+SUBSET = "synthetic_small or emission or capacity_overflow or edge_cases or wide_tile_keys or radix_sort_skewed or adversarial_needles"
 
 
 @pytest.mark.parametrize("env", [{"GS3D_CURSOR_KERNEL": "1"}, {"GS3D_DISABLE_FAST_RANK": "1"},

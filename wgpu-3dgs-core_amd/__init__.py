@@ -140,8 +140,8 @@ class PairOverflowError(GsError):
 
 
 class PairCapacityError(GsError):
-    """gs_renderer_wait_frame: the frame produced more pairs than the renderer's buffers hold; its
-    farthest pairs were dropped.  The next frame grows the buffers: render again."""
+    """gs_renderer_wait_frame: the frame produced more pairs than the renderer's buffers hold and was
+    SKIPPED (its image was not written).  The next frame grows the buffers: render again."""
     code = -26
 
     def __init__(self, info):
@@ -1103,6 +1103,7 @@ class ComputeBundleBuilder:
 # renderer
 # ------------------------------------------------------------------------------------------------
 
+FRAME_FLAG_PAIR_OVERFLOW, FRAME_FLAG_SKIPPED = 1, 2     # gs_frame_result.flags
 STAGE_NAMES = ["repack", "preprocess", "scan", "depth_sort", "expand", "tile_sort", "ranges", "blend", "frame"]
 
 

@@ -1519,8 +1519,8 @@ extern "C" gs_status gs_renderer_wait_frame(gs_renderer *r, gs_frame_result *out
                     "the frame needs more than 2^32 (tile, Gaussian) pairs; pair indices are 32-bit");
     if (fr.flags & gs::FRAME_FLAG_PAIR_OVERFLOW)
         return fail(GS_ERR_PAIR_CAPACITY, fr.pairs_total, r->pair_capacity, 0,
-                    "the frame produced %llu (tile, Gaussian) pairs but the pair buffers hold %llu: its farthest pairs "
-                    "were dropped; render again (the next frame grows the buffers)",
+                    "the frame produced %llu (tile, Gaussian) pairs but the pair buffers hold %llu: the frame was "
+                    "skipped (the image was not written); render again (the next frame grows the buffers)",
                     (unsigned long long)fr.pairs_total, (unsigned long long)r->pair_capacity);
     return GS_OK;
 }
@@ -2075,14 +2075,29 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
 
     // ---- what the previous frames told us (never blocks: an unfinished frame is simply not consulted) ----
     uint64_t want_capacity = r->pair_capacity;
+    uint64_t hist_d[2] = {0, 0};
+    uint32_t hist_gen[2] = {0, 0};
     for (int i = 0; i < 2; i++) {
         if (!r->done_valid[i] || hipEventQuery(r->done[i]) != hipSuccess) continue;
         const gs::FrameResult &fr = r->results[i];
         // gen is published last with a system-scope release (publish_result): read it first
         if (__atomic_load_n(&fr.gen, __ATOMIC_ACQUIRE) != r->done_gen[i] || fr.pairs_total > 0xfffffff0ull) continue;
+        hist_d[i] = fr.pairs_total;
+        hist_gen[i] = r->done_gen[i];
         // grow when the last measured D leaves less than 1/8 of head room
         if (fr.pairs_total + fr.pairs_total / 8 > r->pair_capacity && capacity_for(fr.pairs_total) > want_capacity)
             want_capacity = capacity_for(fr.pairs_total);
+    }
+    // A camera that keeps closing in: D grows frame over frame, and this frame is two or three frames
+    // ahead of the newest result (frames are pipelined).  Extrapolate the last step three frames ahead
+    // and size for that, so that a steady zoom does not run into the skip path.
+    if (hist_gen[0] && hist_gen[1] && (hist_gen[0] + 1u == hist_gen[1] || hist_gen[1] + 1u == hist_gen[0])) {
+        const int newer = hist_gen[0] > hist_gen[1] ? 0 : 1;
+        const uint64_t d_new = hist_d[newer], d_old = hist_d[newer ^ 1];
+        if (d_new > d_old) {
+            const uint64_t ahead = d_new + 3u * (d_new - d_old);
+            if (ahead + ahead / 8 > r->pair_capacity && capacity_for(ahead) > want_capacity) want_capacity = capacity_for(ahead);
+        }
     }
     (void)hipGetLastError();   // hipEventQuery reports hipErrorNotReady through the sticky error too
     FrameShape shape;
@@ -2311,7 +2326,8 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
     if (band_tiles) {
         // GS3D_BLEND_GROUPS = 1 (half-tile lists), 2 (8x8 blocks) or 4 (8x4 blocks, default)
         static const int groups = std::getenv("GS3D_BLEND_GROUPS") ? std::atoi(std::getenv("GS3D_BLEND_GROUPS")) : 4;
-        typedef void (*blend_fn)(const uint32_t *, const uint32_t *, const uint32_t *, gs::FrameConsts, float4 *);
+        typedef void (*blend_fn)(const uint32_t *, const uint32_t *, const uint32_t *, gs::FrameConsts, float4 *,
+                                 const gs::FrameState *);
         static const blend_fn tbl[3][3] = {
             {gs::k_blend<0>, gs::k_blend_grouped<0, 2>, gs::k_blend_grouped<0, 4>},
             {gs::k_blend<1>, gs::k_blend_grouped<1, 2>, gs::k_blend_grouped<1, 4>},
@@ -2319,7 +2335,7 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
         const blend_fn blend = tbl[mode][groups == 1 ? 0 : groups == 2 ? 1 : 2];
         hipLaunchKernelGGL(blend, dim3(band_tiles), dim3(gs::BLEND_THREADS), 0, st,
                            (const uint32_t *)r->zero_region.ptr, (const uint32_t *)r->tvals[r->tsorted_side].ptr,
-                           (const uint32_t *)r->recs.ptr, fc, (float4 *)rgba);
+                           (const uint32_t *)r->recs.ptr, fc, (float4 *)rgba, (const gs::FrameState *)state);
         GS_HIP(hipGetLastError());
         r->launches++;
     }

@@ -110,7 +110,7 @@ constexpr int PLY_WORDS = 62;
 constexpr int CV_GAUSSIAN_WORDS = 56;
 
 // Gaussian::from_ply (src/gaussian.rs:70-92): p = 62 words of one PlyGaussianPod, g = 56 words out.
-// `sqrtf_cr` must be a correctly rounded binary32 square root (host sqrtf; device __fsqrt_rn).
+// `sqrtf_cr` must be a correctly rounded binary32 square root (host sqrtf; device sqrtf, which hipcc rounds correctly by default — NOT __fsqrt_rn, the native approximation).
 template <class Sqrt>
 GS_HD inline void ply_to_gaussian_words(const uint32_t *p, uint32_t *g, Sqrt sqrtf_cr) {
     g[4] = p[0];
@@ -134,6 +134,88 @@ GS_HD inline void ply_to_gaussian_words(const uint32_t *p, uint32_t *g, Sqrt sqr
         g[8 + 3 * k + 1] = p[9 + k + 15];
         g[8 + 3 * k + 2] = p[9 + k + 30];
     }
+}
+
+// ---- Gaussian::from_spz (src/gaussian.rs:134-229) over the decompressed columns (spz.rs:739-771) ----
+
+// where the columns of a decompressed SPZ payload start (positions -> alphas -> colors -> scales ->
+// rotations -> sh) and how to read them; pointers may be host or device memory
+struct SpzView {
+    const uint8_t *pos, *alpha, *color, *scale, *rot, *sh;
+    uint32_t version;           // 1..3: f16 vs 24-bit fixed positions; first-three vs smallest-three quaternions
+    uint32_t fractional_bits;
+    uint32_t ncoef;             // SH coefficients per channel: 0, 3, 8, 15
+};
+
+GS_HD inline float cv_f16_to_f32(uint32_t h) {
+    const uint32_t sign = (h & 0x8000u) << 16, e = (h >> 10) & 0x1fu, m = h & 0x3ffu;
+    if (e == 0) return cv_u2f(cv_f2u((float)m * 5.9604644775390625e-08f) | sign);      // m * 2^-24, exact
+    if (e == 31) return cv_u2f(sign | 0x7f800000u | (m << 13));
+    return cv_u2f(sign | ((e + 112u) << 23) | (m << 13));
+}
+
+// SPZ_COLOR_TO_LINEAR_FRAC_A_B = 0.2820948 / 0.15, SPZ_COLOR_TO_LINEAR_C = (1 - A_B) * (0.5 * 255) — gaussian.rs:127-131
+GS_HD inline float spz_color_ab() { return 0.2820948f / 0.15f; }
+GS_HD inline float spz_color_c() { return (1.0f - spz_color_ab()) * (0.5f * 255.0f); }
+
+template <class Sqrt>
+GS_HD inline void spz_to_gaussian_words(const SpzView &v, size_t i, uint32_t *g, Sqrt sqrtf_cr) {
+    if (v.version == 1) {
+        for (int c = 0; c < 3; c++) {
+            const uint8_t *p = v.pos + 6 * i + 2 * c;
+            g[4 + c] = cv_f2u(cv_f16_to_f32((uint32_t)p[0] | ((uint32_t)p[1] << 8)));
+        }
+    } else {
+        // `1 << fractional_bits` on i32 as Rust evaluates it in release builds (shift count masked to 5
+        // bits); the header byte is untrusted, so the plain C shift would be undefined behaviour
+        const float s = 1.0f / (float)(int32_t)(1u << (v.fractional_bits & 31u));
+        for (int c = 0; c < 3; c++) {
+            const uint8_t *p = v.pos + 9 * i + 3 * c;
+            int32_t fixed = (int32_t)p[0] | ((int32_t)p[1] << 8) | ((int32_t)p[2] << 16);
+            if (fixed & 0x800000) fixed |= (int32_t)0xff000000u;
+            g[4 + c] = cv_f2u((float)fixed * s);
+        }
+    }
+    for (int c = 0; c < 3; c++) g[53 + c] = cv_f2u(gs_expf((float)v.scale[3 * i + c] / 16.0f - 10.0f));
+    if (v.version < 3) {
+        const float x = (float)v.rot[3 * i] / 127.5f - 1.0f, y = (float)v.rot[3 * i + 1] / 127.5f - 1.0f,
+                    z = (float)v.rot[3 * i + 2] / 127.5f - 1.0f;
+        const float l2 = (x * x + y * y) + z * z;
+        const float w2 = 1.0f - l2;
+        g[0] = cv_f2u(x);
+        g[1] = cv_f2u(y);
+        g[2] = cv_f2u(z);
+        g[3] = cv_f2u(sqrtf_cr(w2 > 0.0f ? w2 : 0.0f));        // f32::max(.., 0.0): NaN -> 0
+    } else {
+        const uint8_t *q = v.rot + 4 * i;
+        uint32_t comp = (uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16) | ((uint32_t)q[3] << 24);
+        const uint32_t mask = (1u << 9) - 1u;
+        const uint32_t largest = comp >> 30;
+        float sum = 0.0f, comps[4];
+        for (uint32_t k = 0; k < 4; k++) {   // ascending, as the reference's array::from_fn
+            if (k == largest) {
+                comps[k] = 0.0f;
+                continue;
+            }
+            const uint32_t mag = comp & mask, neg = (comp >> 9) & 1u;
+            comp >>= 10;
+            const float val = 0.70710678118654752440f * ((float)mag / (float)mask) * (neg ? -1.0f : 1.0f);
+            sum += val * val;
+            comps[k] = val;
+        }
+        const float w2 = 1.0f - sum;
+        for (uint32_t k = 0; k < 4; k++) g[k] = cv_f2u(k == largest ? sqrtf_cr(w2 > 0.0f ? w2 : 0.0f) : comps[k]);
+    }
+    uint32_t color = 0;
+    for (int c = 0; c < 3; c++) {
+        const float val = (float)v.color[3 * i + c] * spz_color_ab() + spz_color_c();
+        color |= cv_sat_u8(cv_clamp_0_255(val)) << (8 * c);
+    }
+    color |= (uint32_t)v.alpha[i] << 24;
+    g[7] = color;
+    for (int k = 0; k < 45; k++) g[8 + k] = 0u;
+    for (uint32_t k = 0; k < v.ncoef; k++)
+        for (int c = 0; c < 3; c++) g[8 + 3 * k + c] = cv_f2u(((float)v.sh[(i * v.ncoef + k) * 3 + c] - 128.0f) / 128.0f);
 }
 
 }  // namespace gs

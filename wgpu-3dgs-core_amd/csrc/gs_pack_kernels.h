@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void k_pack_pods(const uint32_t *__restrict__ 
 // k_pack_pods (contiguous span in, LDS, one record per thread LDS -> LDS, contiguous span out); the
 // per-record arithmetic is gs_convert.h's ply_to_gaussian_words, shared with the host path.
 struct DeviceSqrt {
-    __device__ float operator()(float v) const { return __fsqrt_rn(v); }
+    __device__ float operator()(float v) const { return sqrtf(v); }   // correctly rounded (hipcc default); __fsqrt_rn is the native approximation
 };
 template <int SH, int COV>
 __global__ __launch_bounds__(256) void k_from_ply_pods(const uint32_t *__restrict__ ply, uint64_t count,

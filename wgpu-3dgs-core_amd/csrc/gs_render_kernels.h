@@ -145,9 +145,11 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_256(uint32_t v, uint32_
 struct FrameState {
     uint32_t visible;        // V: written by the first depth-sort pass (which also compacts)
     uint32_t pairs;          // min(D, pair capacity): what the tile sort / ranges / blend work on
-    uint32_t pad[6];
+    uint32_t overflow;       // D exceeded the pair capacity: the blend leaves the image untouched (frame skipped)
+    uint32_t pad[5];
 };
-constexpr uint32_t FRAME_FLAG_PAIR_OVERFLOW = 1u;   // D exceeded the pair capacity: farthest pairs dropped
+constexpr uint32_t FRAME_FLAG_PAIR_OVERFLOW = 1u;   // D exceeded the pair capacity
+constexpr uint32_t FRAME_FLAG_SKIPPED = 2u;         // ... so the frame was skipped: the image was NOT written
 
 // pinned host memory, one per frame parity; written by workgroup 0 of k_pairs_emit
 struct FrameResult {
@@ -176,6 +178,7 @@ __global__ void k_publish_result(FrameResult *r, FrameState *state, uint32_t gen
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         state->visible = 0;
         state->pairs = 0;
+        state->overflow = 0;
         publish_result(r, 0u, 0ull, 0u, gen);
     }
 }
@@ -1645,8 +1648,9 @@ __global__ __launch_bounds__(EXP_SB) void k_pairs_cursors(ExpandIO io) {
     __syncthreads();
     const uint64_t d = s_all[0] + s_all[1];
     if (sb == 0u && threadIdx.x == 0u) {
-        const uint32_t over = d > (uint64_t)io.capacity ? FRAME_FLAG_PAIR_OVERFLOW : 0u;
+        const uint32_t over = d > (uint64_t)io.capacity ? (FRAME_FLAG_PAIR_OVERFLOW | FRAME_FLAG_SKIPPED) : 0u;
         io.state->pairs = over ? io.capacity : (uint32_t)d;
+        io.state->overflow = over ? 1u : 0u;
         publish_result(io.result, v_count, d, over, io.gen);
     }
     if (v == 0ull) return;
@@ -1841,8 +1845,9 @@ __global__ __launch_bounds__(SORT_THREADS) void k_pairs_emit(ExpandIO io, uint32
         const uint64_t d = cur.total;
         count = d > (uint64_t)io.capacity ? io.capacity : (uint32_t)d;
         if (block == 0u && threadIdx.x == 0u) {
-            const uint32_t over = d > (uint64_t)io.capacity ? FRAME_FLAG_PAIR_OVERFLOW : 0u;
+            const uint32_t over = d > (uint64_t)io.capacity ? (FRAME_FLAG_PAIR_OVERFLOW | FRAME_FLAG_SKIPPED) : 0u;
             io.state->pairs = count;
+            io.state->overflow = over ? 1u : 0u;
             publish_result(io.result, v_count, d, over, io.gen);
         }
     }
@@ -1999,6 +2004,21 @@ __device__ __forceinline__ float gs_exp(float x) {
     return ldexpf(p, (int)n);
 }
 
+// Slack of the staging cull for one (splat, tile).  The pixel loop evaluates `power` in binary32 from
+// three terms that may cancel (a needle 1000 px long: terms of 1e6, sum of -5): its rounding error over
+// the pixels of the tile is at most 5 u S, S <= (|ca| + |cb| + |cc|) D^2 with D the largest offset from
+// the splat centre to a pixel centre of the tile, 5 u = 3e-7; the cull's own evaluation of the block
+// maximum errs by as much again.  A constant 0.1 (rounds 1-2) is enough for ordinary splats only: an
+// 8K frame with an 800-px needle lost threshold-level pixels against the oracle (round 3).  The
+// threshold handed to the block tests is therefore  pmin - 0.1 - 2 * 3e-7 * (|ca|+|cb|+|cc|) * D^2.
+__device__ __forceinline__ float cull_rounding_slack(float mx, float my, float ca, float cb, float cc, float x0,
+                                                     float y0) {
+    const float ax = fmaxf(fabsf(mx - x0), fabsf(mx - (x0 + 15.0f)));
+    const float ay = fmaxf(fabsf(my - y0), fabsf(my - (y0 + 15.0f)));
+    const float d = fmaxf(ax, ay);
+    return (6.0e-7f * ((fabsf(ca) + fabsf(cb)) + fabsf(cc))) * (d * d);
+}
+
 // Maximum over t in [lo, hi] of the concave parabola q2*t^2 + q1*t + q0 (q2 < 0).  Used only by
 // the conservative cull below, so the hardware reciprocal (1 ulp) is fine here.
 __device__ __forceinline__ float parabola_max(float q2, float q1, float q0, float lo, float hi) {
@@ -2050,7 +2070,11 @@ template <int MODE>
 __global__ __launch_bounds__(BLEND_THREADS) void k_blend(const uint32_t *__restrict__ ranges,
                                                          const uint32_t *__restrict__ idx,
                                                          const uint32_t *__restrict__ recs,
-                                                         FrameConsts fc, float4 *__restrict__ rgba) {
+                                                         FrameConsts fc, float4 *__restrict__ rgba,
+                                                         const FrameState *__restrict__ state) {
+    // A frame that outgrew its pair capacity has lost its FARTHEST pairs: blending the rest would show
+    // holes.  It is skipped instead — the image keeps what it held — and flagged.
+    if (state->overflow) return;
     __shared__ float4 s_a[2][BLEND_BATCH];   // mx, my, ca, cb
     __shared__ float4 s_b[2][BLEND_BATCH];   // cc, opacity, r, g
     __shared__ float2 s_c[2][BLEND_BATCH];   // b, pmin (see below)
@@ -2103,11 +2127,12 @@ __global__ __launch_bounds__(BLEND_THREADS) void k_blend(const uint32_t *__restr
             // in place of the constant -5.6 changes no result, it only skips more work.
             if constexpr (MODE == 0) {
                 pmin = fmaxf(-__logf(255.0f * u2f(r1.y)) - 1.0e-3f, -5.6f);
-                keep0 = splat_touches_rect(mx, my, ca, cb, cc, rx0, rx1, ry0, ry0 + 7.0f, pmin - 0.1f);
-                keep1 = splat_touches_rect(mx, my, ca, cb, cc, rx0, rx1, ry0 + 8.0f, ry0 + 15.0f, pmin - 0.1f);
+                const float thr = (pmin - 0.1f) - cull_rounding_slack(mx, my, ca, cb, cc, rx0, ry0);
+                keep0 = splat_touches_rect(mx, my, ca, cb, cc, rx0, rx1, ry0, ry0 + 7.0f, thr);
+                keep1 = splat_touches_rect(mx, my, ca, cb, cc, rx0, rx1, ry0 + 8.0f, ry0 + 15.0f, thr);
             } else if constexpr (MODE == 1) {
                 pmin = fc.ellipse_pmin;   // exact bound of the pixel test; the cull below gets slack
-                const float thr = pmin - 0.1f - 1.0e-3f * fabsf(pmin);
+                const float thr = (pmin - 0.1f - 1.0e-3f * fabsf(pmin)) - cull_rounding_slack(mx, my, ca, cb, cc, rx0, ry0);
                 keep0 = splat_touches_rect(mx, my, ca, cb, cc, rx0, rx1, ry0, ry0 + 7.0f, thr);
                 keep1 = splat_touches_rect(mx, my, ca, cb, cc, rx0, rx1, ry0 + 8.0f, ry0 + 15.0f, thr);
             } else {
@@ -2265,8 +2290,10 @@ template <int MODE, int G>
 __global__ __launch_bounds__(BLEND_THREADS) void k_blend_grouped(const uint32_t *__restrict__ ranges,
                                                                  const uint32_t *__restrict__ idx,
                                                                  const uint32_t *__restrict__ recs,
-                                                                 FrameConsts fc, float4 *__restrict__ rgba) {
+                                                                 FrameConsts fc, float4 *__restrict__ rgba,
+                                                                 const FrameState *__restrict__ state) {
     static_assert(G == 2 || G == 4, "lane groups per wave");
+    if (state->overflow) return;              // frame skipped: see k_blend
     constexpr int GL = WAVE / G;              // lanes per group
     constexpr int BH = 16 / G;                // block height: G = 2 -> 8, G = 4 -> 4 (block width is 8; GL lanes x 2 pixels)
     constexpr int NL = 2 * G;                 // lists per tile
@@ -2328,7 +2355,8 @@ __global__ __launch_bounds__(BLEND_THREADS) void k_blend_grouped(const uint32_t 
             float pmin;
             if constexpr (MODE == 0) pmin = fmaxf(-__logf(255.0f * u2f(r1.y)) - 1.0e-3f, -5.6f);
             else pmin = fc.ellipse_pmin;
-            thr = MODE == 0 ? pmin - 0.1f : pmin - 0.1f - 1.0e-3f * fabsf(pmin);
+            thr = (MODE == 0 ? pmin - 0.1f : pmin - 0.1f - 1.0e-3f * fabsf(pmin)) -
+                  cull_rounding_slack(mx, my, ca, cb, cc, tx0, ty0);
             s_a[tid] = make_float4(mx, my, ca, cb);
             s_b[tid] = make_float4(cc, pmin, u2f(r1.y), u2f(r1.z));
             s_c[tid] = make_float2(u2f(r1.w), u2f(r2x));

@@ -11,8 +11,10 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <thread>
 #include <vector>
 
+#include "gs_convert.h"
 #include "gs_internal.h"
 
 static_assert(sizeof(gs_spz_header) == 16, "SpzGaussiansHeaderPod is 16 bytes");
@@ -70,6 +72,24 @@ static uint8_t sat_u8(float v) { return !(v > 0.0f) ? 0 : v >= 255.0f ? 255 : (u
 static uint32_t sat_u32(float v) { return !(v > 0.0f) ? 0u : v >= 4294967295.0f ? 0xffffffffu : (uint32_t)v; }
 static int32_t sat_i32(float v) { return v != v ? 0 : v >= 2147483647.0f ? 2147483647 : v <= -2147483648.0f ? (int32_t)0x80000000 : (int32_t)v; }
 
+template <class F>
+static void spz_parallel_for(size_t n, F fn) {
+    unsigned hw = std::thread::hardware_concurrency();
+    size_t threads = n < 32768 ? 1 : (hw ? (hw > 32 ? 32 : hw) : 4);
+    if (threads <= 1) {
+        fn((size_t)0, n);
+        return;
+    }
+    std::vector<std::thread> pool;
+    const size_t per = (n + threads - 1) / threads;
+    for (size_t t = 0; t < threads; t++) {
+        const size_t a = t * per, b = a + per < n ? a + per : n;
+        if (a >= b) break;
+        pool.emplace_back([=] { fn(a, b); });
+    }
+    for (auto &th : pool) th.join();
+}
+
 // column sizes (bytes per Gaussian)
 static size_t pos_bytes(uint32_t version) { return version == 1 ? 6 : 9; }
 static size_t rot_bytes(uint32_t version) { return version >= 3 ? 4 : 3; }
@@ -100,58 +120,16 @@ extern "C" gs_status gs_spz_decode_decompressed(const void *bytes, size_t len, g
     const uint8_t *rot = scale + 3 * n;
     const uint8_t *sh = rot + n * rot_bytes(h.version);
     const uint32_t ncoef = num_coefficients(h.sh_degree);
-    for (size_t i = 0; i < m; i++) {
-        gs_gaussian &g = out[i];
-        if (h.version == 1) {
-            for (int c = 0; c < 3; c++) {
-                uint16_t v;
-                std::memcpy(&v, pos + 6 * i + 2 * c, 2);
-                g.pos[c] = f16_to_f32(v);
-            }
-        } else {
-            // `1 << fractional_bits` on i32 as Rust evaluates it in release builds (shift count masked to
-            // 5 bits); the header byte is untrusted, so the plain C shift would be undefined behaviour
-            const float s = 1.0f / (float)(int32_t)(1u << (h.fractional_bits & 31u));
-            for (int c = 0; c < 3; c++) {
-                const uint8_t *p = pos + 9 * i + 3 * c;
-                int32_t fixed = (int32_t)p[0] | ((int32_t)p[1] << 8) | ((int32_t)p[2] << 16);
-                if (fixed & 0x800000) fixed |= (int32_t)0xff000000u;
-                g.pos[c] = (float)fixed * s;
-            }
+    gs::SpzView view{pos, alpha, color, scale, rot, sh, h.version, h.fractional_bits, ncoef};
+    static_assert(sizeof(gs_gaussian) == gs::CV_GAUSSIAN_WORDS * 4, "gs_gaussian layout");
+    // the per-Gaussian arithmetic is gs_convert.h's, shared with the device kernel (k_from_spz_pods)
+    spz_parallel_for(m, [=](size_t a, size_t e) {
+        for (size_t i = a; i < e; i++) {
+            uint32_t gw[gs::CV_GAUSSIAN_WORDS];
+            gs::spz_to_gaussian_words(view, i, gw, [](float x) { return std::sqrt(x); });
+            std::memcpy(&out[i], gw, sizeof(gw));
         }
-        for (int c = 0; c < 3; c++) g.scale[c] = std::exp((float)scale[3 * i + c] / 16.0f - 10.0f);
-        if (h.version < 3) {
-            float x = (float)rot[3 * i] / 127.5f - 1.0f, y = (float)rot[3 * i + 1] / 127.5f - 1.0f,
-                  z = (float)rot[3 * i + 2] / 127.5f - 1.0f;
-            float l2 = (x * x + y * y) + z * z;
-            g.rot[0] = x; g.rot[1] = y; g.rot[2] = z;
-            g.rot[3] = std::sqrt(std::fmax(1.0f - l2, 0.0f));
-        } else {
-            const uint8_t *q = rot + 4 * i;
-            uint32_t comp = (uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16) | ((uint32_t)q[3] << 24);
-            const uint32_t mask = (1u << 9) - 1u;
-            uint32_t largest = comp >> 30;
-            float sum = 0.0f, comps[4];
-            for (uint32_t k = 0; k < 4; k++) {   // ascending, as the reference's array::from_fn
-                if (k == largest) { comps[k] = 0.0f; continue; }
-                uint32_t mag = comp & mask, neg = (comp >> 9) & 1u;
-                comp >>= 10;
-                float v = 0.70710678118654752440f * ((float)mag / (float)mask) * (neg ? -1.0f : 1.0f);
-                sum += v * v;
-                comps[k] = v;
-            }
-            comps[largest] = std::sqrt(std::fmax(1.0f - sum, 0.0f));
-            std::memcpy(g.rot, comps, 16);
-        }
-        for (int c = 0; c < 3; c++) {
-            float v = (float)color[3 * i + c] * k_ab + k_c;
-            g.color[c] = sat_u8(std::fmin(std::fmax(v, 0.0f), 255.0f));
-        }
-        g.color[3] = alpha[i];
-        for (int k = 0; k < 45; k++) g.sh[k] = 0.0f;
-        for (uint32_t k = 0; k < ncoef; k++)
-            for (int c = 0; c < 3; c++) g.sh[3 * k + c] = ((float)sh[(i * ncoef + k) * 3 + c] - 128.0f) / 128.0f;
-    }
+    });
     return GS_OK;
 }
 
