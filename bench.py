@@ -29,6 +29,7 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 SIMDS, CLOCK_GHZ = 1024, 2.4   # 256 CUs x 4 SIMDs, max clock (MI355X_MICROARCH.md chip table)
+BLEND_LOOP_PK_SHARE = 0.35     # v_pk_* share of the VALU instructions of k_blend_grouped<0,4>'s two loop bodies (ISA: 17 of 48)
 
 DEFAULT_EYE = (0.0, 0.0, 0.0)
 WORKLOADS = {
@@ -279,13 +280,15 @@ def stage_models(wl, res):
     return out
 
 
-def frame_bytes_object(wl, res):
+def frame_bytes_object(wl_name, wl, res):
     """Whole-frame byte models over the frame time (SURVEY.md §8d asks for B_frame / t_frame beside
-    Msplats/s).  Two models: the survey's textbook pipeline (64-bit keys, six 8-bit passes over
-    12-byte pairs) — quoted as an EQUIVALENT rate, not as a fraction of peak, because this
-    implementation does not move those bytes (two-level sort: depth keys of the V visible Gaussians,
-    then 2-byte tile keys) — and the sum of the bytes this implementation's stages move
-    (stage_models), whose rate is a real fraction of the 8 TB/s peak."""
+    Msplats/s).  Three figures: (1) the survey's textbook pipeline (64-bit keys, six 8-bit passes over
+    12-byte pairs) as an EQUIVALENT rate — this implementation does not move those bytes; (2) the sum
+    of the bytes this implementation's HBM-bound stages have to move (stage_models) plus the image —
+    the blend's gathers are NOT in it: its tiles saturate early and the counters show it fetching tens
+    of MB, not D x 40 B (round 2 counted those and overstated the fraction); (3) the HBM traffic the
+    PMC counters measured for one whole frame (sum over every kernel of the frame, separate rocprofv3
+    --pmc passes, profiles/pmc_traffic.json) — the physical figure."""
     n, d, v = wl["n"], res["pairs"], res["visible"]
     px = wl["width"] * wl["height"]
     tiles = ((wl["width"] + 15) // 16) * ((wl["height"] + 15) // 16)
@@ -296,10 +299,19 @@ def frame_bytes_object(wl, res):
                % passes, survey_equivalent_gbs=survey / t / 1e9)
     sm = stage_models(wl, res)
     if sm:
-        mine = sum(x["model_bytes"] for x in sm.values() if x.get("bound") == "hbm") + d * (4 + 36) + px * 16
+        mine = sum(x["model_bytes"] for x in sm.values() if x.get("bound") == "hbm") + px * 16
         out.update(implementation_model_bytes=mine, implementation_gbs=mine / t / 1e9,
                    implementation_frac=mine / t / 1e9 / HBM_PEAK_GBS,
-                   implementation_model="sum of stage_models + blend (D x (4-B index + 36-B record) + W x H x 16)")
+                   implementation_model="sum of the HBM-bound stage_models + W x H x 16 (image); the blend's record "
+                                        "gathers are excluded: measured at tens of MB per frame (PMC), not D x 40 B")
+    pmc, why = pmc_record("frame_%s" % wl_name)
+    if pmc:
+        tot = pmc["fetch_bytes"] + pmc["write_bytes"]
+        out.update(pmc_frame_traffic_bytes=tot, pmc_frame_fetch_bytes=pmc["fetch_bytes"], pmc_frame_write_bytes=pmc["write_bytes"],
+                   pmc_frame_gbs=tot / t / 1e9, pmc_frame_frac=tot / t / 1e9 / HBM_PEAK_GBS,
+                   pmc_note="sum of FETCH_SIZE (x2, gfx950) + WRITE_SIZE over every kernel of one frame / this run's frame time")
+    else:
+        out["pmc_note"] = why
     return out
 
 
@@ -362,20 +374,38 @@ def roofline_object(wl_name, wl, res):
 
 
 def blend_valu_object(res):
+    """VALU issue of the blend kernel, priced with CALIBRATED costs: round 2
+    multiplied SQ_ACTIVE_INST_VALU by a literal 4 "quad-cycles"; the calibration run
+    (tools/calibrate_valu.sh: saturating v_fma_f32 / v_pk_fma_f32 streams at 8 waves per SIMD under the
+    same counters, profiles/*_valu_calibration.txt) shows the counter is ONE per VALU instruction
+    (== SQ_INSTS_VALU) and that an instruction occupies the SIMD's issue for 2.5 (v_fma_f32) to 4.8
+    (v_pk_fma_f32) cycles.  The busy fraction is therefore given as a bracket — every instruction priced
+    as the cheapest / as the dearest of the two — and as an estimate for the kernel's static mix."""
     pmc, why = pmc_record("blend_1m")
+    cal, why2 = pmc_record("valu_calibration")
     ms = res["stages_ms"].get("blend")
     obj = {"bound": "valu", "kernel": "k_blend_grouped<Splat,4>", "avg_launch_ms": ms, "pairs": res["pairs"]}
-    if pmc and ms:
-        cycles = ms * 1e-3 * CLOCK_GHZ * 1e9 * SIMDS
-        obj.update(valu_insts_per_launch=pmc["SQ_INSTS_VALU"], salu_insts_per_launch=pmc.get("SQ_INSTS_SALU"),
+    if pmc and cal and ms:
+        insts = pmc["SQ_INSTS_VALU"]
+        # SIMD-cycles of the launch from the same PMC pass: GRBM_GUI_ACTIVE is the sum over the 8 XCDs
+        simd_cycles = pmc["GRBM_GUI_ACTIVE"] / 8.0 * SIMDS if pmc.get("GRBM_GUI_ACTIVE") else ms * 1e-3 * CLOCK_GHZ * 1e9 * SIMDS
+        c_fma = cal["v_fma_f32"]["simd_cycles_per_inst"]
+        c_pk = cal["v_pk_fma_f32"]["simd_cycles_per_inst"]
+        pk_share = BLEND_LOOP_PK_SHARE
+        obj.update(valu_insts_per_launch=insts, salu_insts_per_launch=pmc.get("SQ_INSTS_SALU"),
                    lds_insts_per_launch=pmc.get("SQ_INSTS_LDS"),
-                   valu_active_cycles=pmc["SQ_ACTIVE_INST_VALU"] * 4,      # the counter is in quad-cycles
-                   valu_busy_frac=pmc["SQ_ACTIVE_INST_VALU"] * 4 / cycles,
-                   valu_wave_insts_per_pair=pmc["SQ_INSTS_VALU"] / max(res["pairs"], 1),
-                   note="fraction of the %d SIMDs' issue cycles at %.1f GHz spent issuing VALU instructions; "
-                        "fp32 vector peak 157.3 TFLOP/s is 64 FLOP/clk/SIMD" % (SIMDS, CLOCK_GHZ))
+                   valu_wave_insts_per_pair=insts / max(res["pairs"], 1),
+                   simd_cycles_per_launch=simd_cycles,
+                   calibrated_cycles_per_inst={"v_fma_f32": c_fma, "v_pk_fma_f32": c_pk},
+                   valu_busy_frac_if_all_fma=insts * c_fma / simd_cycles,
+                   valu_busy_frac_if_all_pk=insts * c_pk / simd_cycles,
+                   valu_busy_frac_static_mix=insts * ((1 - pk_share) * c_fma + pk_share * c_pk) / simd_cycles,
+                   static_pk_share_of_loop=pk_share,
+                   valu_insts_per_simd_per_ns=insts / SIMDS / (ms * 1e6),
+                   note="counter units calibrated against kernels of known VALU-busy fraction 1.0 (profiles/); "
+                        "SQ_ACTIVE_INST_VALU counts instructions on gfx950, not quad-cycles")
     else:
-        obj["note"] = why
+        obj["note"] = why or why2
     return obj
 
 
@@ -501,11 +531,11 @@ def main():
         extras[name] = run(name, min(rsteps, 10), rwarm, 20)
 
     if rank == 0:
-        def summary(w, rr):
+        def summary(w, rr, name=None):
             d = {"workload": w["label"], "value": w["n"] / (rr["ms_per_frame"] * 1e-3) / 1e6, "unit": "Msplats/s",
                  "ms_per_step": rr["ms_per_frame"], "frame_ms": rr.get("frame_ms"), "visible": rr["visible"],
                  "pairs": rr["pairs"], "launches_per_frame": rr["launches"], "stages_ms": rr["stages_ms"],
-                 "stage_models": stage_models(w, rr), "frame_bytes": frame_bytes_object(w, rr)}
+                 "stage_models": stage_models(w, rr), "frame_bytes": frame_bytes_object(name, w, rr)}
             if rr["stages_ms"]:
                 pre = rr["stages_ms"]["preprocess"]
                 d["preprocess_read_frac"] = w["n"] * w["payload"] / (pre * 1e-3) / 1e9 / HBM_PEAK_GBS
@@ -538,7 +568,7 @@ def main():
             "frame_ms": res.get("frame_ms"),
             "stages_ms": res["stages_ms"],
             "stage_models": stage_models(wl, res),
-            "frame_bytes": frame_bytes_object(wl, res),
+            "frame_bytes": frame_bytes_object(args.workload, wl, res),
             "two_frames_in_flight": res.get("two_frames_in_flight"),
             "blend": blend_valu_object(res) if args.workload == "1m" and world == 1 else None,
             "hip_runtime": {"source": hiprt.info()["source"], "libamdhip64": hiprt.mapped()["libamdhip64"],
@@ -554,15 +584,15 @@ def main():
         if roof is not None:
             roof_wl = WORKLOADS[args.roofline_workload]
             line["roofline"] = roofline_object(args.roofline_workload, roof_wl, roof)
-            line["roofline_workload"] = summary(roof_wl, roof)
+            line["roofline_workload"] = summary(roof_wl, roof, args.roofline_workload)
             if nocull is not None:
                 line["roofline_nocull"] = roofline_object("10m-nocull", WORKLOADS["10m-nocull"], nocull)
-                line["roofline_nocull"]["frame"] = summary(WORKLOADS["10m-nocull"], nocull)
+                line["roofline_nocull"]["frame"] = summary(WORKLOADS["10m-nocull"], nocull, "10m-nocull")
                 # the fraction that does not lean on culling, next to the headline one
                 line["roofline"]["frac_nocull"] = line["roofline_nocull"]["frac"]
                 line["roofline"]["achieved_nocull"] = line["roofline_nocull"]["achieved"]
         if extras:
-            line["workloads"] = {k: summary(WORKLOADS[k], v) for k, v in extras.items()}
+            line["workloads"] = {k: summary(WORKLOADS[k], v, k) for k, v in extras.items()}
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(wl, args.cpu_frames)
         print(json.dumps(line), flush=True)

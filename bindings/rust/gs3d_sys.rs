@@ -296,6 +296,8 @@ extern "C" {
     pub fn gs_gaussians_buffer_create_from_gaussians(dev: *mut gs_device, sh: u32, cov: u32, gaussians: *const gs_gaussian, len: usize, out: *mut *mut gs_gaussians_buffer) -> gs_status;
     pub fn gs_gaussians_buffer_create_from_ply(dev: *mut gs_device, sh: u32, cov: u32, ply: *const gs_ply_gaussian_pod, len: usize, out: *mut *mut gs_gaussians_buffer) -> gs_status;
     pub fn gs_gaussians_buffer_update_range_ply(g: *mut gs_gaussians_buffer, s: *mut gs_stream, start: usize, ply: *const gs_ply_gaussian_pod, count: usize) -> gs_status;
+    pub fn gs_gaussians_buffer_create_from_spz(dev: *mut gs_device, sh: u32, cov: u32, bytes: *const c_void, len: usize, header_out: *mut gs_spz_header, out: *mut *mut gs_gaussians_buffer) -> gs_status;
+    pub fn gs_gaussians_buffer_create_from_spz_decompressed(dev: *mut gs_device, sh: u32, cov: u32, bytes: *const c_void, len: usize, header_out: *mut gs_spz_header, out: *mut *mut gs_gaussians_buffer) -> gs_status;
     pub fn gs_pack_device_from_ply(dev: *mut gs_device, s: *mut gs_stream, sh: u32, cov: u32, ply_device: *const gs_ply_gaussian_pod, n: usize, pods_device: *mut c_void) -> gs_status;
     pub fn gs_pack_device(dev: *mut gs_device, s: *mut gs_stream, sh: u32, cov: u32, gaussians_device: *const gs_gaussian, n: usize, pods_device: *mut c_void) -> gs_status;
     pub fn gs_gaussians_buffer_from_buffer(buffer: *mut gs_buffer, sh: u32, cov: u32, out: *mut *mut gs_gaussians_buffer) -> gs_status;

@@ -328,6 +328,17 @@ gs_status gs_gaussians_buffer_create_from_ply(gs_device *dev, gs_sh_config sh, g
 /* the same for [start, start + count) of an existing buffer (update_range semantics and errors) */
 gs_status gs_gaussians_buffer_update_range_ply(gs_gaussians_buffer *g, gs_stream *s, size_t start,
                                                const gs_ply_gaussian_pod *ply, size_t count);
+/* SpzGaussians -> GaussiansBuffer: inflate on the host (a gzip member is sequential), then the
+ * decompressed columns cross PCIe once and ONE kernel does Gaussian::from_spz
+ * (src/gaussian.rs:134-229 over spz.rs:739-771's columns) fused with G::from_gaussian.  The PODs are
+ * bit-equal to gs_spz_decode followed by gs_pack; errors as gs_spz_decode (GS_ERR_SPZ). */
+gs_status gs_gaussians_buffer_create_from_spz(gs_device *dev, gs_sh_config sh, gs_cov3d_config cov,
+                                              const void *bytes, size_t len, gs_spz_header *header_out,
+                                              gs_gaussians_buffer **out);
+gs_status gs_gaussians_buffer_create_from_spz_decompressed(gs_device *dev, gs_sh_config sh, gs_cov3d_config cov,
+                                                           const void *bytes, size_t len,
+                                                           gs_spz_header *header_out,
+                                                           gs_gaussians_buffer **out);
 /* the kernel itself: `n` PlyGaussianPod records in DEVICE memory -> PODs in device memory */
 gs_status gs_pack_device_from_ply(gs_device *dev, gs_stream *s, gs_sh_config sh, gs_cov3d_config cov,
                                   const gs_ply_gaussian_pod *ply_device, size_t n, void *pods_device);

@@ -297,6 +297,8 @@ class GaussiansBuffer {   // src/buffer/gaussian.rs:17-229
     GaussiansBuffer(Device &d, const std::vector<Gaussian> &g) { check(gs_gaussians_buffer_create_from_gaussians(d.raw(), G::sh, G::cov3d, g.data(), g.size(), &h_)); }
     // PlyGaussians -> buffer with Gaussian::from_ply + G::from_gaussian fused in one device kernel
     static GaussiansBuffer new_from_ply(Device &d, const std::vector<PlyGaussianPod> &ply) { GaussiansBuffer b; check(gs_gaussians_buffer_create_from_ply(d.raw(), G::sh, G::cov3d, ply.data(), ply.size(), &b.h_)); return b; }
+    // SPZ file bytes -> buffer: host inflate, then Gaussian::from_spz + G::from_gaussian in one device kernel
+    static GaussiansBuffer new_from_spz(Device &d, const void *bytes, size_t len) { GaussiansBuffer b; check(gs_gaussians_buffer_create_from_spz(d.raw(), G::sh, G::cov3d, bytes, len, nullptr, &b.h_)); return b; }
     void update_range_from_ply(Stream &s, size_t start, const std::vector<PlyGaussianPod> &ply) { check(gs_gaussians_buffer_update_range_ply(h_, s.raw(), start, ply.data(), ply.size())); }
     static GaussiansBuffer new_with_pods(Device &d, const std::vector<uint8_t> &pods) { GaussiansBuffer b; check(gs_gaussians_buffer_create(d.raw(), G::sh, G::cov3d, pods.data(), pods.size() / G::size(), &b.h_)); return b; }
     static GaussiansBuffer new_empty(Device &d, size_t len) { GaussiansBuffer b; check(gs_gaussians_buffer_create(d.raw(), G::sh, G::cov3d, nullptr, len, &b.h_)); return b; }

@@ -213,3 +213,45 @@ def test_device_from_ply_frame_and_load_time(gs, ob, device, stream):
     print("\nLOAD 1M-vertex PLY: device path (H2D 248 MB + k_from_ply_pods) %.3f s = %.2f GB/s of PLY bytes; "
           "threaded host from_ply alone %.3f s" % (t_dev, n * 248 / t_dev / 1e9, t_host))
     r.destroy(); img.release(); buf.destroy()
+
+
+@pytest.mark.parametrize("pod_idx", [0, 4, 8, 11])
+def test_device_from_spz_equals_host_path(gs, ob, device, stream, pod_idx):
+    """SPZ bytes -> PODs with the column decode on the device (host inflate, then Gaussian::from_spz fused
+    with G::from_gaussian in k_from_spz_pods) must be byte-equal to the host path gs_spz_decode + gs_pack:
+    the reference's data file, and files the product's encoder writes for every version x SH degree x
+    fractional-bits combination (f16 / 24-bit positions, first-three / smallest-three quaternions)."""
+    import synth
+    pod = gs.ALL_PODS[pod_idx]
+    cases = [("model.spz", open(os.path.join(GOLD, "model.spz"), "rb").read())]
+    g = synth.scene(70_001, first=31)
+    g["pos"] *= np.float32(0.05)
+    for version in (1, 2, 3):
+        for deg in (0, 1, 2, 3):
+            for bits in ((12,) if (version, deg) != (2, 3) else (8, 12, 16)):
+                opt = gs.spz_options(version=version, sh_degree=deg, fractional_bits=bits)
+                cases.append(("v%d-deg%d-fb%d" % (version, deg, bits), gs.SpzGaussians.write_gaussians(g[:70_001 - 7 * deg], opt)))
+    for name, data in cases:
+        want = pod.from_gaussian(np.ascontiguousarray(gs.SpzGaussians.read_from(data).iter_gaussian(), dtype=gs.GAUSSIAN_DTYPE))
+        buf = gs.GaussiansBuffer.new_from_spz(device, pod, data)
+        got = buf.download(stream)
+        assert len(buf) * pod.size == want.size
+        if not np.array_equal(got, want.reshape(-1)):
+            gw, ww = got.view(np.uint32).reshape(len(buf), -1), np.ascontiguousarray(want).view(np.uint32).reshape(len(buf), -1)
+            rec, word = np.nonzero(gw != ww)
+            raise AssertionError("%s (%s): device from_spz differs from the host path in %d words of %d records; first: "
+                                 "record %d word %d device %08x host %08x" % (name, pod, len(rec), len(np.unique(rec)), rec[0],
+                                                                              word[0], gw[rec[0], word[0]], ww[rec[0], word[0]]))
+        buf.destroy()
+    # the decompressed entry point and the reference's error for a bad magic number
+    import gzip
+    raw = gzip.decompress(cases[0][1])
+    b2 = gs.GaussiansBuffer.new_from_spz(device, pod, raw, decompressed=True)
+    assert len(b2) == b2.spz_header.num_points > 0
+    b2.destroy()
+    bad = bytearray(raw)
+    bad[0] ^= 0xff
+    with pytest.raises(gs.SpzError):
+        gs.GaussiansBuffer.new_from_spz(device, pod, bytes(bad), decompressed=True)
+    with pytest.raises(gs.SpzError):
+        gs.GaussiansBuffer.new_from_spz(device, pod, raw[:len(raw) // 2], decompressed=True)

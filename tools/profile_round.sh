@@ -12,6 +12,8 @@ OUT=$REPO/gpurun_out/profiles_out
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 
+bash tools/calibrate_valu.sh "$TAG" > "$OUT/${TAG}_valu_calibration.log" 2>&1 || { tail -5 "$OUT/${TAG}_valu_calibration.log"; exit 1; }
+
 for WL in 1m 10m 10m-nocull; do
   bash tools/profile.sh "$TAG" "$WL" 7 > "$OUT/${TAG}_${WL}_profile.log" 2>&1 || { tail -5 "$OUT/${TAG}_${WL}_profile.log"; exit 1; }
 done
@@ -33,6 +35,26 @@ for wl in ("1m", "10m", "10m-nocull"):
             rec["preprocess_%s" % wl] = dict(kernel=r["kernel"], avg_us=r["avg_us"], fetch_bytes=r["fetch_bytes_per_launch"],
                                              write_bytes=r["write_bytes_per_launch"])
             break
+# whole-frame HBM traffic: every kernel of one frame, fetch + write per launch x launches per frame
+for wl in ("1m", "10m", "10m-nocull"):
+    rows = json.load(open(os.path.join(out, "%s_%s_summary.json" % (tag, wl))))
+    frames = max([r["calls"] for r in rows if r["kernel"].startswith("k_blend")] or [0])
+    if not frames:
+        continue
+    fetch = write = 0.0
+    per_kernel = {}
+    for r in rows:
+        if not r["kernel"].startswith("k_") or r["fetch_bytes_per_launch"] is None or r["calls"] < frames:
+            continue          # upload-time kernels (repack, morton, ...) run once, not per frame
+        per = r["calls"] / frames
+        fetch += r["fetch_bytes_per_launch"] * per
+        write += r["write_bytes_per_launch"] * per
+        per_kernel[r["kernel"][:60]] = dict(launches_per_frame=per, avg_us=r["avg_us"], fetch_bytes=r["fetch_bytes_per_launch"],
+                                            write_bytes=r["write_bytes_per_launch"])
+    rec["frame_%s" % wl] = dict(fetch_bytes=fetch, write_bytes=write, frames=frames, kernels=per_kernel)
+cal_path = os.path.join(out, "%s_valu_calibration.json" % tag)
+if os.path.exists(cal_path):
+    rec["valu_calibration"] = json.load(open(cal_path))
 blend = {}
 for f in ("%s_1m_sq1.txt" % tag, "%s_1m_sq2.txt" % tag):
     for line in open(os.path.join(out, f)):

@@ -716,6 +716,19 @@ class GaussiansBuffer:
         return GaussiansBuffer(device, pod, h)
 
     @staticmethod
+    def new_from_spz(device, pod, data, decompressed=False):
+        """SPZ file bytes (gzip'd, or the decompressed payload) -> buffer: inflate on the host, then ONE
+        device kernel does Gaussian::from_spz + G::from_gaussian (gs_gaussians_buffer_create_from_spz) —
+        bit-equal to new(device, pod, SpzGaussians.read_from(data).iter_gaussian())."""
+        raw = np.frombuffer(bytes(data), dtype=np.uint8)
+        h, hdr = C.c_void_p(), _capi.SpzHeader()
+        fn = _L.gs_gaussians_buffer_create_from_spz_decompressed if decompressed else _L.gs_gaussians_buffer_create_from_spz
+        _check(fn(device._h, pod.sh, pod.cov, _ptr(raw), raw.size, C.byref(hdr), C.byref(h)))
+        b = GaussiansBuffer(device, pod, h)
+        b.spz_header = hdr
+        return b
+
+    @staticmethod
     def new_with_pods(device, pod, pods):
         pods = np.ascontiguousarray(pods, dtype=np.uint8)
         assert pods.nbytes % pod.size == 0

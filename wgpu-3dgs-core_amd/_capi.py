@@ -123,6 +123,8 @@ SIGNATURES = {
     "gs_gaussians_buffer_create_from_ply": (i32, [vp, i32, i32, vp, sz, vp]),
     "gs_gaussians_buffer_update_range_ply": (i32, [vp, vp, sz, vp, sz]),
     "gs_pack_device_from_ply": (i32, [vp, vp, i32, i32, vp, sz, vp]),
+    "gs_gaussians_buffer_create_from_spz": (i32, [vp, i32, i32, vp, sz, vp, vp]),
+    "gs_gaussians_buffer_create_from_spz_decompressed": (i32, [vp, i32, i32, vp, sz, vp, vp]),
     "gs_gaussians_buffer_from_buffer": (i32, [vp, i32, i32, vp]),
     "gs_gaussians_buffer_destroy": (None, [vp]),
     "gs_gaussians_buffer_len": (sz, [vp]),

@@ -747,6 +747,59 @@ extern "C" gs_status gs_gaussians_buffer_create_from_ply(gs_device *dev, gs_sh_c
     return rc;
 }
 
+// SPZ: the decompressed payload crosses PCIe once; one kernel decodes the columns (Gaussian::from_spz,
+// src/gaussian.rs:134-229) and packs (G::from_gaussian)
+typedef void (*spz_fn)(gs::SpzView, uint64_t, uint32_t *);
+static spz_fn k_tbl_from_spz[4][3] = GS_CFG_TABLE(gs::k_from_spz_pods);
+
+extern "C" gs_status gs_gaussians_buffer_create_from_spz_decompressed(gs_device *dev, gs_sh_config sh,
+                                                                      gs_cov3d_config cov, const void *bytes,
+                                                                      size_t len, gs_spz_header *header_out,
+                                                                      gs_gaussians_buffer **out) {
+    if (!valid_cfg(sh, cov) || !bytes || !out) return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "bad argument");
+    *out = nullptr;
+    gs_spz_header h;
+    size_t off[6];
+    uint32_t ncoef = 0;
+    GS_TRY(gs_spz_payload_layout(bytes, len, &h, off, &ncoef));
+    if (header_out) *header_out = h;
+    const size_t n = h.num_points;
+    GS_TRY(gs_gaussians_buffer_create(dev, sh, cov, nullptr, n, out));
+    if (!n) return GS_OK;
+    gs_status rc = GS_OK;
+    void *staging = nullptr;
+    const size_t used = off[5] + n * 3u * ncoef;             // the payload the header declares (len may be larger)
+    hipError_t e = hipMalloc(&staging, used);
+    if (e != hipSuccess) rc = fail(GS_ERR_OUT_OF_MEMORY, used, 0, 0, "hipMalloc failed: %s", hipGetErrorString(e));
+    if (rc == GS_OK && (e = hipMemcpyAsync(staging, bytes, used, hipMemcpyHostToDevice, dev->internal)) != hipSuccess)
+        rc = fail(GS_ERR_HIP, (uint64_t)e, 0, 0, "upload failed: %s", hipGetErrorString(e));
+    if (rc == GS_OK) {
+        const uint8_t *b = (const uint8_t *)staging;
+        gs::SpzView v{b + off[0], b + off[1], b + off[2], b + off[3], b + off[4], b + off[5], h.version, h.fractional_bits, ncoef};
+        const uint64_t groups = ((uint64_t)n + gs::PACK_GROUP - 1) / gs::PACK_GROUP;
+        hipLaunchKernelGGL(k_tbl_from_spz[sh][cov], dim3((uint32_t)groups), dim3(256), 0, dev->internal, v, (uint64_t)n,
+                           (uint32_t *)(*out)->buf->ptr);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(dev->internal);
+        if (e != hipSuccess) rc = fail(GS_ERR_HIP, (uint64_t)e, 0, 0, "SPZ decode kernel failed: %s", hipGetErrorString(e));
+    }
+    if (staging) (void)hipFree(staging);
+    if (rc != GS_OK) {
+        gs_gaussians_buffer_destroy(*out);
+        *out = nullptr;
+    }
+    return rc;
+}
+
+extern "C" gs_status gs_gaussians_buffer_create_from_spz(gs_device *dev, gs_sh_config sh, gs_cov3d_config cov,
+                                                         const void *bytes, size_t len, gs_spz_header *header_out,
+                                                         gs_gaussians_buffer **out) {
+    if (!bytes || !out) return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "bad argument");
+    std::vector<uint8_t> raw;
+    GS_TRY(gs_spz_gunzip(bytes, len, raw));
+    return gs_gaussians_buffer_create_from_spz_decompressed(dev, sh, cov, raw.data(), raw.size(), header_out, out);
+}
+
 extern "C" gs_status gs_gaussians_buffer_update_range_ply(gs_gaussians_buffer *g, gs_stream *s, size_t start,
                                                           const gs_ply_gaussian_pod *ply, size_t count) {
     if (!g) return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "null buffer");
@@ -1644,8 +1697,14 @@ struct SortCompact {
 template <int TILE>
 static void launch_scan_rows(uint32_t rows, hipStream_t st, uint32_t *ghist, uint32_t stride, gs::SortCount sc,
                              uint32_t *totals) {
-    hipLaunchKernelGGL((gs::k_sort_scan_rows<TILE>), dim3(rows), dim3(gs::SCAN_ROWS_THREADS), 0, st, ghist, stride, sc,
-                       totals);
+    // rows of up to SCAN_ROWS_SMALL_MAX blocks (stride = the host's bound of the block count): one wave per row
+    static const bool small_off = std::getenv("GS3D_SCAN_ROWS_SMALL") && std::getenv("GS3D_SCAN_ROWS_SMALL")[0] == '0';
+    if (stride <= gs::SCAN_ROWS_SMALL_MAX && !small_off)
+        hipLaunchKernelGGL((gs::k_sort_scan_rows_small<TILE>), dim3((rows + 3u) / 4u), dim3(256), 0, st, ghist, stride, sc,
+                           totals, rows);
+    else
+        hipLaunchKernelGGL((gs::k_sort_scan_rows<TILE>), dim3(rows), dim3(gs::SCAN_ROWS_THREADS), 0, st, ghist, stride, sc,
+                           totals);
 }
 
 template <typename K, int RB, int ITEMS>

@@ -159,4 +159,24 @@ __global__ __launch_bounds__(256) void k_from_ply_pods(const uint32_t *__restric
     for (uint32_t q = threadIdx.x; q < ng * NW; q += 256) dst[q] = s_out[q];
 }
 
+// Device load path of an SPZ scene (after the host's inflate): Gaussian::from_spz over the
+// decompressed columns fused with G::from_gaussian.  The columns are byte streams (9 + 1 + 3 + 3 + 4 +
+// 3 ncoef bytes per Gaussian); a thread reads its own bytes — neighbouring threads read neighbouring
+// bytes of every column, so the lines are used whole — and the PODs leave through LDS as one span.
+template <int SH, int COV>
+__global__ __launch_bounds__(256) void k_from_spz_pods(SpzView v, uint64_t count, uint32_t *__restrict__ pods) {
+    constexpr int NW = pod_words(SH, COV);
+    __shared__ uint32_t s_out[PACK_GROUP * NW];               // <= 28 KiB
+    const uint64_t g0 = (uint64_t)blockIdx.x * PACK_GROUP;
+    const uint32_t ng = (uint32_t)(count - g0 < PACK_GROUP ? count - g0 : PACK_GROUP);
+    if (threadIdx.x < ng) {
+        uint32_t gw[GAUSSIAN_WORDS];
+        spz_to_gaussian_words(v, (size_t)(g0 + threadIdx.x), gw, DeviceSqrt());
+        pack_words(SH, COV, gw, s_out + threadIdx.x * NW);
+    }
+    __syncthreads();
+    uint32_t *dst = pods + g0 * NW;
+    for (uint32_t q = threadIdx.x; q < ng * NW; q += 256) dst[q] = s_out[q];
+}
+
 }  // namespace gs

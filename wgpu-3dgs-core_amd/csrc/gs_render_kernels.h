@@ -1279,6 +1279,41 @@ __global__ __launch_bounds__(SCAN_ROWS_THREADS) void k_sort_scan_rows(uint32_t *
     if (threadIdx.x == 0) digit_totals[blockIdx.x] = carry;
 }
 
+// The same scan for SHORT rows (up to a few thousand blocks: every sort of the 1 M frame): one WAVE per
+// row, four rows per workgroup, no LDS and no barrier — 1024-thread workgroups that mostly idle cost
+// 6 us per launch at 1 M, five launches per frame.
+constexpr uint32_t SCAN_ROWS_SMALL_MAX = 2048;     // blocks per row up to which the wave-per-row kernel is used
+template <int TILE>
+__global__ __launch_bounds__(256) void k_sort_scan_rows_small(uint32_t *__restrict__ ghist, uint32_t row_stride,
+                                                              SortCount sc, uint32_t *__restrict__ digit_totals,
+                                                              uint32_t rows) {
+    constexpr uint32_t PER = 4;
+    const uint32_t lane = threadIdx.x & 63u, r = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const uint32_t count = sc.get();
+    const uint32_t num_blocks = (uint32_t)(((uint64_t)count + TILE - 1) / TILE);
+    uint32_t *row = ghist + (uint64_t)r * row_stride;
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < num_blocks; base += WAVE * PER) {
+        const uint32_t i0 = base + lane * PER;
+        uint32_t v[PER], sum = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < PER; k++) {
+            v[k] = i0 + k < num_blocks ? row[i0 + k] : 0u;
+            sum += v[k];
+        }
+        const uint32_t inc = wave_inclusive_scan(sum, lane);
+        uint32_t run = carry + inc - sum;
+#pragma unroll
+        for (uint32_t k = 0; k < PER; k++) {
+            if (i0 + k < num_blocks) row[i0 + k] = run;
+            run += v[k];
+        }
+        carry += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+    }
+    if (lane == 0) digit_totals[r] = carry;
+}
+
 // Stable scatter.  Element order inside a workgroup tile: wave w owns ITEMS*64 consecutive
 // elements, round k of the wave covers 64 consecutive elements, lane order inside a round; ranks
 // are assigned in exactly that order, so equal digits keep their order.

@@ -98,6 +98,27 @@ static size_t payload_bytes(const gs_spz_header &h) {
     return 16 + (size_t)h.num_points * (pos_bytes(h.version) + 1 + 3 + 3 + rot_bytes(h.version) + 3 * num_coefficients(h.sh_degree));
 }
 
+gs_status gs_spz_payload_layout(const void *bytes, size_t len, gs_spz_header *header_out, size_t col_offset[6],
+                                uint32_t *ncoef_out) {
+    if (!bytes) return gs_fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "null argument");
+    if (len < 16) return gs_fail(GS_ERR_SPZ, len, 0, 0, "failed to fill whole buffer");
+    gs_spz_header h;
+    std::memcpy(&h, bytes, 16);
+    gs_status rc = validate_header(h);
+    if (rc != GS_OK) return rc;
+    if (len < payload_bytes(h)) return gs_fail(GS_ERR_SPZ, len, payload_bytes(h), 0, "failed to fill whole buffer");
+    const size_t n = h.num_points;
+    col_offset[0] = 16;
+    col_offset[1] = col_offset[0] + n * pos_bytes(h.version);
+    col_offset[2] = col_offset[1] + n;
+    col_offset[3] = col_offset[2] + 3 * n;
+    col_offset[4] = col_offset[3] + 3 * n;
+    col_offset[5] = col_offset[4] + n * rot_bytes(h.version);
+    if (header_out) *header_out = h;
+    if (ncoef_out) *ncoef_out = num_coefficients(h.sh_degree);
+    return GS_OK;
+}
+
 // ---- Gaussian::from_spz over a decompressed buffer (gaussian.rs:134-229, spz.rs:739-771) --------
 extern "C" gs_status gs_spz_decode_decompressed(const void *bytes, size_t len, gs_spz_header *header_out,
                                                 gs_gaussian *out, size_t capacity, size_t *count_out) {
@@ -242,6 +263,8 @@ extern "C" gs_status gs_spz_encode_decompressed(const gs_gaussian *in, size_t n,
 // the 16-byte SPZ header has been inflated the payload size is known (payload_bytes), and a stream
 // that inflates past it (plus slack) is rejected instead of growing without limit; a stream whose
 // first bytes are not an SPZ header is capped at 1 GiB.
+static gs_status gunzip(const void *bytes, size_t len, std::vector<uint8_t> &out);
+gs_status gs_spz_gunzip(const void *bytes, size_t len, std::vector<uint8_t> &out) { return gunzip(bytes, len, out); }
 static gs_status gunzip(const void *bytes, size_t len, std::vector<uint8_t> &out) {
     constexpr size_t CHUNK = (size_t)1 << 30;
     z_stream zs;
