@@ -203,8 +203,13 @@ def test_from_ply_one_million_matches_oracle_libm(gs, ob):
     p = _synthetic_ply(n)
     g = gs.gaussian_from_ply(p)
     o = ob.gaussians_from_ply(p)
-    for f in ("pos", "sh", "rot"):
+    for f in ("pos", "sh"):
         assert np.array_equal(g[f].view(np.uint32), o[f].view(np.uint32)), f
+    # rot: bit-equal, except that a NaN the arithmetic produces (zero / infinite quaternion) is the
+    # canonical +qNaN in the product (host == device) and whatever x86 returns (-qNaN) in the oracle
+    both_nan = np.isnan(g["rot"]) & np.isnan(o["rot"])
+    assert int(both_nan.sum()) >= 5 and bool((g["rot"].view(np.uint32)[both_nan] == 0x7fc00000).all())
+    assert np.array_equal(g["rot"].view(np.uint32)[~both_nan], o["rot"].view(np.uint32)[~both_nan])
     ds = g["scale"].view(np.uint32).astype(np.int64) - o["scale"].view(np.uint32).astype(np.int64)
     nan_both = np.isnan(g["scale"]) & np.isnan(o["scale"])
     ds[nan_both] = 0

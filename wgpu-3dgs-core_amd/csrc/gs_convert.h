@@ -47,6 +47,12 @@ GS_HD inline double cv_u2d(uint64_t u) {
     return d;
 }
 
+// IEEE 754 leaves the sign and payload of a NaN that ARITHMETIC produces to the implementation: x86
+// returns the negative quiet NaN (0xffc00000) for 0/0 and propagates operand payloads, gfx950 returns
+// +qNaN (0x7fc00000).  Values computed from degenerate input (a zero or infinite quaternion) are
+// therefore canonicalised to +qNaN wherever host and device must agree bit for bit.
+GS_HD inline uint32_t cv_canon_nan_bits(float f) { return f != f ? 0x7fc00000u : cv_f2u(f); }
+
 // T[i] = bits(2^(i/32)) - (i << 47), 2^(i/32) correctly rounded to binary64
 GS_HD inline uint64_t expf_table(uint32_t i) {
     const uint64_t T[32] = {
@@ -119,8 +125,8 @@ GS_HD inline void ply_to_gaussian_words(const uint32_t *p, uint32_t *g, Sqrt sqr
     // Quat::from_xyzw(rot[1], rot[2], rot[3], rot[0]).normalize()
     const float q[4] = {cv_u2f(p[59]), cv_u2f(p[60]), cv_u2f(p[61]), cv_u2f(p[58])};
     const float len = sqrtf_cr(((q[0] * q[0] + q[1] * q[1]) + q[2] * q[2]) + q[3] * q[3]);
-    for (int k = 0; k < 4; k++) g[k] = cv_f2u(q[k] / len);
-    for (int k = 0; k < 3; k++) g[53 + k] = cv_f2u(gs_expf(cv_u2f(p[55 + k])));
+    for (int k = 0; k < 4; k++) g[k] = cv_canon_nan_bits(q[k] / len);
+    for (int k = 0; k < 3; k++) g[53 + k] = cv_canon_nan_bits(gs_expf(cv_u2f(p[55 + k])));
     uint32_t color = 0;
     for (int k = 0; k < 3; k++) {
         const float v = (cv_u2f(p[6 + k]) * 0.2820948f + 0.5f) * 255.0f;        // SH0_TO_LINEAR_FACTOR

@@ -99,7 +99,7 @@ __host__ __device__ inline void pack_words(int sh, int cov, const uint32_t *g, u
         for (int k = 0; k < 3; k++) sc[k].u = g[GW_SCALE + k];
         float qf[4] = {q[0].f, q[1].f, q[2].f, q[3].f}, sf[3] = {sc[0].f, sc[1].f, sc[2].f}, c6[6];
         cov3d_from_rot_scale(qf, sf, c6);
-        for (int k = 0; k < 6; k++) o[k].f = c6[k];
+        for (int k = 0; k < 6; k++) o[k].u = cv_canon_nan_bits(c6[k]);      // computed NaNs: one bit pattern on host and device
         if (cov == COV_SINGLE) {
             for (int k = 0; k < 6; k++) c[k] = o[k].u;
         } else {

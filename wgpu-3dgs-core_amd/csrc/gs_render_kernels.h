@@ -1867,11 +1867,15 @@ __global__ __launch_bounds__(SORT_THREADS) void k_pairs_emit(ExpandIO io, uint32
     uint32_t count;
     if (io.cursors) {
         static_assert(NSLOTS % CURSOR_SLOTS == 0, "a wave starts on a cursor");
+        // the cursor record is requested together with the counts (the table covers the whole grid: a
+        // record past D is stale but in bounds and unused), so that the wave's first batch is two
+        // dependent round trips away instead of three
+        const uint64_t span = o0 / CURSOR_SLOTS, last_span = (uint64_t)io.capacity / CURSOR_SLOTS;   // (the grid is rounded up)
+        const PairCursorRec rec = io.cursors[span < last_span ? span : last_span];
         count = io.state->pairs < io.capacity ? io.state->pairs : io.capacity;   // published by k_pairs_cursors
         cur.chunk = 0;
         cur.prefix = 0;
         if (o0 < count) {
-            const PairCursorRec rec = io.cursors[o0 / CURSOR_SLOTS];
             cur.chunk = rec.chunk;
             cur.prefix = rec.prefix;
         }
