@@ -148,6 +148,15 @@ static void cov3d_single_from_rot_scale(const float q[4], const float s[3], floa
     out[4] = SIG(2, 1);
     out[5] = SIG(2, 2);
 #undef SIG
+    /* IEEE 754 leaves the sign / payload of a NaN that arithmetic PRODUCES to the implementation (x86:
+     * -qNaN for inf - inf, operand payloads propagate; gfx950: +qNaN).  A covariance computed from a
+     * NaN / infinite quaternion or scale is canonicalised to +qNaN so that every platform packs the
+     * same bytes (the product does the same on host and device, csrc/gs_convert.h). */
+    for (int k = 0; k < 6; k++)
+        if (out[k] != out[k]) {
+            const uint32_t canon = 0x7fc00000u;
+            memcpy(&out[k], &canon, 4);
+        }
 }
 
 void gso_pack(int sh, int cov, const gso_gaussian *in, size_t n, void *out_) {

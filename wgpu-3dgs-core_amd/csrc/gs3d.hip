@@ -1684,9 +1684,6 @@ struct SortCompact {
     const uint32_t *chunk_vis = nullptr;
     uint32_t *visible_out = nullptr;
     uint32_t dense_count = 0;        // N: the first pass runs over all slots
-    // the LAST pass also moves the tile rect of every slot to its depth-order position (RectGather); null = off
-    const uint2 *rect_src = nullptr;
-    uint2 *rect_dst = nullptr;
 };
 
 // Stable LSD radix sort of (key, u32 value) pairs on key bits [0, end_bit), RB bits per pass at
@@ -1752,21 +1749,19 @@ static gs_status run_sort_items(const gs_device *dev, void *const keys[2], void 
             if (remap_c > 1) xr = (uint32_t)remap_c;
         }
         const uint32_t sgrid = xr ? 8u * xr * ((pnb + 8u * xr - 1u) / (8u * xr)) : pnb;
-        const bool gather = compact && compact->rect_dst && p == passes - 1;
-        const gs::RectGather rg{gather ? compact->rect_src : nullptr, gather ? compact->rect_dst : nullptr};
-#define GS_SORT_PASS(COMPACT, GATHER)                                                                             \
+#define GS_SORT_PASS(COMPACT)                                                                                     \
     do {                                                                                                          \
         hipLaunchKernelGGL((gs::k_sort_hist<K, RB, COMPACT, ITEMS>), dim3(sgrid), dim3(gs::SORT_THREADS), 0, st, kin, psc, \
                            shift, digit_mask, (uint32_t *)ghist.ptr, cv, pnb, xr);                                \
         launch_scan_rows<(int)TILE>(R, st, (uint32_t *)ghist.ptr, pnb, psc, (uint32_t *)digit_totals.ptr);        \
         if (dev->lds_atomic_ordered)                                                                              \
-            hipLaunchKernelGGL((gs::k_sort_scatter<K, true, RB, COMPACT, ITEMS, GATHER>), dim3(sgrid), dim3(gs::SORT_THREADS), 0,  \
+            hipLaunchKernelGGL((gs::k_sort_scatter<K, true, RB, COMPACT, ITEMS>), dim3(sgrid), dim3(gs::SORT_THREADS), 0,  \
                                st, kin, vin, kout, vout, psc, shift, digit_mask, (const uint32_t *)ghist.ptr,     \
-                               (const uint32_t *)digit_totals.ptr, cv, vo, pnb, xr, rg);                   \
+                               (const uint32_t *)digit_totals.ptr, cv, vo, pnb, xr);                   \
         else                                                                                                      \
-            hipLaunchKernelGGL((gs::k_sort_scatter<K, false, RB, COMPACT, ITEMS, GATHER>), dim3(sgrid), dim3(gs::SORT_THREADS), 0, \
+            hipLaunchKernelGGL((gs::k_sort_scatter<K, false, RB, COMPACT, ITEMS>), dim3(sgrid), dim3(gs::SORT_THREADS), 0, \
                                st, kin, vin, kout, vout, psc, shift, digit_mask, (const uint32_t *)ghist.ptr,     \
-                               (const uint32_t *)digit_totals.ptr, cv, vo, pnb, xr, rg);                   \
+                               (const uint32_t *)digit_totals.ptr, cv, vo, pnb, xr);                   \
     } while (0)
         if (source && p == 0) {
             // the pairs come from the depth-ordered rects: k_pairs_emit writes this pass's input
@@ -1780,19 +1775,16 @@ static gs_status run_sort_items(const gs_device *dev, void *const keys[2], void 
                 if (dev->lds_atomic_ordered)
                     hipLaunchKernelGGL((gs::k_sort_scatter<K, true, RB, false, ITEMS>), dim3(sgrid), dim3(gs::SORT_THREADS),
                                        0, st, kin, vin, kout, vout, psc, shift, digit_mask, (const uint32_t *)ghist.ptr,
-                                       (const uint32_t *)digit_totals.ptr, cv, vo, pnb, xr, rg);
+                                       (const uint32_t *)digit_totals.ptr, cv, vo, pnb, xr);
                 else
                     hipLaunchKernelGGL((gs::k_sort_scatter<K, false, RB, false, ITEMS>), dim3(sgrid), dim3(gs::SORT_THREADS),
                                        0, st, kin, vin, kout, vout, psc, shift, digit_mask, (const uint32_t *)ghist.ptr,
-                                       (const uint32_t *)digit_totals.ptr, cv, vo, pnb, xr, rg);
+                                       (const uint32_t *)digit_totals.ptr, cv, vo, pnb, xr);
             }
         } else if constexpr (sizeof(K) == 4) {
-            if (first && gather) GS_SORT_PASS(true, true);
-            else if (first) GS_SORT_PASS(true, false);
-            else if (gather) GS_SORT_PASS(false, true);
-            else GS_SORT_PASS(false, false);
+            if (first) GS_SORT_PASS(true); else GS_SORT_PASS(false);
         } else {
-            GS_SORT_PASS(false, false);
+            GS_SORT_PASS(false);
         }
 #undef GS_SORT_PASS
         launches += 3;
@@ -2292,7 +2284,6 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
         //      compacts (count V stays on the device, grids from N) ----
         int dside = 0;
         uint32_t dpasses = 0;
-        bool rect_presorted = false;
         {
             void *k2[2] = {r->dkeys[0].ptr, r->dkeys[1].ptr};
             void *v2[2] = {r->dvals[0].ptr, r->dvals[1].ptr};
@@ -2301,13 +2292,6 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
             cp.chunk_vis = (const uint32_t *)r->chunk_vis.ptr;
             cp.visible_out = &state->visible;
             cp.dense_count = n;
-            // GS3D_FUSED_RECT_GATHER=0: the rects are gathered by k_expand_count instead (rounds 1-2)
-            static const bool fused_gather = !(std::getenv("GS3D_FUSED_RECT_GATHER") && std::getenv("GS3D_FUSED_RECT_GATHER")[0] == '0');
-            if (fused_gather) {
-                cp.rect_src = (const uint2 *)r->rect.ptr;
-                cp.rect_dst = (uint2 *)r->sorted_rect.ptr;
-            }
-            rect_presorted = fused_gather;
             const gs::SortCount dc{n, &state->visible};
             if (depth_radix_bits(dbits) == (uint32_t)gs::RADIX_BITS_MAX)
                 GS_TRY((run_sort_rb<uint32_t, gs::RADIX_BITS_MAX>(r->dev, k2, v2, r->ghist, r->digit_totals, dc, dbits, &cp,
@@ -2332,7 +2316,6 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
         eo.tiles_x = fc.tiles_x;
         eo.gen = gen;
         eo.sb_bound = exp_grid / gs::EXP_SB + 1;
-        eo.rect_presorted = rect_presorted ? 1u : 0u;
         // Where a wave of k_pairs_emit starts: found by the wave itself (a search over the super-chunk
         // sums: one step per 256 of them) or looked up in a table that k_pairs_cursors writes first.
         // The table costs a launch and wins once the search needs more than one step (A/B on one box:

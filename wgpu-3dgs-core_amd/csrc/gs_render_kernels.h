@@ -1031,7 +1031,6 @@ struct ExpandIO {
     uint32_t gen;
     uint32_t sb_bound;               // host bound of the number of super-chunks (entries past the real one are zero)
     struct PairCursorRec *cursors;   // [capacity / CURSOR_SLOTS + 1] where the pairs of every 1024-slot span start
-    uint32_t rect_presorted;         // sorted_rect was already written by the last depth-sort pass (GATHER)
 };
 
 // Expansion, part 1: gather the tile rects into depth order (the only random access of the key
@@ -1048,29 +1047,20 @@ __global__ __launch_bounds__(EXP_CHUNK) void k_expand_count(ExpandIO io) {
     const uint32_t v_count = io.state->visible;
     const uint32_t first_chunk = blockIdx.x * EXP_COUNT_CHUNKS;
     if ((uint64_t)first_chunk * EXP_CHUNK >= v_count) return;
-    uint2 r[EXP_COUNT_CHUNKS];
-    if (io.rect_presorted) {
-        // the last depth-sort pass gathered the rects while it scattered the slots: only the sums are left
+    uint32_t slot[EXP_COUNT_CHUNKS];
 #pragma unroll
-        for (uint32_t c = 0; c < EXP_COUNT_CHUNKS; c++) {
-            const uint64_t j = (uint64_t)(first_chunk + c) * EXP_CHUNK + threadIdx.x;
-            r[c] = j < v_count ? io.sorted_rect[j] : make_uint2(0u, 0u);
-        }
-    } else {
-        uint32_t slot[EXP_COUNT_CHUNKS];
-#pragma unroll
-        for (uint32_t c = 0; c < EXP_COUNT_CHUNKS; c++) {
-            const uint64_t j = (uint64_t)(first_chunk + c) * EXP_CHUNK + threadIdx.x;
-            slot[c] = j < v_count ? io.order[j] : 0xffffffffu;
-        }
-#pragma unroll
-        for (uint32_t c = 0; c < EXP_COUNT_CHUNKS; c++) r[c] = slot[c] != 0xffffffffu ? io.rect[slot[c]] : make_uint2(0u, 0u);
+    for (uint32_t c = 0; c < EXP_COUNT_CHUNKS; c++) {
+        const uint64_t j = (uint64_t)(first_chunk + c) * EXP_CHUNK + threadIdx.x;
+        slot[c] = j < v_count ? io.order[j] : 0xffffffffu;
     }
+    uint2 r[EXP_COUNT_CHUNKS];
+#pragma unroll
+    for (uint32_t c = 0; c < EXP_COUNT_CHUNKS; c++) r[c] = slot[c] != 0xffffffffu ? io.rect[slot[c]] : make_uint2(0u, 0u);
     const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
 #pragma unroll
     for (uint32_t c = 0; c < EXP_COUNT_CHUNKS; c++) {
         const uint64_t j = (uint64_t)(first_chunk + c) * EXP_CHUNK + threadIdx.x;
-        if (j < v_count && !io.rect_presorted) io.sorted_rect[j] = r[c];
+        if (j < v_count) io.sorted_rect[j] = r[c];
         uint32_t v = ((r[c].y & 0xffffu) - (r[c].x & 0xffffu)) * ((r[c].y >> 16) - (r[c].x >> 16));
         v = wave_reduce_add(v);
         if (lane == 0) s_red[c][wid] = v;
@@ -1279,10 +1269,11 @@ __global__ __launch_bounds__(SCAN_ROWS_THREADS) void k_sort_scan_rows(uint32_t *
     if (threadIdx.x == 0) digit_totals[blockIdx.x] = carry;
 }
 
-// The same scan for SHORT rows (up to a few thousand blocks: every sort of the 1 M frame): one WAVE per
-// row, four rows per workgroup, no LDS and no barrier — 1024-thread workgroups that mostly idle cost
-// 6 us per launch at 1 M, five launches per frame.
-constexpr uint32_t SCAN_ROWS_SMALL_MAX = 2048;     // blocks per row up to which the wave-per-row kernel is used
+// The same scan for SHORT rows (up to 256 blocks = one step: the depth sort's rows at 1 M): one WAVE
+// per row, four rows per workgroup, no LDS and no barrier.  Worth 0.8 us per launch at 1 M (A/B on
+// one box: depth sort 60.9 -> 58.6 us); rows that need several dependent steps per wave are slower
+// this way than with the 4096-wide workgroup (tile sort at 1 M, 780 blocks: 50.2 -> 52.4 us).
+constexpr uint32_t SCAN_ROWS_SMALL_MAX = 256;      // blocks per row up to which the wave-per-row kernel is used: one step
 template <int TILE>
 __global__ __launch_bounds__(256) void k_sort_scan_rows_small(uint32_t *__restrict__ ghist, uint32_t row_stride,
                                                               SortCount sc, uint32_t *__restrict__ digit_totals,
@@ -1349,23 +1340,14 @@ __device__ __forceinline__ void scatter_clear(ScatterShared<K, RB, ITEMS> &sh) {
 
 // Everything after a workgroup holds its tile in registers (key[k], val[k] = element
 // wave_off + k * 64 + lane of the tile; padding = all-ones key): rank, local reorder, coalesced store.
-// GATHER (the LAST pass of the frame's depth sort): the values are mirror slots and the pass also
-// moves each slot's tile rect to the slot's final (depth-order) position — the random 8-byte gather
-// of the key path, issued here ITEMS deep per thread behind a kernel that otherwise waits on LDS,
-// instead of in a kernel of its own (k_expand_count) that re-reads the order it was just given.
-struct RectGather {
-    const uint2 *src;      // [N] tile rects by slot
-    uint2 *dst;            // [V] tile rects in depth order
-};
-
-template <typename K, bool FAST_RANK, int RB, bool COMPACT, int ITEMS, bool GATHER = false>
+template <typename K, bool FAST_RANK, int RB, bool COMPACT, int ITEMS>
 __device__ __forceinline__ void scatter_ranked(ScatterShared<K, RB, ITEMS> &sh, K (&key)[ITEMS], uint32_t (&val)[ITEMS],
                                                uint32_t in_tile, uint32_t block, uint32_t num_blocks,
                                                K *__restrict__ keys_out,
                                                uint32_t *__restrict__ vals_out, uint32_t shift, uint32_t digit_mask,
                                                const uint32_t *__restrict__ ghist,
                                                const uint32_t *__restrict__ digit_totals,
-                                               uint32_t *__restrict__ visible_out, RectGather rg = RectGather{nullptr, nullptr}) {
+                                               uint32_t *__restrict__ visible_out) {
     constexpr int R = 1 << RB;
     constexpr int DPT = R / SORT_THREADS;        // digits per thread: thread t owns digits [t*DPT, t*DPT+DPT)
     auto &s_wave_hist = sh.wave_hist;
@@ -1461,31 +1443,6 @@ __device__ __forceinline__ void scatter_ranked(ScatterShared<K, RB, ITEMS> &sh, 
     __syncthreads();
     // without COMPACT the padding of a partial tile carries the all-ones key and sorts to the end
     const uint32_t live = COMPACT ? live_total : in_tile;
-    if constexpr (GATHER) {
-        uint32_t dstv[ITEMS], slotv[ITEMS];
-        uint2 rv[ITEMS];
-#pragma unroll
-        for (int k = 0; k < ITEMS; k++) {
-            const uint32_t pos = k * SORT_THREADS + tid;
-            dstv[k] = 0xffffffffu;
-            if (pos < live) {
-                const K kk = s_keys[pos];
-                dstv[k] = s_delta[(uint32_t)(kk >> shift) & digit_mask] + pos;
-                slotv[k] = s_vals[pos];
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < ITEMS; k++)
-            if (dstv[k] != 0xffffffffu) rv[k] = rg.src[slotv[k]];      // ITEMS independent gathers in flight
-#pragma unroll
-        for (int k = 0; k < ITEMS; k++)
-            if (dstv[k] != 0xffffffffu) {
-                if (keys_out) keys_out[dstv[k]] = s_keys[k * SORT_THREADS + tid];
-                vals_out[dstv[k]] = slotv[k];
-                rg.dst[dstv[k]] = rv[k];
-            }
-        return;
-    }
 #pragma unroll
     for (int k = 0; k < ITEMS; k++) {
         uint32_t pos = k * SORT_THREADS + tid;
@@ -1499,13 +1456,13 @@ __device__ __forceinline__ void scatter_ranked(ScatterShared<K, RB, ITEMS> &sh, 
     }
 }
 
-template <typename K, bool FAST_RANK, int RB, bool COMPACT, int ITEMS, bool GATHER = false>
+template <typename K, bool FAST_RANK, int RB, bool COMPACT, int ITEMS>
 __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
     const K *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, K *__restrict__ keys_out,
     uint32_t *__restrict__ vals_out, SortCount sc, uint32_t shift, uint32_t digit_mask,
     const uint32_t *__restrict__ ghist, const uint32_t *__restrict__ digit_totals,
     const uint32_t *__restrict__ chunk_vis, uint32_t *__restrict__ visible_out, uint32_t num_tiles,
-    uint32_t xcd_chunk, RectGather rg) {
+    uint32_t xcd_chunk) {
     constexpr int TILE = SORT_THREADS * ITEMS;
     __shared__ ScatterShared<K, RB, ITEMS> sh;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
@@ -1536,8 +1493,8 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
         if constexpr (COMPACT) val[k] = tile_base + e;
         else val[k] = ok ? vals_in[tile_base + e] : 0u;
     }
-    scatter_ranked<K, FAST_RANK, RB, COMPACT, ITEMS, GATHER>(sh, key, val, in_tile, block, num_tiles, keys_out, vals_out,
-                                                             shift, digit_mask, ghist, digit_totals, visible_out, rg);
+    scatter_ranked<K, FAST_RANK, RB, COMPACT, ITEMS>(sh, key, val, in_tile, block, num_tiles, keys_out, vals_out, shift,
+                                                     digit_mask, ghist, digit_totals, visible_out);
 }
 
 // ---------------------------------------------------------------------------------------------
