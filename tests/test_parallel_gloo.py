@@ -2,8 +2,9 @@
 band plans (default and cost-balanced), per-rank band rendering into the gather buffer, the
 all-gather and the reassembly; the gathered frame must equal the single-rank frame bit for bit.
 The band renderer here is the CPU oracle (tests may use it); on GPUs bench.py plugs the HIP
-renderer into the same functions (tests/test_gpu_render.py::test_sharded_path_single_gpu drives
-the HIP renderer through them on one GPU)."""
+renderer into the same functions (tests/test_gpu_fullsize.py::test_sharded_path_single_gpu_4k drives
+the HIP renderer through them on one GPU, and tests/test_gpu_rccl.py runs the real RCCL collective of
+a world of one through FramePipeline)."""
 import os
 import socket
 import sys

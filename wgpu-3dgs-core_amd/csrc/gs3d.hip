@@ -133,6 +133,7 @@ template <class F>
 static void parallel_for(size_t n, F fn) {
     unsigned hw = std::thread::hardware_concurrency();
     size_t threads = n < 65536 ? 1 : (hw ? (hw > 32 ? 32 : hw) : 4);
+    if (const char *e = std::getenv("GS3D_HOST_THREADS")) threads = std::atoi(e) > 0 ? (size_t)std::atoi(e) : threads;
     if (threads <= 1) {
         fn((size_t)0, n);
         return;
@@ -1600,7 +1601,13 @@ extern "C" gs_status gs_renderer_stats(gs_renderer *r, gs_frame_stats *out) {
 typedef void (*preprocess_fn)(const uint4 *, uint32_t, gs::FrameConsts, gs::PreOut);
 typedef void (*block_bounds_fn)(const uint4 *, uint32_t, float *);
 static preprocess_fn k_tbl_preprocess[4][3] = GS_CFG_TABLE(gs::k_preprocess);
-static preprocess_fn k_tbl_preprocess_banded[4][3] = GS_CFG_TABLE(gs::k_preprocess_banded);
+#define GS_CFG_TABLE3(kernel, P)                                                                                  \
+    {                                                                                                             \
+        {kernel<0, 0, P>, kernel<0, 1, P>, kernel<0, 2, P>}, {kernel<1, 0, P>, kernel<1, 1, P>, kernel<1, 2, P>}, \
+        {kernel<2, 0, P>, kernel<2, 1, P>, kernel<2, 2, P>}, {kernel<3, 0, P>, kernel<3, 1, P>, kernel<3, 2, P>}, \
+    }
+static preprocess_fn k_tbl_preprocess_banded[4][3] = GS_CFG_TABLE3(gs::k_preprocess_banded, true);
+static preprocess_fn k_tbl_preprocess_banded_serial[4][3] = GS_CFG_TABLE3(gs::k_preprocess_banded, false);
 static block_bounds_fn k_tbl_block_bounds[4][3] = GS_CFG_TABLE(gs::k_block_bounds);
 
 // frame constants from the uniforms
@@ -2254,7 +2261,9 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
         po.zero_words = (uint32_t)(ranges_words + esb_words);
         po.key_bias = near_bits;
         po.block_bounds = (const float *)g->block_bounds;
-        hipLaunchKernelGGL((banded ? k_tbl_preprocess_banded : k_tbl_preprocess)[g->sh][g->cov], dim3(nchunks),
+        // GS3D_PRE_PIPELINE=0: the two-phase kernel without the prefetch of the next Gaussian's geometry chunks
+        static const bool pre_serial = std::getenv("GS3D_PRE_PIPELINE") && std::getenv("GS3D_PRE_PIPELINE")[0] == '0';
+        hipLaunchKernelGGL((banded ? (pre_serial ? k_tbl_preprocess_banded_serial : k_tbl_preprocess_banded) : k_tbl_preprocess)[g->sh][g->cov], dim3(nchunks),
                            dim3(gs::PP_THREADS), 0, st, (const uint4 *)g->planar, n, fc, po);
         GS_HIP(hipGetLastError());
         r->launches++;

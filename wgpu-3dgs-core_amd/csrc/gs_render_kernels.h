@@ -854,7 +854,7 @@ __global__ __launch_bounds__(PP_THREADS) void k_preprocess(const uint4 *__restri
 // (EXEC-masked loads: a 128-byte line none of whose lanes survived is not fetched).  With the
 // mirror in spatial order the Gaussians a view (or a rank's tile-row band) culls fill whole lines.
 // Same arithmetic, same outputs as k_preprocess.
-template <int SH, int COV>
+template <int SH, int COV, bool PIPELINED = true>
 __global__ __launch_bounds__(PP_THREADS) void k_preprocess_banded(const uint4 *__restrict__ planar, uint32_t n,
                                                                   FrameConsts fc, PreOut io) {
     __shared__ uint32_t s_red[8];
@@ -867,24 +867,58 @@ __global__ __launch_bounds__(PP_THREADS) void k_preprocess_banded(const uint4 *_
     constexpr int NC = NW / 4;
     constexpr int G0 = cov_word0(SH) / 4;                              // first chunk holding covariance words
     constexpr int G1 = (cov_word0(SH) + cov_bytes(COV) / 4 - 1) / 4;   // last one
+    constexpr int NG = G1 - G0 + 1;
     const uint32_t base = blockIdx.x * PP_CHUNK;
+    const bool nt = fc.nt_loads != 0u;
     uint32_t local = 0, local_vis = 0;
+    // geometry chunks (position / colour + covariance) of one Gaussian
+    auto load_geom = [&](uint32_t i, uint4 &v0, uint4 (&vg)[NG]) {
+        v0 = load_planar(planar + planar_at(0, i, NC), nt);
+#pragma unroll
+        for (int c = G0; c <= G1; c++)
+            if (c != 0) vg[c - G0] = load_planar(planar + planar_at(c, i, NC), nt);
+    };
+    // PIPELINED (round 3): the geometry chunks of Gaussian k + 1 are requested BEFORE Gaussian k is
+    // projected, shaded and stored, so that (a) a wave has two dependent round trips per Gaussian in
+    // flight instead of one after the other, and (b) waiting for them does not also wait for Gaussian
+    // k's stores, which on gfx950 retire through the same in-order counter as the loads issued after them.
+    uint4 v0_next = make_uint4(0u, 0u, 0u, 0u), vg_next[NG];
+#pragma unroll
+    for (int c = 0; c < NG; c++) vg_next[c] = make_uint4(0u, 0u, 0u, 0u);
+    if constexpr (PIPELINED) {
+        const uint32_t i0 = base + threadIdx.x;
+        if (i0 < n) load_geom(i0, v0_next, vg_next);
+    }
 #pragma unroll 1
     for (int k = 0; k < PP_ITEMS; k++) {
         const uint32_t i = base + k * PP_THREADS + threadIdx.x;
+        uint4 v0, vg[NG];
+        if constexpr (PIPELINED) {
+            v0 = v0_next;
+#pragma unroll
+            for (int c = 0; c < NG; c++) vg[c] = vg_next[c];
+            asm volatile("" : "+v"(v0.x), "+v"(v0.y), "+v"(v0.z), "+v"(v0.w));
+#pragma unroll
+            for (int c = 0; c < NG; c++)
+                asm volatile("" : "+v"(vg[c].x), "+v"(vg[c].y), "+v"(vg[c].z), "+v"(vg[c].w));
+            if (k + 1 < PP_ITEMS) {
+                const uint32_t inext = i + PP_THREADS;
+                if (inext < n) load_geom(inext, v0_next, vg_next);
+            }
+        }
         if (i < n) {
             uint32_t w[NW];
-            uint4 v0 = load_planar(planar + planar_at(0, i, NC), fc.nt_loads != 0u);
-            uint4 vg[G1 - G0 + 1];
+            if constexpr (!PIPELINED) {
+                load_geom(i, v0, vg);
+                asm volatile("" : "+v"(v0.x), "+v"(v0.y), "+v"(v0.z), "+v"(v0.w));
 #pragma unroll
-            for (int c = G0; c <= G1; c++)
-                if (c != 0) vg[c - G0] = load_planar(planar + planar_at(c, i, NC), fc.nt_loads != 0u);
-            asm volatile("" : "+v"(v0.x), "+v"(v0.y), "+v"(v0.z), "+v"(v0.w));
+                for (int c = 0; c < NG; c++)
+                    asm volatile("" : "+v"(vg[c].x), "+v"(vg[c].y), "+v"(vg[c].z), "+v"(vg[c].w));
+            }
             w[0] = v0.x; w[1] = v0.y; w[2] = v0.z; w[3] = v0.w;
 #pragma unroll
             for (int c = G0; c <= G1; c++) {
                 if (c == 0) continue;
-                asm volatile("" : "+v"(vg[c - G0].x), "+v"(vg[c - G0].y), "+v"(vg[c - G0].z), "+v"(vg[c - G0].w));
                 w[4 * c + 0] = vg[c - G0].x;
                 w[4 * c + 1] = vg[c - G0].y;
                 w[4 * c + 2] = vg[c - G0].z;
@@ -898,7 +932,7 @@ __global__ __launch_bounds__(PP_THREADS) void k_preprocess_banded(const uint4 *_
                 if constexpr (S1 >= S0) {
                     uint4 vs[S1 - S0 + 1];
 #pragma unroll
-                    for (int c = S0; c <= S1; c++) vs[c - S0] = load_planar(planar + planar_at(c, i, NC), fc.nt_loads != 0u);
+                    for (int c = S0; c <= S1; c++) vs[c - S0] = load_planar(planar + planar_at(c, i, NC), nt);
 #pragma unroll
                     for (int c = S0; c <= S1; c++) {
                         asm volatile("" : "+v"(vs[c - S0].x), "+v"(vs[c - S0].y), "+v"(vs[c - S0].z), "+v"(vs[c - S0].w));

@@ -76,6 +76,7 @@ template <class F>
 static void spz_parallel_for(size_t n, F fn) {
     unsigned hw = std::thread::hardware_concurrency();
     size_t threads = n < 32768 ? 1 : (hw ? (hw > 32 ? 32 : hw) : 4);
+    if (const char *e = std::getenv("GS3D_HOST_THREADS")) threads = std::atoi(e) > 0 ? (size_t)std::atoi(e) : threads;
     if (threads <= 1) {
         fn((size_t)0, n);
         return;
