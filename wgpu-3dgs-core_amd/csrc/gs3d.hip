@@ -1600,14 +1600,20 @@ extern "C" gs_status gs_renderer_stats(gs_renderer *r, gs_frame_stats *out) {
 
 typedef void (*preprocess_fn)(const uint4 *, uint32_t, gs::FrameConsts, gs::PreOut);
 typedef void (*block_bounds_fn)(const uint4 *, uint32_t, float *);
-static preprocess_fn k_tbl_preprocess[4][3] = GS_CFG_TABLE(gs::k_preprocess);
-#define GS_CFG_TABLE3(kernel, P)                                                                                  \
+#define GS_CFG_TABLE_X(kernel, ...)                                                                              \
     {                                                                                                             \
-        {kernel<0, 0, P>, kernel<0, 1, P>, kernel<0, 2, P>}, {kernel<1, 0, P>, kernel<1, 1, P>, kernel<1, 2, P>}, \
-        {kernel<2, 0, P>, kernel<2, 1, P>, kernel<2, 2, P>}, {kernel<3, 0, P>, kernel<3, 1, P>, kernel<3, 2, P>}, \
+        {kernel<0, 0, __VA_ARGS__>, kernel<0, 1, __VA_ARGS__>, kernel<0, 2, __VA_ARGS__>},                        \
+        {kernel<1, 0, __VA_ARGS__>, kernel<1, 1, __VA_ARGS__>, kernel<1, 2, __VA_ARGS__>},                        \
+        {kernel<2, 0, __VA_ARGS__>, kernel<2, 1, __VA_ARGS__>, kernel<2, 2, __VA_ARGS__>},                        \
+        {kernel<3, 0, __VA_ARGS__>, kernel<3, 1, __VA_ARGS__>, kernel<3, 2, __VA_ARGS__>},                        \
     }
-static preprocess_fn k_tbl_preprocess_banded[4][3] = GS_CFG_TABLE3(gs::k_preprocess_banded, true);
-static preprocess_fn k_tbl_preprocess_banded_serial[4][3] = GS_CFG_TABLE3(gs::k_preprocess_banded, false);
+// [non-temporal mirror loads][...]: the cache policy is a template parameter (a run-time flag put a
+// branch and a wait behind every load)
+static preprocess_fn k_tbl_preprocess[2][4][3] = {GS_CFG_TABLE_X(gs::k_preprocess, false), GS_CFG_TABLE_X(gs::k_preprocess, true)};
+// [nt][pipelined]
+static preprocess_fn k_tbl_preprocess_banded[2][2][4][3] = {
+    {GS_CFG_TABLE_X(gs::k_preprocess_banded, false, false), GS_CFG_TABLE_X(gs::k_preprocess_banded, true, false)},
+    {GS_CFG_TABLE_X(gs::k_preprocess_banded, false, true), GS_CFG_TABLE_X(gs::k_preprocess_banded, true, true)}};
 static block_bounds_fn k_tbl_block_bounds[4][3] = GS_CFG_TABLE(gs::k_block_bounds);
 
 // frame constants from the uniforms
@@ -2263,7 +2269,8 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
         po.block_bounds = (const float *)g->block_bounds;
         // GS3D_PRE_PIPELINE=0: the two-phase kernel without the prefetch of the next Gaussian's geometry chunks
         static const bool pre_serial = std::getenv("GS3D_PRE_PIPELINE") && std::getenv("GS3D_PRE_PIPELINE")[0] == '0';
-        hipLaunchKernelGGL((banded ? (pre_serial ? k_tbl_preprocess_banded_serial : k_tbl_preprocess_banded) : k_tbl_preprocess)[g->sh][g->cov], dim3(nchunks),
+        const int nt = fc.nt_loads ? 1 : 0;
+        hipLaunchKernelGGL((banded ? k_tbl_preprocess_banded[nt][pre_serial ? 0 : 1] : k_tbl_preprocess[nt])[g->sh][g->cov], dim3(nchunks),
                            dim3(gs::PP_THREADS), 0, st, (const uint4 *)g->planar, n, fc, po);
         GS_HIP(hipGetLastError());
         r->launches++;

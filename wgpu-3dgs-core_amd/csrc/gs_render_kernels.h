@@ -568,12 +568,17 @@ __device__ __forceinline__ void eval_sh(const uint32_t *w, uint32_t deg, bool no
 
 // streaming read of the mirror: every byte is read once per frame.  nt = the non-temporal cache policy
 typedef uint32_t u32x4_nt __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ uint4 load_planar(const uint4 *__restrict__ p, bool nt) {
-    if (nt) {
+// NT is a COMPILE-TIME choice: as a run-time flag every load sat in its own if / else, and hipcc put an
+// s_waitcnt vmcnt(0) behind each of them — the record's 14 chunk loads ran as 14 dependent round trips
+// (rounds 1-2 believed them "back to back"; the ISA said otherwise, round 3).
+template <bool NT>
+__device__ __forceinline__ uint4 load_planar(const uint4 *__restrict__ p) {
+    if constexpr (NT) {
         const u32x4_nt t = __builtin_nontemporal_load((const u32x4_nt *)p);
         return make_uint4(t.x, t.y, t.z, t.w);
+    } else {
+        return *p;
     }
-    return *p;
 }
 
 // ln k, correctly rounded to binary32, k = opacity byte (alpha = (k / 255) exp(power)
@@ -801,7 +806,7 @@ __device__ __forceinline__ void pre_finish_culled(const PreOut &io) {
 // look-back over the workgroups.  The inclusive frontier advances one look-back window per status
 // round trip across the XCDs, and every waiting workgroup keeps its registers: 0.43 -> 0.54 ms with
 // a 64-wide window, 0.60 ms with a 256-wide one.)
-template <int SH, int COV>
+template <int SH, int COV, bool NT = false>
 __global__ __launch_bounds__(PP_THREADS) void k_preprocess(const uint4 *__restrict__ planar, uint32_t n,
                                                            FrameConsts fc, PreOut io) {
     __shared__ uint32_t s_red[8];
@@ -824,7 +829,7 @@ __global__ __launch_bounds__(PP_THREADS) void k_preprocess(const uint4 *__restri
             // uniform sh_deg branches), which serialises 4-5 HBM round trips per Gaussian.
             uint4 v[NC];
 #pragma unroll
-            for (int c = 0; c < NC; c++) v[c] = load_planar(planar + planar_at(c, i, NC), fc.nt_loads != 0u);
+            for (int c = 0; c < NC; c++) v[c] = load_planar<NT>(planar + planar_at(c, i, NC));
             uint32_t w[NW];
 #pragma unroll
             for (int c = 0; c < NC; c++) {
@@ -854,7 +859,7 @@ __global__ __launch_bounds__(PP_THREADS) void k_preprocess(const uint4 *__restri
 // (EXEC-masked loads: a 128-byte line none of whose lanes survived is not fetched).  With the
 // mirror in spatial order the Gaussians a view (or a rank's tile-row band) culls fill whole lines.
 // Same arithmetic, same outputs as k_preprocess.
-template <int SH, int COV, bool PIPELINED = true>
+template <int SH, int COV, bool PIPELINED = true, bool NT = false>
 __global__ __launch_bounds__(PP_THREADS) void k_preprocess_banded(const uint4 *__restrict__ planar, uint32_t n,
                                                                   FrameConsts fc, PreOut io) {
     __shared__ uint32_t s_red[8];
@@ -869,14 +874,13 @@ __global__ __launch_bounds__(PP_THREADS) void k_preprocess_banded(const uint4 *_
     constexpr int G1 = (cov_word0(SH) + cov_bytes(COV) / 4 - 1) / 4;   // last one
     constexpr int NG = G1 - G0 + 1;
     const uint32_t base = blockIdx.x * PP_CHUNK;
-    const bool nt = fc.nt_loads != 0u;
     uint32_t local = 0, local_vis = 0;
     // geometry chunks (position / colour + covariance) of one Gaussian
     auto load_geom = [&](uint32_t i, uint4 &v0, uint4 (&vg)[NG]) {
-        v0 = load_planar(planar + planar_at(0, i, NC), nt);
+        v0 = load_planar<NT>(planar + planar_at(0, i, NC));
 #pragma unroll
         for (int c = G0; c <= G1; c++)
-            if (c != 0) vg[c - G0] = load_planar(planar + planar_at(c, i, NC), nt);
+            if (c != 0) vg[c - G0] = load_planar<NT>(planar + planar_at(c, i, NC));
     };
     // PIPELINED (round 3): the geometry chunks of Gaussian k + 1 are requested BEFORE Gaussian k is
     // projected, shaded and stored, so that (a) a wave has two dependent round trips per Gaussian in
@@ -932,7 +936,7 @@ __global__ __launch_bounds__(PP_THREADS) void k_preprocess_banded(const uint4 *_
                 if constexpr (S1 >= S0) {
                     uint4 vs[S1 - S0 + 1];
 #pragma unroll
-                    for (int c = S0; c <= S1; c++) vs[c - S0] = load_planar(planar + planar_at(c, i, NC), nt);
+                    for (int c = S0; c <= S1; c++) vs[c - S0] = load_planar<NT>(planar + planar_at(c, i, NC));
 #pragma unroll
                     for (int c = S0; c <= S1; c++) {
                         asm volatile("" : "+v"(vs[c - S0].x), "+v"(vs[c - S0].y), "+v"(vs[c - S0].z), "+v"(vs[c - S0].w));
@@ -1203,8 +1207,12 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_hist(const K *__restrict_
     static_assert(ITEMS % PER_VEC == 0, "tile must be a whole number of 16-byte vectors per thread");
     if (count - base >= TILE) {
         const uint4 *src = (const uint4 *)(keys + base);
-        // all loads of the tile are issued before the first LDS atomic (the per-chunk test of the
-        // compacting pass used to sit between them: a scalar load, a wait and a branch per vector)
+        // ALL loads of the tile are issued back to back before the first LDS atomic, and pinned there:
+        // hipcc neither hoists a global load above a ds_add nor keeps hoisted ones apart from their
+        // uses — left alone it emitted load, s_waitcnt vmcnt(0), four atomics, eight times in a row
+        // (the kernel ran at 2 TB/s).  No branch sits between the loads either: a chunk the compacting
+        // pass must skip (block-culled: its keys are stale) is redirected to vector 0's address, whose
+        // line is being fetched anyway, and ignored below.
         bool ok[VECS];
         uint4 qv[VECS];
 #pragma unroll
@@ -1214,10 +1222,9 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_hist(const K *__restrict_
             if constexpr (COMPACT) ok[v] = chunk_vis[(base >> 10) + v] != 0u;
         }
 #pragma unroll
-        for (int v = 0; v < VECS; v++) {
-            qv[v] = make_uint4(SORT_INVALID_KEY, SORT_INVALID_KEY, SORT_INVALID_KEY, SORT_INVALID_KEY);
-            if (ok[v]) qv[v] = src[v * SORT_THREADS + threadIdx.x];
-        }
+        for (int v = 0; v < VECS; v++) qv[v] = src[(ok[v] ? v : 0) * SORT_THREADS + threadIdx.x];
+#pragma unroll
+        for (int v = 0; v < VECS; v++) asm volatile("" : "+v"(qv[v].x), "+v"(qv[v].y), "+v"(qv[v].z), "+v"(qv[v].w));
 #pragma unroll
         for (int v = 0; v < VECS; v++) {
             if (COMPACT && !ok[v]) continue;
@@ -1523,9 +1530,18 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
     for (int k = 0; k < ITEMS; k++) {
         const uint32_t e = wave_off + k * WAVE + lane;     // element of the tile (no 32-bit wrap near 2^32)
         const bool ok = e < in_tile && (!COMPACT || chunk_ok[COMPACT ? k / 16 : 0]);
-        key[k] = ok ? keys_in[tile_base + e] : (K)~(K)0;
-        if constexpr (COMPACT) val[k] = tile_base + e;
-        else val[k] = ok ? vals_in[tile_base + e] : 0u;
+        if constexpr (COMPACT) {
+            // no branch around the load: a skipped chunk (block-culled: stale keys) reads the tile's first
+            // element instead — always there, its line is fetched anyway — and is masked afterwards.  With
+            // the load inside `ok ? load : ~0` hipcc emitted a branch and an s_waitcnt vmcnt(0) per key:
+            // 32 dependent round trips per thread in the frame's first depth pass.
+            const K raw = keys_in[tile_base + (ok ? e : 0u)];
+            key[k] = ok ? raw : (K)~(K)0;
+            val[k] = tile_base + e;
+        } else {
+            key[k] = ok ? keys_in[tile_base + e] : (K)~(K)0;
+            val[k] = ok ? vals_in[tile_base + e] : 0u;
+        }
     }
     scatter_ranked<K, FAST_RANK, RB, COMPACT, ITEMS>(sh, key, val, in_tile, block, num_tiles, keys_out, vals_out, shift,
                                                      digit_mask, ghist, digit_totals, visible_out);
