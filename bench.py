@@ -350,7 +350,7 @@ def roofline_object(wl_name, wl, res):
     pmc, why = pmc_record("preprocess_%s" % wl_name)
     obj = {
         "bound": "hbm",
-        "kernel": "k_preprocess_banded<ShSingle,RotScale>" if wl["sh"] != 3 else "k_preprocess<ShNone,RotScale>",
+        "kernel": "k_preprocess_banded<ShSingle,RotScale,pipelined,nt>" if wl["sh"] != 3 else "k_preprocess<ShNone,RotScale>",
         "workload": wl["label"],
         "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
         "algorithmic_bytes_per_launch": alg, "avg_launch_ms": ms,

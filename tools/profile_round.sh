@@ -97,11 +97,11 @@ for r in trace:
     if "k_repack_planar" in n:
         cur = []
         groups.append(cur)
-    elif cur is not None and "k_preprocess_banded<0, 0>" in n:
+    elif cur is not None and "k_preprocess_banded<0, 0" in n:
         cur.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
 groups = [g for g in groups if g]
 with open("%s/%s_bench_default_agreement.txt" % (out, tag), "w") as f:
-    f.write("roofline kernel k_preprocess_banded<0, 0>, average launch duration of the SAME launches of the default command:\n")
+    f.write("roofline kernel k_preprocess_banded<ShSingle, RotScale, pipelined, nt>, average launch duration of the SAME launches of the default command:\n")
     f.write("bench.py (HIP events on the launch stream, its timing run) vs rocprofv3 --kernel-trace (all launches of the workload)\n")
     for (key, wl), g in zip((("roofline", "10m"), ("roofline_nocull", "10m-nocull")), groups):
         if key in b:

@@ -830,6 +830,7 @@ __global__ __launch_bounds__(PP_THREADS) void k_preprocess(const uint4 *__restri
             uint4 v[NC];
 #pragma unroll
             for (int c = 0; c < NC; c++) v[c] = load_planar<NT>(planar + planar_at(c, i, NC));
+            __builtin_amdgcn_sched_barrier(0);   // no load may sink below this point, no use may rise above it
             uint32_t w[NW];
 #pragma unroll
             for (int c = 0; c < NC; c++) {
@@ -1223,6 +1224,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_hist(const K *__restrict_
         }
 #pragma unroll
         for (int v = 0; v < VECS; v++) qv[v] = src[(ok[v] ? v : 0) * SORT_THREADS + threadIdx.x];
+        __builtin_amdgcn_sched_barrier(0);   // every load is issued before the first pin / use
 #pragma unroll
         for (int v = 0; v < VECS; v++) asm volatile("" : "+v"(qv[v].x), "+v"(qv[v].y), "+v"(qv[v].z), "+v"(qv[v].w));
 #pragma unroll
