@@ -2386,13 +2386,11 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
         static const int groups = std::getenv("GS3D_BLEND_GROUPS") ? std::atoi(std::getenv("GS3D_BLEND_GROUPS")) : 4;
         typedef void (*blend_fn)(const uint32_t *, const uint32_t *, const uint32_t *, gs::FrameConsts, float4 *,
                                  const gs::FrameState *);
-        // GS3D_BLEND_PREFETCH=0: the staging of a batch requests its records itself (rounds 1-2)
-        static const bool prefetch = !(std::getenv("GS3D_BLEND_PREFETCH") && std::getenv("GS3D_BLEND_PREFETCH")[0] == '0');
-        static const blend_fn tbl[3][4] = {
-            {gs::k_blend<0>, gs::k_blend_grouped<0, 2>, gs::k_blend_grouped<0, 4, true>, gs::k_blend_grouped<0, 4, false>},
-            {gs::k_blend<1>, gs::k_blend_grouped<1, 2>, gs::k_blend_grouped<1, 4, true>, gs::k_blend_grouped<1, 4, false>},
-            {gs::k_blend<2>, gs::k_blend_grouped<2, 2>, gs::k_blend_grouped<2, 4, true>, gs::k_blend_grouped<2, 4, false>}};
-        const blend_fn blend = tbl[mode][groups == 1 ? 0 : groups == 2 ? 1 : prefetch ? 2 : 3];
+        static const blend_fn tbl[3][3] = {
+            {gs::k_blend<0>, gs::k_blend_grouped<0, 2>, gs::k_blend_grouped<0, 4>},
+            {gs::k_blend<1>, gs::k_blend_grouped<1, 2>, gs::k_blend_grouped<1, 4>},
+            {gs::k_blend<2>, gs::k_blend_grouped<2, 2>, gs::k_blend_grouped<2, 4>}};
+        const blend_fn blend = tbl[mode][groups == 1 ? 0 : groups == 2 ? 1 : 2];
         hipLaunchKernelGGL(blend, dim3(band_tiles), dim3(gs::BLEND_THREADS), 0, st,
                            (const uint32_t *)r->zero_region.ptr, (const uint32_t *)r->tvals[r->tsorted_side].ptr,
                            (const uint32_t *)r->recs.ptr, fc, (float4 *)rgba, (const gs::FrameState *)state);

@@ -2334,7 +2334,7 @@ __device__ __forceinline__ bool splat_touches_rect2(float mx, float my, float ca
 // with the index of a null record whose exponent test never passes, so lanes whose list is shorter
 // than the wave's longest simply idle.  Results are bit-identical to k_blend: culling only removes
 // (splat, block) pairs whose alpha is below 1/255 at every pixel of the block.
-template <int MODE, int G, bool PREFETCH = true>
+template <int MODE, int G>
 __global__ __launch_bounds__(BLEND_THREADS) void k_blend_grouped(const uint32_t *__restrict__ ranges,
                                                                  const uint32_t *__restrict__ idx,
                                                                  const uint32_t *__restrict__ recs,
@@ -2377,19 +2377,6 @@ __global__ __launch_bounds__(BLEND_THREADS) void k_blend_grouped(const uint32_t 
         s_c[NULL_REC] = make_float2(0.0f, 0.0f);
     }
 
-    u32x4_a4 pf_r0 = {0u, 0u, 0u, 0u}, pf_r1 = {0u, 0u, 0u, 0u};
-    uint32_t pf_r2x = 0u;
-    uint32_t pf_idx = 0u;
-    if constexpr (PREFETCH) {
-        // two batches in flight: the records of the first batch and the index of the second
-        if (start + tid < end) {
-            const uint32_t *rec = recs + (uint64_t)idx[start + tid] * REC_WORDS;
-            pf_r0 = *(const u32x4_a4 *)(rec);
-            pf_r1 = *(const u32x4_a4 *)(rec + 4);
-            pf_r2x = rec[8];
-        }
-        if (start + tid + BLEND_BATCH < end) pf_idx = idx[start + tid + BLEND_BATCH];
-    }
     for (uint32_t b0 = start; b0 < end; b0 += BLEND_BATCH) {
         // stop fetching once every pixel of the tile is finished
         if (lane == 0) s_alive[wid] = remaining;
@@ -2407,30 +2394,11 @@ __global__ __launch_bounds__(BLEND_THREADS) void k_blend_grouped(const uint32_t 
         const uint32_t j = b0 + tid;
         float mx = 0.0f, my = 0.0f, ca = 0.0f, cb = 0.0f, cc = 0.0f, thr = 0.0f;
         const bool have = j < end;
-        u32x4_a4 r0 = {0u, 0u, 0u, 0u}, r1 = {0u, 0u, 0u, 0u};
-        uint32_t r2x = 0u;
-        if constexpr (PREFETCH) {
-            // this batch's record was requested while the previous batch was being blended (or before
-            // the loop); now request the NEXT batch's: index -> record is two dependent round trips that
-            // otherwise sit in front of every batch's pixel loop
-            r0 = pf_r0;
-            r1 = pf_r1;
-            r2x = pf_r2x;
-            if (j + BLEND_BATCH < end) {          // records of batch b + 1, from the index requested a batch ago
-                const uint32_t *rec = recs + (uint64_t)pf_idx * REC_WORDS;
-                pf_r0 = *(const u32x4_a4 *)(rec);
-                pf_r1 = *(const u32x4_a4 *)(rec + 4);
-                pf_r2x = rec[8];
-            }
-            if (j + 2u * BLEND_BATCH < end) pf_idx = idx[j + 2u * BLEND_BATCH];      // index of batch b + 2
-            __builtin_amdgcn_sched_barrier(0);
-        } else if (have) {
-            const uint32_t *rec = recs + (uint64_t)idx[j] * REC_WORDS;
-            r0 = *(const u32x4_a4 *)(rec);
-            r1 = *(const u32x4_a4 *)(rec + 4);
-            r2x = rec[8];
-        }
         if (have) {
+            const uint32_t *rec = recs + (uint64_t)idx[j] * REC_WORDS;
+            const u32x4_a4 r0 = *(const u32x4_a4 *)(rec);
+            const u32x4_a4 r1 = *(const u32x4_a4 *)(rec + 4);
+            const uint32_t r2x = rec[8];
             mx = u2f(r0.x); my = u2f(r0.y); ca = u2f(r0.z); cb = u2f(r0.w); cc = u2f(r1.x);
             float pmin;
             if constexpr (MODE == 0) pmin = fmaxf(-__logf(255.0f * u2f(r1.y)) - 1.0e-3f, -5.6f);
