@@ -368,7 +368,9 @@ gs_status gs_gaussians_buffer_update_gaussians(gs_gaussians_buffer *g, gs_stream
 gs_status gs_gaussians_buffer_update_range_gaussians(gs_gaussians_buffer *g, gs_stream *s,
                                                      size_t start, const gs_gaussian *gaussians,
                                                      size_t count);
-/* download::<G> (pods) and download_gaussians — :186-195 (blocking) */
+/* download::<G> (pods) and download_gaussians — :186-195 (blocking).  download_gaussians converts
+ * POD -> Gaussian (GaussianPod::into_gaussian) on the DEVICE and copies struct Gaussian records back;
+ * GS_ERR_LOSSY_CONFIG for ShNone / Cov3dSingle / Cov3dHalf, where the reference panics. */
 gs_status gs_gaussians_buffer_download(gs_gaussians_buffer *g, gs_stream *s, void *pods_out,
                                        size_t count);
 gs_status gs_gaussians_buffer_download_gaussians(gs_gaussians_buffer *g, gs_stream *s,

@@ -183,26 +183,10 @@ extern "C" gs_status gs_unpack_to_gaussian(gs_sh_config sh, gs_cov3d_config cov,
     const uint8_t *in = (const uint8_t *)pods;
     parallel_for(n, [=](size_t a, size_t b) {
         for (size_t i = a; i < b; i++) {
-            const uint8_t *p = in + i * stride;
-            gs_gaussian &g = out[i];
-            std::memcpy(g.pos, p, 12);
-            std::memcpy(g.color, p + 12, 4);
-            const uint8_t *s = p + 16;
-            for (int k = 0; k < 45; k++) {
-                if (sh == GS_SH_SINGLE) {
-                    std::memcpy(&g.sh[k], s + 4 * k, 4);
-                } else if (sh == GS_SH_HALF) {
-                    uint16_t h;
-                    std::memcpy(&h, s + 2 * k, 2);
-                    g.sh[k] = f16_to_f32_host(h);
-                } else {
-                    float v = (float)(int8_t)s[k] / 127.0f;
-                    g.sh[k] = v < -1.0f ? -1.0f : v;
-                }
-            }
-            const uint8_t *c = s + gs::sh_bytes(sh);
-            std::memcpy(g.rot, c, 16);
-            std::memcpy(g.scale, c + 16, 12);
+            uint32_t pw[56], gw[gs::GAUSSIAN_WORDS];
+            std::memcpy(pw, in + i * stride, stride);
+            gs::unpack_words(sh, pw, gw);       // the same code the device kernel runs (k_unpack_pods)
+            std::memcpy(&out[i], gw, sizeof(gw));
         }
     });
     return GS_OK;
@@ -909,14 +893,44 @@ extern "C" gs_status gs_gaussians_buffer_download(gs_gaussians_buffer *g, gs_str
     return gs_buffer_download(g->buf, s, pods_out, count * pod_stride(g));
 }
 
+// GaussiansBuffer::download::<Gaussian> (src/buffer/gaussian.rs:186-196): the PODs are converted back
+// on the DEVICE (k_unpack_pods, slice by slice through a staging buffer) and the struct Gaussian
+// records come over PCIe ready to use; bit-equal to downloading the PODs and gs_unpack_to_gaussian.
+typedef void (*unpack_fn)(const uint32_t *, uint64_t, uint32_t *);
+static unpack_fn k_tbl_unpack[3] = {gs::k_unpack_pods<0>, gs::k_unpack_pods<1>, gs::k_unpack_pods<2>};
+
 extern "C" gs_status gs_gaussians_buffer_download_gaussians(gs_gaussians_buffer *g, gs_stream *s,
                                                             gs_gaussian *out, size_t count) {
     if (!g) return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "null buffer");
     if (g->sh == GS_SH_NONE || g->cov != GS_COV3D_ROT_SCALE)
-        return gs_unpack_to_gaussian((gs_sh_config)g->sh, (gs_cov3d_config)g->cov, out, 0, out);
-    std::vector<uint8_t> pods(count * pod_stride(g));
-    GS_TRY(gs_gaussians_buffer_download(g, s, pods.data(), count));
-    return gs_unpack_to_gaussian((gs_sh_config)g->sh, (gs_cov3d_config)g->cov, pods.data(), count, out);
+        return gs_unpack_to_gaussian((gs_sh_config)g->sh, (gs_cov3d_config)g->cov, out, 0, out);   // the reference's error
+    if (count > gs_gaussians_buffer_len(g))
+        return fail(GS_ERR_INVALID_ARGUMENT, count, gs_gaussians_buffer_len(g), 0, "count too large");
+    if (!count) return GS_OK;
+    if (!out) return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "null out");
+    gs_device *dev = g->buf->dev;
+    GS_TRY(use_device(dev));
+    hipStream_t st = stream_of(dev, s);
+    constexpr size_t SLICE = 2u << 20;
+    const size_t slice = count < SLICE ? count : SLICE;
+    void *staging = nullptr;
+    hipError_t e = hipMalloc(&staging, slice * sizeof(gs_gaussian));
+    if (e != hipSuccess)
+        return fail(GS_ERR_OUT_OF_MEMORY, slice * sizeof(gs_gaussian), 0, 0, "hipMalloc failed: %s", hipGetErrorString(e));
+    gs_status rc = GS_OK;
+    const size_t stride = pod_stride(g);
+    for (size_t first = 0; first < count && rc == GS_OK; first += slice) {
+        const size_t cnt = count - first < slice ? count - first : slice;
+        const uint64_t groups = ((uint64_t)cnt + gs::PACK_GROUP - 1) / gs::PACK_GROUP;
+        hipLaunchKernelGGL(k_tbl_unpack[g->sh], dim3((uint32_t)groups), dim3(256), 0, st,
+                           (const uint32_t *)((const uint8_t *)g->buf->ptr + first * stride), (uint64_t)cnt, (uint32_t *)staging);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(out + first, staging, cnt * sizeof(gs_gaussian), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) rc = fail(GS_ERR_DOWNLOAD, (uint64_t)e, 0, 0, "download failed: %s", hipGetErrorString(e));
+    }
+    (void)hipFree(staging);
+    return rc;
 }
 
 extern "C" void gs_gaussians_buffer_mark_dirty(gs_gaussians_buffer *g) {

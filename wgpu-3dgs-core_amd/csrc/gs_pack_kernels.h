@@ -131,6 +131,49 @@ __global__ __launch_bounds__(256) void k_pack_pods(const uint32_t *__restrict__ 
     for (uint32_t q = threadIdx.x; q < ng * NW; q += 256) dst[q] = s_out[q];
 }
 
+// GaussianPod::into_gaussian (src/buffer/gaussian.rs:186-196, gaussian_config.rs:61-117): one POD ->
+// one Gaussian (56 words); only for the lossless configurations (SH != None, Cov3dRotScale), which the
+// callers check.  Shared by the host path (gs_unpack_to_gaussian) and the device kernel.
+__host__ __device__ inline void unpack_words(int sh, const uint32_t *p, uint32_t *g) {
+    g[GW_POS] = p[0];
+    g[GW_POS + 1] = p[1];
+    g[GW_POS + 2] = p[2];
+    g[GW_COLOR] = p[3];
+    const uint32_t *s = p + 4;
+    for (int k = 0; k < 45; k++) {
+        if (sh == SH_SINGLE) {
+            g[GW_SH + k] = s[k];
+        } else if (sh == SH_HALF) {
+            g[GW_SH + k] = cv_f2u(cv_f16_to_f32((s[k >> 1] >> (16 * (k & 1))) & 0xffffu));
+        } else {
+            const float v = (float)(int8_t)((s[k >> 2] >> (8 * (k & 3))) & 0xffu) / 127.0f;
+            g[GW_SH + k] = cv_f2u(v < -1.0f ? -1.0f : v);
+        }
+    }
+    const uint32_t *c = p + cov_word0(sh);
+    for (int k = 0; k < 4; k++) g[GW_ROT + k] = c[k];
+    for (int k = 0; k < 3; k++) g[GW_SCALE + k] = c[4 + k];
+}
+
+// Device side of GaussiansBuffer::download::<Gaussian>: PODs -> struct Gaussian records, LDS-staged on
+// both sides like k_pack_pods (COV is RotScale by construction).
+template <int SH>
+__global__ __launch_bounds__(256) void k_unpack_pods(const uint32_t *__restrict__ pods, uint64_t count,
+                                                     uint32_t *__restrict__ gaussians) {
+    constexpr int NW = pod_words(SH, COV_ROT_SCALE);
+    __shared__ uint32_t s_in[PACK_GROUP * NW];
+    __shared__ uint32_t s_out[PACK_GROUP * GAUSSIAN_WORDS];
+    const uint64_t g0 = (uint64_t)blockIdx.x * PACK_GROUP;
+    const uint32_t ng = (uint32_t)(count - g0 < PACK_GROUP ? count - g0 : PACK_GROUP);
+    const uint32_t *src = pods + g0 * NW;
+    for (uint32_t q = threadIdx.x; q < ng * NW; q += 256) s_in[q] = src[q];
+    __syncthreads();
+    if (threadIdx.x < ng) unpack_words(SH, s_in + threadIdx.x * NW, s_out + threadIdx.x * GAUSSIAN_WORDS);
+    __syncthreads();
+    uint32_t *dst = gaussians + g0 * GAUSSIAN_WORDS;
+    for (uint32_t q = threadIdx.x; q < ng * GAUSSIAN_WORDS; q += 256) dst[q] = s_out[q];
+}
+
 // Device load path of a PLY scene: Gaussian::from_ply fused with G::from_gaussian.  Same structure as
 // k_pack_pods (contiguous span in, LDS, one record per thread LDS -> LDS, contiguous span out); the
 // per-record arithmetic is gs_convert.h's ply_to_gaussian_words, shared with the host path.
