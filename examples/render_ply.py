@@ -23,14 +23,17 @@ def main():
     ap.add_argument("--mode", default="splat", choices=["splat", "ellipse", "point"])
     ap.add_argument("--pod", default="ShSingle/Cov3dRotScale")
     args = ap.parse_args()
-    source = gs.GaussiansSource.Spz if args.scene.endswith(".spz") else gs.GaussiansSource.Ply
-    gaussians = gs.Gaussians.read_from_file(args.scene, source).iter_gaussian()
     sh, cov = args.pod.split("/")
     pod = getattr(gs, "GaussianPodWith%s%sConfigs" % (sh, cov))
     W, H = (int(v) for v in args.size.split("x"))
     dev = gs.Device(0)
     stream = dev.create_stream()
-    buf = gs.GaussiansBuffer.new(dev, pod, gaussians)
+    # the device-side load path: the file's records cross PCIe as they are; from_ply / from_spz and the
+    # pack to the POD layout run in one kernel (gs_gaussians_buffer_create_from_ply / _from_spz)
+    if args.scene.endswith(".spz"):
+        buf = gs.GaussiansBuffer.new_from_spz(dev, pod, open(args.scene, "rb").read())
+    else:
+        buf = gs.GaussiansBuffer.new_from_ply(dev, pod, gs.PlyGaussians.read_from_file(args.scene))
     img = gs.Buffer(dev, size=W * H * 16)
     cam = gs.camera_look_at(tuple(float(v) for v in args.eye.split(",")), tuple(float(v) for v in args.target.split(",")),
                             (0, 1, 0), float(np.deg2rad(60.0)), W, H)
@@ -44,7 +47,7 @@ def main():
     with open(args.out, "wb") as f:
         f.write(b"P6\n%d %d\n255\n" % (W, H))
         f.write(rgb8.tobytes())
-    print("%d Gaussians, %d visible, %d (tile, Gaussian) pairs -> %s" % (len(gaussians), st.visible, st.pairs, args.out))
+    print("%d Gaussians, %d visible, %d (tile, Gaussian) pairs -> %s" % (len(buf), st.visible, st.pairs, args.out))
 
 
 if __name__ == "__main__":

@@ -48,8 +48,8 @@ def run(name):
     order = ob.spatial_order(wl["sh"], wl["cov"], pods)
     ob.set_rect_version(1)
     rgba1, d1, v1, _ = ob.render(wl["sh"], wl["cov"], pods, gt, mt, cam, want_image=True, order=order)
-    ob.set_rect_version(2)
-    rgba, d, v, _ = ob.render(wl["sh"], wl["cov"], pods, gt, mt, cam, want_image=True, order=order)
+    ob.set_rect_version(3)      # the default since round 3 (version 2 + the rounding guard): identical tile counts on
+    rgba, d, v, _ = ob.render(  # these workloads (tests/test_rect_versions.py), so fullsize_v2.json standswl["sh"], wl["cov"], pods, gt, mt, cam, want_image=True, order=order)
     dt = time.time() - t0
     if not np.array_equal(rgba.view(np.uint32), rgba1.view(np.uint32)):
         raise SystemExit("%s: rect versions 1 and 2 give different frames" % name)

@@ -162,3 +162,22 @@ def test_adversarial_needle_scan_guarded_clip_changes_no_image(both_versions):
                 clipped += f[3][1] < f[1][1]
                 kept_square += f[3][1] == f[1][1]
     assert clipped > 20 and kept_square > 20
+
+
+def test_guard_leaves_the_synthetic_workloads_untouched(both_versions):
+    """Version 3 differs from version 2 only for splats whose rounding bound exceeds half the head room
+    (needles): on the 1 M workload of BASELINE.json every Gaussian gets the same tile rect from both,
+    and V / D equal tests/golden/fullsize_v2.json (checked offline for 10 M, 10 M-4K and 50 M as well:
+    identical per-Gaussian tile counts), which is why the full-size goldens did not have to move."""
+    import synth
+    ob = both_versions
+    g = json.load(open(os.path.join(HERE, "golden", "fullsize_v2.json")))["1m"]
+    pods = ob.pack(g["sh"], g["cov"], synth.scene(g["n"]))
+    cam = helpers.default_camera(ob, g["width"], g["height"])
+    gt, mt = ob.gaussian_transform(sh_deg=g["sh_deg"]), ob.model_transform()
+    tiles = {}
+    for v in (2, 3):
+        ob.set_rect_version(v)
+        tiles[v] = ob.preprocess(g["sh"], g["cov"], pods, gt, mt, cam)[1]
+    assert np.array_equal(tiles[2], tiles[3])
+    assert (int((tiles[3] > 0).sum()), int(tiles[3].sum(dtype=np.int64))) == (g["visible"], g["pairs"])
