@@ -155,6 +155,18 @@ int main() {
         pack_device<G>(dev, s, src, gs.size(), dst);
         REQUIRE(dst.download<uint8_t>(s) == G::from_gaussians(gs));
     }
+    {   // device load path: PLY vertex records -> PODs in one kernel == host from_ply + host pack;
+        // SPZ bytes (host inflate + device column decode) == host decode + host pack
+        PlyGaussians ply = PlyGaussians::from_gaussians(gs);
+        auto from_ply = GaussiansBuffer<G>::new_from_ply(dev, ply.pods);
+        std::vector<Gaussian> via_host(ply.pods.size());
+        gs_gaussian_from_ply(ply.pods.data(), ply.pods.size(), via_host.data());
+        REQUIRE(from_ply.len() == 15 && from_ply.download(s) == G::from_gaussians(via_host));
+        auto spz_bytes = SpzGaussians::from_gaussians(gs).write_to();
+        auto from_spz = GaussiansBuffer<G>::new_from_spz(dev, spz_bytes.data(), spz_bytes.size());
+        auto decoded = SpzGaussians::read_from(spz_bytes.data(), spz_bytes.size()).iter_gaussian();
+        REQUIRE(from_spz.len() == 15 && from_spz.download(s) == G::from_gaussians(decoded));
+    }
     double sum = 0; for (float v : px) sum += v;
     REQUIRE(st.gaussians == 15 && std::isfinite(sum));
     std::printf("cpp mirror OK: visible %llu pairs %llu checksum %.6f\n", (unsigned long long)st.visible, (unsigned long long)st.pairs, sum);
