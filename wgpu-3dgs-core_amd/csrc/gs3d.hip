@@ -1733,6 +1733,34 @@ static void launch_scan_rows(uint32_t rows, hipStream_t st, uint32_t *ghist, uin
                            totals);
 }
 
+// one scatter launch (FAST_RANK chosen by the device probe); KO = type of the keys the pass writes
+template <typename KI, typename KO, int RB, bool COMPACT, int ITEMS>
+static void launch_scatter(const gs_device *dev, hipStream_t st, uint32_t sgrid, const KI *kin, const uint32_t *vin, KO *kout,
+                           uint32_t ko_shift, uint32_t *vout, gs::SortCount psc, uint32_t shift, uint32_t digit_mask,
+                           const uint32_t *ghist, const uint32_t *totals, const uint32_t *cv, uint32_t *vo, uint32_t pnb,
+                           uint32_t xr) {
+    if (dev->lds_atomic_ordered)
+        hipLaunchKernelGGL((gs::k_sort_scatter<KI, true, RB, COMPACT, ITEMS, KO>), dim3(sgrid), dim3(gs::SORT_THREADS), 0, st, kin, vin,
+                           kout, ko_shift, vout, psc, shift, digit_mask, ghist, totals, cv, vo, pnb, xr);
+    else
+        hipLaunchKernelGGL((gs::k_sort_scatter<KI, false, RB, COMPACT, ITEMS, KO>), dim3(sgrid), dim3(gs::SORT_THREADS), 0, st, kin, vin,
+                           kout, ko_shift, vout, psc, shift, digit_mask, ghist, totals, cv, vo, pnb, xr);
+}
+
+// one radix pass: histogram -> row scan -> scatter
+template <typename KI, typename KO, int RB, bool COMPACT, int ITEMS>
+static void launch_pass(const gs_device *dev, hipStream_t st, uint32_t sgrid, const KI *kin, const uint32_t *vin, KO *kout,
+                        uint32_t ko_shift, uint32_t *vout, gs::SortCount psc, uint32_t shift, uint32_t digit_mask, DevArray &ghist,
+                        DevArray &digit_totals, const uint32_t *cv, uint32_t *vo, uint32_t pnb, uint32_t xr) {
+    constexpr uint32_t R = 1u << RB;
+    constexpr int TILE = gs::SORT_THREADS * ITEMS;
+    hipLaunchKernelGGL((gs::k_sort_hist<KI, RB, COMPACT, ITEMS>), dim3(sgrid), dim3(gs::SORT_THREADS), 0, st, kin, psc, shift,
+                       digit_mask, (uint32_t *)ghist.ptr, cv, pnb, xr);
+    launch_scan_rows<TILE>(R, st, (uint32_t *)ghist.ptr, pnb, psc, (uint32_t *)digit_totals.ptr);
+    launch_scatter<KI, KO, RB, COMPACT, ITEMS>(dev, st, sgrid, kin, vin, kout, ko_shift, vout, psc, shift, digit_mask,
+                                               (const uint32_t *)ghist.ptr, (const uint32_t *)digit_totals.ptr, cv, vo, pnb, xr);
+}
+
 template <typename K, int RB, int ITEMS>
 static gs_status run_sort_items(const gs_device *dev, void *const keys[2], void *const vals[2], DevArray &ghist,
                              DevArray &digit_totals, gs::SortCount sc, uint32_t end_bit, const SortCompact *compact,
@@ -1778,20 +1806,6 @@ static gs_status run_sort_items(const gs_device *dev, void *const keys[2], void 
             if (remap_c > 1) xr = (uint32_t)remap_c;
         }
         const uint32_t sgrid = xr ? 8u * xr * ((pnb + 8u * xr - 1u) / (8u * xr)) : pnb;
-#define GS_SORT_PASS(COMPACT)                                                                                     \
-    do {                                                                                                          \
-        hipLaunchKernelGGL((gs::k_sort_hist<K, RB, COMPACT, ITEMS>), dim3(sgrid), dim3(gs::SORT_THREADS), 0, st, kin, psc, \
-                           shift, digit_mask, (uint32_t *)ghist.ptr, cv, pnb, xr);                                \
-        launch_scan_rows<(int)TILE>(R, st, (uint32_t *)ghist.ptr, pnb, psc, (uint32_t *)digit_totals.ptr);        \
-        if (dev->lds_atomic_ordered)                                                                              \
-            hipLaunchKernelGGL((gs::k_sort_scatter<K, true, RB, COMPACT, ITEMS>), dim3(sgrid), dim3(gs::SORT_THREADS), 0,  \
-                               st, kin, vin, kout, vout, psc, shift, digit_mask, (const uint32_t *)ghist.ptr,     \
-                               (const uint32_t *)digit_totals.ptr, cv, vo, pnb, xr);                   \
-        else                                                                                                      \
-            hipLaunchKernelGGL((gs::k_sort_scatter<K, false, RB, COMPACT, ITEMS>), dim3(sgrid), dim3(gs::SORT_THREADS), 0, \
-                               st, kin, vin, kout, vout, psc, shift, digit_mask, (const uint32_t *)ghist.ptr,     \
-                               (const uint32_t *)digit_totals.ptr, cv, vo, pnb, xr);                   \
-    } while (0)
         if (source && p == 0) {
             // the pairs come from the depth-ordered rects: k_pairs_emit writes this pass's input
             // (keys[side] / vals[side]) and its histogram at once
@@ -1801,21 +1815,35 @@ static gs_status run_sort_items(const gs_device *dev, void *const keys[2], void 
                 hipLaunchKernelGGL((gs::k_pairs_emit<K, RB, ITEMS>), dim3(sgrid), dim3(gs::SORT_THREADS), 0, st, src,
                                    digit_mask, (uint32_t *)ghist.ptr, (K *)keys[side], pnb, xr);
                 launch_scan_rows<(int)TILE>(R, st, (uint32_t *)ghist.ptr, pnb, psc, (uint32_t *)digit_totals.ptr);
-                if (dev->lds_atomic_ordered)
-                    hipLaunchKernelGGL((gs::k_sort_scatter<K, true, RB, false, ITEMS>), dim3(sgrid), dim3(gs::SORT_THREADS),
-                                       0, st, kin, vin, kout, vout, psc, shift, digit_mask, (const uint32_t *)ghist.ptr,
-                                       (const uint32_t *)digit_totals.ptr, cv, vo, pnb, xr);
-                else
-                    hipLaunchKernelGGL((gs::k_sort_scatter<K, false, RB, false, ITEMS>), dim3(sgrid), dim3(gs::SORT_THREADS),
-                                       0, st, kin, vin, kout, vout, psc, shift, digit_mask, (const uint32_t *)ghist.ptr,
-                                       (const uint32_t *)digit_totals.ptr, cv, vo, pnb, xr);
+                launch_scatter<K, K, RB, false, ITEMS>(dev, st, sgrid, kin, vin, kout, 0u, vout, psc, shift, digit_mask,
+                                                       (const uint32_t *)ghist.ptr, (const uint32_t *)digit_totals.ptr, cv, vo, pnb, xr);
             }
         } else if constexpr (sizeof(K) == 4) {
-            if (first) GS_SORT_PASS(true); else GS_SORT_PASS(false);
+            // Narrow keys (the frame's depth sort only): the pass BEFORE the last stores key >> (shift of
+            // the last pass) as u16 — all the last pass still needs — and the last pass runs on 16-bit keys:
+            // 2 bytes less per element written, 2 x 2 bytes less read.  GS3D_NARROW_KEYS=0 switches it off.
+            static const bool narrow_on = !(std::getenv("GS3D_NARROW_KEYS") && std::getenv("GS3D_NARROW_KEYS")[0] == '0');
+            const bool narrow = narrow_on && compact && passes >= 2;
+            const bool writes_narrow = narrow && p == passes - 2, reads_narrow = narrow && p == passes - 1;
+            if (reads_narrow) {
+                launch_pass<uint16_t, uint16_t, RB, false, ITEMS>(dev, st, sgrid, (const uint16_t *)keys[side], vin, (uint16_t *)nullptr, 0u,
+                                                                  vout, psc, 0u, digit_mask, ghist, digit_totals, cv, vo, pnb, xr);
+            } else if (writes_narrow) {
+                const uint32_t next_shift = shift + bits;
+                if (first)
+                    launch_pass<uint32_t, uint16_t, RB, true, ITEMS>(dev, st, sgrid, (const uint32_t *)kin, vin, (uint16_t *)keys[side ^ 1],
+                                                                     next_shift, vout, psc, shift, digit_mask, ghist, digit_totals, cv, vo, pnb, xr);
+                else
+                    launch_pass<uint32_t, uint16_t, RB, false, ITEMS>(dev, st, sgrid, (const uint32_t *)kin, vin, (uint16_t *)keys[side ^ 1],
+                                                                      next_shift, vout, psc, shift, digit_mask, ghist, digit_totals, cv, vo, pnb, xr);
+            } else if (first) {
+                launch_pass<K, K, RB, true, ITEMS>(dev, st, sgrid, kin, vin, kout, 0u, vout, psc, shift, digit_mask, ghist, digit_totals, cv, vo, pnb, xr);
+            } else {
+                launch_pass<K, K, RB, false, ITEMS>(dev, st, sgrid, kin, vin, kout, 0u, vout, psc, shift, digit_mask, ghist, digit_totals, cv, vo, pnb, xr);
+            }
         } else {
-            GS_SORT_PASS(false);
+            launch_pass<K, K, RB, false, ITEMS>(dev, st, sgrid, kin, vin, kout, 0u, vout, psc, shift, digit_mask, ghist, digit_totals, cv, vo, pnb, xr);
         }
-#undef GS_SORT_PASS
         launches += 3;
         shift += bits;
         side ^= 1;
@@ -1841,6 +1869,9 @@ static gs_status run_sort_rb(const gs_device *dev, void *const keys[2], void *co
         if (sizeof(K) == 2) {
             const uint32_t passes = (end_bit + RB - 1) / RB;
             large = passes ? (end_bit + passes - 1) / passes > 7u : false;
+            // GS3D_TILE_SORT_LARGE=0/1 forces 4096- / 8192-key tiles for the 16-bit tile keys (A/B runs)
+            static const int force = std::getenv("GS3D_TILE_SORT_LARGE") ? std::atoi(std::getenv("GS3D_TILE_SORT_LARGE")) : -1;
+            if (force >= 0) large = force != 0;
         }
         if (large)
             return run_sort_items<K, RB, gs::SortCfg<K>::ITEMS_LARGE>(dev, keys, vals, ghist, digit_totals, sc, end_bit,

@@ -1383,10 +1383,13 @@ __device__ __forceinline__ void scatter_clear(ScatterShared<K, RB, ITEMS> &sh) {
 
 // Everything after a workgroup holds its tile in registers (key[k], val[k] = element
 // wave_off + k * 64 + lane of the tile; padding = all-ones key): rank, local reorder, coalesced store.
-template <typename K, bool FAST_RANK, int RB, bool COMPACT, int ITEMS>
+// KO / ko_shift: the keys this pass WRITES may be narrower than the keys it sorts — the pass before the
+// last one of the frame's depth sort stores only the bits the last pass still needs (key >> ko_shift
+// as u16: 9 of 27 bits are left), which saves 2 bytes per element written and 2 x 2 bytes read.
+template <typename K, bool FAST_RANK, int RB, bool COMPACT, int ITEMS, typename KO = K>
 __device__ __forceinline__ void scatter_ranked(ScatterShared<K, RB, ITEMS> &sh, K (&key)[ITEMS], uint32_t (&val)[ITEMS],
                                                uint32_t in_tile, uint32_t block, uint32_t num_blocks,
-                                               K *__restrict__ keys_out,
+                                               KO *__restrict__ keys_out, uint32_t ko_shift,
                                                uint32_t *__restrict__ vals_out, uint32_t shift, uint32_t digit_mask,
                                                const uint32_t *__restrict__ ghist,
                                                const uint32_t *__restrict__ digit_totals,
@@ -1493,15 +1496,15 @@ __device__ __forceinline__ void scatter_ranked(ScatterShared<K, RB, ITEMS> &sh, 
             K kk = s_keys[pos];
             uint32_t d = (uint32_t)(kk >> shift) & digit_mask;
             uint32_t dst = s_delta[d] + pos;
-            if (keys_out) keys_out[dst] = kk;      // null: nobody reads the keys of this pass (last depth pass)
+            if (keys_out) keys_out[dst] = (KO)(kk >> ko_shift);      // null: nobody reads the keys of this pass (last depth pass)
             vals_out[dst] = s_vals[pos];
         }
     }
 }
 
-template <typename K, bool FAST_RANK, int RB, bool COMPACT, int ITEMS>
+template <typename K, bool FAST_RANK, int RB, bool COMPACT, int ITEMS, typename KO = K>
 __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
-    const K *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, K *__restrict__ keys_out,
+    const K *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, KO *__restrict__ keys_out, uint32_t ko_shift,
     uint32_t *__restrict__ vals_out, SortCount sc, uint32_t shift, uint32_t digit_mask,
     const uint32_t *__restrict__ ghist, const uint32_t *__restrict__ digit_totals,
     const uint32_t *__restrict__ chunk_vis, uint32_t *__restrict__ visible_out, uint32_t num_tiles,
@@ -1545,8 +1548,8 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
             val[k] = ok ? vals_in[tile_base + e] : 0u;
         }
     }
-    scatter_ranked<K, FAST_RANK, RB, COMPACT, ITEMS>(sh, key, val, in_tile, block, num_tiles, keys_out, vals_out, shift,
-                                                     digit_mask, ghist, digit_totals, visible_out);
+    scatter_ranked<K, FAST_RANK, RB, COMPACT, ITEMS, KO>(sh, key, val, in_tile, block, num_tiles, keys_out, ko_shift, vals_out,
+                                                         shift, digit_mask, ghist, digit_totals, visible_out);
 }
 
 // ---------------------------------------------------------------------------------------------
