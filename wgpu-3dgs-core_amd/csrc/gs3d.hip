@@ -1450,6 +1450,7 @@ struct gs_renderer {
     uint32_t key_bias;
     int dsorted_side, tsorted_side;
     bool wide_tiles;  // tile keys are u32 (more than 65536 tiles) instead of u16
+    bool rect32;      // the last frame's tile rects are packed (gs::rect_pack32)
     uint32_t launches;                    // kernel launches of the last frame (diagnostic)
     hipStream_t last_stream;
     bool have_frame;                      // last_stream is meaningful (the null stream is a valid stream)
@@ -1495,6 +1496,7 @@ extern "C" gs_status gs_renderer_create(gs_device *dev, gs_renderer **out) {
     r->key_bias = 0;
     r->dsorted_side = r->tsorted_side = 0;
     r->wide_tiles = false;
+    r->rect32 = false;
     r->launches = 0;
     r->last_stream = nullptr;
     r->have_frame = false;
@@ -1682,6 +1684,10 @@ static void make_frame_consts(const gs_gaussian_transform_pod *gt, const gs_mode
         fc.clip_rect = gt->flags[0] == GS_DISPLAY_SPLAT && !rect_v1 ? 1u : 0u;
     }
     fc.ellipse_pmin = -0.5f * (fc.max_std_dev * fc.max_std_dev);
+    {   // packed 4-byte tile rects while both tile counts fit 8 bits (images up to 4096 px); GS3D_RECT32=0: always uint2
+        static const bool rect32_off = std::getenv("GS3D_RECT32") && std::getenv("GS3D_RECT32")[0] == '0';
+        fc.rect32 = !rect32_off && fc.tiles_x <= 256u && fc.tiles_y <= 256u ? 1u : 0u;
+    }
     // block culling gain (see block_is_culled): |W R_m S_m|_F^2 bounds the squared spectral norm of
     // the linear part whatever the caller's view matrix is; 0.1 % head room for the f32 arithmetic
     float ws2 = 0.0f;
@@ -1812,8 +1818,12 @@ static gs_status run_sort_items(const gs_device *dev, void *const keys[2], void 
             if constexpr (sizeof(K) <= 4) {
                 gs::ExpandIO src = *source;
                 src.tvals = (uint32_t *)vals[side];
-                hipLaunchKernelGGL((gs::k_pairs_emit<K, RB, ITEMS>), dim3(sgrid), dim3(gs::SORT_THREADS), 0, st, src,
-                                   digit_mask, (uint32_t *)ghist.ptr, (K *)keys[side], pnb, xr);
+                if (sizeof(K) == 2 && src.rect32)
+                    hipLaunchKernelGGL((gs::k_pairs_emit<K, RB, ITEMS, sizeof(K) == 2>), dim3(sgrid), dim3(gs::SORT_THREADS), 0, st,
+                                       src, digit_mask, (uint32_t *)ghist.ptr, (K *)keys[side], pnb, xr);
+                else
+                    hipLaunchKernelGGL((gs::k_pairs_emit<K, RB, ITEMS, false>), dim3(sgrid), dim3(gs::SORT_THREADS), 0, st, src,
+                                       digit_mask, (uint32_t *)ghist.ptr, (K *)keys[side], pnb, xr);
                 launch_scan_rows<(int)TILE>(R, st, (uint32_t *)ghist.ptr, pnb, psc, (uint32_t *)digit_totals.ptr);
                 launch_scatter<K, K, RB, false, ITEMS>(dev, st, sgrid, kin, vin, kout, 0u, vout, psc, shift, digit_mask,
                                                        (const uint32_t *)ghist.ptr, (const uint32_t *)digit_totals.ptr, cv, vo, pnb, xr);
@@ -2249,6 +2259,7 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
     r->n = n;
     r->tiles_x = fc.tiles_x;
     r->tiles_y = fc.tiles_y;
+    r->rect32 = fc.rect32 != 0u;
     r->last_stream = st;
     r->have_frame = true;
     r->launches = 0;
@@ -2379,6 +2390,7 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
         eo.tiles_x = fc.tiles_x;
         eo.gen = gen;
         eo.sb_bound = exp_grid / gs::EXP_SB + 1;
+        eo.rect32 = fc.rect32;
         // Where a wave of k_pairs_emit starts: found by the wave itself (a search over the super-chunk
         // sums: one step per 256 of them) or looked up in a table that k_pairs_cursors writes first.
         // The table costs a launch and wins once the search needs more than one step (A/B on one box:
@@ -2386,8 +2398,12 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
         static const int cursor_env = std::getenv("GS3D_CURSOR_KERNEL") ? std::atoi(std::getenv("GS3D_CURSOR_KERNEL")) : -1;
         const bool cursor_kernel = cursor_env >= 0 ? cursor_env != 0 : eo.sb_bound > 256u;
         eo.cursors = cursor_kernel ? (gs::PairCursorRec *)r->cursors.ptr : nullptr;
-        hipLaunchKernelGGL(gs::k_expand_count, dim3((exp_grid + gs::EXP_COUNT_CHUNKS - 1) / gs::EXP_COUNT_CHUNKS),
-                           dim3(gs::EXP_CHUNK), 0, st, eo);
+        if (eo.rect32)
+            hipLaunchKernelGGL(gs::k_expand_count<true>, dim3((exp_grid + gs::EXP_COUNT_CHUNKS - 1) / gs::EXP_COUNT_CHUNKS),
+                               dim3(gs::EXP_CHUNK), 0, st, eo);
+        else
+            hipLaunchKernelGGL(gs::k_expand_count<false>, dim3((exp_grid + gs::EXP_COUNT_CHUNKS - 1) / gs::EXP_COUNT_CHUNKS),
+                               dim3(gs::EXP_CHUNK), 0, st, eo);
         r->launches++;
         if (cursor_kernel) {
             hipLaunchKernelGGL(gs::k_pairs_cursors, dim3(eo.sb_bound), dim3(gs::EXP_SB), 0, st, eo);
@@ -2495,7 +2511,13 @@ extern "C" gs_status gs_renderer_download_projected(gs_renderer *r, gs_projected
     std::vector<uint2> rect(total);
     GS_TRY(download_sync(r, recs.data(), r->recs.ptr, total * 4 * gs::REC_WORDS));
     GS_TRY(download_slot_depths(r, depth));
-    GS_TRY(download_sync(r, rect.data(), r->rect.ptr, total * 8));
+    if (r->rect32) {
+        std::vector<uint32_t> packed(total);
+        GS_TRY(download_sync(r, packed.data(), r->rect.ptr, total * 4));
+        for (size_t k = 0; k < total; k++) gs::rect_unpack32(packed[k], rect[k].x, rect[k].y);   // (culled slots: never looked at)
+    } else {
+        GS_TRY(download_sync(r, rect.data(), r->rect.ptr, total * 8));
+    }
     if (r->last_order) {
         order.resize(total);
         GS_TRY(download_sync(r, order.data(), r->last_order->ptr, total * 4));

@@ -50,7 +50,23 @@ struct FrameConsts {
     uint32_t clip_rect;            // display mode Splat: the tile rect is clipped to the splat's visible box
     float cull_gain;               // block culling: size^2 * |R_m S_m|_F^2 * (fx^2 (1+limx^2) + fy^2 (1+limy^2)); 0 = off
     float ellipse_pmin;            // display mode Ellipse: -max_std_dev^2 / 2
+    uint32_t rect32;               // tile rects are stored packed in 4 bytes (at most 256 tiles along either axis)
 };
+
+// Tile rect of a visible Gaussian.  Two storage formats: uint2 (x0 | y0 << 16, x1 | y1 << 16; any image)
+// and, while the image has at most 256 x 256 tiles (4096 px), ONE word x0 | y0 << 8 | (w - 1) << 16 |
+// (h - 1) << 24 — 4 bytes less per visible Gaussian written by preprocess, written again in depth order
+// by k_expand_count and read by k_pairs_emit.  A packed rect is never empty; culled slots are
+// recognised by their depth key, not by their rect.
+__host__ __device__ inline uint32_t rect_pack32(uint32_t r0, uint32_t r1) {
+    const uint32_t x0 = r0 & 0xffffu, y0 = r0 >> 16, x1 = r1 & 0xffffu, y1 = r1 >> 16;
+    return x0 | (y0 << 8) | ((x1 - x0 - 1u) << 16) | ((y1 - y0 - 1u) << 24);
+}
+__host__ __device__ inline void rect_unpack32(uint32_t p, uint32_t &r0, uint32_t &r1) {
+    const uint32_t x0 = p & 0xffu, y0 = (p >> 8) & 0xffu, w = ((p >> 16) & 0xffu) + 1u, h = (p >> 24) + 1u;
+    r0 = x0 | (y0 << 16);
+    r1 = (x0 + w) | ((y0 + h) << 16);
+}
 
 // ---------------------------------------------------------------------------------------------
 // wave / block primitives
@@ -847,7 +863,8 @@ __global__ __launch_bounds__(PP_THREADS) void k_preprocess(const uint4 *__restri
             *(u32x4_a4 *)(o + 4) = u32x4_a4{rec[1].x, rec[1].y, rec[1].z, rec[1].w};
             o[8] = rec[2].x;
             io.depth[i] = cnt ? rec[2].y - io.key_bias : 0xffffffffu;
-            io.rect[i] = cnt ? make_uint2(rec[2].z, rec[2].w) : make_uint2(0u, 0u);
+            if (fc.rect32) ((uint32_t *)io.rect)[i] = cnt ? rect_pack32(rec[2].z, rec[2].w) : 0u;
+            else io.rect[i] = cnt ? make_uint2(rec[2].z, rec[2].w) : make_uint2(0u, 0u);
             local += cnt;
             local_vis += cnt ? 1u : 0u;
         }
@@ -955,7 +972,8 @@ __global__ __launch_bounds__(PP_THREADS) void k_preprocess_banded(const uint4 *_
                 *(u32x4_a4 *)(o) = u32x4_a4{rec[0].x, rec[0].y, rec[0].z, rec[0].w};
                 *(u32x4_a4 *)(o + 4) = u32x4_a4{rec[1].x, rec[1].y, rec[1].z, rec[1].w};
                 o[8] = rec[2].x;
-                io.rect[i] = make_uint2(rec[2].z, rec[2].w);
+                if (fc.rect32) ((uint32_t *)io.rect)[i] = cnt ? rect_pack32(rec[2].z, rec[2].w) : 0u;
+                else io.rect[i] = make_uint2(rec[2].z, rec[2].w);
             }
             io.depth[i] = cnt ? rec[2].y - io.key_bias : 0xffffffffu;
             local += cnt;
@@ -1070,6 +1088,7 @@ struct ExpandIO {
     uint32_t gen;
     uint32_t sb_bound;               // host bound of the number of super-chunks (entries past the real one are zero)
     struct PairCursorRec *cursors;   // [capacity / CURSOR_SLOTS + 1] where the pairs of every 1024-slot span start
+    uint32_t rect32;                 // rect / sorted_rect hold packed 4-byte rects (rect_pack32)
 };
 
 // Expansion, part 1: gather the tile rects into depth order (the only random access of the key
@@ -1081,6 +1100,7 @@ struct ExpandIO {
 // The grid covers the host's upper bound of V (= N); workgroups past the real V exit at once.
 constexpr uint32_t EXP_COUNT_CHUNKS = 8;
 static_assert(EXP_SB % EXP_COUNT_CHUNKS == 0, "a count workgroup must not straddle super-chunks");
+template <bool RECT32>
 __global__ __launch_bounds__(EXP_CHUNK) void k_expand_count(ExpandIO io) {
     __shared__ uint32_t s_red[EXP_COUNT_CHUNKS][4];
     const uint32_t v_count = io.state->visible;
@@ -1092,15 +1112,26 @@ __global__ __launch_bounds__(EXP_CHUNK) void k_expand_count(ExpandIO io) {
         const uint64_t j = (uint64_t)(first_chunk + c) * EXP_CHUNK + threadIdx.x;
         slot[c] = j < v_count ? io.order[j] : 0xffffffffu;
     }
+    // the gather: 8 (4) bytes per visible Gaussian from a compact array, EXP_COUNT_CHUNKS in flight per thread
     uint2 r[EXP_COUNT_CHUNKS];
+    uint32_t rp[EXP_COUNT_CHUNKS];
 #pragma unroll
-    for (uint32_t c = 0; c < EXP_COUNT_CHUNKS; c++) r[c] = slot[c] != 0xffffffffu ? io.rect[slot[c]] : make_uint2(0u, 0u);
+    for (uint32_t c = 0; c < EXP_COUNT_CHUNKS; c++) {
+        if constexpr (RECT32) rp[c] = slot[c] != 0xffffffffu ? ((const uint32_t *)io.rect)[slot[c]] : 0u;
+        else r[c] = slot[c] != 0xffffffffu ? io.rect[slot[c]] : make_uint2(0u, 0u);
+    }
     const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
 #pragma unroll
     for (uint32_t c = 0; c < EXP_COUNT_CHUNKS; c++) {
         const uint64_t j = (uint64_t)(first_chunk + c) * EXP_CHUNK + threadIdx.x;
-        if (j < v_count) io.sorted_rect[j] = r[c];
-        uint32_t v = ((r[c].y & 0xffffu) - (r[c].x & 0xffffu)) * ((r[c].y >> 16) - (r[c].x >> 16));
+        uint32_t v;
+        if constexpr (RECT32) {
+            if (j < v_count) ((uint32_t *)io.sorted_rect)[j] = rp[c];
+            v = j < v_count ? (((rp[c] >> 16) & 0xffu) + 1u) * ((rp[c] >> 24) + 1u) : 0u;
+        } else {
+            if (j < v_count) io.sorted_rect[j] = r[c];
+            v = ((r[c].y & 0xffffu) - (r[c].x & 0xffffu)) * ((r[c].y >> 16) - (r[c].x >> 16));
+        }
         v = wave_reduce_add(v);
         if (lane == 0) s_red[c][wid] = v;
     }
@@ -1730,7 +1761,7 @@ struct PairGenShared {                 // LDS private to one wave
 // A lane owns GEN_PER consecutive slots of a 256-slot group, so one max-scan over the lanes serves
 // 256 pairs.  Every iteration of the outer loop advances j (bounded by v_count): the wave always
 // terminates.
-template <typename K, int NSLOTS, typename Count>
+template <typename K, int NSLOTS, bool RECT32, typename Count>
 __device__ __forceinline__ void pair_generate(const ExpandIO &io, uint32_t v_count, uint64_t o0, uint32_t n_slots,
                                               const PairCursor &cur, uint32_t lane, PairGenShared<K, NSLOTS> &sh,
                                               Count count) {
@@ -1749,23 +1780,44 @@ __device__ __forceinline__ void pair_generate(const ExpandIO &io, uint32_t v_cou
     const uint4 *order4 = (const uint4 *)io.order;
     const uint4 *rect4 = (const uint4 *)io.sorted_rect;
     uint4 g_next = order4[(j >> 2) + lane];
-    uint4 ra_next = rect4[(j >> 1) + 2 * lane], rb_next = rect4[(j >> 1) + 2 * lane + 1];
+    // RECT32: the four rects of a lane are one 16-byte vector (rect_pack32); otherwise two
+    uint4 ra_next, rb_next = make_uint4(0u, 0u, 0u, 0u);
+    if constexpr (RECT32) {
+        ra_next = rect4[(j >> 2) + lane];
+    } else {
+        ra_next = rect4[(j >> 1) + 2 * lane];
+        rb_next = rect4[(j >> 1) + 2 * lane + 1];
+    }
     __builtin_amdgcn_wave_barrier();
     while (rel < n && j < v_count) {
         const uint32_t g[GEN_PER] = {g_next.x, g_next.y, g_next.z, g_next.w};
-        const uint32_t r0[GEN_PER] = {ra_next.x, ra_next.z, rb_next.x, rb_next.z};
-        const uint32_t r1[GEN_PER] = {ra_next.y, ra_next.w, rb_next.y, rb_next.w};
+        const uint4 ra = ra_next, rb = rb_next;
         if (j + GEN_BATCH < v_count) {
             g_next = order4[((j + GEN_BATCH) >> 2) + lane];
-            ra_next = rect4[((j + GEN_BATCH) >> 1) + 2 * lane];
-            rb_next = rect4[((j + GEN_BATCH) >> 1) + 2 * lane + 1];
+            if constexpr (RECT32) {
+                ra_next = rect4[((j + GEN_BATCH) >> 2) + lane];
+            } else {
+                ra_next = rect4[((j + GEN_BATCH) >> 1) + 2 * lane];
+                rb_next = rect4[((j + GEN_BATCH) >> 1) + 2 * lane + 1];
+            }
         }
-        uint32_t w[GEN_PER], cnt[GEN_PER], mine = 0;
+        // per Gaussian: rect width, tile count, tile id of the rect's origin
+        uint32_t w[GEN_PER], cnt[GEN_PER], origin[GEN_PER], mine = 0;
 #pragma unroll
         for (int k = 0; k < GEN_PER; k++) {
             const bool live = j + GEN_PER * lane + k < v_count;
-            w[k] = (r1[k] & 0xffffu) - (r0[k] & 0xffffu);
-            cnt[k] = live ? __umul24(w[k], (r1[k] >> 16) - (r0[k] >> 16)) : 0u;
+            if constexpr (RECT32) {
+                const uint32_t pk = k == 0 ? ra.x : k == 1 ? ra.y : k == 2 ? ra.z : ra.w;
+                w[k] = ((pk >> 16) & 0xffu) + 1u;
+                cnt[k] = live ? __umul24(w[k], (pk >> 24) + 1u) : 0u;
+                origin[k] = __umul24((pk >> 8) & 0xffu, io.tiles_x) + (pk & 0xffu);
+            } else {
+                const uint32_t r0 = k == 0 ? ra.x : k == 1 ? ra.z : k == 2 ? rb.x : rb.z;
+                const uint32_t r1 = k == 0 ? ra.y : k == 1 ? ra.w : k == 2 ? rb.y : rb.w;
+                w[k] = (r1 & 0xffffu) - (r0 & 0xffffu);
+                cnt[k] = live ? __umul24(w[k], (r1 >> 16) - (r0 >> 16)) : 0u;
+                origin[k] = __umul24(r0 >> 16, io.tiles_x) + (r0 & 0xffffu);
+            }
             mine += cnt[k];
         }
         const uint32_t incl = wave_inclusive_scan(mine, lane);
@@ -1777,8 +1829,7 @@ __device__ __forceinline__ void pair_generate(const ExpandIO &io, uint32_t v_cou
 #pragma unroll
             for (int k = 0; k < GEN_PER; k++) {
                 const uint32_t idx = GEN_PER * lane + k;
-                sh.tab[idx] = make_uint4((uint32_t)start, g[k], __umul24(r0[k] >> 16, io.tiles_x) + (r0[k] & 0xffffu),
-                                         w[k] ? w[k] : 1u);
+                sh.tab[idx] = make_uint4((uint32_t)start, g[k], origin[k], w[k] ? w[k] : 1u);
                 if (cnt[k] != 0u) {
                     if (start <= lo) last = idx + 1u;
                     else if (start < hi) sh.vals[start] = idx + 1u;
@@ -1860,7 +1911,7 @@ __device__ __forceinline__ void pair_generate(const ExpandIO &io, uint32_t v_cou
 
 // Pairs of one sort tile + the histogram of their first digit; workgroup 0 also publishes D (clamped
 // to the pair capacity), the overflow flag and the frame result.  Grid: capacity / TILE workgroups.
-template <typename K, int RB, int ITEMS>
+template <typename K, int RB, int ITEMS, bool RECT32 = false>
 __global__ __launch_bounds__(SORT_THREADS) void k_pairs_emit(ExpandIO io, uint32_t digit_mask,
                                                              uint32_t *__restrict__ ghist, K *__restrict__ tkeys,
                                                              uint32_t num_blocks, uint32_t xcd_chunk) {
@@ -1912,7 +1963,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_pairs_emit(ExpandIO io, uint32
         const uint32_t n_slots = count - o0 < (uint64_t)NSLOTS ? (uint32_t)(count - o0) : NSLOTS;
         uint32_t *hist = s_hist[threadIdx.x & (uint32_t)(COPIES - 1)];
         PairGenShared<K, NSLOTS> &sh = s_gen[wid];
-        pair_generate<K>(io, v_count, o0, n_slots, cur, lane, sh,
+        pair_generate<K, NSLOTS, RECT32>(io, v_count, o0, n_slots, cur, lane, sh,
                          [&](uint32_t tile) { atomicAdd(&hist[tile & digit_mask], 1u); });
         // the wave's slots leave in whole 16-byte vectors (o0 is a multiple of NSLOTS: aligned)
         uint32_t *vout = io.tvals + o0;
