@@ -250,23 +250,34 @@ def stage_models(wl, res):
     st = res["stages_ms"]
     if not st:
         return {}
-    tiles = ((wl["width"] + 15) // 16) * ((wl["height"] + 15) // 16)
+    tiles_x, tiles_y = (wl["width"] + 15) // 16, (wl["height"] + 15) // 16
+    tiles = tiles_x * tiles_y
     tile_bits = max(tiles - 1, 1).bit_length()
     tpasses = -(-tile_bits // 8)
     tkey = 2 if tiles <= 65536 else 4
     dpasses = max(res["sort_passes"] - tpasses, 1)
+    rb = 4 if tiles_x <= 256 and tiles_y <= 256 else 8          # packed tile rects
+    rect_writers = v if wl["sh"] != 3 else n                    # the two-phase kernel masks the rects of culled lanes
+    # depth sort: pass 0 reads the N dense keys twice and writes V x (4 + 4); pass p > 0 reads its keys for the
+    # histogram, keys + slots for the scatter, writes keys + slots; the pass before the last writes 2-byte keys,
+    # the last one reads them and writes the slots only
+    depth = n * 4 * 2 + v * ((2 if dpasses == 2 else 4) + 4 if dpasses > 1 else 4)
+    for p in range(1, dpasses):
+        kin = 2 if p == dpasses - 1 else 4
+        kout = 0 if p == dpasses - 1 else (2 if p == dpasses - 2 else 4)
+        depth += v * kin + v * (kin + 4) + v * (kout + 4)
     models = {
-        "preprocess": (n * wl["payload"] + v * 36 + n * 12,
-                       "read N x payload; write 36-B records of the V visible, 4-B key + 8-B rect of all N"),
-        "depth_sort": (n * 4 * 2 + v * 8 + (dpasses - 1) * v * 8 * 3,
-                       "first pass reads the N dense keys twice (hist, scatter) and writes V x 8 B; "
-                       "each further pass reads V x 8 B twice and writes it once"),
-        "expand": (v * (4 + 8) + v * 8,
-                   "k_expand_count: V x (4-B slot + 8-B rect gather) -> V x 8 B (the pairs themselves are produced "
-                   "by the first kernel of the tile sort)"),
-        "tile_sort": (v * (4 + 8) + d * (tkey + 4) + d * (tkey + 4) * 2 + (tpasses - 1) * d * (tkey + (tkey + 4) * 2),
-                      "k_pairs_emit: V x 12 B in, D x (key + 4 B) out, first histogram fused; first scatter: D x (key + "
-                      "4 B) read and written; each further pass: D keys (hist) + D x (key + 4 B) read and written"),
+        "preprocess": (n * wl["payload"] + v * 36 + n * 4 + rect_writers * rb,
+                       "read N x payload; write 36-B records of the V visible, 4-B keys of all N, %d-B rects of the %s"
+                       % (rb, "V visible" if wl["sh"] != 3 else "N"),),
+        "depth_sort": (depth, "pass 0 reads the N dense keys twice (hist, scatter) and writes V x (key + 4 B); each further "
+                              "pass reads its keys (hist) and keys + slots (scatter) and writes them; 2-byte keys into the last pass"),
+        "expand": (v * (4 + rb) + v * rb,
+                   "k_expand_count: V x (4-B slot + %d-B rect gather) -> V x %d B (the pairs themselves are produced "
+                   "by the first kernel of the tile sort); sector waste of the gather not modelled" % (rb, rb)),
+        "tile_sort": (v * (4 + rb) + d * (tkey + 4) + d * (tkey + 4) * 2 + (tpasses - 1) * d * (tkey + (tkey + 4) * 2),
+                      "k_pairs_emit: V x (4 + %d) B in, D x (key + 4 B) out, first histogram fused; first scatter: D x (key + "
+                      "4 B) read and written; each further pass: D keys (hist) + D x (key + 4 B) read and written" % rb),
         "ranges": (d * tkey + tiles * 8, "D keys read, tile ranges written"),
     }
     out = {}
