@@ -1417,7 +1417,7 @@ __device__ __forceinline__ void scatter_clear(ScatterShared<K, RB, ITEMS> &sh) {
 // KO / ko_shift: the keys this pass WRITES may be narrower than the keys it sorts — the pass before the
 // last one of the frame's depth sort stores only the bits the last pass still needs (key >> ko_shift
 // as u16: 9 of 27 bits are left), which saves 2 bytes per element written and 2 x 2 bytes read.
-template <typename K, bool FAST_RANK, int RB, bool COMPACT, int ITEMS, typename KO = K>
+template <typename K, bool FAST_RANK, int RB, bool COMPACT, int ITEMS, typename KO = K, bool BATCHED = true>
 __device__ __forceinline__ void scatter_ranked(ScatterShared<K, RB, ITEMS> &sh, K (&key)[ITEMS], uint32_t (&val)[ITEMS],
                                                uint32_t in_tile, uint32_t block, uint32_t num_blocks,
                                                KO *__restrict__ keys_out, uint32_t ko_shift,
@@ -1508,32 +1508,83 @@ __device__ __forceinline__ void scatter_ranked(ScatterShared<K, RB, ITEMS> &sh, 
     }
     __syncthreads();
 
-    // local reorder through LDS so that each digit run is written by consecutive lanes
+    // Local reorder through LDS so that each digit run is written by consecutive lanes.  Both loops
+    // below are written in BATCHES of CH elements — all LDS reads of a batch, a scheduling barrier, then
+    // what depends on them — because the ISA of rounds 1-2 (tools/isa_audit.py) ran every element as its
+    // own chain: `ds_read base; s_waitcnt; ds_write` sixteen times here (hipcc will not move a read of
+    // wave_hist above a write to keys / vals of the same LDS struct), and in the store loop, behind a
+    // branch per element, `ds_read key; wait; ds_read delta; wait; store; ds_read val; wait; store` —
+    // 3 dependent LDS round trips x ITEMS per thread, in kernels that have 2-5 waves per SIMD to hide them.
+    if constexpr (!BATCHED) {          // rounds 1-2, kept for the A/B (GS3D_SCATTER_BATCHED=0)
 #pragma unroll
-    for (int k = 0; k < ITEMS; k++) {
-        if (COMPACT && (uint32_t)key[k] == SORT_INVALID_KEY) continue;
-        uint32_t d = (uint32_t)(key[k] >> shift) & digit_mask;
-        uint32_t pos = s_wave_hist[wid][d] + rank[k];
-        s_keys[pos] = key[k];
-        s_vals[pos] = val[k];
+        for (int k = 0; k < ITEMS; k++) {
+            if (COMPACT && (uint32_t)key[k] == SORT_INVALID_KEY) continue;
+            uint32_t d = (uint32_t)(key[k] >> shift) & digit_mask;
+            uint32_t pos = s_wave_hist[wid][d] + rank[k];
+            s_keys[pos] = key[k];
+            s_vals[pos] = val[k];
+        }
+        __syncthreads();
+        const uint32_t live_u = COMPACT ? live_total : in_tile;
+#pragma unroll
+        for (int k = 0; k < ITEMS; k++) {
+            uint32_t pos = k * SORT_THREADS + tid;
+            if (pos < live_u) {
+                K kk = s_keys[pos];
+                uint32_t d = (uint32_t)(kk >> shift) & digit_mask;
+                uint32_t dst = s_delta[d] + pos;
+                if (keys_out) keys_out[dst] = (KO)(kk >> ko_shift);
+                vals_out[dst] = s_vals[pos];
+            }
+        }
+        return;
+    }
+    constexpr int CH = ITEMS < 16 ? ITEMS : 16;
+#pragma unroll
+    for (int k0 = 0; k0 < ITEMS; k0 += CH) {
+        uint32_t wbase[CH];
+#pragma unroll
+        for (int j = 0; j < CH; j++) wbase[j] = s_wave_hist[wid][(uint32_t)(key[k0 + j] >> shift) & digit_mask];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < CH; j++) {
+            if (COMPACT && (uint32_t)key[k0 + j] == SORT_INVALID_KEY) continue;
+            const uint32_t pos = wbase[j] + rank[k0 + j];
+            s_keys[pos] = key[k0 + j];
+            s_vals[pos] = val[k0 + j];
+        }
     }
     __syncthreads();
     // without COMPACT the padding of a partial tile carries the all-ones key and sorts to the end
     const uint32_t live = COMPACT ? live_total : in_tile;
 #pragma unroll
-    for (int k = 0; k < ITEMS; k++) {
-        uint32_t pos = k * SORT_THREADS + tid;
-        if (pos < live) {
-            K kk = s_keys[pos];
-            uint32_t d = (uint32_t)(kk >> shift) & digit_mask;
-            uint32_t dst = s_delta[d] + pos;
-            if (keys_out) keys_out[dst] = (KO)(kk >> ko_shift);      // null: nobody reads the keys of this pass (last depth pass)
-            vals_out[dst] = s_vals[pos];
+    for (int k0 = 0; k0 < ITEMS; k0 += CH) {
+        K kk[CH];
+        uint32_t vv[CH], dl[CH];
+#pragma unroll
+        for (int j = 0; j < CH; j++) {
+            const uint32_t pos = (k0 + j) * SORT_THREADS + tid;
+            const uint32_t p = pos < live ? pos : 0u;          // (no branch around the reads: slot 0 is always there)
+            kk[j] = s_keys[p];
+            vv[j] = s_vals[p];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < CH; j++) dl[j] = s_delta[(uint32_t)(kk[j] >> shift) & digit_mask];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < CH; j++) {
+            const uint32_t pos = (k0 + j) * SORT_THREADS + tid;
+            if (pos < live) {
+                const uint32_t dst = dl[j] + pos;
+                if (keys_out) keys_out[dst] = (KO)(kk[j] >> ko_shift);      // null: nobody reads the keys of this pass (last depth pass)
+                vals_out[dst] = vv[j];
+            }
         }
     }
 }
 
-template <typename K, bool FAST_RANK, int RB, bool COMPACT, int ITEMS, typename KO = K>
+template <typename K, bool FAST_RANK, int RB, bool COMPACT, int ITEMS, typename KO = K, bool BATCHED = true>
 __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
     const K *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, KO *__restrict__ keys_out, uint32_t ko_shift,
     uint32_t *__restrict__ vals_out, SortCount sc, uint32_t shift, uint32_t digit_mask,
@@ -1579,7 +1630,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
             val[k] = ok ? vals_in[tile_base + e] : 0u;
         }
     }
-    scatter_ranked<K, FAST_RANK, RB, COMPACT, ITEMS, KO>(sh, key, val, in_tile, block, num_tiles, keys_out, ko_shift, vals_out,
+    scatter_ranked<K, FAST_RANK, RB, COMPACT, ITEMS, KO, BATCHED>(sh, key, val, in_tile, block, num_tiles, keys_out, ko_shift, vals_out,
                                                          shift, digit_mask, ghist, digit_totals, visible_out);
 }
 
