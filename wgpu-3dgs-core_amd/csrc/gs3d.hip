@@ -1745,17 +1745,12 @@ static void launch_scatter(const gs_device *dev, hipStream_t st, uint32_t sgrid,
                            uint32_t ko_shift, uint32_t *vout, gs::SortCount psc, uint32_t shift, uint32_t digit_mask,
                            const uint32_t *ghist, const uint32_t *totals, const uint32_t *cv, uint32_t *vo, uint32_t pnb,
                            uint32_t xr) {
-    // GS3D_SCATTER_BATCHED=0: the element-by-element reorder / store loops of rounds 1-2 (A/B)
-    static const bool unbatched = std::getenv("GS3D_SCATTER_BATCHED") && std::getenv("GS3D_SCATTER_BATCHED")[0] == '0';
-#define GS_LAUNCH_SCATTER(FAST, BATCHED)                                                                                   \
-    hipLaunchKernelGGL((gs::k_sort_scatter<KI, FAST, RB, COMPACT, ITEMS, KO, BATCHED>), dim3(sgrid), dim3(gs::SORT_THREADS), 0, st, \
-                       kin, vin, kout, ko_shift, vout, psc, shift, digit_mask, ghist, totals, cv, vo, pnb, xr)
-    if (dev->lds_atomic_ordered) {
-        if (unbatched) GS_LAUNCH_SCATTER(true, false); else GS_LAUNCH_SCATTER(true, true);
-    } else {
-        if (unbatched) GS_LAUNCH_SCATTER(false, false); else GS_LAUNCH_SCATTER(false, true);
-    }
-#undef GS_LAUNCH_SCATTER
+    if (dev->lds_atomic_ordered)
+        hipLaunchKernelGGL((gs::k_sort_scatter<KI, true, RB, COMPACT, ITEMS, KO>), dim3(sgrid), dim3(gs::SORT_THREADS), 0, st, kin, vin,
+                           kout, ko_shift, vout, psc, shift, digit_mask, ghist, totals, cv, vo, pnb, xr);
+    else
+        hipLaunchKernelGGL((gs::k_sort_scatter<KI, false, RB, COMPACT, ITEMS, KO>), dim3(sgrid), dim3(gs::SORT_THREADS), 0, st, kin, vin,
+                           kout, ko_shift, vout, psc, shift, digit_mask, ghist, totals, cv, vo, pnb, xr);
 }
 
 // one radix pass: histogram -> row scan -> scatter

@@ -1417,7 +1417,7 @@ __device__ __forceinline__ void scatter_clear(ScatterShared<K, RB, ITEMS> &sh) {
 // KO / ko_shift: the keys this pass WRITES may be narrower than the keys it sorts — the pass before the
 // last one of the frame's depth sort stores only the bits the last pass still needs (key >> ko_shift
 // as u16: 9 of 27 bits are left), which saves 2 bytes per element written and 2 x 2 bytes read.
-template <typename K, bool FAST_RANK, int RB, bool COMPACT, int ITEMS, typename KO = K, bool BATCHED = true>
+template <typename K, bool FAST_RANK, int RB, bool COMPACT, int ITEMS, typename KO = K>
 __device__ __forceinline__ void scatter_ranked(ScatterShared<K, RB, ITEMS> &sh, K (&key)[ITEMS], uint32_t (&val)[ITEMS],
                                                uint32_t in_tile, uint32_t block, uint32_t num_blocks,
                                                KO *__restrict__ keys_out, uint32_t ko_shift,
@@ -1515,30 +1515,8 @@ __device__ __forceinline__ void scatter_ranked(ScatterShared<K, RB, ITEMS> &sh, 
     // wave_hist above a write to keys / vals of the same LDS struct), and in the store loop, behind a
     // branch per element, `ds_read key; wait; ds_read delta; wait; store; ds_read val; wait; store` —
     // 3 dependent LDS round trips x ITEMS per thread, in kernels that have 2-5 waves per SIMD to hide them.
-    if constexpr (!BATCHED) {          // rounds 1-2, kept for the A/B (GS3D_SCATTER_BATCHED=0)
-#pragma unroll
-        for (int k = 0; k < ITEMS; k++) {
-            if (COMPACT && (uint32_t)key[k] == SORT_INVALID_KEY) continue;
-            uint32_t d = (uint32_t)(key[k] >> shift) & digit_mask;
-            uint32_t pos = s_wave_hist[wid][d] + rank[k];
-            s_keys[pos] = key[k];
-            s_vals[pos] = val[k];
-        }
-        __syncthreads();
-        const uint32_t live_u = COMPACT ? live_total : in_tile;
-#pragma unroll
-        for (int k = 0; k < ITEMS; k++) {
-            uint32_t pos = k * SORT_THREADS + tid;
-            if (pos < live_u) {
-                K kk = s_keys[pos];
-                uint32_t d = (uint32_t)(kk >> shift) & digit_mask;
-                uint32_t dst = s_delta[d] + pos;
-                if (keys_out) keys_out[dst] = (KO)(kk >> ko_shift);
-                vals_out[dst] = s_vals[pos];
-            }
-        }
-        return;
-    }
+    // A/B on one box (gpurun_out/r03n/ab.log): depth sort 0.157 -> 0.152 ms at 10 M, 0.575 -> 0.551 ms at
+    // 50 M; tile sort 0.571 -> 0.538 ms at 4K, 0.247 -> 0.244 ms at 1080p — occupancy had hidden most of it.
     constexpr int CH = ITEMS < 16 ? ITEMS : 16;
 #pragma unroll
     for (int k0 = 0; k0 < ITEMS; k0 += CH) {
@@ -1584,7 +1562,7 @@ __device__ __forceinline__ void scatter_ranked(ScatterShared<K, RB, ITEMS> &sh, 
     }
 }
 
-template <typename K, bool FAST_RANK, int RB, bool COMPACT, int ITEMS, typename KO = K, bool BATCHED = true>
+template <typename K, bool FAST_RANK, int RB, bool COMPACT, int ITEMS, typename KO = K>
 __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
     const K *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, KO *__restrict__ keys_out, uint32_t ko_shift,
     uint32_t *__restrict__ vals_out, SortCount sc, uint32_t shift, uint32_t digit_mask,
@@ -1630,7 +1608,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
             val[k] = ok ? vals_in[tile_base + e] : 0u;
         }
     }
-    scatter_ranked<K, FAST_RANK, RB, COMPACT, ITEMS, KO, BATCHED>(sh, key, val, in_tile, block, num_tiles, keys_out, ko_shift, vals_out,
+    scatter_ranked<K, FAST_RANK, RB, COMPACT, ITEMS, KO>(sh, key, val, in_tile, block, num_tiles, keys_out, ko_shift, vals_out,
                                                          shift, digit_mask, ghist, digit_totals, visible_out);
 }
 
