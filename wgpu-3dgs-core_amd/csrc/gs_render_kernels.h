@@ -2551,9 +2551,16 @@ __global__ __launch_bounds__(BLEND_THREADS) void k_blend_grouped(const uint32_t 
             for (int l = 0; l < NL; l++) s_cnt[wid][l] = (uint32_t)__popcll(m[l]);
         }
         __syncthreads();
+        {   // (the other wave's counts are read as one batch: behind a branch per list hipcc emitted eight
+            // ds_read + s_waitcnt pairs in a row)
+            uint32_t lbase[NL];
 #pragma unroll
-        for (int l = 0; l < NL; l++)
-            if ((m[l] >> lane) & 1ull) s_list[l][(wid ? s_cnt[0][l] : 0u) + mbcnt(m[l])] = (uint8_t)tid;
+            for (int l = 0; l < NL; l++) lbase[l] = s_cnt[0][l];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int l = 0; l < NL; l++)
+                if ((m[l] >> lane) & 1ull) s_list[l][(wid ? lbase[l] : 0u) + mbcnt(m[l])] = (uint8_t)tid;
+        }
         // trip count of MY wave: its longest list (wave-uniform)
         uint32_t trip = 0;
 #pragma unroll
