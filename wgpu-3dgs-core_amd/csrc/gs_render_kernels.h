@@ -2413,7 +2413,7 @@ __device__ __forceinline__ bool splat_touches_rect2(float mx, float my, float ca
 // A splat of a few pixels radius touches far fewer 8x4 blocks x 32 pixels than 16x8 half-tiles x
 // 128 pixels, so the number of loop iterations drops (1 M scene: x0.65 for G = 4, x0.77 for
 // G = 2, tools/blend_sim.py) at an unchanged instruction count per iteration.  The staged splat
-// records are stored once per batch; the per-block lists hold one-byte indices into them, padded
+// records are stored once per batch; the per-block lists hold 16-bit byte offsets of them, padded
 // with the index of a null record whose exponent test never passes, so lanes whose list is shorter
 // than the wave's longest simply idle.  Results are bit-identical to k_blend: culling only removes
 // (splat, block) pairs whose alpha is below 1/255 at every pixel of the block.
@@ -2429,10 +2429,12 @@ __global__ __launch_bounds__(BLEND_THREADS) void k_blend_grouped(const uint32_t 
     constexpr int BH = 16 / G;                // block height: G = 2 -> 8, G = 4 -> 4 (block width is 8; GL lanes x 2 pixels)
     constexpr int NL = 2 * G;                 // lists per tile
     constexpr uint32_t NULL_REC = BLEND_BATCH;
-    __shared__ float4 s_a[BLEND_BATCH + 1];   // mx, my, ca, cb
-    __shared__ float4 s_b[BLEND_BATCH + 1];   // cc, pmin, opacity, r
-    __shared__ float2 s_c[BLEND_BATCH + 1];   // g, b
-    __shared__ __attribute__((aligned(16))) uint8_t s_list[NL][BLEND_BATCH];
+    // One 48-byte LDS record per staged splat: {mx, my, ca, cb | cc, pmin, opacity, r | g, b, -, -}.  The
+    // lists hold the records' BYTE OFFSETS (16 bits each), so a step's three LDS reads share one address
+    // register and differ only in the instruction's immediate offset: no shift / mask per step.
+    constexpr uint32_t RS = 48;
+    __shared__ __attribute__((aligned(16))) float s_rec[(BLEND_BATCH + 1) * (RS / 4)];
+    __shared__ __attribute__((aligned(16))) uint16_t s_list[NL][BLEND_BATCH];
     __shared__ uint32_t s_cnt[2][NL];         // [staging wave][list]
     __shared__ uint32_t s_alive[2];
 
@@ -2455,9 +2457,9 @@ __global__ __launch_bounds__(BLEND_THREADS) void k_blend_grouped(const uint32_t 
     uint32_t remaining = __builtin_amdgcn_readfirstlane(
         (uint32_t)__popcll(__ballot(in0)) + (uint32_t)__popcll(__ballot(in1)));
     if (tid == 0) {   // the null record: power = 0 everywhere, pmin = 1 -> "power >= pmin" never holds
-        s_a[NULL_REC] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        s_b[NULL_REC] = make_float4(0.0f, 1.0f, 0.0f, 0.0f);
-        s_c[NULL_REC] = make_float2(0.0f, 0.0f);
+        *(float4 *)(s_rec + NULL_REC * (RS / 4)) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        *(float4 *)(s_rec + NULL_REC * (RS / 4) + 4) = make_float4(0.0f, 1.0f, 0.0f, 0.0f);
+        *(float2 *)(s_rec + NULL_REC * (RS / 4) + 8) = make_float2(0.0f, 0.0f);
     }
 
     for (uint32_t b0 = start; b0 < end; b0 += BLEND_BATCH) {
@@ -2469,8 +2471,8 @@ __global__ __launch_bounds__(BLEND_THREADS) void k_blend_grouped(const uint32_t 
         // lists start out as all-null (the previous batch's loops ended before the barrier above)
         {
             uint32_t *l32 = (uint32_t *)&s_list[0][0];
-            constexpr uint32_t fill = NULL_REC * 0x01010101u;
-            for (uint32_t q = tid; q < NL * BLEND_BATCH / 4; q += BLEND_THREADS) l32[q] = fill;
+            constexpr uint32_t fill = (NULL_REC * RS) * 0x00010001u;
+            for (uint32_t q = tid; q < NL * BLEND_BATCH / 2; q += BLEND_THREADS) l32[q] = fill;
         }
         // stage one splat per thread, test it against every block of the tile; the verdicts live as
         // wave ballots in scalar registers (a per-lane array of 2G flags cost 40 vector registers)
@@ -2488,9 +2490,9 @@ __global__ __launch_bounds__(BLEND_THREADS) void k_blend_grouped(const uint32_t 
             else pmin = fc.ellipse_pmin;
             thr = (MODE == 0 ? pmin - 0.1f : pmin - 0.1f - 1.0e-3f * fabsf(pmin)) -
                   cull_rounding_slack(mx, my, ca, cb, cc, tx0, ty0);
-            s_a[tid] = make_float4(mx, my, ca, cb);
-            s_b[tid] = make_float4(cc, pmin, u2f(r1.y), u2f(r1.z));
-            s_c[tid] = make_float2(u2f(r1.w), u2f(r2x));
+            *(float4 *)(s_rec + tid * (RS / 4)) = make_float4(mx, my, ca, cb);
+            *(float4 *)(s_rec + tid * (RS / 4) + 4) = make_float4(cc, pmin, u2f(r1.y), u2f(r1.z));
+            *(float2 *)(s_rec + tid * (RS / 4) + 8) = make_float2(u2f(r1.w), u2f(r2x));
         }
         // The tile's 2G blocks form a grid of 2 columns x G rows (8 wide, BH high).  The exact
         // maximum of the concave exponent over a block comes from the block's two edges facing the
@@ -2559,7 +2561,7 @@ __global__ __launch_bounds__(BLEND_THREADS) void k_blend_grouped(const uint32_t 
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int l = 0; l < NL; l++)
-                if ((m[l] >> lane) & 1ull) s_list[l][(wid ? lbase[l] : 0u) + mbcnt(m[l])] = (uint8_t)tid;
+                if ((m[l] >> lane) & 1ull) s_list[l][(wid ? lbase[l] : 0u) + mbcnt(m[l])] = (uint16_t)(tid * RS);
         }
         // trip count of MY wave: its longest list (wave-uniform)
         uint32_t trip = 0;
@@ -2573,16 +2575,17 @@ __global__ __launch_bounds__(BLEND_THREADS) void k_blend_grouped(const uint32_t 
 
         if (remaining != 0u) {
             // Two splats per trip, in registers A and B: while A is blended B's record is already
-            // on its way from LDS and the indices of the next pair are being read (one 16-bit read:
-            // lists are rows of bytes, the trip count is rounded up to even and the padding is the
+            // on its way from LDS and the offsets of the next pair are being read (one 32-bit read:
+            // lists are rows of 16-bit offsets, the trip count is rounded up to even and the padding is the
             // null index, so the extra step of an odd list blends nothing).  One structured loop,
             // one conditional block per step: no continue / break inside (hipcc turned those into a
             // scalar state machine of ~25 instructions and 5 branches per iteration).
-            const uint16_t *mine = (const uint16_t *)s_list[my_list];
+            const uint32_t *mine = (const uint32_t *)s_list[my_list];
+            const char *rbase = (const char *)s_rec;
             const uint32_t trips = (trip + 1u) >> 1;
             uint32_t pair = mine[0];
-            float4 a_A = s_a[pair & 0xffu], b_A = s_b[pair & 0xffu];
-            uint32_t id_A = pair & 0xffu;
+            uint32_t id_A = pair & 0xffffu;
+            float4 a_A = *(const float4 *)(rbase + id_A), b_A = *(const float4 *)(rbase + id_A + 16);
 #define GS_BLEND_STEP(AREC, BREC, ID)                                                                          \
     {                                                                                                         \
         const float dx = AREC.x - pxf;                                                                        \
@@ -2602,7 +2605,7 @@ __global__ __launch_bounds__(BLEND_THREADS) void k_blend_grouped(const uint32_t 
             p1 = power.y <= 0.0f && power.y >= BREC.y;                                                        \
         }                                                                                                     \
         if (__builtin_amdgcn_ballot_w64(p0 || p1) != 0ull) {                                                  \
-            const float2 cq = s_c[ID]; /* g, b */                                                             \
+            const float2 cq = *(const float2 *)(rbase + ID + 32); /* g, b */                                  \
             f32x2 alpha;                                                                                      \
             if constexpr (MODE == 0) {                                                                        \
                 /* exp exactly as in k_blend */                                              \
@@ -2629,7 +2632,9 @@ __global__ __launch_bounds__(BLEND_THREADS) void k_blend_grouped(const uint32_t 
             /* fma(rgb, 0 * T, C) == C exactly, so no selects are needed on T and C */                        \
             f32x2 alpha_eff = {act0 ? alpha.x : 0.0f, act1 ? alpha.y : 0.0f};                                 \
             f32x2 test_T = T * (f32x2{1.0f, 1.0f} - alpha_eff);                                               \
-            const bool fin0 = act0 && test_T.x < 0.0001f, fin1 = act1 && test_T.y < 0.0001f;                  \
+            /* (no "act &&": a pixel that skips the splat has test_T == T, and T of a live, finished or */     \
+            /* out-of-image pixel is never below 1e-4) */                                                     \
+            const bool fin0 = test_T.x < 0.0001f, fin1 = test_T.y < 0.0001f;                                  \
             const uint64_t f0 = __builtin_amdgcn_ballot_w64(fin0), f1 = __builtin_amdgcn_ballot_w64(fin1);    \
             if ((f0 | f1) != 0ull) { /* rare: some pixel reached T < 1e-4 -> it stops here */                 \
                 if (fin0) { pyf.x = DEAD; alpha_eff.x = 0.0f; test_T.x = T.x; }                               \
@@ -2644,13 +2649,13 @@ __global__ __launch_bounds__(BLEND_THREADS) void k_blend_grouped(const uint32_t 
         }                                                                                                     \
     }
             for (uint32_t q = 0; q < trips && remaining != 0u; q++) {
-                const uint32_t id_B = pair >> 8;
-                const float4 a_B = s_a[id_B], b_B = s_b[id_B];
-                pair = mine[q + 1 < (uint32_t)(BLEND_BATCH / 2) ? q + 1 : q];      // indices of the next trip
+                const uint32_t id_B = pair >> 16;
+                const float4 a_B = *(const float4 *)(rbase + id_B), b_B = *(const float4 *)(rbase + id_B + 16);
+                pair = mine[q + 1 < (uint32_t)(BLEND_BATCH / 2) ? q + 1 : q];      // offsets of the next trip
                 GS_BLEND_STEP(a_A, b_A, id_A)
-                id_A = pair & 0xffu;
-                a_A = s_a[id_A];
-                b_A = s_b[id_A];
+                id_A = pair & 0xffffu;
+                a_A = *(const float4 *)(rbase + id_A);
+                b_A = *(const float4 *)(rbase + id_A + 16);
                 GS_BLEND_STEP(a_B, b_B, id_B)
             }
 #undef GS_BLEND_STEP
