@@ -326,6 +326,53 @@ def test_block_culling_with_cancelling_translations(gs, ob, device, stream):
     buf.destroy(); img.release(); r.destroy()
 
 
+def test_block_list_mode_follows_the_view(gs, ob, device, stream):
+    """The block test runs either inside the preprocess kernel or ahead of it (k_block_cull + block list,
+    DESIGN.md §4.2), chosen per frame from what the newest finished frame saw.  One renderer, views that
+    see everything / a corner / nothing in an order that takes every transition (test in the kernel ->
+    list -> list -> in the kernel -> list after a gap, an empty list): every frame equals the oracle's,
+    and the extra launch shows up exactly where the rule says."""
+    import synth
+    if os.environ.get("GS3D_BLOCK_LIST") or os.environ.get("GS3D_BLOCK_CULL") == "0" or os.environ.get("GS3D_SPATIAL_ORDER") == "0":
+        pytest.skip("the rule under test is overridden by a debug switch")
+    n = 90_000
+    g = synth.scene(n, first=4242)
+    sh, cov = 1, 0
+    pod = gs.GaussianPod(sh, cov)
+    pods = pod.from_gaussian(g)
+    buf = gs.GaussiansBuffer.new_with_pods(device, pod, pods)
+    order = _mirror_order(ob, buf, stream, sh, cov, pods)
+    W, H = 320, 192
+    img = gs.Buffer(device, size=W * H * 16)
+    r = gs.Renderer(device)
+    gt, mt = gs.gaussian_transform_pod(sh_deg=3), gs.model_transform_pod()
+    ogt, omt = ob.GaussianTransform.from_buffer_copy(bytes(gt)), ob.ModelTransform.from_buffer_copy(bytes(mt))
+    views = {"all": ((0, 0, 12), (0, 0, -14), 70.0), "corner": ((0, 0, 0), (13, 7, -3), 25.0), "none": ((0, 0, 0), (0, 0, 5), 60.0)}
+    seq = ["all", "corner", "corner", "all", "all", "none", "none", "all", "all", "corner", "corner"]
+    launches, vis_seen = [], []
+    for k, name in enumerate(seq):
+        eye, target, fov = views[name]
+        ocam = ob.camera_look_at(eye, target, (0, 1, 0), float(np.deg2rad(fov)), W, H, 0.1, 100.0)
+        cam = helpers.copy_camera(ocam, gs.Camera)
+        r.render(stream, buf, gt, mt, cam, img.device_ptr())
+        got = img.download(stream, np.float32).reshape(H, W, 4)
+        st = r.stats()
+        exp, d, vis, _ = ob.render(sh, cov, pods, ogt, omt, ocam, order=order)
+        assert (st.visible, st.pairs) == (vis, d), (k, name, st.visible, vis, st.pairs, d)
+        assert np.array_equal(got.view(np.uint32), exp.view(np.uint32)), (k, name)
+        launches.append(r.wait_frame().launches)
+        vis_seen.append(vis)
+    assert vis_seen[0] > n // 2 and vis_seen[1] < n // 2 and vis_seen[5] == 0, vis_seen
+    # frame k takes the list when frame k - 1 (finished: the test downloads every image) saw < n / 2
+    for k in range(1, len(seq)):
+        took_list = vis_seen[k - 1] < n // 2
+        same_view_other_mode = [j for j in range(1, len(seq)) if seq[j] == seq[k] and (vis_seen[j - 1] < n // 2) != took_list]
+        for j in same_view_other_mode:
+            assert launches[k] - launches[j] == (1 if took_list else -1), (k, j, launches)
+    assert any(vis_seen[k - 1] < n // 2 for k in range(1, len(seq))) and any(vis_seen[k - 1] >= n // 2 for k in range(2, len(seq)))
+    buf.destroy(); img.release(); r.destroy()
+
+
 def test_pathological_gaussians_do_not_derail_the_frame(gs, ob, device, stream):
     """NaN / inf positions, zero, denormal, huge and NaN scales, non-unit and NaN quaternions mixed
     into a normal scene: every one of them must be culled or rendered exactly as the oracle does

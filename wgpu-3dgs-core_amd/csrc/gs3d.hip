@@ -1432,7 +1432,8 @@ struct FrameShape {
 
 struct gs_renderer {
     gs_device *dev;
-    DevArray recs, depth, rect, sorted_rect, exp_sums, cursors, chunk_tiles, chunk_vis, state, zero_region, scan_tmp;
+    DevArray recs, depth, rect, sorted_rect, exp_sums, cursors, chunk_tiles, chunk_vis, state, zero_region, scan_tmp, block_list;
+    uint32_t block_list_clean_for = 0;   // frame generation whose blocks_alive counter is known to be zero
     DevArray dkeys[2], dvals[2];          // (depth bits - bias, mirror slot), capacity N
     DevArray tkeys[2], tvals[2];          // (tile id, mirror slot), capacity pair_capacity
     DevArray ghist, digit_totals;
@@ -1515,7 +1516,7 @@ extern "C" void gs_renderer_destroy(gs_renderer *r) {
     (void)hipSetDevice(r->dev->ordinal);
     if (r->have_frame) (void)hipStreamSynchronize(r->last_stream);   // kernels of the last frame write pinned memory
     DevArray *arrs[] = {&r->recs, &r->depth, &r->rect, &r->sorted_rect, &r->exp_sums, &r->cursors, &r->chunk_tiles, &r->chunk_vis,
-                        &r->state, &r->zero_region, &r->scan_tmp, &r->dkeys[0], &r->dkeys[1], &r->dvals[0],
+                        &r->state, &r->zero_region, &r->scan_tmp, &r->block_list, &r->dkeys[0], &r->dkeys[1], &r->dvals[0],
                         &r->dvals[1], &r->tkeys[0], &r->tkeys[1], &r->tvals[0], &r->tvals[1], &r->ghist,
                         &r->digit_totals};
     for (DevArray *a : arrs) dev_free(*a);
@@ -2198,6 +2199,7 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
     uint64_t want_capacity = r->pair_capacity;
     uint64_t hist_d[2] = {0, 0};
     uint32_t hist_gen[2] = {0, 0};
+    uint32_t hist_v[2] = {0, 0};
     for (int i = 0; i < 2; i++) {
         if (!r->done_valid[i] || hipEventQuery(r->done[i]) != hipSuccess) continue;
         const gs::FrameResult &fr = r->results[i];
@@ -2205,6 +2207,7 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
         if (__atomic_load_n(&fr.gen, __ATOMIC_ACQUIRE) != r->done_gen[i] || fr.pairs_total > 0xfffffff0ull) continue;
         hist_d[i] = fr.pairs_total;
         hist_gen[i] = r->done_gen[i];
+        hist_v[i] = fr.visible;
         // grow when the last measured D leaves less than 1/8 of head room
         if (fr.pairs_total + fr.pairs_total / 8 > r->pair_capacity && capacity_for(fr.pairs_total) > want_capacity)
             want_capacity = capacity_for(fr.pairs_total);
@@ -2325,6 +2328,33 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
         po.zero_words = (uint32_t)(ranges_words + esb_words);
         po.key_bias = near_bits;
         po.block_bounds = (const float *)g->block_bounds;
+        po.block_list = nullptr;
+        po.block_count = nullptr;
+        // Block list (k_block_cull): one thread per block tests it, the survivors are handed to the first
+        // workgroups of the preprocess grid.  GS3D_BLOCK_LIST=0 keeps the test inside the preprocess kernel.
+        // It pays when most blocks are culled (a rank's band of 8 at 50 M: preprocess 0.57 -> 0.41 ms) and
+        // costs its launch when few are (whole 1080p frame at 10 M: +4 us), so it is taken when the newest
+        // finished frame of this shape saw less than half of the Gaussians, or — no such frame yet — when
+        // the frame is a band.  GS3D_BLOCK_LIST=0/1 forces.
+        static const int block_list_env = std::getenv("GS3D_BLOCK_LIST") ? std::atoi(std::getenv("GS3D_BLOCK_LIST")) : -1;
+        bool use_list = fc.band_ty1 - fc.band_ty0 < fc.tiles_y;
+        if (!sizing && (hist_gen[0] || hist_gen[1])) use_list = hist_v[hist_gen[0] > hist_gen[1] ? 0 : 1] < n / 2u;
+        if (block_list_env >= 0) use_list = block_list_env != 0;
+        if (fc.cull_gain > 0.0f && use_list) {
+            GS_TRY(dev_reserve(r->block_list, (size_t)nchunks * 4));
+            // the list length of frame `gen` is counted in blocks_alive[gen & 1], which the k_block_cull of
+            // frame gen - 1 cleared; when that frame did not run one (first frame, other buffer kinds in
+            // between) the pair is cleared here
+            if (r->block_list_clean_for != gen) GS_HIP(hipMemsetAsync(state->blocks_alive, 0, sizeof(state->blocks_alive), st));
+            r->block_list_clean_for = gen + 1u;
+            hipLaunchKernelGGL(gs::k_block_cull, dim3((nchunks + 255u) / 256u), dim3(256), 0, st, (const float *)g->block_bounds,
+                               nchunks, fc, (uint32_t *)r->block_list.ptr, state, gen & 1u, (uint32_t *)r->chunk_tiles.ptr,
+                               (uint32_t *)r->chunk_vis.ptr);
+            GS_HIP(hipGetLastError());
+            r->launches++;
+            po.block_list = (const uint32_t *)r->block_list.ptr;
+            po.block_count = &state->blocks_alive[gen & 1u];
+        }
         // GS3D_PRE_PIPELINE=0: the two-phase kernel without the prefetch of the next Gaussian's geometry chunks
         static const bool pre_serial = std::getenv("GS3D_PRE_PIPELINE") && std::getenv("GS3D_PRE_PIPELINE")[0] == '0';
         const int nt = fc.nt_loads ? 1 : 0;

@@ -162,7 +162,8 @@ struct FrameState {
     uint32_t visible;        // V: written by the first depth-sort pass (which also compacts)
     uint32_t pairs;          // min(D, pair capacity): what the tile sort / ranges / blend work on
     uint32_t overflow;       // D exceeded the pair capacity: the blend leaves the image untouched (frame skipped)
-    uint32_t pad[5];
+    uint32_t blocks_alive[2];   // [frame parity] length of the block list (k_block_cull); the other entry is cleared for the next frame
+    uint32_t pad[3];
 };
 constexpr uint32_t FRAME_FLAG_PAIR_OVERFLOW = 1u;   // D exceeded the pair capacity
 constexpr uint32_t FRAME_FLAG_SKIPPED = 2u;         // ... so the frame was skipped: the image was NOT written
@@ -772,6 +773,8 @@ struct PreOut {
     uint32_t zero_words;
     uint32_t key_bias;
     const float *block_bounds;
+    const uint32_t *block_list;      // non-null: workgroup i takes block block_list[i], i < *block_count (k_block_cull ran)
+    const uint32_t *block_count;
 };
 
 // this workgroup's share of the per-frame clear job
@@ -781,7 +784,7 @@ __device__ __forceinline__ void pre_begin(const PreOut &io) {
 }
 
 // per-chunk sums (tiles touched, visible count)
-__device__ __forceinline__ void pre_finish(const PreOut &io, uint32_t local_tiles, uint32_t local_vis,
+__device__ __forceinline__ void pre_finish(const PreOut &io, uint32_t block, uint32_t local_tiles, uint32_t local_vis,
                                            uint32_t *s_red) {
     local_tiles = wave_reduce_add(local_tiles);
     local_vis = wave_reduce_add(local_vis);
@@ -792,8 +795,8 @@ __device__ __forceinline__ void pre_finish(const PreOut &io, uint32_t local_tile
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        io.chunk_tiles[blockIdx.x] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
-        io.chunk_vis[blockIdx.x] = (s_red[4] + s_red[5]) + (s_red[6] + s_red[7]);
+        io.chunk_tiles[block] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+        io.chunk_vis[block] = (s_red[4] + s_red[5]) + (s_red[6] + s_red[7]);
     }
 }
 
@@ -869,7 +872,7 @@ __global__ __launch_bounds__(PP_THREADS) void k_preprocess(const uint4 *__restri
             local_vis += cnt ? 1u : 0u;
         }
     }
-    pre_finish(io, local, local_vis, s_red);
+    pre_finish(io, blockIdx.x, local, local_vis, s_red);
 }
 
 // Two-phase variant for records with SH: phase 1 loads only the chunks that hold position, colour
@@ -882,7 +885,15 @@ __global__ __launch_bounds__(PP_THREADS) void k_preprocess_banded(const uint4 *_
                                                                   FrameConsts fc, PreOut io) {
     __shared__ uint32_t s_red[8];
     pre_begin(io);
-    if (fc.cull_gain > 0.0f && block_is_culled(io.block_bounds + (uint64_t)blockIdx.x * 8u, fc)) {
+    uint32_t block = blockIdx.x;
+    if (io.block_list) {
+        // block list (k_block_cull): the surviving blocks are taken by the FIRST *block_count workgroups,
+        // back to back; the rest of the grid leaves without a single vector instruction.  (With the test
+        // in here, a rank's band — five of six blocks culled — spent a third of the CUs' workgroup slots
+        // on workgroups that load their bounds, test them on all 256 threads and leave.)
+        if (blockIdx.x >= *io.block_count) return;
+        block = io.block_list[blockIdx.x];
+    } else if (fc.cull_gain > 0.0f && block_is_culled(io.block_bounds + (uint64_t)blockIdx.x * 8u, fc)) {
         pre_finish_culled(io);
         return;
     }
@@ -891,7 +902,7 @@ __global__ __launch_bounds__(PP_THREADS) void k_preprocess_banded(const uint4 *_
     constexpr int G0 = cov_word0(SH) / 4;                              // first chunk holding covariance words
     constexpr int G1 = (cov_word0(SH) + cov_bytes(COV) / 4 - 1) / 4;   // last one
     constexpr int NG = G1 - G0 + 1;
-    const uint32_t base = blockIdx.x * PP_CHUNK;
+    const uint32_t base = block * PP_CHUNK;
     uint32_t local = 0, local_vis = 0;
     // geometry chunks (position / colour + covariance) of one Gaussian
     auto load_geom = [&](uint32_t i, uint4 &v0, uint4 (&vg)[NG]) {
@@ -980,7 +991,44 @@ __global__ __launch_bounds__(PP_THREADS) void k_preprocess_banded(const uint4 *_
             local_vis += cnt ? 1u : 0u;
         }
     }
-    pre_finish(io, local, local_vis, s_red);
+    pre_finish(io, block, local, local_vis, s_red);
+}
+
+// The block test of a whole frame, one thread per block (instead of 256 threads of every preprocess
+// workgroup testing the same block): the surviving blocks are appended to `list` (a workgroup's 256 blocks
+// stay together and ascending; the order of the workgroups is whatever the atomics make it — every block
+// writes its own slots, so the order changes nothing), culled blocks get their two chunk scalars
+// cleared here.  The list length lives in state->blocks_alive[parity]; the other entry is cleared for
+// the next frame (frames of a renderer run one after the other).
+__global__ __launch_bounds__(256) void k_block_cull(const float *__restrict__ bb, uint32_t nblocks, FrameConsts fc,
+                                                    uint32_t *__restrict__ list, FrameState *state, uint32_t parity,
+                                                    uint32_t *__restrict__ chunk_tiles, uint32_t *__restrict__ chunk_vis) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    bool alive = false;
+    if (i < nblocks) {
+        alive = !block_is_culled(bb + (uint64_t)i * 8u, fc);
+        if (!alive) {
+            chunk_tiles[i] = 0u;
+            chunk_vis[i] = 0u;
+        }
+    }
+    // one atomic per workgroup (same-address atomics serialise in the L2): the workgroup's 256 blocks stay
+    // together and ascending
+    __shared__ uint32_t s_cnt[4];
+    __shared__ uint32_t s_base;
+    const uint64_t m = __ballot(alive);
+    const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+    if (lane == 0u) s_cnt[wid] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0u) {
+        const uint32_t tot = (s_cnt[0] + s_cnt[1]) + (s_cnt[2] + s_cnt[3]);
+        s_base = tot ? atomicAdd(&state->blocks_alive[parity], tot) : 0u;
+    }
+    __syncthreads();
+    uint32_t base = s_base;
+    for (uint32_t w = 0; w < wid; w++) base += s_cnt[w];
+    if (alive) list[base + mbcnt(m)] = i;
+    if (i == 0u) state->blocks_alive[parity ^ 1u] = 0u;
 }
 
 // ---------------------------------------------------------------------------------------------
