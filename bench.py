@@ -29,7 +29,7 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 SIMDS, CLOCK_GHZ = 1024, 2.4   # 256 CUs x 4 SIMDs, max clock (MI355X_MICROARCH.md chip table)
-BLEND_LOOP_PK_SHARE = 0.35     # v_pk_* share of the VALU instructions of k_blend_grouped<0,4>'s two loop bodies (ISA: 17 of 48)
+BLEND_LOOP_PK_SHARE = 0.50     # v_pk_* share of the VALU instructions of k_blend_grouped<0,4>'s two loop bodies (ISA: 38 of 76, rare finished-pixel blocks left out)
 
 DEFAULT_EYE = (0.0, 0.0, 0.0)
 WORKLOADS = {
