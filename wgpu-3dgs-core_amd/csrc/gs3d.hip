@@ -1746,12 +1746,17 @@ static void launch_scatter(const gs_device *dev, hipStream_t st, uint32_t sgrid,
                            uint32_t ko_shift, uint32_t *vout, gs::SortCount psc, uint32_t shift, uint32_t digit_mask,
                            const uint32_t *ghist, const uint32_t *totals, const uint32_t *cv, uint32_t *vo, uint32_t pnb,
                            uint32_t xr) {
+    // inputs that cannot stay in the L2s anyway are read non-temporally (top bit of the last argument; see
+    // k_sort_scatter).  GS3D_NT_SCATTER=0/1 forces.
+    static const int nt_env = std::getenv("GS3D_NT_SCATTER") ? std::atoi(std::getenv("GS3D_NT_SCATTER")) : -1;
+    const bool nt = !COMPACT && (nt_env >= 0 ? nt_env != 0 : (uint64_t)psc.count * (sizeof(KI) + 4u) > (32ull << 20));
+    const uint32_t xr_nt = xr | (nt ? 0x80000000u : 0u);
     if (dev->lds_atomic_ordered)
         hipLaunchKernelGGL((gs::k_sort_scatter<KI, true, RB, COMPACT, ITEMS, KO>), dim3(sgrid), dim3(gs::SORT_THREADS), 0, st, kin, vin,
-                           kout, ko_shift, vout, psc, shift, digit_mask, ghist, totals, cv, vo, pnb, xr);
+                           kout, ko_shift, vout, psc, shift, digit_mask, ghist, totals, cv, vo, pnb, xr_nt);
     else
         hipLaunchKernelGGL((gs::k_sort_scatter<KI, false, RB, COMPACT, ITEMS, KO>), dim3(sgrid), dim3(gs::SORT_THREADS), 0, st, kin, vin,
-                           kout, ko_shift, vout, psc, shift, digit_mask, ghist, totals, cv, vo, pnb, xr);
+                           kout, ko_shift, vout, psc, shift, digit_mask, ghist, totals, cv, vo, pnb, xr_nt);
 }
 
 // one radix pass: histogram -> row scan -> scatter
