@@ -2463,7 +2463,20 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
                                                               st, tside, tpasses, r->launches, src)));
         }
         mark(ST_RANGES);
-        if (capacity) {
+        // Tile ranges: by a search per tile once reading every key again costs more than a few dependent
+        // probes per tile (GS3D_RANGES_SEARCH=0/1 forces).
+        static const int ranges_env = std::getenv("GS3D_RANGES_SEARCH") ? std::atoi(std::getenv("GS3D_RANGES_SEARCH")) : -1;
+        const bool ranges_search = ranges_env >= 0 ? ranges_env != 0 : capacity >= (8u << 20);
+        if (capacity && ranges_search) {
+            if (wide)
+                hipLaunchKernelGGL(gs::k_tile_ranges_search<uint32_t>, dim3((num_tiles + 3u) / 4u), dim3(256), 0, st,
+                                   (const uint32_t *)r->tkeys[tside].ptr, tc, zero, num_tiles);
+            else
+                hipLaunchKernelGGL(gs::k_tile_ranges_search<uint16_t>, dim3((num_tiles + 3u) / 4u), dim3(256), 0, st,
+                                   (const uint16_t *)r->tkeys[tside].ptr, tc, zero, num_tiles);
+            GS_HIP(hipGetLastError());
+            r->launches++;
+        } else if (capacity) {
             if (wide)
                 hipLaunchKernelGGL(gs::k_tile_ranges<uint32_t>, dim3((uint32_t)(((uint64_t)capacity + 1023) / 1024)), dim3(256), 0, st,
                                    (const uint32_t *)r->tkeys[tside].ptr, tc, zero);

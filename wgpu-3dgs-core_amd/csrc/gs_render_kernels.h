@@ -2181,6 +2181,43 @@ __global__ __launch_bounds__(256) void k_tile_ranges(const TK *__restrict__ tkey
     }
 }
 
+// The same ranges by SEARCH: one wave per tile, its two halves find the first key >= tile and the first
+// key >= tile + 1 with a 32-ary search (32 probes per round and half; 127 M keys: 6 rounds of dependent
+// loads, whatever D is), instead of every key being read once more.  Neighbouring tiles probe the same
+// sectors in the early rounds, so the traffic stays far below the key array's size.  Same output as
+// k_tile_ranges, including (0, 0) for a tile without pairs.
+template <typename TK>
+__global__ __launch_bounds__(256) void k_tile_ranges_search(const TK *__restrict__ tkeys, SortCount sc,
+                                                            uint32_t *__restrict__ ranges, uint32_t num_tiles) {
+    const uint32_t count = sc.get();
+    const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+    const uint32_t t = blockIdx.x * 4u + wid;
+    if (t >= num_tiles) return;                      // wave-uniform
+    const uint32_t h = lane >> 5, l = lane & 31u;
+    const uint32_t target = t + h;
+    uint32_t lo = 0, len = count;                    // the answer lies in [lo, lo + len]; uniform per half
+    while (__any(len != 0u)) {
+        // probes at lo + (i + 1) * step - 1, i = 0..31 (those inside the interval): sorted keys make "key <
+        // target" true for the first k of them, so the answer moves to [lo + k * step, + step - 1]
+        const uint32_t step = len / 32u + 1u;
+        const uint64_t p = (uint64_t)lo + (uint64_t)(l + 1u) * step - 1u;
+        const bool in = p < (uint64_t)lo + len;      // false for every lane of a half that is done (len == 0)
+        const bool less = in && (uint32_t)tkeys[in ? p : 0u] < target;
+        const uint64_t m = __ballot(less);
+        const uint32_t k = (uint32_t)__popc((uint32_t)(m >> (32u * h)));
+        const uint32_t end = lo + len;
+        lo += k * step;                              // <= end: only floor(len / step) probes are inside
+        const uint32_t rem = end - lo;
+        len = len == 0u ? 0u : (rem < step - 1u ? rem : step - 1u);
+    }
+    const uint32_t lb0 = __shfl(lo, 0, WAVE), lb1 = __shfl(lo, 32, WAVE);
+    if (lane == 0u) {
+        const bool any = lb1 > lb0;
+        ranges[2u * t] = any ? lb0 : 0u;
+        ranges[2u * t + 1u] = any ? lb1 : 0u;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // blend (row x5b)
 // ---------------------------------------------------------------------------------------------
