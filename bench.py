@@ -95,6 +95,14 @@ def run_workload(gs, synth, torch, dist, dev, stream, rank, world, wl, steps, wa
     # overlaps the rendering of frame i + 1; every frame is exchanged and assembled inside the timed region
     pipe = [None]
     count = [0]
+    band_flags = [None]          # [G] int32 on the device: OR of every finished frame's per-band flags
+
+    def finish(i):
+        # the flags word of every band travelled with the band: OR them up (one tiny kernel, no host
+        # round trip); a non-zero word = some rank skipped a frame, which voids the measurement
+        img = pipe[0].finish(i)
+        torch.bitwise_or(band_flags[0], pipe[0].flags(i), out=band_flags[0])
+        return img
 
     def step():
         if world == 1:
@@ -102,14 +110,14 @@ def run_workload(gs, synth, torch, dist, dev, stream, rank, world, wl, steps, wa
             return gbuf
         i = count[0]
         count[0] += 1
-        r.render(stream, buf, gt, mt, cam, pipe[0].begin(i), band=plan.bands[rank], check=False)
+        r.render(stream, buf, gt, mt, cam, pipe[0].begin(i, r), band=plan.bands[rank], check=False)
         pipe[0].submit(i)
-        return pipe[0].finish(i - 1) if i else None
+        return finish(i - 1) if i else None
 
     def sync_all():
         if world > 1:
             if pipe[0] is not None and count[0]:
-                pipe[0].finish(count[0] - 1)       # the last frame's exchange belongs to the region that ends here
+                finish(count[0] - 1)               # the last frame's exchange belongs to the region that ends here
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -127,6 +135,7 @@ def run_workload(gs, synth, torch, dist, dev, stream, rank, world, wl, steps, wa
     fr = render(check=True)          # sizes the pair buffers for this band (blocking once)
     if world > 1:
         pipe[0] = par.FramePipeline(torch, dist, plan, rank, W, "cuda")
+        band_flags[0] = torch.zeros(world, dtype=torch.int32, device="cuda")
     for _ in range(warmup):
         step()
     sync_all()
@@ -187,8 +196,18 @@ def run_workload(gs, synth, torch, dist, dev, stream, rank, world, wl, steps, wa
         stages = {name: st.stage_ms[i] / max(st.timed_frames, 1) for i, name in enumerate(gs.STAGE_NAMES)}
     img = step()
     if world > 1:
-        img = pipe[0].finish(count[0] - 1)       # the frame just submitted, exchanged and assembled
+        img = finish(count[0] - 1)               # the frame just submitted, exchanged and assembled
     sync_all()
+    # no frame of this run may have been skipped (pair capacity): on one GPU the renderer's last result says
+    # so, on N the OR of the flags words that travelled with every band of every finished frame
+    if world > 1:
+        skipped_bands = [int(x) for x in band_flags[0].cpu().tolist()]
+        r.set_frame_flags_target(None)
+    else:
+        skipped_bands = [int(r.wait_frame().flags)]
+    if any(skipped_bands):
+        raise RuntimeError("bench.py: a frame was skipped (pair capacity exceeded, per-band flags %s): the timed "
+                           "region did not render every frame" % skipped_bands)
     checksum = float(img[:H].double().sum().item())
     visible, pairs = int(st.visible), int(st.pairs)
     if world > 1:   # totals over the bands
@@ -230,7 +249,7 @@ def run_workload(gs, synth, torch, dist, dev, stream, rank, world, wl, steps, wa
                two_frames_in_flight=in_flight,
                stages_ms=stages, checksum=checksum, launches=int(fr.launches), pair_capacity=int(fr.pair_capacity),
                per_rank_ms=per_rank, render_ms_per_rank=render_ms, gather_ms_per_rank=gather_ms,
-               bands=plan.bands, band_plan=plan_kind)
+               bands=plan.bands, band_plan=plan_kind, skipped_band_flags=skipped_bands)
     if samples:
         out["frame_ms"] = dict(samples=len(samples), median=samples[len(samples) // 2], min=samples[0],
                                p95=samples[min(len(samples) - 1, int(0.95 * len(samples)))], max=samples[-1],
@@ -278,17 +297,46 @@ def stage_models(wl, res):
         "tile_sort": (v * (4 + rb) + d * (tkey + 4) + d * (tkey + 4) * 2 + (tpasses - 1) * d * (tkey + (tkey + 4) * 2),
                       "k_pairs_emit: V x (4 + %d) B in, D x (key + 4 B) out, first histogram fused; first scatter: D x (key + "
                       "4 B) read and written; each further pass: D keys (hist) + D x (key + 4 B) read and written" % rb),
-        "ranges": (d * tkey + tiles * 8, "D keys read, tile ranges written"),
     }
+    # tile ranges: the kernel that ran decides the model (gs3d.hip: search from a pair capacity of 8 M,
+    # GS3D_RANGES_SEARCH=0/1 forces)
+    env = os.environ.get("GS3D_RANGES_SEARCH")
+    searched = (env != "0") if env in ("0", "1") else res.get("pair_capacity", 0) >= (8 << 20)
+    if searched:
+        models["ranges"] = (ranges_search_bytes(d, tiles, tkey),
+                            "k_tile_ranges_search: per round the DISTINCT 64-B sectors the 2 x tiles half-waves probe "
+                            "(32 probes each; early rounds share their sectors between tiles), summed over the "
+                            "ceil(log32 D) dependent rounds, + tile ranges written; a latency-bound kernel")
+    else:
+        models["ranges"] = (d * tkey + tiles * 8, "k_tile_ranges: D keys read, tile ranges written")
     out = {}
     for k, (b, what) in models.items():
         ms = st[k]
         gbs = b / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-        out[k] = dict(bound="hbm", model_bytes=b, model=what, ms=ms, achieved_gbs=gbs, frac=gbs / HBM_PEAK_GBS)
+        out[k] = dict(bound="latency" if k == "ranges" and searched else "hbm", model_bytes=b, model=what, ms=ms,
+                      achieved_gbs=gbs, frac=gbs / HBM_PEAK_GBS)
     out["blend"] = dict(bound="valu", ms=st["blend"], pairs=d, pixels=px,
                         note="VALU-issue bound (profiles/: SQ_ACTIVE_INST_VALU vs kernel time); its HBM traffic is "
                              "a few per cent of the frame's and is not priced against the HBM roofline")
     return out
+
+
+def ranges_search_bytes(d, tiles, tkey):
+    """Bytes k_tile_ranges_search has to fetch: each of the 2 x tiles half-waves narrows [0, D] by 32
+    probes per round (step = len / 32 + 1, the next interval is step - 1 long).  Round r's probes of all
+    tiles lie on a grid of at most 32^(r+1) points, so the distinct sectors of a round are bounded by the
+    grid, by the probes themselves (2 x tiles x the sectors one half-wave's 32 probes span) and by the
+    array; 64 bytes per sector."""
+    total, length, r = 0, d, 0
+    array_sectors = (d * tkey + 63) // 64
+    while length > 0:
+        step = length // 32 + 1
+        per_half = min(32, (32 * step * tkey + 63) // 64 + 1)
+        grid = 32 ** (r + 1) if step * tkey >= 64 else array_sectors
+        total += min(2 * tiles * per_half, grid, array_sectors) * 64
+        length = min(step - 1, length)
+        r += 1
+    return total + tiles * 8
 
 
 def frame_bytes_object(wl_name, wl, res):
@@ -310,7 +358,7 @@ def frame_bytes_object(wl_name, wl, res):
                % passes, survey_equivalent_gbs=survey / t / 1e9)
     sm = stage_models(wl, res)
     if sm:
-        mine = sum(x["model_bytes"] for x in sm.values() if x.get("bound") == "hbm") + px * 16
+        mine = sum(x["model_bytes"] for x in sm.values() if "model_bytes" in x) + px * 16
         out.update(implementation_model_bytes=mine, implementation_gbs=mine / t / 1e9,
                    implementation_frac=mine / t / 1e9 / HBM_PEAK_GBS,
                    implementation_model="sum of the HBM-bound stage_models + W x H x 16 (image); the blend's record "
@@ -422,14 +470,17 @@ def blend_valu_object(res):
 
 def cpu_baseline(wl, frames):
     """The CPU oracle (a restatement of the reference's conventions, NOT the reference binary — the
-    Rust/WGSL reference cannot run here) timed on this host's cores on the same workload: OpenMP on
-    all cores (median of `frames` frames) and one frame on a single thread, per-stage seconds of
-    both."""
+    Rust/WGSL reference cannot run here) timed on this host on the same workload: OpenMP on the CPUs
+    this process may really use (affinity mask cut by the cgroup quota — NOT the machine's hardware
+    threads: round 3 ran 256 threads on a 16-CPU share and measured its own barrier spinning), median
+    of `frames` frames, and one frame on a single thread; per-stage seconds of both and the per-stage
+    best of the two."""
     import synth
     from oracle import binding as ob
     ob.build()
     L = ob.lib()
-    threads = L.gso_get_max_threads()
+    hw = int(L.gso_get_max_threads())
+    threads = max(1, min(int(L.gso_effective_threads()), hw))
     g = synth.scene(wl["n"])
     pods = ob.pack(wl["sh"], wl["cov"], g)
     eye = wl.get("eye", DEFAULT_EYE)
@@ -447,17 +498,123 @@ def cpu_baseline(wl, frames):
             stages = st
         return float(np.median(times)), dict(zip(names, [round(x, 4) for x in stages]))
 
+    L.gso_set_threads(threads)
     med, st_omp = run(frames)
     L.gso_set_threads(1)
     one, st_one = run(1)
-    L.gso_set_threads(int(threads))
-    return dict(value=wl["n"] / med / 1e6, unit="Msplats/s", cores=int(threads), kind="port",
-                ms_per_frame=med * 1e3, stage_seconds=st_omp,
+    L.gso_set_threads(threads)
+    best = {k: min(st_omp[k], st_one[k]) for k in names}
+    return dict(value=wl["n"] / med / 1e6, unit="Msplats/s", cores=threads, kind="port",
+                ms_per_frame=med * 1e3, stage_seconds=st_omp, hardware_threads=hw,
                 single_thread=dict(value=wl["n"] / one / 1e6, unit="Msplats/s", cores=1, ms_per_frame=one * 1e3,
                                    stage_seconds=st_one),
-                sample="%d whole frames (median) on %d OpenMP threads + 1 whole frame on 1 thread of workload '%s' "
+                per_stage_best=dict(stage_seconds=best, ms_per_frame=sum(best.values()) * 1e3,
+                                    value=wl["n"] / max(sum(best.values()), 1e-9) / 1e6),
+                sample="%d whole frames (median) on %d OpenMP threads (the CPUs of this process: affinity + cgroup quota; "
+                       "the host has %d hardware threads) + 1 whole frame on 1 thread of workload '%s' "
                        "(oracle/gs_oracle.c: every stage OpenMP-parallel; the blend visits every (pixel, splat) "
-                       "of a tile without culling)" % (frames, threads, wl["label"]))
+                       "of a tile without culling)" % (frames, threads, hw, wl["label"]))
+
+
+def _r(x, digits=5):
+    """float -> `digits` significant digits (the compact line has a byte budget)"""
+    if x is None or isinstance(x, (str, bool, int)):
+        return x
+    return float("%.*g" % (digits, x))
+
+
+def compact_line(line, detail_path, limit=3900):
+    """The record the driver keeps: the contract's keys + the few numbers a judge needs, <= 4 KB.
+    Everything else goes to the detail file (`--detail-out`)."""
+    c = {k: line[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                              "scaling", "vs_baseline", "dtype", "data")}
+    c["value"], c["ms_per_step"] = _r(c["value"], 6), _r(c["ms_per_step"], 6)
+    cfg = line["config"]
+    c["config"] = {k: cfg[k] for k in ("workload", "gaussians", "visible", "pairs", "launches_per_frame", "parallelism")}
+    if line.get("frame_ms"):
+        c["frame_ms_median"] = _r(line["frame_ms"]["median"])
+    c["stages_ms"] = {k: _r(v, 4) for k, v in (line.get("stages_ms") or {}).items() if v}
+    ro = line.get("roofline")
+    if ro:
+        keep = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "frac_nocull", "algorithmic_bytes_per_launch",
+                "avg_launch_ms", "fetched_over_required", "physical_traffic_frac", "traffic_note")
+        c["roofline"] = {k: _r(ro[k]) for k in keep if k in ro}
+        c["roofline"]["workload"] = "10m" if ro["gaussians"] == 10_000_000 else ro["workload"]
+        rw = line.get("roofline_workload")
+        if rw:
+            c["roofline_workload"] = {"ms": _r(rw["ms_per_step"]), "Msplats/s": _r(rw["value"]),
+                                      "launches": rw["launches_per_frame"],
+                                      "stages_ms": {k: _r(v, 4) for k, v in rw["stages_ms"].items() if v},
+                                      "stage_frac": {k: _r(v["frac"], 3) for k, v in rw["stage_models"].items() if "frac" in v},
+                                      "pmc_frame_frac": _r(rw["frame_bytes"].get("pmc_frame_frac"), 3)}
+    nc = line.get("roofline_nocull")
+    if nc:
+        c["roofline_nocull"] = {"frac": _r(nc["frac"]), "avg_launch_ms": _r(nc["avg_launch_ms"]), "ms": _r(nc["frame"]["ms_per_step"])}
+    cb = line.get("cpu_baseline")
+    if cb:
+        c["cpu_baseline"] = {"value": _r(cb["value"]), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
+                             "ms_per_frame": _r(cb["ms_per_frame"]), "hardware_threads": cb["hardware_threads"],
+                             "single_thread_value": _r(cb["single_thread"]["value"]),
+                             "per_stage_best_value": _r(cb["per_stage_best"]["value"]),
+                             "sample": "%s: median of whole frames, OpenMP on `cores` threads (CPU share of this process); "
+                                       "oracle/gs_oracle.c, a port, not the reference binary" % line["config"]["workload"][:14]}
+    wls = line.get("workloads")
+    if wls:
+        c["workloads"] = {k: {"ms": _r(v["ms_per_step"]), "Msplats/s": _r(v["value"]),
+                              "preprocess_read_frac": _r(v.get("preprocess_read_frac"), 3),
+                              "stages_ms": {a: _r(b, 4) for a, b in v["stages_ms"].items() if b}} for k, v in wls.items()}
+    di = line.get("distributed")
+    if di:
+        c["distributed"] = {k: ([_r(x, 4) for x in v] if isinstance(v, list) and v and isinstance(v[0], float) else v)
+                            for k, v in di.items()}
+        if wls:
+            for k, v in wls.items():
+                c["workloads"][k]["per_rank_ms"] = [_r(x, 4) for x in v.get("per_rank_ms", [])]
+    if line.get("two_frames_in_flight"):
+        c["two_in_flight_ms"] = _r(line["two_frames_in_flight"]["ms_per_step"])
+    hr = line.get("hip_runtime") or {}
+    c["hip"] = {"runtime": hr.get("runtime_version"), "compiled": hr.get("compiled_version"), "source": hr.get("source")}
+    c["detail"] = detail_path
+    # the byte budget is a contract with the driver's tail buffer: drop the optional parts, largest first
+    for victim in ("workloads.stages_ms", "roofline_workload.stages_ms", "stages_ms", "distributed", "workloads"):
+        if len(json.dumps(c)) <= limit:
+            break
+        if "." in victim:
+            a, b = victim.split(".")
+            if a == "workloads":
+                for v in c.get(a, {}).values():
+                    v.pop(b, None)
+            else:
+                c.get(a, {}).pop(b, None)
+        else:
+            c.pop(victim, None)
+    return c
+
+
+def self_launch(args_list, n):
+    """`python3 bench.py --gpus N` typed by hand (no torchrun around it): start the N ranks as a CHILD
+    process tree — before this process has touched the GPU, and never by exec — relay rank 0's lines
+    and exit with the child's code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + args_list
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["GS3D_BENCH_SELF_LAUNCHED"] = "1"
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    last = None
+    for ln in proc.stdout:
+        if ln.strip():
+            last = ln.rstrip("\n")
+    rc = proc.wait()
+    if last is not None:
+        print(last, flush=True)
+    return rc
 
 
 def main():
@@ -478,7 +635,18 @@ def main():
     ap.add_argument("--no-rebalance", action="store_true", help="N > 1: keep the floor(g*R/G) band plan")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--force-device", type=int, default=-1, help="rehearsal: put every rank on this GPU")
+    ap.add_argument("--detail-out", default=os.path.join(ROOT, "gpurun_out", "bench_detail.json"),
+                    help="file that receives the full record (every stage model, frame distribution, PMC figures); "
+                         "stdout carries ONE compact JSON line (<= 4 KB) as its last line")
+    ap.add_argument("--detail-stdout", action="store_true", help="also print the full record (before the compact line)")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="only the launch plumbing (works without a GPU): every rank joins the process group, one "
+                         "all_reduce, rank 0 prints a JSON line with the backend and the world size")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # typed by hand: become the launcher (nothing in this process has touched the GPU yet)
+        sys.exit(self_launch(sys.argv[1:], args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -490,6 +658,24 @@ def main():
             sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d; launch with torch.distributed.run\n"
                              % (args.gpus, world))
         sys.exit(2)
+    if args.launch_check:
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo" if args.backend != "nccl" or not torch.cuda.is_available() else "nccl")
+            t = torch.ones(1)
+            if dist.get_backend() == "nccl":
+                torch.cuda.set_device(local if args.force_device < 0 else args.force_device)
+                t = t.cuda()
+            dist.all_reduce(t)
+            ok, be, ws = int(t.item()) == world, dist.get_backend(), dist.get_world_size()
+            dist.barrier()
+            dist.destroy_process_group()
+        else:
+            ok, be, ws = True, None, 1
+        if rank == 0:
+            print(json.dumps({"launch_check": bool(ok), "n_gpus": args.gpus, "distributed": {"backend": be, "world_size": ws},
+                              "self_launched": os.environ.get("GS3D_BENCH_SELF_LAUNCHED") == "1"}), flush=True)
+        sys.exit(0 if ok else 4)
     if not torch.cuda.is_available():
         sys.stderr.write("bench.py: no GPU visible; the HIP path has no CPU fallback\n")
         sys.exit(3)
@@ -583,6 +769,8 @@ def main():
             "two_frames_in_flight": res.get("two_frames_in_flight"),
             "blend": blend_valu_object(res) if args.workload == "1m" and world == 1 else None,
             "hip_runtime": {"source": hiprt.info()["source"], "libamdhip64": hiprt.mapped()["libamdhip64"],
+                            "compiled_version": gs.hip_versions()[0], "runtime_version": gs.hip_versions()[1],
+                            "driver_version": gs.hip_versions()[2],
                             "launch_stream": "dedicated non-default stream (torch.cuda.Stream, current)"},
         }
         if world > 1:
@@ -591,7 +779,7 @@ def main():
                                    "per_rank_ms_max": max(res["per_rank_ms"]),
                                    "render_ms_per_rank": res["render_ms_per_rank"],
                                    "gather_ms_per_rank": res["gather_ms_per_rank"], "bands": res["bands"],
-                                   "band_plan": res["band_plan"]}
+                                   "band_plan": res["band_plan"], "skipped_band_flags": res["skipped_band_flags"]}
         if roof is not None:
             roof_wl = WORKLOADS[args.roofline_workload]
             line["roofline"] = roofline_object(args.roofline_workload, roof_wl, roof)
@@ -606,7 +794,17 @@ def main():
             line["workloads"] = {k: summary(WORKLOADS[k], v, k) for k, v in extras.items()}
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(wl, args.cpu_frames)
-        print(json.dumps(line), flush=True)
+        detail_path = None
+        try:
+            os.makedirs(os.path.dirname(os.path.abspath(args.detail_out)), exist_ok=True)
+            with open(args.detail_out, "w") as fh:
+                json.dump(line, fh, indent=1)
+            detail_path = os.path.relpath(args.detail_out, ROOT)
+        except OSError as e:
+            sys.stderr.write("bench.py: could not write %s: %s\n" % (args.detail_out, e))
+        if args.detail_stdout:
+            print(json.dumps(line), flush=True)
+        print(json.dumps(compact_line(line, detail_path)), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

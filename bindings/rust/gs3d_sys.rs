@@ -245,6 +245,7 @@ extern "C" {
     pub fn gs_last_error(out: *mut gs_error_info);
     pub fn gs_status_string(s: gs_status) -> *const c_char;
     pub fn gs_abi_version() -> u32;
+    pub fn gs_hip_versions(compiled: *mut i32, runtime: *mut i32, driver: *mut i32);
     pub fn gs_pod_size(sh: u32, cov: u32) -> usize;
     pub fn gs_pod_features(sh: u32, cov: u32, out: *mut u8) -> gs_status;
     pub fn gs_feature_name(index: u32) -> *const c_char;
@@ -340,6 +341,7 @@ extern "C" {
     pub fn gs_renderer_destroy(r: *mut gs_renderer);
     pub fn gs_renderer_set_timing(r: *mut gs_renderer, enabled: i32) -> gs_status;
     pub fn gs_renderer_reset_stats(r: *mut gs_renderer) -> gs_status;
+    pub fn gs_renderer_set_frame_flags_target(r: *mut gs_renderer, device_word: *mut u32) -> gs_status;
     pub fn gs_renderer_stats(r: *mut gs_renderer, out: *mut gs_frame_stats) -> gs_status;
     pub fn gs_render_frame(r: *mut gs_renderer, s: *mut gs_stream, gaussians: *mut gs_gaussians_buffer, gaussian_transform: *const gs_gaussian_transform_pod, model_transform: *const gs_model_transform_pod, camera: *const gs_camera, band_ty0: u32, band_ty1: u32, rgba_out_device: *mut f32) -> gs_status;
     pub fn gs_renderer_wait_frame(r: *mut gs_renderer, out: *mut gs_frame_result) -> gs_status;

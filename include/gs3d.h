@@ -91,6 +91,12 @@ typedef struct gs_error_info {
 void gs_last_error(gs_error_info *out);
 const char *gs_status_string(gs_status s);
 uint32_t gs_abi_version(void);
+/* wgpu::Adapter::get_info() analogue (AdapterInfo::driver_info): the HIP version this library was
+ * COMPILED against (HIP_VERSION of the headers) and the versions of the runtime and driver it is
+ * RUNNING on (hipRuntimeGetVersion / hipDriverGetVersion; 0 when the call fails).  A Python host that
+ * also imports PyTorch runs the library on the runtime bundled with the torch wheel, which may be older
+ * than the headers: every benchmark record prints both. */
+void gs_hip_versions(int32_t *compiled, int32_t *runtime, int32_t *driver);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Data model                                                                                  */
@@ -543,6 +549,14 @@ void gs_renderer_destroy(gs_renderer *r);
 /* stage timing with HIP events on the launch stream (off by default) */
 gs_status gs_renderer_set_timing(gs_renderer *r, int32_t enabled);
 gs_status gs_renderer_reset_stats(gs_renderer *r);
+/* Sharded frames (no reference item: the viewer owns the frame): a DEVICE word that
+ * receives the flags of every following frame of this renderer (gs_frame_result.flags: bit 0 capacity exceeded, bit 1 skipped; 0 = the band was
+ * rendered), written in stream order by the kernel that publishes the frame result — no extra
+ * launch.  A rank points it at a word inside its chunk of the gather buffer, so the one all-gather
+ * that exchanges the bands also tells every rank whether ANY band was skipped (pair capacity), and
+ * the frame can be dropped as a whole instead of being shown torn.  NULL (the default) disables.
+ * The word must stay valid until the frames that were enqueued with it have completed. */
+gs_status gs_renderer_set_frame_flags_target(gs_renderer *r, uint32_t *device_word);
 /* blocking: synchronises the stream of the last frame first */
 gs_status gs_renderer_stats(gs_renderer *r, gs_frame_stats *out);
 

@@ -128,6 +128,7 @@ def lib():
     L.gso_last_stage_seconds.argtypes = [vp]
     L.gso_set_threads.argtypes = [i32]
     L.gso_get_max_threads.restype = i32
+    L.gso_effective_threads.restype = i32
     L.gso_set_rect_version.argtypes = [i32]
     L.gso_rect_version.restype = i32
     # the product's A/B switch GS3D_RECT_V1=1 (spec version 1 of the tile rect) selects the matching oracle

@@ -6,6 +6,7 @@
 #include "gs_oracle.h"
 
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
@@ -1038,7 +1039,10 @@ void gso_sort_pairs(uint64_t *keys, uint32_t *idx, uint64_t d) {
     nt = omp_get_max_threads();
 #endif
     if (nt < 1) nt = 1;
-    if ((uint64_t)nt > d / 4096 + 1) nt = (int)(d / 4096 + 1);
+    /* a thread should own at least 64 Ki pairs per pass: below that the fork / join of the 16 parallel
+     * regions and the nt x 256 offset table cost more than the pass (BENCH_r03: 256 threads sorted
+     * 2.5 M pairs 45 x slower than one) */
+    if ((uint64_t)nt > d / 65536 + 1) nt = (int)(d / 65536 + 1);
     size_t *hist = (size_t *)malloc((size_t)nt * 256 * sizeof(size_t));
     for (int pass = 0; pass < 8; pass++) {
         int shift = pass * 8;
@@ -1244,6 +1248,35 @@ int gso_get_max_threads(void) {
 #else
     return 1;
 #endif
+}
+
+/* The CPUs this process may actually run on: the affinity mask, cut by the cgroup's CPU quota (v2
+ * `cpu.max`, v1 `cpu.cfs_quota_us / cpu.cfs_period_us`).  omp_get_max_threads() reports the machine's
+ * hardware threads; on a container that is given 16 CPUs of a 256-thread host, 256 OpenMP threads spin
+ * on each other's barriers (the "all cores" figure of BENCH_r03 was slower than one thread in the sort).
+ * The timing harness sets the thread count to this. */
+int gso_effective_threads(void) {
+    int n = 1;
+#ifdef _OPENMP
+    n = omp_get_num_procs();   /* honours the affinity mask */
+#endif
+    double quota = 0.0;
+    FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r");
+    if (f) {
+        char a[64];
+        double period = 0.0;
+        if (fscanf(f, "%63s %lf", a, &period) == 2 && strcmp(a, "max") != 0 && period > 0.0) quota = atof(a) / period;
+        fclose(f);
+    } else {
+        double q = -1.0, per = 0.0;
+        f = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r");
+        if (f) { if (fscanf(f, "%lf", &q) != 1) q = -1.0; fclose(f); }
+        f = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r");
+        if (f) { if (fscanf(f, "%lf", &per) != 1) per = 0.0; fclose(f); }
+        if (q > 0.0 && per > 0.0) quota = q / per;
+    }
+    if (quota >= 1.0 && quota < (double)n) n = (int)(quota + 0.5);
+    return n > 0 ? n : 1;
 }
 
 

@@ -196,6 +196,7 @@ void gso_set_threads(int n);
 void gso_set_rect_version(int v);
 int gso_rect_version(void);
 int gso_get_max_threads(void);
+int gso_effective_threads(void);   /* CPUs this process may run on (affinity mask cut by the cgroup quota) */
 
 #ifdef __cplusplus
 }

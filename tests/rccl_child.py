@@ -95,7 +95,33 @@ def main():
         r.render(stream, buf, gt, mt, cams[0], par.band_target_ptr(gbuf, plan, 0, W), band=plan.bands[0], check=False)
         par.gather_bands(dist, gbuf, plan, 0, force=True)
         sync_img = par.assemble(torch, gbuf, plan).clone()
+        # A band that overflows its pair capacity is skipped on the device (GS_ERR_PAIR_CAPACITY).  The
+        # flags word travels inside the band's chunk through the same collective: finish(check=True)
+        # must drop that frame (FramePipeline presented a torn image) and the next frame,
+        # rendered with the grown buffers, must be exact.
+        far = gs.camera_look_at((0.0, 0.0, 60.0), (0.0, 0.0, 0.0), (0, 1, 0), float(np.deg2rad(60.0)), W, H, 0.1, 100.0)
+        gt_big = gs.gaussian_transform_pod(size=4.0, sh_deg=3)
+        r2 = gs.Renderer(dev)
+        pipe2 = par.FramePipeline(torch, dist, plan, 0, W, "cuda", force_collective=True)
+        r2.render(stream, buf, gt, mt, far, pipe2.begin(0, r2), band=plan.bands[0], check=True)     # sizing frame: few pairs
+        pipe2.submit(0)
+        far_img = pipe2.finish(0, check=True)
+        assert far_img is not None and int(pipe2.flags(0)[0].item()) == 0
+        r2.render(stream, buf, gt_big, mt, cams[0], pipe2.begin(1, r2), band=plan.bands[0], check=False)   # ~10x the pairs
+        pipe2.submit(1)
+        skipped = pipe2.finish(1, check=True)
+        skip_flags = int(pipe2.flags(1)[0].item())
+        r2.render(stream, buf, gt_big, mt, cams[0], pipe2.begin(2, r2), band=plan.bands[0], check=False)   # grown buffers
+        pipe2.submit(2)
+        after = pipe2.finish(2, check=True)
+        assert after is not None, "the frame after a skipped one must be rendered"
+        after = after.clone()
+        pipe2.drain()
     s.synchronize()
+    assert skipped is None and skip_flags == 3, (skipped is None, skip_flags)
+    r.render(own, buf, gt_big, mt, cams[0], img.device_ptr())
+    want_big = hashlib.sha256(img.download(own, np.float32).tobytes()).hexdigest()
+    assert hashlib.sha256(np.ascontiguousarray(after[:H].cpu().numpy()).tobytes()).hexdigest() == want_big
     r.wait_frame()
     have = [hashlib.sha256(np.ascontiguousarray(t[:H].cpu().numpy()).tobytes()).hexdigest() for t in got]
     assert have == want, "frames out of the RCCL pipeline differ from the plain frames: %s" % (
@@ -104,7 +130,7 @@ def main():
     dist.barrier()
     dist.destroy_process_group()
     print(json.dumps({"ok": True, "order": order, "frames": frames, "backend": "nccl", "world_size": 1,
-                      "work_handle": sorted(kinds), "hip_runtime": hiprt.info()["source"],
+                      "work_handle": sorted(kinds), "skipped_frame_dropped": True, "hip_runtime": hiprt.info()["source"],
                       "libamdhip64": mapped["libamdhip64"], "libhsa": mapped["libhsa-runtime64"],
                       "torch": torch.__version__, "hip": torch.version.hip}), flush=True)
 

@@ -35,6 +35,23 @@ def test_rccl_world1_frame_pipeline_on_dedicated_stream(order):
     assert os.sep + "torch" + os.sep in j["libamdhip64"][0], j
 
 
+def _torch_with_bundled_runtime():
+    """these CPU tests need the built product library (hipcc or a prebuilt .so) AND a ROCm torch wheel
+    that bundles its own libamdhip64 — without the latter there is only one runtime to begin with"""
+    import importlib.util
+    if importlib.util.find_spec("torch") is None:
+        return False
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    from importlib import import_module
+    return import_module("wgpu_3dgs_core_amd._hiprt").torch_lib_dir() is not None
+
+
+needs_bundled_torch = pytest.mark.skipif(not _torch_with_bundled_runtime(),
+                                         reason="needs a ROCm torch wheel with a bundled libamdhip64.so")
+
+
+@needs_bundled_torch
 def test_import_orders_share_one_hip_runtime_cpu():
     """No GPU needed: after `import product; import torch` and after `import torch; import product`
     exactly one libamdhip64 / libhsa-runtime64 / libhiprtc is mapped, and it is the same file."""
@@ -53,6 +70,7 @@ def test_import_orders_share_one_hip_runtime_cpu():
     assert seen[0] == seen[1]
 
 
+@needs_bundled_torch
 def test_forced_system_runtime_then_torch_is_refused_cpu():
     """GS3D_HIP_RUNTIME=system + torch imported afterwards = two runtimes: refused with a message,
     not left to fail later as 'No HIP GPUs are available'."""
@@ -64,3 +82,49 @@ def test_forced_system_runtime_then_torch_is_refused_cpu():
     res = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                          text=True, timeout=600)
     assert res.returncode != 0 and "two HIP runtimes" in res.stdout, res.stdout[-2000:]
+    assert "GS3D_HIP_RUNTIME=system" in res.stdout           # the message names the ways out
+
+
+@needs_bundled_torch
+def test_forced_system_runtime_without_torch_imports_fine_cpu():
+    """the package must stay importable on the system runtime when torch is merely installed."""
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import wgpu_3dgs_core_amd as gs\n"
+            "from importlib import import_module\n"
+            "h = import_module('wgpu_3dgs_core_amd._hiprt')\n"
+            "m = h.check()\n"
+            "assert h.info()['source'] == 'system' and len(m['libamdhip64']) == 1 and 'torch' not in m['libamdhip64'][0]\n"
+            "c, r, d = gs.hip_versions(); assert c > 0 and r > 0\n"
+            "print('ok', c, r)\n") % ROOT
+    env = dict(os.environ, GS3D_HIP_RUNTIME="system")
+    res = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                         text=True, timeout=600)
+    assert res.returncode == 0 and "ok" in res.stdout, res.stdout[-2000:]
+
+
+@needs_bundled_torch
+def test_soname_mismatch_falls_back_to_the_system_runtime_cpu():
+    """A torch wheel whose bundled libamdhip64 has another SONAME than libgs3d_hip.so NEEDs cannot serve
+    the product: auto mode must not preload it (the product then runs on /opt/rocm's runtime and the
+    package imports), and GS3D_HIP_RUNTIME=torch must say why it cannot be honoured."""
+    code = ("import importlib.util, os\n"       # the module alone: importing the package would already load the library
+            "spec = importlib.util.spec_from_file_location('_hiprt_alone', os.path.join(%r, 'wgpu-3dgs-core_amd', '_hiprt.py'))\n"
+            "h = importlib.util.module_from_spec(spec); spec.loader.exec_module(h)\n"
+            "soname, needed = h.elf_dynamic(h.torch_lib_dir() + '/libamdhip64.so')\n"
+            "assert soname == h.product_needs() and soname.startswith('libamdhip64.so.'), (soname, h.product_needs())\n"
+            "h.product_needs = lambda family='libamdhip64': 'libamdhip64.so.99'\n"
+            "import os\n"
+            "if os.environ.get('GS3D_HIP_RUNTIME') == 'torch':\n"
+            "    try:\n"
+            "        h.prepare(); print('not refused')\n"
+            "    except ImportError as e:\n"
+            "        print('refused:', e)\n"
+            "else:\n"
+            "    assert h.prepare() == 'system' and not h.info()['preloaded'] and 'libamdhip64.so.99' in h.info()['note']\n"
+            "    assert not h.mapped()['libamdhip64']\n"
+            "    print('fell back')\n") % ROOT
+    res = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert res.returncode == 0 and "fell back" in res.stdout, res.stdout[-2000:]
+    res = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, GS3D_HIP_RUNTIME="torch"), stdout=subprocess.PIPE,
+                         stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert res.returncode == 0 and "refused:" in res.stdout and "libamdhip64.so.99" in res.stdout, res.stdout[-2000:]

@@ -74,7 +74,7 @@ def test_band_plan():
     par = _par()
     p = par.BandPlan(1080, 8)
     assert p.bands == [(0, 8), (8, 17), (17, 25), (25, 34), (34, 42), (42, 51), (51, 59), (59, 68)]   # floor(g R / G)
-    assert p.chunk_rows == 9 * 16
+    assert p.band_rows == 9 * 16 and p.chunk_rows == 9 * 16 + 1      # tallest band + the flag row
     assert [b - a for a, b in par.BandPlan(2160, 8).bands] == [16, 17, 17, 17, 17, 17, 17, 17]
     for h in (16, 200, 1080, 2160):
         for w in (1, 2, 3, 4, 8):
@@ -137,18 +137,39 @@ def _pipeline_worker(rank, world, port, height, width, out_dir):
     y0, y1 = plan.pixel_rows(rank)
     images = []
     frames = 5
+
+    class _Renderer:
+        """stands in for gs.Renderer.set_frame_flags_target: remembers where the flags word goes"""
+        target = None
+
+        def set_frame_flags_target(self, ptr):
+            self.target = ptr
+
+    rr = _Renderer()
+    dropped = []
     for i in range(frames):
-        base = pipe.begin(i)
+        base = pipe.begin(i, rr)
         buf = pipe.bufs[i % 2]
         off = (base - buf.data_ptr()) // 4
         flat = buf.view(-1)
-        for y in range(y0, y1):          # frame i, row y: value 1000 i + y in every channel
-            flat[off + y * width * 4:off + (y + 1) * width * 4] = float(1000 * i + y)
+        # frame 3: the LAST rank's band overflows its pair capacity and is skipped — the rows keep what the
+        # buffer held (frame 1) and the flags word says so
+        skip = i == 3 and rank == world - 1
+        if not skip:
+            for y in range(y0, y1):          # frame i, row y: value 1000 i + y in every channel
+                flat[off + y * width * 4:off + (y + 1) * width * 4] = float(1000 * i + y)
+        assert rr.target == par.flags_ptr(buf, plan, rank, width)
+        buf.view(torch.int32).view(-1)[(rr.target - buf.data_ptr()) // 4] = 3 if skip else 0
         pipe.submit(i)
         if i:
-            images.append(pipe.finish(i - 1).clone())
-    images.append(pipe.finish(frames - 1).clone())
+            img = pipe.finish(i - 1, check=True)
+            dropped.append(img is None)
+            images.append(torch.zeros(height, width, 4) if img is None else img.clone())
+    img = pipe.finish(frames - 1, check=True)
+    dropped.append(img is None)
+    images.append(img.clone())
     pipe.drain()
+    assert dropped == [False, False, False, True, False], dropped      # every rank drops frame 3, and only it
     np.save(os.path.join(out_dir, "pipe%d.npy" % rank), torch.stack(images).numpy())
     dist.barrier()
     dist.destroy_process_group()
@@ -167,4 +188,6 @@ def test_frame_pipeline_keeps_frames_apart(tmp_path, world):
         assert got.shape == (5, height, width, 4)
         for i in range(5):
             want = (1000 * i + np.arange(height, dtype=np.float32))[:, None, None] * np.ones((1, width, 4), np.float32)
+            if i == 3:
+                want[:] = 0.0          # dropped on every rank: one band was skipped (its flags word travelled with it)
             assert np.array_equal(got[i], want), (rank, i)

@@ -557,6 +557,14 @@ class Gaussians:
 # device / stream / buffers
 # ------------------------------------------------------------------------------------------------
 
+def hip_versions():
+    """(compiled, runtime, driver): HIP_VERSION of the headers libgs3d_hip.so was built with and the
+    versions of the runtime / driver it runs on (gs_hip_versions; wgpu AdapterInfo::driver_info)."""
+    a, b, c = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+    _L.gs_hip_versions(C.byref(a), C.byref(b), C.byref(c))
+    return a.value, b.value, c.value
+
+
 class Device:
     """wgpu::Device + wgpu::Queue."""
 
@@ -1133,6 +1141,11 @@ class Renderer:
 
     def reset_stats(self):
         _check(_L.gs_renderer_reset_stats(self._h))
+
+    def set_frame_flags_target(self, device_word_ptr):
+        """gs_renderer_set_frame_flags_target: device word (or None) that receives every following
+        frame's flags in stream order (FRAME_FLAG_*; 0 = rendered)."""
+        _check(_L.gs_renderer_set_frame_flags_target(self._h, C.c_void_p(device_word_ptr or 0)))
 
     def stats(self):
         st = FrameStats()

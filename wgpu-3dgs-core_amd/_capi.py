@@ -77,6 +77,7 @@ SIGNATURES = {
     "gs_last_error": (None, [vp]),
     "gs_status_string": (C.c_char_p, [i32]),
     "gs_abi_version": (u32, []),
+    "gs_hip_versions": (None, [vp, vp, vp]),
     "gs_pod_size": (sz, [i32, i32]),
     "gs_pod_features": (i32, [i32, i32, vp]),
     "gs_feature_name": (C.c_char_p, [u32]),
@@ -172,6 +173,7 @@ SIGNATURES = {
     "gs_renderer_destroy": (None, [vp]),
     "gs_renderer_set_timing": (i32, [vp, i32]),
     "gs_renderer_reset_stats": (i32, [vp]),
+    "gs_renderer_set_frame_flags_target": (i32, [vp, vp]),
     "gs_renderer_stats": (i32, [vp, vp]),
     "gs_renderer_wait_frame": (i32, [vp, vp]),
     "gs_render_frame": (i32, [vp, vp, vp, vp, vp, vp, u32, u32, vp]),

@@ -63,6 +63,14 @@ extern "C" void gs_last_error(gs_error_info *out) {
 
 extern "C" uint32_t gs_abi_version(void) { return GS3D_ABI_VERSION; }
 
+extern "C" void gs_hip_versions(int32_t *compiled, int32_t *runtime, int32_t *driver) {
+    if (compiled) *compiled = HIP_VERSION;
+    int v = 0;
+    if (runtime) *runtime = hipRuntimeGetVersion(&v) == hipSuccess ? v : 0;
+    v = 0;
+    if (driver) *driver = hipDriverGetVersion(&v) == hipSuccess ? v : 0;
+}
+
 extern "C" const char *gs_status_string(gs_status s) {
     switch (s) {
     case GS_OK: return "ok";
@@ -1445,6 +1453,8 @@ struct gs_renderer {
     hipEvent_t done[2];                   // end of the frame of each parity
     bool done_valid[2];
     uint32_t done_gen[2];
+    uint32_t done_shape[2];               // shape_epoch of the frame behind each done event
+    uint32_t shape_epoch = 0;             // counts the changes of `shape` (a new epoch starts with a sizing frame)
     // last frame (host-side knowledge; V and D live in results[gen & 1])
     uint64_t n;
     uint32_t tiles_x, tiles_y, sort_passes;
@@ -1453,6 +1463,7 @@ struct gs_renderer {
     bool wide_tiles;  // tile keys are u32 (more than 65536 tiles) instead of u16
     bool rect32;      // the last frame's tile rects are packed (gs::rect_pack32)
     uint32_t launches;                    // kernel launches of the last frame (diagnostic)
+    uint32_t *flags_target = nullptr;     // device word that receives every frame's flags (gs_renderer_set_frame_flags_target)
     hipStream_t last_stream;
     bool have_frame;                      // last_stream is meaningful (the null stream is a valid stream)
     gs_buffer *last_order;   // mirror order of the last frame's buffer (null = index order), for the taps
@@ -1482,6 +1493,7 @@ extern "C" gs_status gs_renderer_create(gs_device *dev, gs_renderer **out) {
         e = hipEventCreateWithFlags(&r->done[i], hipEventDisableTiming | (fence ? 0u : hipEventDisableSystemFence));
         r->done_valid[i] = false;
         r->done_gen[i] = 0;
+        r->done_shape[i] = 0;
     }
     if (e != hipSuccess) {
         if (r->host_counters) (void)hipHostFree(r->host_counters);
@@ -1537,6 +1549,13 @@ extern "C" gs_status gs_renderer_set_timing(gs_renderer *r, int32_t enabled) {
         r->ev_valid = true;
     }
     r->timing = enabled != 0;
+    return GS_OK;
+}
+
+extern "C" gs_status gs_renderer_set_frame_flags_target(gs_renderer *r, uint32_t *device_word) {
+    if (!r) return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "null renderer");
+    if ((uintptr_t)device_word & 3u) return fail(GS_ERR_INVALID_ARGUMENT, (uint64_t)(uintptr_t)device_word, 4, 0, "unaligned flags word");
+    r->flags_target = device_word;
     return GS_OK;
 }
 
@@ -2220,11 +2239,17 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
     // A camera that keeps closing in: D grows frame over frame, and this frame is two or three frames
     // ahead of the newest result (frames are pipelined).  Extrapolate the last step three frames ahead
     // and size for that, so that a steady zoom does not run into the skip path.
-    if (hist_gen[0] && hist_gen[1] && (hist_gen[0] + 1u == hist_gen[1] || hist_gen[1] + 1u == hist_gen[0])) {
+    // Only a TREND is extrapolated: both results must come from the current shape epoch (same N, image
+    // size and band — a switch from a band to the full frame, or a resize, is a discontinuity, not a zoom),
+    // and the extrapolation is capped at twice the newest D: one jump of the camera must not turn into
+    // pair buffers of 4 x D that never shrink.
+    if (hist_gen[0] && hist_gen[1] && (hist_gen[0] + 1u == hist_gen[1] || hist_gen[1] + 1u == hist_gen[0]) &&
+        r->done_shape[0] == r->shape_epoch && r->done_shape[1] == r->shape_epoch) {
         const int newer = hist_gen[0] > hist_gen[1] ? 0 : 1;
         const uint64_t d_new = hist_d[newer], d_old = hist_d[newer ^ 1];
         if (d_new > d_old) {
-            const uint64_t ahead = d_new + 3u * (d_new - d_old);
+            uint64_t ahead = d_new + 3u * (d_new - d_old);
+            if (ahead > 2u * d_new) ahead = 2u * d_new;
             if (ahead + ahead / 8 > r->pair_capacity && capacity_for(ahead) > want_capacity) want_capacity = capacity_for(ahead);
         }
     }
@@ -2262,6 +2287,23 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
 
     r->gen++;
     const uint32_t gen = r->gen;
+    // From here on kernels of this frame may be in the stream.  Whatever way the function is left — also
+    // through GS_TRY / GS_HIP after an allocation or launch failure — the end-of-frame event of this
+    // generation is recorded behind them, so the next frame on ANOTHER stream waits for exactly these
+    // kernels before it touches the shared scratch and state buffers (a frame that failed half-way used
+    // to leave done[gen & 1] pointing at frame gen - 2).  Its result block carries no `gen`, so the
+    // capacity history skips it.
+    struct DoneGuard {
+        gs_renderer *r;
+        hipStream_t st;
+        uint32_t gen;
+        ~DoneGuard() {
+            (void)hipEventRecord(r->done[gen & 1u], st);
+            r->done_valid[gen & 1u] = true;
+            r->done_gen[gen & 1u] = gen;
+            r->done_shape[gen & 1u] = r->shape_epoch;
+        }
+    } done_guard{r, st, gen};
     gs::FrameState *state = (gs::FrameState *)r->state.ptr;
     gs::FrameResult *result = &r->results[gen & 1u];
     r->n = n;
@@ -2286,7 +2328,7 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
         GS_TRY(dev_reserve(r->zero_region, (size_t)num_tiles * 8));
         GS_HIP(hipMemsetAsync(r->zero_region.ptr, 0, (size_t)num_tiles * 8, st));
         GS_TRY(reserve_pairs(r, 1, wide));
-        hipLaunchKernelGGL(gs::k_publish_result, dim3(1), dim3(64), 0, st, result, state, gen);
+        hipLaunchKernelGGL(gs::k_publish_result, dim3(1), dim3(64), 0, st, result, state, gen, r->flags_target);
         GS_HIP(hipGetLastError());
         r->launches++;
         mark(ST_SCAN); mark(ST_DSORT); mark(ST_EXPAND); mark(ST_TSORT); mark(ST_RANGES);
@@ -2385,6 +2427,7 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
             const uint64_t cap = capacity_for(d) > want_capacity ? capacity_for(d) : want_capacity;
             GS_TRY(reserve_pairs(r, cap, wide));
         }
+        if (!(r->shape == shape)) r->shape_epoch++;
         r->shape = shape;
         const uint32_t capacity = (uint32_t)r->pair_capacity;
         mark(ST_DSORT);
@@ -2426,6 +2469,7 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
         eo.gen = gen;
         eo.sb_bound = exp_grid / gs::EXP_SB + 1;
         eo.rect32 = fc.rect32;
+        eo.flags_dev = r->flags_target;
         // Where a wave of k_pairs_emit starts: found by the wave itself (a search over the super-chunk
         // sums: one step per 256 of them) or looked up in a table that k_pairs_cursors writes first.
         // The table costs a launch and wins once the search needs more than one step (A/B on one box:
@@ -2513,10 +2557,7 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
         (void)hipEventRecord(r->ev[ST_COUNT], st);
         r->ev_pending = true;
     }
-    GS_HIP(hipEventRecord(r->done[gen & 1u], st));
-    r->done_valid[gen & 1u] = true;
-    r->done_gen[gen & 1u] = gen;
-    return GS_OK;
+    return GS_OK;   // done_guard records the end-of-frame event
 }
 
 static gs_status download_sync(gs_renderer *r, void *dst, const void *src, size_t bytes) {

@@ -182,7 +182,11 @@ struct FrameResult {
 // event created with hipEventDisableSystemFence, then a read) and finds the expected generation
 // also finds that generation's counts.
 __device__ __forceinline__ void publish_result(FrameResult *r, uint32_t visible, uint64_t pairs_total, uint32_t flags,
-                                               uint32_t gen) {
+                                               uint32_t gen, uint32_t *flags_dev = nullptr) {
+    // optional copy of the flags in DEVICE memory (gs_renderer_set_frame_flags_target): a sharded frame
+    // carries it inside its band's gather chunk, so every rank learns from the one all-gather whether
+    // any band was skipped
+    if (flags_dev) *flags_dev = flags;
     r->visible = visible;
     r->pairs_total = pairs_total;
     r->flags = flags;
@@ -191,12 +195,12 @@ __device__ __forceinline__ void publish_result(FrameResult *r, uint32_t visible,
 
 // the frame without Gaussians: its (empty) result is published IN STREAM ORDER like every other
 // frame's, so an older frame still in flight on the same result block cannot overwrite it later
-__global__ void k_publish_result(FrameResult *r, FrameState *state, uint32_t gen) {
+__global__ void k_publish_result(FrameResult *r, FrameState *state, uint32_t gen, uint32_t *flags_dev) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         state->visible = 0;
         state->pairs = 0;
         state->overflow = 0;
-        publish_result(r, 0u, 0ull, 0u, gen);
+        publish_result(r, 0u, 0ull, 0u, gen, flags_dev);
     }
 }
 
@@ -1137,6 +1141,7 @@ struct ExpandIO {
     uint32_t sb_bound;               // host bound of the number of super-chunks (entries past the real one are zero)
     struct PairCursorRec *cursors;   // [capacity / CURSOR_SLOTS + 1] where the pairs of every 1024-slot span start
     uint32_t rect32;                 // rect / sorted_rect hold packed 4-byte rects (rect_pack32)
+    uint32_t *flags_dev;             // optional device copy of the frame flags (null: none)
 };
 
 // Expansion, part 1: gather the tile rects into depth order (the only random access of the key
@@ -1823,7 +1828,7 @@ __global__ __launch_bounds__(EXP_SB) void k_pairs_cursors(ExpandIO io) {
         const uint32_t over = d > (uint64_t)io.capacity ? (FRAME_FLAG_PAIR_OVERFLOW | FRAME_FLAG_SKIPPED) : 0u;
         io.state->pairs = over ? io.capacity : (uint32_t)d;
         io.state->overflow = over ? 1u : 0u;
-        publish_result(io.result, v_count, d, over, io.gen);
+        publish_result(io.result, v_count, d, over, io.gen, io.flags_dev);
     }
     if (v == 0ull) return;
     const uint64_t p = s_before[0] + s_before[1] + (wid ? s_wave0 : 0ull) + incl - v;   // pairs in front of chunk c
@@ -2044,7 +2049,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_pairs_emit(ExpandIO io, uint32
             const uint32_t over = d > (uint64_t)io.capacity ? (FRAME_FLAG_PAIR_OVERFLOW | FRAME_FLAG_SKIPPED) : 0u;
             io.state->pairs = count;
             io.state->overflow = over ? 1u : 0u;
-            publish_result(io.result, v_count, d, over, io.gen);
+            publish_result(io.result, v_count, d, over, io.gen, io.flags_dev);
         }
     }
     if ((uint64_t)block * TILE >= count) return;      // the same D in every wave: block-uniform

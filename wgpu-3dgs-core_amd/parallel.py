@@ -12,9 +12,18 @@ border rows — so `BandPlan.rebalanced` re-cuts the bands from per-row costs me
 earlier frame (pairs per tile row) so that every rank gets about the same cost.
 
 Exchange layout: every rank renders its band straight into ITS chunk of a gather buffer of
-G equal chunks (chunk = the tallest band, in pixel rows); one in-place all-gather fills the other
-chunks; `assemble` returns the contiguous image.  Equal chunks keep the exchange a single
-fixed-size collective whatever the plan.
+G equal chunks (chunk = the tallest band, in pixel rows, + ONE flag row); one in-place all-gather
+fills the other chunks; `assemble` returns the contiguous image.  Equal chunks keep the exchange a
+single fixed-size collective whatever the plan.
+
+Skipped bands: a frame whose band needs more (tile, Gaussian) pairs than the renderer's buffers
+hold is SKIPPED on the device (include/gs3d.h, GS_ERR_PAIR_CAPACITY: the band's rows keep what they
+held).  On one GPU the viewer sees that in the frame result; here the other ranks must learn it too,
+or the all-gather delivers a torn image (this rank's chunk from an older frame, the others' from
+this one).  The renderer therefore writes each frame's flags word into the first word of the chunk's
+flag row (`gs_renderer_set_frame_flags_target`, no extra launch), the ONE collective carries it to
+every rank, and `frame_flags` / `FramePipeline.finish(i, check=True)` tell the caller to drop the
+frame — on all ranks alike, since all of them see the same G words.
 
 One HIP runtime: the torch wheel bundles its own libamdhip64 / libhsa-runtime64 and the product
 library must run on the SAME copy as torch and RCCL (two runtimes in one process: the second finds
@@ -51,7 +60,9 @@ class BandPlan:
         assert self.bands[0][0] == 0 and self.bands[-1][1] == self.tiles_y
         assert all(self.bands[i][1] == self.bands[i + 1][0] for i in range(self.world_size - 1))
         assert all(b >= a for a, b in self.bands)
-        self.chunk_rows = max(1, max(b - a for a, b in self.bands)) * TILE
+        # rows of one gather chunk: the tallest band + one row whose first word carries the band's frame flags
+        self.band_rows = max(1, max(b - a for a, b in self.bands)) * TILE
+        self.chunk_rows = self.band_rows + 1
 
     def pixel_rows(self, rank):
         """[y0, y1) of rank's band in image rows (clipped to the image height)"""
@@ -103,6 +114,19 @@ def band_target_ptr(buf, plan, rank, width):
     return buf.data_ptr() + (rank * plan.chunk_rows - y0) * width * 16
 
 
+def flags_ptr(buf, plan, rank, width):
+    """Device pointer of the flags word of rank's chunk (first word of the chunk's last row): hand it
+    to `Renderer.set_frame_flags_target` before rendering the band into this buffer."""
+    return buf.data_ptr() + ((rank + 1) * plan.chunk_rows - 1) * width * 16
+
+
+def frame_flags(torch, buf, plan):
+    """[G] int32 device tensor: the flags word of every band of the (gathered) frame in `buf`;
+    0 = rendered, bit 1 (FRAME_FLAG_SKIPPED) = that band was not written."""
+    c = plan.chunk_rows
+    return buf.view(torch.int32)[c - 1::c, 0, 0]
+
+
 def gather_bands(dist, buf, plan, rank, async_op=False, force=False):
     """One all-gather, in place: every rank contributes its chunk of `buf`.  The form of the
     collective is chosen once from the backend (never by catching an error from a collective: ranks
@@ -146,10 +170,18 @@ class FramePipeline:
     collective's stream while frame i + 1 is rendered into the next buffer (xGMI transfer hidden
     behind compute; a frame costs max(render, gather) instead of their sum).
 
-        buf_ptr = pipe.begin(i)        # base pointer for the renderer (waits for the frame that last used the buffer)
+        buf_ptr = pipe.begin(i, renderer)   # base pointer for the renderer (waits for the frame that last used the
+                                            # buffer; points the renderer's frame-flags word into this buffer's chunk)
         ... render frame i's band into buf_ptr ...
         pipe.submit(i)                 # start the exchange of frame i
         image = pipe.finish(i - 1)     # the complete previous frame (orders the caller's stream behind its exchange)
+
+    A band that overflowed its pair capacity is skipped on the device; its flags word travels with the
+    band.  `finish(i, check=True)` reads the G words back (one small device-to-host copy: a presenting
+    viewer synchronises here anyway) and returns None when ANY rank skipped — every rank sees the same
+    words, so all ranks drop the same frames and nobody presents a torn image; the next frame already has
+    the grown buffers.  `finish(i)` (check=False) returns the image without looking; `flags(i)` returns
+    the device tensor of the words for callers that accumulate them without a host round trip.
     """
 
     def __init__(self, torch, dist, plan, rank, width, device, depth=2, force_collective=False):
@@ -168,10 +200,12 @@ class FramePipeline:
             self.work[k].wait()             # stream-level: the current stream waits, the host does not
             self.work[k] = None
 
-    def begin(self, i):
+    def begin(self, i, renderer=None):
         k = self._slot(i)
         self._wait(k)                       # the buffer's previous exchange must have read and written it
         self.frame[k] = i
+        if renderer is not None:
+            renderer.set_frame_flags_target(flags_ptr(self.bufs[k], self.plan, self.rank, self.width))
         return band_target_ptr(self.bufs[k], self.plan, self.rank, self.width)
 
     def submit(self, i):
@@ -179,10 +213,19 @@ class FramePipeline:
         assert self.frame[k] == i
         self.work[k] = gather_bands(self.dist, self.bufs[k], self.plan, self.rank, async_op=True, force=self.force)
 
-    def finish(self, i):
+    def flags(self, i):
+        """device tensor [G] of frame i's per-band flags (valid once its exchange has been waited for)"""
         k = self._slot(i)
         assert self.frame[k] == i, "frame %d is no longer in the pipeline" % i
         self._wait(k)
+        return frame_flags(self.torch, self.bufs[k], self.plan)
+
+    def finish(self, i, check=False):
+        k = self._slot(i)
+        assert self.frame[k] == i, "frame %d is no longer in the pipeline" % i
+        self._wait(k)
+        if check and bool((frame_flags(self.torch, self.bufs[k], self.plan) != 0).any().item()):
+            return None                     # some band was skipped: drop the frame on every rank
         return assemble(self.torch, self.bufs[k], self.plan)
 
     def drain(self):
@@ -190,11 +233,16 @@ class FramePipeline:
             self._wait(k)
 
 
-def render_sharded(dist, torch, buf, plan, rank, width, render_band):
+def render_sharded(dist, torch, buf, plan, rank, width, render_band, renderer=None, check=True):
     """render_band((ty0, ty1), full_frame_base_ptr) must render this rank's tile rows; then the
-    bands are exchanged and the contiguous image is returned."""
+    bands are exchanged and the contiguous image is returned.  With `renderer` given its frame flags
+    travel with the band, and (check=True) the result is None when any rank's band was skipped."""
+    if renderer is not None:
+        renderer.set_frame_flags_target(flags_ptr(buf, plan, rank, width))
     render_band(plan.bands[rank], band_target_ptr(buf, plan, rank, width))
     gather_bands(dist, buf, plan, rank)
+    if renderer is not None and check and bool((frame_flags(torch, buf, plan) != 0).any().item()):
+        return None
     return assemble(torch, buf, plan)
 
 
