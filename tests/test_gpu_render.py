@@ -360,6 +360,16 @@ def test_block_list_mode_follows_the_view(gs, ob, device, stream):
         exp, d, vis, _ = ob.render(sh, cov, pods, ogt, omt, ocam, order=order)
         assert (st.visible, st.pairs) == (vis, d), (k, name, st.visible, vis, st.pairs, d)
         assert np.array_equal(got.view(np.uint32), exp.view(np.uint32)), (k, name)
+        # the taps of EVERY frame — list frames keep their per-slot arrays in list space, the
+        # translation back to Gaussian indices goes through the block list and the mirror order
+        o_proj, o_tiles, _, _, o_skeys, o_sidx, o_ranges, _ = _oracle_frame(ob, sh, cov, pods, ogt, omt, ocam, order=order)
+        g_proj, g_tiles = r.download_projected(n)
+        assert np.array_equal(g_tiles, o_tiles), (k, name)
+        seen = o_tiles > 0
+        assert np.array_equal(g_proj[seen].view(np.uint8), o_proj[seen].view(np.uint8)), (k, name)
+        g_skeys, g_sidx = r.download_sorted()
+        assert np.array_equal(g_skeys, o_skeys) and np.array_equal(g_sidx, o_sidx), (k, name)
+        assert np.array_equal(r.download_ranges((W // 16) * (H // 16)), o_ranges), (k, name)
         launches.append(r.wait_frame().launches)
         vis_seen.append(vis)
     assert vis_seen[0] > n // 2 and vis_seen[1] < n // 2 and vis_seen[5] == 0, vis_seen
@@ -371,6 +381,53 @@ def test_block_list_mode_follows_the_view(gs, ob, device, stream):
             assert launches[k] - launches[j] == (1 if took_list else -1), (k, j, launches)
     assert any(vis_seen[k - 1] < n // 2 for k in range(1, len(seq))) and any(vis_seen[k - 1] >= n // 2 for k in range(2, len(seq)))
     buf.destroy(); img.release(); r.destroy()
+
+
+@pytest.mark.parametrize("n", [1, 1023, 1024, 1025, 70_001, 300_123])
+def test_list_frames_with_a_partial_last_block(gs, ob, device, stream, n):
+    """A list frame writes its outputs in list space, [0, blocks * 1024): the lanes of the buffer's last,
+    partial block past N sit inside that range and must read as culled; more than 256 blocks take more than
+    one group of k_block_cull (the look-back across groups); a band keeps only part of the blocks.  Image,
+    counts and every tap equal the oracle's, for the full frame forced onto the list and for two bands."""
+    import synth
+    if os.environ.get("GS3D_BLOCK_CULL") == "0" or os.environ.get("GS3D_BLOCK_LIST") == "0":
+        pytest.skip("the list is switched off")
+    g = synth.scene(n, first=77)
+    sh, cov = 2, 0
+    pod = gs.GaussianPod(sh, cov)
+    pods = pod.from_gaussian(g)
+    buf = gs.GaussiansBuffer.new_with_pods(device, pod, pods)
+    order = _mirror_order(ob, buf, stream, sh, cov, pods)
+    W, H = 640, 368
+    tiles_y = H // 16
+    img = gs.Buffer(device, size=W * H * 16)
+    gt, mt = gs.gaussian_transform_pod(sh_deg=2), gs.model_transform_pod()
+    ogt, omt = ob.GaussianTransform.from_buffer_copy(bytes(gt)), ob.ModelTransform.from_buffer_copy(bytes(mt))
+    for band in ((0, tiles_y), (3, 9), (tiles_y - 2, tiles_y)):
+        # a band's first frame takes the list; a whole frame takes it once the previous frame saw less than
+        # half of the Gaussians: the whole-frame case looks through a narrow field of view
+        ocam = helpers.default_camera(ob, W, H, vfov_deg=22.0 if band == (0, tiles_y) else 60.0)
+        cam = helpers.copy_camera(ocam, gs.Camera)
+        r = gs.Renderer(device)
+        for rep in range(2):             # the sizing frame and a steady-state frame
+            fr = r.render(stream, buf, gt, mt, cam, img.device_ptr(), band=band)
+        if n >= 1024:
+            assert fr.launches == r.render(stream, buf, gt, mt, cam, img.device_ptr(), band=band).launches
+        o_proj, o_tiles, _, _, o_skeys, o_sidx, o_ranges, o_rgba = _oracle_frame(ob, sh, cov, pods, ogt, omt, ocam, band, order=order)
+        st = r.stats()
+        assert (st.visible, st.pairs) == (int((o_tiles > 0).sum()), len(o_skeys)), (n, band)
+        g_proj, g_tiles = r.download_projected(n)
+        assert np.array_equal(g_tiles, o_tiles), (n, band)
+        seen = o_tiles > 0
+        assert np.array_equal(g_proj[seen].view(np.uint8), o_proj[seen].view(np.uint8)), (n, band)
+        g_skeys, g_sidx = r.download_sorted()
+        assert np.array_equal(g_skeys, o_skeys) and np.array_equal(g_sidx, o_sidx), (n, band)
+        assert np.array_equal(r.download_ranges((W // 16) * tiles_y), o_ranges), (n, band)
+        got = img.download(stream, np.float32).reshape(H, W, 4)
+        y0, y1 = band[0] * 16, min(band[1] * 16, H)
+        assert np.array_equal(got[y0:y1].view(np.uint32), o_rgba[y0:y1].view(np.uint32)), (n, band)
+        r.destroy()
+    buf.destroy(); img.release()
 
 
 def test_pathological_gaussians_do_not_derail_the_frame(gs, ob, device, stream):

@@ -1441,7 +1441,9 @@ struct FrameShape {
 struct gs_renderer {
     gs_device *dev;
     DevArray recs, depth, rect, sorted_rect, exp_sums, cursors, chunk_tiles, chunk_vis, state, zero_region, scan_tmp, block_list;
-    uint32_t block_list_clean_for = 0;   // frame generation whose blocks_alive counter is known to be zero
+    DevArray cull_status;                 // k_block_cull: one (tag << 10 | count) word per group of 256 blocks
+    bool list_mode = false;               // the last frame's per-slot arrays are in LIST space (k_block_cull ran)
+    uint32_t cull_last_gen = 0, cull_last_groups = 0;   // frame / group count of the last k_block_cull (status tags)
     DevArray dkeys[2], dvals[2];          // (depth bits - bias, mirror slot), capacity N
     DevArray tkeys[2], tvals[2];          // (tile id, mirror slot), capacity pair_capacity
     DevArray ghist, digit_totals;
@@ -1528,7 +1530,7 @@ extern "C" void gs_renderer_destroy(gs_renderer *r) {
     (void)hipSetDevice(r->dev->ordinal);
     if (r->have_frame) (void)hipStreamSynchronize(r->last_stream);   // kernels of the last frame write pinned memory
     DevArray *arrs[] = {&r->recs, &r->depth, &r->rect, &r->sorted_rect, &r->exp_sums, &r->cursors, &r->chunk_tiles, &r->chunk_vis,
-                        &r->state, &r->zero_region, &r->scan_tmp, &r->block_list, &r->dkeys[0], &r->dkeys[1], &r->dvals[0],
+                        &r->state, &r->zero_region, &r->scan_tmp, &r->block_list, &r->cull_status, &r->dkeys[0], &r->dkeys[1], &r->dvals[0],
                         &r->dvals[1], &r->tkeys[0], &r->tkeys[1], &r->tvals[0], &r->tvals[1], &r->ghist,
                         &r->digit_totals};
     for (DevArray *a : arrs) dev_free(*a);
@@ -1738,7 +1740,8 @@ struct SortCompact {
     const uint32_t *dense_keys = nullptr;   // [N] keys by slot, 0xffffffff = culled (read by pass 0 instead of keys[0])
     const uint32_t *chunk_vis = nullptr;
     uint32_t *visible_out = nullptr;
-    uint32_t dense_count = 0;        // N: the first pass runs over all slots
+    uint32_t dense_count = 0;        // N: the first pass runs over all slots (host bound: sizes the grid)
+    const uint32_t *dense_count_dev = nullptr;   // optional device word: the slots that really hold data (list frames)
 };
 
 // Stable LSD radix sort of (key, u32 value) pairs on key bits [0, end_bit), RB bits per pass at
@@ -1820,7 +1823,7 @@ static gs_status run_sort_items(const gs_device *dev, void *const keys[2], void 
         // writes the order only
         K *kout = compact && p == passes - 1 ? (K *)nullptr : (K *)keys[side ^ 1];
         uint32_t *vout = (uint32_t *)vals[side ^ 1];
-        const gs::SortCount psc = first ? gs::SortCount{compact->dense_count, nullptr} : sc;
+        const gs::SortCount psc = first ? gs::SortCount{compact->dense_count, compact->dense_count_dev} : sc;
         const uint32_t pnb = first ? (uint32_t)(((uint64_t)compact->dense_count + TILE - 1) / TILE) : nb;
         if (first) GS_TRY(dev_reserve(ghist, (size_t)pnb * R * 4));
         const uint32_t *cv = first ? compact->chunk_vis : nullptr;
@@ -2313,6 +2316,7 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
     r->last_stream = st;
     r->have_frame = true;
     r->launches = 0;
+    r->list_mode = false;
 
     // depth keys = bits of the (positive) view depth minus the bits of the near plane: every visible
     // depth lies in (near, far), so only bit_length(bits(far) - bits(near)) bits need sorting — a
@@ -2387,20 +2391,30 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
         bool use_list = fc.band_ty1 - fc.band_ty0 < fc.tiles_y;
         if (!sizing && (hist_gen[0] || hist_gen[1])) use_list = hist_v[hist_gen[0] > hist_gen[1] ? 0 : 1] < n / 2u;
         if (block_list_env >= 0) use_list = block_list_env != 0;
+        // the list frame keeps its outputs in list space: list_slots = blocks * 1024 must fit 32 bits, and the
+        // look-back of k_block_cull is written for at most 2^20 groups of 256 blocks
+        if (n > 0xfffff000u) use_list = false;
+        r->list_mode = false;
         if (fc.cull_gain > 0.0f && use_list) {
+            const uint32_t groups = (nchunks + 255u) / 256u;
             GS_TRY(dev_reserve(r->block_list, (size_t)nchunks * 4));
-            // the list length of frame `gen` is counted in blocks_alive[gen & 1], which the k_block_cull of
-            // frame gen - 1 cleared; when that frame did not run one (first frame, other buffer kinds in
-            // between) the pair is cleared here
-            if (r->block_list_clean_for != gen) GS_HIP(hipMemsetAsync(state->blocks_alive, 0, sizeof(state->blocks_alive), st));
-            r->block_list_clean_for = gen + 1u;
-            hipLaunchKernelGGL(gs::k_block_cull, dim3((nchunks + 255u) / 256u), dim3(256), 0, st, (const float *)g->block_bounds,
-                               nchunks, fc, (uint32_t *)r->block_list.ptr, state, gen & 1u, (uint32_t *)r->chunk_tiles.ptr,
-                               (uint32_t *)r->chunk_vis.ptr);
+            GS_TRY(dev_reserve(r->cull_status, (size_t)groups * 4));
+            // Tag of this frame's status words: 22 bits of the generation.  A word must never hold this tag
+            // before its group publishes: consecutive list frames over the same groups overwrite every word
+            // with the previous tag; in every other case (first use, a gap of frames without the list, another
+            // group count) the words are cleared first, and the tag 0 is skipped.
+            const uint32_t tag = (gen & 0x3fffffu) ? (gen & 0x3fffffu) : 0x3fffffu;
+            if (r->cull_last_gen + 1u != gen || r->cull_last_groups != groups || (gen & 0x3fffffu) <= 1u)
+                GS_HIP(hipMemsetAsync(r->cull_status.ptr, 0, (size_t)groups * 4, st));
+            r->cull_last_gen = gen;
+            r->cull_last_groups = groups;
+            hipLaunchKernelGGL(gs::k_block_cull, dim3(groups), dim3(256), 0, st, (const float *)g->block_bounds, nchunks, fc,
+                               (uint32_t *)r->block_list.ptr, state, (uint32_t *)r->cull_status.ptr, tag, groups);
             GS_HIP(hipGetLastError());
             r->launches++;
             po.block_list = (const uint32_t *)r->block_list.ptr;
-            po.block_count = &state->blocks_alive[gen & 1u];
+            po.block_count = &state->list_blocks;
+            r->list_mode = true;
         }
         // GS3D_PRE_PIPELINE=0: the two-phase kernel without the prefetch of the next Gaussian's geometry chunks
         static const bool pre_serial = std::getenv("GS3D_PRE_PIPELINE") && std::getenv("GS3D_PRE_PIPELINE")[0] == '0';
@@ -2414,7 +2428,8 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
         if (sizing) {
             // First frame of this shape: measure D before sizing the pair buffers (the only blocking
             // step; steady-state frames take the capacity from the history instead)
-            gs::ScanJob jt{(const uint32_t *)r->chunk_tiles.ptr, (uint32_t *)r->scan_tmp.ptr, r->host_counters, nchunks};
+            gs::ScanJob jt{(const uint32_t *)r->chunk_tiles.ptr, (uint32_t *)r->scan_tmp.ptr, r->host_counters, nchunks,
+                           r->list_mode ? &state->list_blocks : nullptr};
             hipLaunchKernelGGL(gs::k_scan_chunks, dim3(1), dim3(1024), 0, st, jt, jt);
             GS_HIP(hipGetLastError());
             GS_HIP(hipStreamSynchronize(st));
@@ -2444,6 +2459,7 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
             cp.chunk_vis = (const uint32_t *)r->chunk_vis.ptr;
             cp.visible_out = &state->visible;
             cp.dense_count = n;
+            cp.dense_count_dev = r->list_mode ? &state->list_slots : nullptr;   // list frame: only the surviving blocks' slots
             const gs::SortCount dc{n, &state->visible};
             if (depth_radix_bits(dbits) == (uint32_t)gs::RADIX_BITS_MAX)
                 GS_TRY((run_sort_rb<uint32_t, gs::RADIX_BITS_MAX>(r->dev, k2, v2, r->ghist, r->digit_totals, dc, dbits, &cp,
@@ -2569,16 +2585,47 @@ static gs_status download_sync(gs_renderer *r, void *dst, const void *src, size_
     return GS_OK;
 }
 
-// depth bits of every mirror slot of the last frame (0xffffffff = culled): the dense keys of
-// preprocess plus the key bias; chunks without visible Gaussians may be block-culled and stale
-static gs_status download_slot_depths(gs_renderer *r, std::vector<uint32_t> &depth) {
-    depth.assign(r->n, 0xffffffffu);
+// Which Gaussian every OUTPUT slot of the last frame holds (0xffffffff: none — padding past N).  The
+// per-slot arrays of a frame (records, depth keys, rects, the values of the sorts) are indexed by
+// mirror slot, or — when k_block_cull handed the preprocess kernel its blocks — by LIST slot: list
+// position * 1024 + lane.  Either way the taps translate back to Gaussian indices here: through the
+// block list (if any) and the buffer's mirror order (if any).
+static gs_status download_slot_map(gs_renderer *r, std::vector<uint32_t> &gaussian_of_slot) {
+    gaussian_of_slot.clear();
     if (!r->have_frame || !r->n) return GS_OK;
-    const size_t nchunks = (r->n + gs::PP_CHUNK - 1) / gs::PP_CHUNK;
+    std::vector<uint32_t> order;
+    if (r->last_order) {
+        order.resize(r->n);
+        GS_TRY(download_sync(r, order.data(), r->last_order->ptr, r->n * 4));
+    }
+    if (!r->list_mode) {
+        gaussian_of_slot.resize(r->n);
+        for (size_t slot = 0; slot < r->n; slot++) gaussian_of_slot[slot] = order.empty() ? (uint32_t)slot : order[slot];
+        return GS_OK;
+    }
+    gs::FrameState fs;
+    GS_TRY(download_sync(r, &fs, r->state.ptr, sizeof(fs)));
+    std::vector<uint32_t> list(fs.list_blocks);
+    GS_TRY(download_sync(r, list.data(), r->block_list.ptr, (size_t)fs.list_blocks * 4));
+    gaussian_of_slot.assign((size_t)fs.list_blocks * gs::PP_CHUNK, 0xffffffffu);
+    for (size_t b = 0; b < list.size(); b++)
+        for (size_t l = 0; l < gs::PP_CHUNK; l++) {
+            const size_t slot = (size_t)list[b] * gs::PP_CHUNK + l;
+            if (slot < r->n) gaussian_of_slot[b * gs::PP_CHUNK + l] = order.empty() ? (uint32_t)slot : order[slot];
+        }
+    return GS_OK;
+}
+
+// depth bits of every output slot of the last frame (0xffffffff = culled): the dense keys of
+// preprocess plus the key bias; chunks without visible Gaussians may be block-culled and stale
+static gs_status download_slot_depths(gs_renderer *r, size_t slots, std::vector<uint32_t> &depth) {
+    depth.assign(slots, 0xffffffffu);
+    if (!r->have_frame || !slots) return GS_OK;
+    const size_t nchunks = (slots + gs::PP_CHUNK - 1) / gs::PP_CHUNK;
     std::vector<uint32_t> chunk_vis(nchunks);
-    GS_TRY(download_sync(r, depth.data(), r->depth.ptr, r->n * 4));
+    GS_TRY(download_sync(r, depth.data(), r->depth.ptr, slots * 4));
     GS_TRY(download_sync(r, chunk_vis.data(), r->chunk_vis.ptr, nchunks * 4));
-    for (size_t slot = 0; slot < r->n; slot++) {
+    for (size_t slot = 0; slot < slots; slot++) {
         if (chunk_vis[slot / gs::PP_CHUNK] == 0u) depth[slot] = 0xffffffffu;
         else if (depth[slot] != 0xffffffffu) depth[slot] += r->key_bias;
     }
@@ -2594,12 +2641,18 @@ extern "C" gs_status gs_renderer_download_projected(gs_renderer *r, gs_projected
     GS_TRY(use_device(r->dev));
     static_assert(sizeof(gs_projected) == 48, "record size");
     if (!n) return GS_OK;
-    // the device arrays are indexed by mirror slot; a partial request (n < N) still needs all slots
-    const size_t total = r->n;
-    std::vector<uint32_t> recs(total * gs::REC_WORDS), depth, order;
+    // a Gaussian whose block the list dropped has no slot at all: it is culled
+    if (tiles_out) std::memset(tiles_out, 0, n * sizeof(uint32_t));
+    if (proj_out) std::memset(proj_out, 0, n * sizeof(gs_projected));
+    // the device arrays are indexed by output slot; a partial request (n < N) still needs all slots
+    std::vector<uint32_t> slot_map, depth;
+    GS_TRY(download_slot_map(r, slot_map));
+    const size_t total = slot_map.size();
+    if (!total) return GS_OK;
+    std::vector<uint32_t> recs(total * gs::REC_WORDS);
     std::vector<uint2> rect(total);
     GS_TRY(download_sync(r, recs.data(), r->recs.ptr, total * 4 * gs::REC_WORDS));
-    GS_TRY(download_slot_depths(r, depth));
+    GS_TRY(download_slot_depths(r, total, depth));
     if (r->rect32) {
         std::vector<uint32_t> packed(total);
         GS_TRY(download_sync(r, packed.data(), r->rect.ptr, total * 4));
@@ -2607,12 +2660,8 @@ extern "C" gs_status gs_renderer_download_projected(gs_renderer *r, gs_projected
     } else {
         GS_TRY(download_sync(r, rect.data(), r->rect.ptr, total * 8));
     }
-    if (r->last_order) {
-        order.resize(total);
-        GS_TRY(download_sync(r, order.data(), r->last_order->ptr, total * 4));
-    }
     for (size_t slot = 0; slot < total; slot++) {
-        const size_t i = order.empty() ? slot : order[slot];   // Gaussian index of this slot
+        const size_t i = slot_map[slot];   // Gaussian index of this slot
         if (i >= n) continue;
         // a slot absent from the depth keys is culled (its chunk may even have been block-culled,
         // in which case its per-slot arrays are stale)
@@ -2622,7 +2671,6 @@ extern "C" gs_status gs_renderer_download_projected(gs_renderer *r, gs_projected
         if (tiles_out) tiles_out[i] = vis ? w * h : 0u;
         if (proj_out) {
             gs_projected &p = proj_out[i];
-            std::memset(&p, 0, sizeof(p));
             if (vis) {
                 std::memcpy(&p, &recs[slot * gs::REC_WORDS], 36);
                 std::memcpy(&p.depth, &depth[slot], 4);
@@ -2648,20 +2696,14 @@ extern "C" gs_status gs_renderer_download_sorted(gs_renderer *r, uint64_t *keys_
     if (pairs_out) *pairs_out = d;
     uint64_t m = d < capacity ? d : capacity;
     if (!m) return GS_OK;
-    std::vector<uint32_t> idx(m);   // mirror slots
+    std::vector<uint32_t> idx(m), slot_map;   // output slots of the pairs; slot -> Gaussian
     GS_TRY(download_sync(r, idx.data(), r->tvals[r->tsorted_side].ptr, m * 4));
-    if (idx_out) {
-        if (r->last_order) {
-            std::vector<uint32_t> order(r->n);
-            GS_TRY(download_sync(r, order.data(), r->last_order->ptr, r->n * 4));
-            for (uint64_t j = 0; j < m; j++) idx_out[j] = order[idx[j]];
-        } else {
-            std::memcpy(idx_out, idx.data(), m * 4);
-        }
-    }
+    GS_TRY(download_slot_map(r, slot_map));
+    if (idx_out)
+        for (uint64_t j = 0; j < m; j++) idx_out[j] = slot_map[idx[j]];
     if (keys_out) {
         std::vector<uint32_t> depth;
-        GS_TRY(download_slot_depths(r, depth));
+        GS_TRY(download_slot_depths(r, slot_map.size(), depth));
         if (r->wide_tiles) {
             std::vector<uint32_t> t(m);
             GS_TRY(download_sync(r, t.data(), r->tkeys[r->tsorted_side].ptr, m * 4));

@@ -162,8 +162,10 @@ struct FrameState {
     uint32_t visible;        // V: written by the first depth-sort pass (which also compacts)
     uint32_t pairs;          // min(D, pair capacity): what the tile sort / ranges / blend work on
     uint32_t overflow;       // D exceeded the pair capacity: the blend leaves the image untouched (frame skipped)
-    uint32_t blocks_alive[2];   // [frame parity] length of the block list (k_block_cull); the other entry is cleared for the next frame
-    uint32_t pad[3];
+    uint32_t list_blocks;    // length of the block list (k_block_cull), written by the workgroup that drew the last ticket
+    uint32_t list_slots;     // = list_blocks * 1024: the preprocess outputs of a list frame live in LIST space, [0, list_slots)
+    uint32_t cull_ticket;    // k_block_cull: workgroups take their group of 256 blocks in ticket order; the last ticket resets it
+    uint32_t pad[2];
 };
 constexpr uint32_t FRAME_FLAG_PAIR_OVERFLOW = 1u;   // D exceeded the pair capacity
 constexpr uint32_t FRAME_FLAG_SKIPPED = 2u;         // ... so the frame was skipped: the image was NOT written
@@ -777,7 +779,11 @@ struct PreOut {
     uint32_t zero_words;
     uint32_t key_bias;
     const float *block_bounds;
-    const uint32_t *block_list;      // non-null: workgroup i takes block block_list[i], i < *block_count (k_block_cull ran)
+    const uint32_t *block_list;      // non-null: workgroup i takes block block_list[i], i < *block_count (k_block_cull ran) AND
+                                     // writes its outputs in LIST space: per-slot arrays at i * 1024 + lane, chunk scalars at i.
+                                     // The list is ascending, so list-space order == mirror order among the surviving blocks
+                                     // (ties of the depth sort break the same way), and everything behind this kernel — the
+                                     // compacting depth pass, its histogram, the sizing scan — walks list_slots, not N.
     const uint32_t *block_count;
 };
 
@@ -822,9 +828,11 @@ __device__ __forceinline__ void pre_finish_culled(const PreOut &io) {
 // the depth sort reads the dense keys and simply does not rank the culled ones.
 //
 // What bounds it (tools/mb/mb_rw.hip, 10 M x 224 B on MI355X): the read pattern alone streams at
-// 6.3 TB/s (0.354 ms); every written byte costs about three read bytes, whatever the store
-// pattern — 4 B/Gaussian +0.035 ms, 12 B +0.083 ms, 48 B +0.165 ms as whole-array planes, as one
-// contiguous span per workgroup, staged through LDS and burst out, or as these streams.
+// 6.3 TB/s (0.354 ms).  On the view that culls nothing the two-phase kernel below moves its 2.24 GB
+// of reads + 0.48 GB of writes in 0.45-0.50 ms = 5.4-6.0 TB/s of physical traffic: the mixed
+// read / write ceiling of the part, not a property of the store pattern (rounds 1-2 quoted a
+// "0.52 ms read + write floor" from a microbenchmark whose loads were issued as dependent round
+// trips; withdrawn in round 3).
 // (Tried in round 2 and rejected: compacting the visible (key, slot) pairs here with a decoupled
 // look-back over the workgroups.  The inclusive frontier advances one look-back window per status
 // round trip across the XCDs, and every waiting workgroup keeps its registers: 0.43 -> 0.54 ms with
@@ -907,6 +915,9 @@ __global__ __launch_bounds__(PP_THREADS) void k_preprocess_banded(const uint4 *_
     constexpr int G1 = (cov_word0(SH) + cov_bytes(COV) / 4 - 1) / 4;   // last one
     constexpr int NG = G1 - G0 + 1;
     const uint32_t base = block * PP_CHUNK;
+    // where this workgroup's outputs go: list space when it was handed its block by the list
+    const uint32_t out_chunk = io.block_list ? blockIdx.x : block;
+    const uint32_t obase = out_chunk * PP_CHUNK;
     uint32_t local = 0, local_vis = 0;
     // geometry chunks (position / colour + covariance) of one Gaussian
     auto load_geom = [&](uint32_t i, uint4 &v0, uint4 (&vg)[NG]) {
@@ -981,58 +992,79 @@ __global__ __launch_bounds__(PP_THREADS) void k_preprocess_banded(const uint4 *_
                 }
                 shade_one<SH>(w, fc, d, rec);
             }
+            const uint32_t oi = obase + (i - base);
             if (cnt || !fc.mask_culled_records) {
                 // (the rect of a culled Gaussian is never read: its key says "culled")
-                uint32_t *o = io.recs + (uint64_t)i * REC_WORDS;
+                uint32_t *o = io.recs + (uint64_t)oi * REC_WORDS;
                 *(u32x4_a4 *)(o) = u32x4_a4{rec[0].x, rec[0].y, rec[0].z, rec[0].w};
                 *(u32x4_a4 *)(o + 4) = u32x4_a4{rec[1].x, rec[1].y, rec[1].z, rec[1].w};
                 o[8] = rec[2].x;
-                if (fc.rect32) ((uint32_t *)io.rect)[i] = cnt ? rect_pack32(rec[2].z, rec[2].w) : 0u;
-                else io.rect[i] = make_uint2(rec[2].z, rec[2].w);
+                if (fc.rect32) ((uint32_t *)io.rect)[oi] = cnt ? rect_pack32(rec[2].z, rec[2].w) : 0u;
+                else io.rect[oi] = make_uint2(rec[2].z, rec[2].w);
             }
-            io.depth[i] = cnt ? rec[2].y - io.key_bias : 0xffffffffu;
+            io.depth[oi] = cnt ? rec[2].y - io.key_bias : 0xffffffffu;
             local += cnt;
             local_vis += cnt ? 1u : 0u;
+        } else if (io.block_list) {
+            // the buffer's last, partial block in list space: the lanes past N sit INSIDE [0, list_slots)
+            // and are read by the compacting depth pass — they must say "culled"
+            io.depth[obase + (i - base)] = 0xffffffffu;
         }
     }
-    pre_finish(io, block, local, local_vis, s_red);
+    pre_finish(io, out_chunk, local, local_vis, s_red);
 }
 
 // The block test of a whole frame, one thread per block (instead of 256 threads of every preprocess
-// workgroup testing the same block): the surviving blocks are appended to `list` (a workgroup's 256 blocks
-// stay together and ascending; the order of the workgroups is whatever the atomics make it — every block
-// writes its own slots, so the order changes nothing), culled blocks get their two chunk scalars
-// cleared here.  The list length lives in state->blocks_alive[parity]; the other entry is cleared for
-// the next frame (frames of a renderer run one after the other).
+// workgroup testing the same block).  The surviving blocks are written to `list` in ASCENDING order
+// (round 4): a workgroup tests a group of 256 blocks, publishes its count and adds up the counts of all
+// groups in front of it — a decoupled look-back over one status word per group, (tag << 10) | count
+// written and polled with agent-scope (sc1) accesses; data and tag share the word, so no fence is
+// needed.  Groups are handed out by a TICKET (the order in which workgroups actually start), so a
+// workgroup only ever waits for workgroups that started before it: forward progress does not depend on
+// the dispatch order or on the whole grid being resident.  The workgroup that draws the last ticket
+// resets the ticket for the next frame; the one that owns the last group publishes the list length.
+// Ascending matters because the preprocess kernel writes its outputs in LIST order (PreOut::block_list):
+// list order must be mirror order for the depth sort's ties to break as they do without the list.
 __global__ __launch_bounds__(256) void k_block_cull(const float *__restrict__ bb, uint32_t nblocks, FrameConsts fc,
-                                                    uint32_t *__restrict__ list, FrameState *state, uint32_t parity,
-                                                    uint32_t *__restrict__ chunk_tiles, uint32_t *__restrict__ chunk_vis) {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    bool alive = false;
-    if (i < nblocks) {
-        alive = !block_is_culled(bb + (uint64_t)i * 8u, fc);
-        if (!alive) {
-            chunk_tiles[i] = 0u;
-            chunk_vis[i] = 0u;
-        }
-    }
-    // one atomic per workgroup (same-address atomics serialise in the L2): the workgroup's 256 blocks stay
-    // together and ascending
-    __shared__ uint32_t s_cnt[4];
-    __shared__ uint32_t s_base;
-    const uint64_t m = __ballot(alive);
+                                                    uint32_t *__restrict__ list, FrameState *state,
+                                                    uint32_t *__restrict__ status, uint32_t tag, uint32_t groups) {
+    __shared__ uint32_t s_group, s_cnt[4], s_sum[4];
     const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+    if (threadIdx.x == 0u) {
+        const uint32_t t = atomicAdd(&state->cull_ticket, 1u);
+        if (t + 1u == groups) atomicExch(&state->cull_ticket, 0u);   // every ticket of this launch is out
+        s_group = t;
+    }
+    __syncthreads();
+    const uint32_t g = s_group;
+    const uint32_t i = g * 256u + threadIdx.x;
+    const bool alive = i < nblocks && !block_is_culled(bb + (uint64_t)i * 8u, fc);
+    const uint64_t m = __ballot(alive);
     if (lane == 0u) s_cnt[wid] = (uint32_t)__popcll(m);
     __syncthreads();
-    if (threadIdx.x == 0u) {
-        const uint32_t tot = (s_cnt[0] + s_cnt[1]) + (s_cnt[2] + s_cnt[3]);
-        s_base = tot ? atomicAdd(&state->blocks_alive[parity], tot) : 0u;
+    const uint32_t tot = (s_cnt[0] + s_cnt[1]) + (s_cnt[2] + s_cnt[3]);
+    if (threadIdx.x == 0u) __hip_atomic_store(&status[g], (tag << 10) | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // look back: thread t adds up groups t, t + 256, ... in front of this one (each published by a workgroup
+    // whose ticket is smaller, i.e. one that is already running)
+    uint32_t before = 0;
+    for (uint32_t p = threadIdx.x; p < g; p += 256u) {
+        uint32_t v = __hip_atomic_load(&status[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while ((v >> 10) != tag) {
+            __builtin_amdgcn_s_sleep(2);
+            v = __hip_atomic_load(&status[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        before += v & 1023u;
     }
+    before = wave_reduce_add(before);
+    if (lane == 0u) s_sum[wid] = before;
     __syncthreads();
-    uint32_t base = s_base;
+    uint32_t base = (s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]);
+    if (g + 1u == groups && threadIdx.x == 0u) {
+        state->list_blocks = base + tot;
+        state->list_slots = (base + tot) * (uint32_t)PP_CHUNK;
+    }
     for (uint32_t w = 0; w < wid; w++) base += s_cnt[w];
     if (alive) list[base + mbcnt(m)] = i;
-    if (i == 0u) state->blocks_alive[parity ^ 1u] = 0u;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1045,6 +1077,7 @@ struct ScanJob {
     uint32_t *offsets;   // exclusive prefix per chunk
     uint32_t *total;     // grand total (may point into pinned host memory)
     uint32_t num;
+    const uint32_t *num_dev = nullptr;   // optional device word: the real length (<= num)
 };
 
 __global__ __launch_bounds__(1024) void k_scan_chunks(ScanJob j0, ScanJob j1) {
@@ -1052,7 +1085,11 @@ __global__ __launch_bounds__(1024) void k_scan_chunks(ScanJob j0, ScanJob j1) {
     __shared__ uint32_t s_wave[16];
     __shared__ uint32_t s_carry;
     __shared__ unsigned long long s_total64;   // exact grand total: past 32 bits it is reported as 0xffffffff
-    const ScanJob job = blockIdx.x == 0 ? j0 : j1;
+    ScanJob job = blockIdx.x == 0 ? j0 : j1;
+    if (job.num_dev) {
+        const uint32_t real = *job.num_dev;
+        if (real < job.num) job.num = real;
+    }
     uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
     __shared__ uint32_t s_half[2];
     if (threadIdx.x == 0) {
