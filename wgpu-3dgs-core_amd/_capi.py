@@ -196,6 +196,21 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # GS3D_LIB=<path>: load ANOTHER build of libgs3d_hip.so (tools/build_rev.sh builds one from a git
+    # revision) — same-box A/B runs of two versions of the kernels; never set in production
+    override = os.environ.get("GS3D_LIB")
+    if override:
+        _hiprt.prepare()
+        lib = C.CDLL(override)
+        _hiprt.check()
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name, None)
+            if fn is None:
+                continue                 # an older revision may lack the newest entry points
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+        return lib
     if not os.path.exists(_build.LIB_PATH) or _build.needs_build():
         try:
             _build.build()

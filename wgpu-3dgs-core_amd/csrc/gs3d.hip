@@ -2273,9 +2273,12 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
     }
     mark(ST_PRE);
 
-    GS_TRY(dev_reserve(r->recs, nn * 4 * gs::REC_WORDS + 16));
-    GS_TRY(dev_reserve(r->depth, nn * 4));
-    GS_TRY(dev_reserve(r->rect, nn * 8));
+    // per-slot outputs of preprocess: whole chunks — a list frame addresses them in list space, where the
+    // buffer's last, partial block may sit anywhere and its lanes past N are written too (as "culled")
+    const size_t nslots = nc * (size_t)gs::PP_CHUNK;
+    GS_TRY(dev_reserve(r->recs, nslots * 4 * gs::REC_WORDS + 16));
+    GS_TRY(dev_reserve(r->depth, nslots * 4));
+    GS_TRY(dev_reserve(r->rect, nslots * 8));
     GS_TRY(dev_reserve(r->sorted_rect, (nn + 1024) * 8));   // padded: k_pairs_emit reads whole batches
     GS_TRY(dev_reserve(r->chunk_tiles, nc * 4));
     GS_TRY(dev_reserve(r->chunk_vis, nc * 4));

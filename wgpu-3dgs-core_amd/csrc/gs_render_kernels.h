@@ -954,6 +954,11 @@ __global__ __launch_bounds__(PP_THREADS) void k_preprocess_banded(const uint4 *_
                 if (inext < n) load_geom(inext, v0_next, vg_next);
             }
         }
+        // the key of every lane of the chunk is stored, also past N (the buffer's last, partial block): in
+        // list space those lanes sit INSIDE [0, list_slots) and the compacting depth pass reads them.  ONE
+        // store after the branch — a second store inside it landed between the prefetch loads of the next
+        // Gaussian and made their wait cover it too (stores and loads retire through one in-order counter).
+        uint32_t key = 0xffffffffu;
         if (i < n) {
             uint32_t w[NW];
             if constexpr (!PIPELINED) {
@@ -1002,14 +1007,11 @@ __global__ __launch_bounds__(PP_THREADS) void k_preprocess_banded(const uint4 *_
                 if (fc.rect32) ((uint32_t *)io.rect)[oi] = cnt ? rect_pack32(rec[2].z, rec[2].w) : 0u;
                 else io.rect[oi] = make_uint2(rec[2].z, rec[2].w);
             }
-            io.depth[oi] = cnt ? rec[2].y - io.key_bias : 0xffffffffu;
+            if (cnt) key = rec[2].y - io.key_bias;
             local += cnt;
             local_vis += cnt ? 1u : 0u;
-        } else if (io.block_list) {
-            // the buffer's last, partial block in list space: the lanes past N sit INSIDE [0, list_slots)
-            // and are read by the compacting depth pass — they must say "culled"
-            io.depth[obase + (i - base)] = 0xffffffffu;
         }
+        io.depth[obase + (i - base)] = key;
     }
     pre_finish(io, out_chunk, local, local_vis, s_red);
 }
@@ -1667,7 +1669,13 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
     const bool nt_inputs = (xcd_chunk_nt >> 31) != 0u;
     const uint32_t xcd_chunk = xcd_chunk_nt & 0x7fffffffu;
     const uint32_t block = scatter_tile_of(blockIdx.x, xcd_chunk);
-    if (block >= live_tiles) return;
+    if (block >= live_tiles) {
+        // a list frame whose list is empty (every block culled) has no tile at all: V = 0 must still be
+        // published, or the frame state keeps the previous frame's count
+        if constexpr (COMPACT)
+            if (live_tiles == 0u && blockIdx.x == 0u && tid == 0u) *visible_out = 0u;
+        return;
+    }
     scatter_clear(sh);
 
     const uint32_t tile_base = block * TILE;
