@@ -44,7 +44,7 @@ def main():
                 rows.append((name, j))
                 st = j["stages_ms"]
                 print("%-5s %-14s ms/step %.4f  median %.4f | %s" % (
-                    wl, name, j["ms_per_step"], (j.get("frame_ms") or {}).get("median", 0.0),
+                    wl, name, j["ms_per_step"], j.get("frame_ms_median") or (j.get("frame_ms") or {}).get("median", 0.0),
                     " ".join("%s %.4f" % (k[:6], v) for k, v in st.items() if k not in ("repack", "scan", "frame"))), flush=True)
     return 0
 

@@ -1442,6 +1442,7 @@ struct gs_renderer {
     gs_device *dev;
     DevArray recs, depth, rect, sorted_rect, exp_sums, cursors, chunk_tiles, chunk_vis, state, zero_region, scan_tmp, block_list;
     DevArray cull_status;                 // k_block_cull: one (tag << 10 | count) word per group of 256 blocks
+    DevArray chunk_hist;                  // [chunks][256] first-digit histogram of every chunk's depth keys (PreOut::chunk_hist)
     bool list_mode = false;               // the last frame's per-slot arrays are in LIST space (k_block_cull ran)
     uint32_t cull_last_gen = 0, cull_last_groups = 0;   // frame / group count of the last k_block_cull (status tags)
     DevArray dkeys[2], dvals[2];          // (depth bits - bias, mirror slot), capacity N
@@ -1530,7 +1531,7 @@ extern "C" void gs_renderer_destroy(gs_renderer *r) {
     (void)hipSetDevice(r->dev->ordinal);
     if (r->have_frame) (void)hipStreamSynchronize(r->last_stream);   // kernels of the last frame write pinned memory
     DevArray *arrs[] = {&r->recs, &r->depth, &r->rect, &r->sorted_rect, &r->exp_sums, &r->cursors, &r->chunk_tiles, &r->chunk_vis,
-                        &r->state, &r->zero_region, &r->scan_tmp, &r->block_list, &r->cull_status, &r->dkeys[0], &r->dkeys[1], &r->dvals[0],
+                        &r->state, &r->zero_region, &r->scan_tmp, &r->block_list, &r->cull_status, &r->chunk_hist, &r->dkeys[0], &r->dkeys[1], &r->dvals[0],
                         &r->dvals[1], &r->tkeys[0], &r->tkeys[1], &r->tvals[0], &r->tvals[1], &r->ghist,
                         &r->digit_totals};
     for (DevArray *a : arrs) dev_free(*a);
@@ -1734,6 +1735,14 @@ static uint32_t depth_radix_bits(uint32_t key_bits) {
     return (key_bits + 8) / 9 < (key_bits + 7) / 8 ? (uint32_t)gs::RADIX_BITS_MAX : (uint32_t)gs::RADIX_BITS;
 }
 
+// mask of the FIRST digit of a sort of `key_bits` bits in passes of at most `rb` bits (the balanced widths of
+// run_sort_items: 27 bits -> 9 + 9 + 9, 13 -> 7 + 6); the preprocess kernel counts that digit per chunk
+static uint32_t first_digit_mask(uint32_t key_bits, uint32_t rb) {
+    const uint32_t passes = (key_bits + rb - 1) / rb;
+    const uint32_t bits = passes ? (key_bits + passes - 1) / passes : 0u;
+    return (1u << bits) - 1u;
+}
+
 // The frame's compacting first pass (see gs_render_kernels.h, COMPACT): dense keys in, the index is
 // the value, chunks without visible Gaussians are skipped, V comes out in *visible_out.
 struct SortCompact {
@@ -1742,6 +1751,7 @@ struct SortCompact {
     uint32_t *visible_out = nullptr;
     uint32_t dense_count = 0;        // N: the first pass runs over all slots (host bound: sizes the grid)
     const uint32_t *dense_count_dev = nullptr;   // optional device word: the slots that really hold data (list frames)
+    const uint32_t *chunk_hist = nullptr;        // per-chunk histogram of the first digit, counted by the preprocess kernel
 };
 
 // Stable LSD radix sort of (key, u32 value) pairs on key bits [0, end_bit), RB bits per pass at
@@ -1785,11 +1795,24 @@ static void launch_scatter(const gs_device *dev, hipStream_t st, uint32_t sgrid,
 template <typename KI, typename KO, int RB, bool COMPACT, int ITEMS>
 static void launch_pass(const gs_device *dev, hipStream_t st, uint32_t sgrid, const KI *kin, const uint32_t *vin, KO *kout,
                         uint32_t ko_shift, uint32_t *vout, gs::SortCount psc, uint32_t shift, uint32_t digit_mask, DevArray &ghist,
-                        DevArray &digit_totals, const uint32_t *cv, uint32_t *vo, uint32_t pnb, uint32_t xr) {
+                        DevArray &digit_totals, const uint32_t *cv, uint32_t *vo, uint32_t pnb, uint32_t xr,
+                        const uint32_t *chunk_hist = nullptr) {
     constexpr uint32_t R = 1u << RB;
     constexpr int TILE = gs::SORT_THREADS * ITEMS;
-    hipLaunchKernelGGL((gs::k_sort_hist<KI, RB, COMPACT, ITEMS>), dim3(sgrid), dim3(gs::SORT_THREADS), 0, st, kin, psc, shift,
-                       digit_mask, (uint32_t *)ghist.ptr, cv, pnb, xr);
+    // GS3D_CHUNK_HIST=0: the compacting pass counts its histogram from the keys again (A/B, tests)
+    static const bool chunk_hist_off = std::getenv("GS3D_CHUNK_HIST") && std::getenv("GS3D_CHUNK_HIST")[0] == '0';
+    bool summed = false;
+    if constexpr (COMPACT && TILE % gs::PP_CHUNK == 0) {
+        if (chunk_hist && !chunk_hist_off) {
+            // the preprocess kernel counted this digit per chunk: sum the chunks' rows instead of re-reading the keys
+            hipLaunchKernelGGL((gs::k_sort_hist_chunks<RB, ITEMS>), dim3(sgrid), dim3(gs::SORT_THREADS), 0, st, chunk_hist, psc,
+                               (uint32_t *)ghist.ptr, cv, pnb, xr);
+            summed = true;
+        }
+    }
+    if (!summed)
+        hipLaunchKernelGGL((gs::k_sort_hist<KI, RB, COMPACT, ITEMS>), dim3(sgrid), dim3(gs::SORT_THREADS), 0, st, kin, psc, shift,
+                           digit_mask, (uint32_t *)ghist.ptr, cv, pnb, xr);
     launch_scan_rows<TILE>(R, st, (uint32_t *)ghist.ptr, pnb, psc, (uint32_t *)digit_totals.ptr);
     launch_scatter<KI, KO, RB, COMPACT, ITEMS>(dev, st, sgrid, kin, vin, kout, ko_shift, vout, psc, shift, digit_mask,
                                                (const uint32_t *)ghist.ptr, (const uint32_t *)digit_totals.ptr, cv, vo, pnb, xr);
@@ -1870,12 +1893,14 @@ static gs_status run_sort_items(const gs_device *dev, void *const keys[2], void 
                 const uint32_t next_shift = shift + bits;
                 if (first)
                     launch_pass<uint32_t, uint16_t, RB, true, ITEMS>(dev, st, sgrid, (const uint32_t *)kin, vin, (uint16_t *)keys[side ^ 1],
-                                                                     next_shift, vout, psc, shift, digit_mask, ghist, digit_totals, cv, vo, pnb, xr);
+                                                                     next_shift, vout, psc, shift, digit_mask, ghist, digit_totals, cv, vo, pnb, xr,
+                                                                     compact->chunk_hist);
                 else
                     launch_pass<uint32_t, uint16_t, RB, false, ITEMS>(dev, st, sgrid, (const uint32_t *)kin, vin, (uint16_t *)keys[side ^ 1],
                                                                       next_shift, vout, psc, shift, digit_mask, ghist, digit_totals, cv, vo, pnb, xr);
             } else if (first) {
-                launch_pass<K, K, RB, true, ITEMS>(dev, st, sgrid, kin, vin, kout, 0u, vout, psc, shift, digit_mask, ghist, digit_totals, cv, vo, pnb, xr);
+                launch_pass<K, K, RB, true, ITEMS>(dev, st, sgrid, kin, vin, kout, 0u, vout, psc, shift, digit_mask, ghist, digit_totals, cv, vo, pnb, xr,
+                                                   compact->chunk_hist);
             } else {
                 launch_pass<K, K, RB, false, ITEMS>(dev, st, sgrid, kin, vin, kout, 0u, vout, psc, shift, digit_mask, ghist, digit_totals, cv, vo, pnb, xr);
             }
@@ -2282,6 +2307,7 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
     GS_TRY(dev_reserve(r->sorted_rect, (nn + 1024) * 8));   // padded: k_pairs_emit reads whole batches
     GS_TRY(dev_reserve(r->chunk_tiles, nc * 4));
     GS_TRY(dev_reserve(r->chunk_vis, nc * 4));
+    GS_TRY(dev_reserve(r->chunk_hist, nc * (size_t)gs::PP_THREADS * 4));
     GS_TRY(dev_reserve(r->scan_tmp, nc * 4));
     for (int i = 0; i < 2; i++) {
         GS_TRY(dev_reserve(r->dkeys[i], nn * 4));
@@ -2382,6 +2408,8 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
         po.zero_words = (uint32_t)(ranges_words + esb_words);
         po.key_bias = near_bits;
         po.block_bounds = (const float *)g->block_bounds;
+        po.chunk_hist = (uint32_t *)r->chunk_hist.ptr;
+        po.digit_mask = first_digit_mask(dbits, depth_radix_bits(dbits));
         po.block_list = nullptr;
         po.block_count = nullptr;
         // Block list (k_block_cull): one thread per block tests it, the survivors are handed to the first
@@ -2463,6 +2491,7 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
             cp.visible_out = &state->visible;
             cp.dense_count = n;
             cp.dense_count_dev = r->list_mode ? &state->list_slots : nullptr;   // list frame: only the surviving blocks' slots
+            cp.chunk_hist = (const uint32_t *)r->chunk_hist.ptr;
             const gs::SortCount dc{n, &state->visible};
             if (depth_radix_bits(dbits) == (uint32_t)gs::RADIX_BITS_MAX)
                 GS_TRY((run_sort_rb<uint32_t, gs::RADIX_BITS_MAX>(r->dev, k2, v2, r->ghist, r->digit_totals, dc, dbits, &cp,

@@ -785,17 +785,29 @@ struct PreOut {
                                      // (ties of the depth sort break the same way), and everything behind this kernel — the
                                      // compacting depth pass, its histogram, the sizing scan — walks list_slots, not N.
     const uint32_t *block_count;
+    uint32_t *chunk_hist;            // [chunks][256] words: histogram of the chunk's keys on the FIRST digit of the depth
+                                     // sort (low `digit_mask` bits), two 16-bit counts per word (a chunk holds <= 1024 keys).
+                                     // Counted here, where the keys sit in registers: the compacting pass's histogram
+                                     // kernel then sums 1 KB rows instead of re-reading 4 KB of keys per chunk.
+    uint32_t digit_mask;
 };
+constexpr int PRE_HIST_BINS = 1 << 9;   // RADIX_BITS_MAX bins
 
 // this workgroup's share of the per-frame clear job
 __device__ __forceinline__ void pre_begin(const PreOut &io) {
     for (uint32_t i = blockIdx.x * PP_THREADS + threadIdx.x; i < io.zero_words; i += gridDim.x * PP_THREADS)
         io.zero_ptr[i] = 0u;
 }
+// a workgroup that is going to project Gaussians clears its digit histogram first
+__device__ __forceinline__ void pre_hist_clear(uint32_t *s_dhist) {
+#pragma unroll
+    for (int q = 0; q < PRE_HIST_BINS / PP_THREADS; q++) s_dhist[threadIdx.x + q * PP_THREADS] = 0u;
+    __syncthreads();
+}
 
 // per-chunk sums (tiles touched, visible count)
 __device__ __forceinline__ void pre_finish(const PreOut &io, uint32_t block, uint32_t local_tiles, uint32_t local_vis,
-                                           uint32_t *s_red) {
+                                           uint32_t *s_red, const uint32_t *s_dhist) {
     local_tiles = wave_reduce_add(local_tiles);
     local_vis = wave_reduce_add(local_vis);
     const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
@@ -808,6 +820,9 @@ __device__ __forceinline__ void pre_finish(const PreOut &io, uint32_t block, uin
         io.chunk_tiles[block] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
         io.chunk_vis[block] = (s_red[4] + s_red[5]) + (s_red[6] + s_red[7]);
     }
+    // the chunk's digit histogram (every LDS atomic of the workgroup is behind the barrier above): 1 KB, coalesced
+    static_assert(PRE_HIST_BINS == 2 * PP_THREADS, "two bins per thread");
+    io.chunk_hist[(uint64_t)block * PP_THREADS + threadIdx.x] = s_dhist[2u * threadIdx.x] | (s_dhist[2u * threadIdx.x + 1u] << 16);
 }
 
 // whole block provably invisible: nothing is read, nothing is written but the two chunk scalars
@@ -841,11 +856,13 @@ template <int SH, int COV, bool NT = false>
 __global__ __launch_bounds__(PP_THREADS) void k_preprocess(const uint4 *__restrict__ planar, uint32_t n,
                                                            FrameConsts fc, PreOut io) {
     __shared__ uint32_t s_red[8];
+    __shared__ uint32_t s_dhist[PRE_HIST_BINS];
     pre_begin(io);
     if (fc.cull_gain > 0.0f && block_is_culled(io.block_bounds + (uint64_t)blockIdx.x * 8u, fc)) {
         pre_finish_culled(io);
         return;
     }
+    pre_hist_clear(s_dhist);
     constexpr int NW = pod_words(SH, COV);
     constexpr int NC = NW / 4;
     const uint32_t base = blockIdx.x * PP_CHUNK;
@@ -877,14 +894,16 @@ __global__ __launch_bounds__(PP_THREADS) void k_preprocess(const uint4 *__restri
             *(u32x4_a4 *)(o) = u32x4_a4{rec[0].x, rec[0].y, rec[0].z, rec[0].w};
             *(u32x4_a4 *)(o + 4) = u32x4_a4{rec[1].x, rec[1].y, rec[1].z, rec[1].w};
             o[8] = rec[2].x;
-            io.depth[i] = cnt ? rec[2].y - io.key_bias : 0xffffffffu;
+            const uint32_t key = cnt ? rec[2].y - io.key_bias : 0xffffffffu;
+            io.depth[i] = key;
+            if (cnt) atomicAdd(&s_dhist[key & io.digit_mask], 1u);
             if (fc.rect32) ((uint32_t *)io.rect)[i] = cnt ? rect_pack32(rec[2].z, rec[2].w) : 0u;
             else io.rect[i] = cnt ? make_uint2(rec[2].z, rec[2].w) : make_uint2(0u, 0u);
             local += cnt;
             local_vis += cnt ? 1u : 0u;
         }
     }
-    pre_finish(io, blockIdx.x, local, local_vis, s_red);
+    pre_finish(io, blockIdx.x, local, local_vis, s_red, s_dhist);
 }
 
 // Two-phase variant for records with SH: phase 1 loads only the chunks that hold position, colour
@@ -896,6 +915,7 @@ template <int SH, int COV, bool PIPELINED = true, bool NT = false>
 __global__ __launch_bounds__(PP_THREADS) void k_preprocess_banded(const uint4 *__restrict__ planar, uint32_t n,
                                                                   FrameConsts fc, PreOut io) {
     __shared__ uint32_t s_red[8];
+    __shared__ uint32_t s_dhist[PRE_HIST_BINS];
     pre_begin(io);
     uint32_t block = blockIdx.x;
     if (io.block_list) {
@@ -909,6 +929,7 @@ __global__ __launch_bounds__(PP_THREADS) void k_preprocess_banded(const uint4 *_
         pre_finish_culled(io);
         return;
     }
+    pre_hist_clear(s_dhist);
     constexpr int NW = pod_words(SH, COV);
     constexpr int NC = NW / 4;
     constexpr int G0 = cov_word0(SH) / 4;                              // first chunk holding covariance words
@@ -1007,13 +1028,16 @@ __global__ __launch_bounds__(PP_THREADS) void k_preprocess_banded(const uint4 *_
                 if (fc.rect32) ((uint32_t *)io.rect)[oi] = cnt ? rect_pack32(rec[2].z, rec[2].w) : 0u;
                 else io.rect[oi] = make_uint2(rec[2].z, rec[2].w);
             }
-            if (cnt) key = rec[2].y - io.key_bias;
+            if (cnt) {
+                key = rec[2].y - io.key_bias;
+                atomicAdd(&s_dhist[key & io.digit_mask], 1u);
+            }
             local += cnt;
             local_vis += cnt ? 1u : 0u;
         }
         io.depth[obase + (i - base)] = key;
     }
-    pre_finish(io, out_chunk, local, local_vis, s_red);
+    pre_finish(io, out_chunk, local, local_vis, s_red, s_dhist);
 }
 
 // The block test of a whole frame, one thread per block (instead of 256 threads of every preprocess
@@ -1386,6 +1410,44 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_hist(const K *__restrict_
 #pragma unroll
         for (int c = 0; c < COPIES; c++) sum += s_hist[c][digit];
         ghist[(uint64_t)digit * num_blocks + block] = sum;
+    }
+}
+
+// The histogram of the frame's COMPACTING first pass without touching the keys: the preprocess kernel
+// counted the first digit per 1024-slot chunk while the keys were in its registers (PreOut::chunk_hist, two
+// 16-bit counts per word, 1 KB per chunk); a tile of the pass is TILE / 1024 whole chunks, so its row entries
+// are the sums of that many 1 KB rows.  Same output and same workgroup -> tile order as k_sort_hist<.., COMPACT>
+// (which read 4 KB of keys per chunk behind 1024 LDS atomics: 21 us at 10 M, 95 us at 50 M).  Chunks whose
+// visible count is 0 may be block-culled: their rows are stale and skipped, like their keys.
+template <int RB, int ITEMS>
+__global__ __launch_bounds__(SORT_THREADS) void k_sort_hist_chunks(const uint32_t *__restrict__ chunk_hist, SortCount sc,
+                                                                   uint32_t *__restrict__ ghist,
+                                                                   const uint32_t *__restrict__ chunk_vis, uint32_t num_blocks,
+                                                                   uint32_t xcd_chunk) {
+    constexpr uint32_t TILE = SORT_THREADS * ITEMS;
+    constexpr uint32_t C = TILE / PP_CHUNK;
+    constexpr uint32_t R = 1u << RB;
+    static_assert(TILE % PP_CHUNK == 0 && SORT_THREADS == PP_THREADS && R <= (uint32_t)PRE_HIST_BINS, "whole chunks per tile");
+    const uint32_t count = sc.get();
+    const uint32_t block = scatter_tile_of(blockIdx.x, xcd_chunk);
+    if ((uint64_t)block * TILE >= count) return;
+    const uint32_t chunk0 = block * C;
+    const uint32_t live = (uint32_t)(((uint64_t)count - (uint64_t)block * TILE + PP_CHUNK - 1) / PP_CHUNK);   // chunks of this tile that hold slots
+    uint32_t w[C];
+    bool ok[C];
+#pragma unroll
+    for (uint32_t c = 0; c < C; c++) ok[c] = c < live && chunk_vis[chunk0 + (c < live ? c : 0u)] != 0u;
+#pragma unroll
+    for (uint32_t c = 0; c < C; c++) w[c] = chunk_hist[(uint64_t)(chunk0 + (ok[c] ? c : 0u)) * SORT_THREADS + threadIdx.x];
+    uint32_t lo = 0, hi = 0;
+#pragma unroll
+    for (uint32_t c = 0; c < C; c++) {
+        lo += ok[c] ? w[c] & 0xffffu : 0u;
+        hi += ok[c] ? w[c] >> 16 : 0u;
+    }
+    if (2u * threadIdx.x < R) {
+        ghist[(uint64_t)(2u * threadIdx.x) * num_blocks + block] = lo;
+        ghist[(uint64_t)(2u * threadIdx.x + 1u) * num_blocks + block] = hi;
     }
 }
 
@@ -2753,6 +2815,11 @@ __global__ __launch_bounds__(BLEND_THREADS) void k_blend_grouped(const uint32_t 
             p0 = d2.x <= 2.25f && BREC.y <= 0.0f; /* the null record carries pmin = 1 */                      \
             p1 = d2.y <= 2.25f && BREC.y <= 0.0f;                                                             \
         } else {                                                                                              \
+            /* "power >= pmin" (pmin = -ln(255 opacity) - 1e-3 >= -5.6) is more than a pre-test of          */ \
+            /* "alpha >= 1/255": it is the DOMAIN GUARD of the exp below (the integer-add ldexp is only      */ \
+            /* valid for arguments in [-5.6, 0]; finished pixels are parked at y = 1e15, power = -1e30), and */ \
+            /* the any-lane branch it feeds skips most steps of a deep tile, whose pixels are long finished: */ \
+            /* round 4 removed both for one build — wrong pixels, and the 10 M blend 0.157 -> 1.80 ms.       */ \
             p0 = power.x <= 0.0f && power.x >= BREC.y;                                                        \
             p1 = power.y <= 0.0f && power.y >= BREC.y;                                                        \
         }                                                                                                     \
