@@ -1806,14 +1806,15 @@ static void launch_pass(const gs_device *dev, hipStream_t st, uint32_t sgrid, co
         if (chunk_hist && !chunk_hist_off) {
             // the preprocess kernel counted this digit per chunk: sum the chunks' rows instead of re-reading the keys
             hipLaunchKernelGGL((gs::k_sort_hist_chunks<RB, ITEMS>), dim3(sgrid), dim3(gs::SORT_THREADS), 0, st, chunk_hist, psc,
-                               (uint32_t *)ghist.ptr, cv, pnb, xr);
+                               digit_mask, (uint32_t *)ghist.ptr, cv, pnb, xr);
             summed = true;
         }
     }
     if (!summed)
         hipLaunchKernelGGL((gs::k_sort_hist<KI, RB, COMPACT, ITEMS>), dim3(sgrid), dim3(gs::SORT_THREADS), 0, st, kin, psc, shift,
                            digit_mask, (uint32_t *)ghist.ptr, cv, pnb, xr);
-    launch_scan_rows<TILE>(R, st, (uint32_t *)ghist.ptr, pnb, psc, (uint32_t *)digit_totals.ptr);
+    (void)R;
+    launch_scan_rows<TILE>(digit_mask + 1u, st, (uint32_t *)ghist.ptr, pnb, psc, (uint32_t *)digit_totals.ptr);   // live rows only
     launch_scatter<KI, KO, RB, COMPACT, ITEMS>(dev, st, sgrid, kin, vin, kout, ko_shift, vout, psc, shift, digit_mask,
                                                (const uint32_t *)ghist.ptr, (const uint32_t *)digit_totals.ptr, cv, vo, pnb, xr);
 }
@@ -1875,7 +1876,7 @@ static gs_status run_sort_items(const gs_device *dev, void *const keys[2], void 
                 else
                     hipLaunchKernelGGL((gs::k_pairs_emit<K, RB, ITEMS, false>), dim3(sgrid), dim3(gs::SORT_THREADS), 0, st, src,
                                        digit_mask, (uint32_t *)ghist.ptr, (K *)keys[side], pnb, xr);
-                launch_scan_rows<(int)TILE>(R, st, (uint32_t *)ghist.ptr, pnb, psc, (uint32_t *)digit_totals.ptr);
+                launch_scan_rows<(int)TILE>(digit_mask + 1u, st, (uint32_t *)ghist.ptr, pnb, psc, (uint32_t *)digit_totals.ptr);
                 launch_scatter<K, K, RB, false, ITEMS>(dev, st, sgrid, kin, vin, kout, 0u, vout, psc, shift, digit_mask,
                                                        (const uint32_t *)ghist.ptr, (const uint32_t *)digit_totals.ptr, cv, vo, pnb, xr);
             }

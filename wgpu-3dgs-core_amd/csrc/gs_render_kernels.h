@@ -1403,13 +1403,21 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_hist(const K *__restrict_
         }
     }
     __syncthreads();
+    // only the LIVE rows (digits that can occur: digit <= digit_mask) are written, scanned and read — a pass
+    // of 6 bits run by the 8-bit instantiation used to write, scan and read 256 rows, 192 of them all zero.
+    // (All sums first, then the stores: with each store next to its sum hipcc waited for the first store
+    // to complete before the LDS reads of the second.)
+    uint32_t sum[DPT];
+#pragma unroll
+    for (int q = 0; q < DPT; q++) {
+        sum[q] = 0;
+#pragma unroll
+        for (int c = 0; c < COPIES; c++) sum[q] += s_hist[c][threadIdx.x + q * SORT_THREADS];
+    }
 #pragma unroll
     for (int q = 0; q < DPT; q++) {
         const uint32_t digit = threadIdx.x + q * SORT_THREADS;
-        uint32_t sum = 0;
-#pragma unroll
-        for (int c = 0; c < COPIES; c++) sum += s_hist[c][digit];
-        ghist[(uint64_t)digit * num_blocks + block] = sum;
+        if (digit <= digit_mask) ghist[(uint64_t)digit * num_blocks + block] = sum[q];
     }
 }
 
@@ -1421,7 +1429,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_hist(const K *__restrict_
 // visible count is 0 may be block-culled: their rows are stale and skipped, like their keys.
 template <int RB, int ITEMS>
 __global__ __launch_bounds__(SORT_THREADS) void k_sort_hist_chunks(const uint32_t *__restrict__ chunk_hist, SortCount sc,
-                                                                   uint32_t *__restrict__ ghist,
+                                                                   uint32_t digit_mask, uint32_t *__restrict__ ghist,
                                                                    const uint32_t *__restrict__ chunk_vis, uint32_t num_blocks,
                                                                    uint32_t xcd_chunk) {
     constexpr uint32_t TILE = SORT_THREADS * ITEMS;
@@ -1445,9 +1453,9 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_hist_chunks(const uint32_
         lo += ok[c] ? w[c] & 0xffffu : 0u;
         hi += ok[c] ? w[c] >> 16 : 0u;
     }
-    if (2u * threadIdx.x < R) {
+    if (2u * threadIdx.x <= digit_mask) {     // live rows only (k_sort_hist); the mask is 2^b - 1: row 2t + 1 is live with row 2t
         ghist[(uint64_t)(2u * threadIdx.x) * num_blocks + block] = lo;
-        ghist[(uint64_t)(2u * threadIdx.x + 1u) * num_blocks + block] = hi;
+        if (digit_mask) ghist[(uint64_t)(2u * threadIdx.x + 1u) * num_blocks + block] = hi;
     }
 }
 
@@ -1646,15 +1654,26 @@ __device__ __forceinline__ void scatter_ranked(ScatterShared<K, RB, ITEMS> &sh, 
         uint32_t tot[DPT], mine = 0;
 #pragma unroll
         for (int q = 0; q < DPT; q++) {
-            tot[q] = digit_totals[tid * DPT + q];
+            // rows past the digit mask do not exist this pass (nobody wrote, scanned or totalled them): the load
+            // goes to a clamped row and is masked afterwards — no branch around it (a load behind a branch gets
+            // its own s_waitcnt: DESIGN.md §4.2)
+            const uint32_t d = tid * DPT + q;
+            const uint32_t t = digit_totals[d <= digit_mask ? d : digit_mask];
+            tot[q] = d <= digit_mask ? t : 0u;
             mine += tot[q];
+        }
+        uint32_t gh[DPT];
+#pragma unroll
+        for (int q = 0; q < DPT; q++) {
+            const uint32_t d = tid * DPT + q;
+            gh[q] = ghist[(uint64_t)(d <= digit_mask ? d : digit_mask) * num_blocks + block];
         }
         uint32_t all;
         uint32_t digit_base = block_exclusive_scan_256(mine, s_scan, all);
 #pragma unroll
         for (int q = 0; q < DPT; q++) {
             const uint32_t digit = tid * DPT + q;
-            s_delta[digit] = digit_base + ghist[(uint64_t)digit * num_blocks + block] - bin0[q];
+            s_delta[digit] = digit_base + (digit <= digit_mask ? gh[q] : 0u) - bin0[q];
             digit_base += tot[q];
         }
         if constexpr (COMPACT)
@@ -2188,13 +2207,17 @@ __global__ __launch_bounds__(SORT_THREADS) void k_pairs_emit(ExpandIO io, uint32
         }
     }
     __syncthreads();
+    uint32_t sum[DPT];
+#pragma unroll
+    for (int q = 0; q < DPT; q++) {
+        sum[q] = 0;
+#pragma unroll
+        for (int c = 0; c < COPIES; c++) sum[q] += s_hist[c][threadIdx.x + q * SORT_THREADS];
+    }
 #pragma unroll
     for (int q = 0; q < DPT; q++) {
         const uint32_t digit = threadIdx.x + q * SORT_THREADS;
-        uint32_t sum = 0;
-#pragma unroll
-        for (int c = 0; c < COPIES; c++) sum += s_hist[c][digit];
-        ghist[(uint64_t)digit * num_blocks + block] = sum;
+        if (digit <= digit_mask) ghist[(uint64_t)digit * num_blocks + block] = sum[q];   // live rows only (k_sort_hist)
     }
 }
 
