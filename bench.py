@@ -310,6 +310,12 @@ def stage_models(wl, res):
     else:
         models["ranges"] = (d * tkey + tiles * 8, "k_tile_ranges: D keys read, tile ranges written")
     out = {}
+    in_blend = os.environ.get("GS3D_RANGES_IN_BLEND")
+    if (in_blend == "1") if in_blend in ("0", "1") else tiles > 16384:     # gs3d.hip: the rule that picks the range path
+        # the blend workgroups find their own range (blend_tile_range): there is no range kernel to price
+        models.pop("ranges")
+        out["ranges"] = dict(bound="fused", ms=st["ranges"], note="tile ranges are found by the blend workgroups themselves "
+                             "(32-ary search per tile inside k_blend_grouped); no launch, no stage of its own")
     for k, (b, what) in models.items():
         ms = st[k]
         gbs = b / (ms * 1e-3) / 1e9 if ms > 0 else 0.0

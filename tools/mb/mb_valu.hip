@@ -29,6 +29,16 @@ __global__ __launch_bounds__(256) void k(float *out, int iters, float seed) {
             if constexpr (KIND == 7) asm volatile("v_exp_f32 %0, %0" : "+v"(a[i]));
             if constexpr (KIND == 8) asm volatile("v_cmp_ge_f32 s[20:21], %0, %1\n\ts_and_b64 s[22:23], s[20:21], s[22:23]" : : "v"(a[i]), "v"(c0) : "s20", "s21", "s22", "s23", "scc");   // s_and_b64 writes SCC: undeclared, it broke the loop branch
             if constexpr (KIND == 9) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[i]) : "v"(f32x2{c0, c0}));
+            // round 4: the remaining classes of k_blend_grouped<0,4>'s step (tools/blend_table.py prices the loop with these)
+            if constexpr (KIND == 10) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(a[i]) : "v"(c0));
+            if constexpr (KIND == 11) asm volatile("v_cmp_ge_f32 s[20:21], %0, %1" : : "v"(a[i]), "v"(c0) : "s20", "s21");
+            if constexpr (KIND == 12) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(c0));
+            if constexpr (KIND == 13) asm volatile("v_mov_b64 %0, %1" : "=v"(p[i]) : "v"(p[(i + 1) % UNROLL]));
+            if constexpr (KIND == 14) asm volatile("v_and_b32 %0, 0xffff, %0" : "+v"(a[i]));
+            if constexpr (KIND == 15) asm volatile("v_cmp_ge_f32 vcc, %0, %1" : : "v"(a[i]), "v"(c0) : "vcc");
+            // one DEPENDENT chain per thread, as the exp polynomial of the blend step is: pk_fma -> s_nop 0 -> pk_fma ...
+            if constexpr (KIND == 16) asm volatile("v_pk_fma_f32 %0, %0, %1, %2\n\ts_nop 0" : "+v"(p[0]) : "v"(f32x2{c0, c0}), "v"(f32x2{c1, c1}));
+            if constexpr (KIND == 17) asm volatile("v_pk_fma_f32 %0, %0, %1, %2 op_sel_hi:[1,0,0]" : "+v"(p[i]) : "s"(f32x2{c0, c0}), "v"(f32x2{c1, c1}));
         }
     }
     float s = 0;
@@ -42,7 +52,7 @@ static void run(const char *name, int instr_per_item) {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const int iters = 4096;
     printf("%-34s", name);
-    for (int wps : {1, 2, 4, 8}) {               // waves per SIMD: blocks of 256 threads = 1 wave per SIMD each
+    for (int wps : {1, 2, 4, 7, 8}) {            // waves per SIMD: blocks of 256 threads = 1 wave per SIMD each (the blend runs at 7)
         const int blocks = 256 * wps;
         hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(256), 0, 0, out, 16, 1.0f);
         CK(hipDeviceSynchronize());
@@ -95,6 +105,14 @@ int main(int argc, char **argv) {
     run<6>("v_lshl_add_u32", 1);
     run<7>("v_exp_f32", 1);
     run<8>("v_cmp -> sgpr + s_and_b64 (2)", 2);
+    run<10>("v_sub_f32", 1);
+    run<11>("v_cmp_ge_f32 -> sgpr pair", 1);
+    run<15>("v_cmp_ge_f32 -> vcc", 1);
+    run<12>("v_cndmask_b32 (vcc)", 1);
+    run<13>("v_mov_b64", 1);
+    run<14>("v_and_b32", 1);
+    run<16>("v_pk_fma_f32 dependent + s_nop", 1);
+    run<17>("v_pk_fma_f32 sgpr operand", 1);
     printf("(ns per wave-instruction per SIMD; at 2.4 GHz one cycle = 0.417 ns)\n");
     return 0;
 }

@@ -2357,6 +2357,7 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
     r->key_bias = near_bits;
     const uint32_t tile_bits = bit_length(num_tiles ? num_tiles - 1 : 0);
 
+    gs::TileKeys tile_keys{nullptr, nullptr, 0u, 0u};   // null keys: the blend reads its ranges from the range array
     if (n == 0) {
         // nothing to project: clear the ranges, blend the background
         GS_TRY(dev_reserve(r->zero_region, (size_t)num_tiles * 8));
@@ -2556,11 +2557,24 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
                                                               st, tside, tpasses, r->launches, src)));
         }
         mark(ST_RANGES);
-        // Tile ranges: by a search per tile once reading every key again costs more than a few dependent
-        // probes per tile (GS3D_RANGES_SEARCH=0/1 forces).
+        // Tile ranges, three ways.  (1) One pass over the sorted keys (k_tile_ranges).  (2) A 32-ary search per tile
+        // (k_tile_ranges_search) once reading every key again costs more than a few dependent probes per tile: from
+        // a pair capacity of 8 M (GS3D_RANGES_SEARCH=0/1 forces).  (3) The same search run by the blend workgroups
+        // themselves (blend_tile_range_wg): no launch in front of the blend, but a workgroup that waits for its
+        // probes is occupancy the VALU-bound blend misses — same-box A/B (gpurun_out/r04l/ab.log): blend +3.5 us at
+        // 1 M and 10 M, +10 us at 4K, +12 us at 50 M against 6.8 / 10.5 / 35 / 19 us of range kernel saved: frames
+        // +1.5 % at 1 M, +-0 at 10 M, -0.5 % at 50 M, -2.3 % at 4K.  It is taken where it pays: images of more than
+        // 16384 tiles, where neither stand-alone kernel is cheap (GS3D_RANGES_IN_BLEND=0/1 forces).
+        static const int in_blend_env = std::getenv("GS3D_RANGES_IN_BLEND") ? std::atoi(std::getenv("GS3D_RANGES_IN_BLEND")) : -1;
+        const bool ranges_in_blend = in_blend_env >= 0 ? in_blend_env != 0 : num_tiles > 16384u;
         static const int ranges_env = std::getenv("GS3D_RANGES_SEARCH") ? std::atoi(std::getenv("GS3D_RANGES_SEARCH")) : -1;
         const bool ranges_search = ranges_env >= 0 ? ranges_env != 0 : capacity >= (8u << 20);
-        if (capacity && ranges_search) {
+        if (capacity && ranges_in_blend) {
+            tile_keys.keys = r->tkeys[tside].ptr;
+            tile_keys.count_dev = &state->pairs;
+            tile_keys.count_bound = capacity;
+            tile_keys.wide = wide ? 1u : 0u;
+        } else if (capacity && ranges_search) {
             if (wide)
                 hipLaunchKernelGGL(gs::k_tile_ranges_search<uint32_t>, dim3((num_tiles + 3u) / 4u), dim3(256), 0, st,
                                    (const uint32_t *)r->tkeys[tside].ptr, tc, zero, num_tiles);
@@ -2588,16 +2602,16 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
     if (band_tiles) {
         // GS3D_BLEND_GROUPS = 1 (half-tile lists), 2 (8x8 blocks) or 4 (8x4 blocks, default)
         static const int groups = std::getenv("GS3D_BLEND_GROUPS") ? std::atoi(std::getenv("GS3D_BLEND_GROUPS")) : 4;
-        typedef void (*blend_fn)(const uint32_t *, const uint32_t *, const uint32_t *, gs::FrameConsts, float4 *,
-                                 const gs::FrameState *);
+        typedef void (*blend_fn)(uint32_t *, const uint32_t *, const uint32_t *, gs::FrameConsts, float4 *,
+                                 const gs::FrameState *, gs::TileKeys);
         static const blend_fn tbl[3][3] = {
             {gs::k_blend<0>, gs::k_blend_grouped<0, 2>, gs::k_blend_grouped<0, 4>},
             {gs::k_blend<1>, gs::k_blend_grouped<1, 2>, gs::k_blend_grouped<1, 4>},
             {gs::k_blend<2>, gs::k_blend_grouped<2, 2>, gs::k_blend_grouped<2, 4>}};
         const blend_fn blend = tbl[mode][groups == 1 ? 0 : groups == 2 ? 1 : 2];
         hipLaunchKernelGGL(blend, dim3(band_tiles), dim3(gs::BLEND_THREADS), 0, st,
-                           (const uint32_t *)r->zero_region.ptr, (const uint32_t *)r->tvals[r->tsorted_side].ptr,
-                           (const uint32_t *)r->recs.ptr, fc, (float4 *)rgba, (const gs::FrameState *)state);
+                           (uint32_t *)r->zero_region.ptr, (const uint32_t *)r->tvals[r->tsorted_side].ptr,
+                           (const uint32_t *)r->recs.ptr, fc, (float4 *)rgba, (const gs::FrameState *)state, tile_keys);
         GS_HIP(hipGetLastError());
         r->launches++;
     }

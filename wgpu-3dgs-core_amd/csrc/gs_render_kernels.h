@@ -2420,6 +2420,77 @@ __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) {
     return __builtin_elementwise_fma(a, b, c);
 }
 
+// A tile's [start, end) found by the blend workgroup ITSELF (round 4): the same 32-ary search as
+// k_tile_ranges_search, run by each of the workgroup's waves on its own (no LDS, no barrier; the second
+// wave's probes hit the sectors the first one just pulled in).  The stand-alone range kernel was a
+// dependent launch of 5-35 us in front of the blend (4.8 us at 1 M: five dependent probe rounds and nothing
+// else on the chip; 35 us at 4K, where it read every key); inside the blend only the first wave of
+// workgroups waits for its probes with nothing to overlap — every later workgroup searches while the other
+// six workgroups of its CU blend.  keys == null: read the range from `ranges` (the frame without Gaussians;
+// GS3D_RANGES_IN_BLEND=0).  Lane 0 of wave 0 stores the range for the taps (gs_renderer_download_ranges).
+struct TileKeys {
+    const void *keys;             // sorted tile ids of the D pairs (u16, or u32 when `wide`)
+    const uint32_t *count_dev;    // D (FrameState.pairs)
+    uint32_t count_bound;         // pair capacity
+    uint32_t wide;
+};
+__device__ __forceinline__ void blend_tile_range(const TileKeys &tk, uint32_t *__restrict__ ranges, uint32_t tile,
+                                                 uint32_t lane, bool writer, uint32_t &start, uint32_t &end) {
+    if (!tk.keys) {
+        start = ranges[2 * tile];
+        end = ranges[2 * tile + 1];
+        return;
+    }
+    uint32_t count = *tk.count_dev;
+    count = count < tk.count_bound ? count : tk.count_bound;
+    const uint32_t h = lane >> 5, l = lane & 31u;
+    const uint32_t target = tile + h;
+    uint32_t lo = 0, len = count;                    // the answer lies in [lo, lo + len]; uniform per half
+    while (__any(len != 0u)) {
+        const uint32_t step = len / 32u + 1u;
+        const uint64_t p = (uint64_t)lo + (uint64_t)(l + 1u) * step - 1u;
+        const bool in = p < (uint64_t)lo + len;
+        const uint64_t q = in ? p : 0u;
+        const uint32_t key = tk.wide ? ((const uint32_t *)tk.keys)[q] : (uint32_t)((const uint16_t *)tk.keys)[q];
+        const bool less = in && key < target;
+        const uint64_t m = __ballot(less);
+        const uint32_t k = (uint32_t)__popc((uint32_t)(m >> (32u * h)));
+        const uint32_t stop = lo + len;
+        lo += k * step;
+        const uint32_t rem = stop - lo;
+        len = len == 0u ? 0u : (rem < step - 1u ? rem : step - 1u);
+    }
+    const uint32_t lb0 = __shfl(lo, 0, WAVE), lb1 = __shfl(lo, 32, WAVE);
+    const bool any = lb1 > lb0;
+    start = any ? lb0 : 0u;
+    end = any ? lb1 : 0u;
+    if (writer && lane == 0u) {
+        ranges[2u * tile] = start;
+        ranges[2u * tile + 1u] = end;
+    }
+}
+// the workgroup form: wave 0 searches, the other wave takes the result from LDS behind one barrier (both
+// waves searching doubled the probes and cost the blend 4-7 us of occupancy)
+__device__ __forceinline__ void blend_tile_range_wg(const TileKeys &tk, uint32_t *__restrict__ ranges, uint32_t tile,
+                                                    uint32_t lane, uint32_t wid, uint32_t *s_range, uint32_t &start,
+                                                    uint32_t &end) {
+    if (!tk.keys) {
+        start = ranges[2 * tile];
+        end = ranges[2 * tile + 1];
+        return;
+    }
+    if (wid == 0u) {
+        blend_tile_range(tk, ranges, tile, lane, true, start, end);
+        if (lane == 0u) {
+            s_range[0] = start;
+            s_range[1] = end;
+        }
+    }
+    __syncthreads();
+    start = s_range[0];
+    end = s_range[1];
+}
+
 constexpr int BLEND_THREADS = 128;
 constexpr int BLEND_BATCH = 128;
 
@@ -2435,11 +2506,11 @@ constexpr int BLEND_BATCH = 128;
 // MODE = GaussianDisplayMode: 0 splat (the Gaussian falloff), 1 ellipse (flat
 // alpha = min(0.99, opacity) inside the max_std_dev ellipse), 2 point (flat alpha inside a 1.5-px dot).
 template <int MODE>
-__global__ __launch_bounds__(BLEND_THREADS) void k_blend(const uint32_t *__restrict__ ranges,
+__global__ __launch_bounds__(BLEND_THREADS) void k_blend(uint32_t *__restrict__ ranges,
                                                          const uint32_t *__restrict__ idx,
                                                          const uint32_t *__restrict__ recs,
                                                          FrameConsts fc, float4 *__restrict__ rgba,
-                                                         const FrameState *__restrict__ state) {
+                                                         const FrameState *__restrict__ state, TileKeys tk) {
     // A frame that outgrew its pair capacity has lost its FARTHEST pairs: blending the rest would show
     // holes.  It is skipped instead — the image keeps what it held — and flagged.
     if (state->overflow) return;
@@ -2459,7 +2530,9 @@ __global__ __launch_bounds__(BLEND_THREADS) void k_blend(const uint32_t *__restr
     const float rx0 = (float)(tx * 16u) + 0.5f, rx1 = rx0 + 15.0f;
     const float ry0 = (float)(ty * 16u) + 0.5f;
 
-    const uint32_t start = ranges[2 * tile], end = ranges[2 * tile + 1];
+    uint32_t start, end;
+    __shared__ uint32_t s_range[2];
+    blend_tile_range_wg(tk, ranges, tile, lane, wid, s_range, start, end);
     f32x2 T = {1.0f, 1.0f}, C0 = {0.0f, 0.0f}, C1 = {0.0f, 0.0f}, C2 = {0.0f, 0.0f};
     const bool in0 = px < fc.width && py0 < fc.height, in1 = px < fc.width && py1 < fc.height;
     // A finished (or out-of-image) pixel is parked at y = DEAD: its exponent becomes hugely
@@ -2655,11 +2728,11 @@ __device__ __forceinline__ bool splat_touches_rect2(float mx, float my, float ca
 // than the wave's longest simply idle.  Results are bit-identical to k_blend: culling only removes
 // (splat, block) pairs whose alpha is below 1/255 at every pixel of the block.
 template <int MODE, int G>
-__global__ __launch_bounds__(BLEND_THREADS) void k_blend_grouped(const uint32_t *__restrict__ ranges,
+__global__ __launch_bounds__(BLEND_THREADS) void k_blend_grouped(uint32_t *__restrict__ ranges,
                                                                  const uint32_t *__restrict__ idx,
                                                                  const uint32_t *__restrict__ recs,
                                                                  FrameConsts fc, float4 *__restrict__ rgba,
-                                                                 const FrameState *__restrict__ state) {
+                                                                 const FrameState *__restrict__ state, TileKeys tk) {
     static_assert(G == 2 || G == 4, "lane groups per wave");
     if (state->overflow) return;              // frame skipped: see k_blend
     constexpr int GL = WAVE / G;              // lanes per group
@@ -2686,7 +2759,9 @@ __global__ __launch_bounds__(BLEND_THREADS) void k_blend_grouped(const uint32_t 
     const uint32_t my_list = wid * G + gi;
     const float tx0 = (float)(tx * 16u) + 0.5f, ty0 = (float)(ty * 16u) + 0.5f;   // tile origin, pixel centres
 
-    const uint32_t start = ranges[2 * tile], end = ranges[2 * tile + 1];
+    uint32_t start, end;
+    __shared__ uint32_t s_range[2];
+    blend_tile_range_wg(tk, ranges, tile, lane, wid, s_range, start, end);
     f32x2 T = {1.0f, 1.0f}, C0 = {0.0f, 0.0f}, C1 = {0.0f, 0.0f}, C2 = {0.0f, 0.0f};
     const bool in0 = px < fc.width && py0 < fc.height, in1 = px < fc.width && py1 < fc.height;
     constexpr float DEAD = 1.0e15f;           // finished / out-of-image pixels are parked far away (see k_blend)
