@@ -469,6 +469,13 @@ def blend_valu_object(res):
                    valu_insts_per_simd_per_ns=insts / SIMDS / (ms * 1e6),
                    note="counter units calibrated against kernels of known VALU-busy fraction 1.0 (profiles/); "
                         "SQ_ACTIVE_INST_VALU counts instructions on gfx950, not quad-cycles")
+        # the bracket closed (round 4): every class of the loop priced with ITS OWN stream (tools/blend_table.py)
+        try:
+            bi = json.load(open(os.path.join(ROOT, "profiles", "blend_issue.json")))
+            obj.update(valu_busy_frac_priced_by_class=insts * bi["ns_per_valu_inst_loop_mix"] / (ms * 1e6 * SIMDS),
+                       priced_ns_per_valu_inst=bi["ns_per_valu_inst_loop_mix"], priced_by=bi["source"])
+        except (OSError, KeyError, ValueError):
+            pass
     else:
         obj["note"] = why or why2
     return obj
@@ -578,6 +585,8 @@ def compact_line(line, detail_path, limit=3900):
                 c["workloads"][k]["per_rank_ms"] = [_r(x, 4) for x in v.get("per_rank_ms", [])]
     if line.get("two_frames_in_flight"):
         c["two_in_flight_ms"] = _r(line["two_frames_in_flight"]["ms_per_step"])
+    if (line.get("blend") or {}).get("valu_busy_frac_priced_by_class") is not None:
+        c["blend_valu_issue_frac"] = _r(line["blend"]["valu_busy_frac_priced_by_class"], 3)   # VALU issue, priced class by class
     hr = line.get("hip_runtime") or {}
     c["hip"] = {"runtime": hr.get("runtime_version"), "compiled": hr.get("compiled_version"), "source": hr.get("source")}
     c["detail"] = detail_path

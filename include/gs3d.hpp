@@ -457,9 +457,15 @@ class Renderer {
     // PairCapacityError when it exceeded the pair capacity (the next frame has larger buffers)
     gs_frame_result wait_frame() { gs_frame_result fr; check(gs_renderer_wait_frame(h_, &fr)); return fr; }
     gs_frame_stats stats() { gs_frame_stats st; check(gs_renderer_stats(h_, &st)); return st; }
+    // sharded frames: a DEVICE word that receives every following frame's flags in stream order (nullptr: off)
+    void set_frame_flags_target(uint32_t *device_word) { check(gs_renderer_set_frame_flags_target(h_, device_word)); }
   private:
     gs_renderer *h_ = nullptr;
 };
+
+// HIP version of the headers the library was compiled with / of the runtime / of the driver it runs on
+struct HipVersions { int32_t compiled, runtime, driver; };
+inline HipVersions hip_versions() { HipVersions v{0, 0, 0}; gs_hip_versions(&v.compiled, &v.runtime, &v.driver); return v; }
 
 // G::from_gaussian on the device: `count` struct Gaussian records in `gaussians` -> PODs in `pods`
 template <class G>

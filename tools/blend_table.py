@@ -107,6 +107,8 @@ def main():
     ap.add_argument("--valu-log", required=True, help="output of tools/mb/mb_valu on the GPU box")
     ap.add_argument("--pmc", default=os.path.join(ROOT, "profiles", "pmc_traffic.json"))
     ap.add_argument("--waves", default="7w")
+    ap.add_argument("--json-out", default=os.path.join(ROOT, "profiles", "blend_issue.json"),
+                    help="machine-readable summary for bench.py's `blend` object")
     args = ap.parse_args()
 
     cost = {}
@@ -143,6 +145,13 @@ def main():
     for cls, c in sorted(counts.items(), key=lambda kv: -kv[1]):
         cal = cal_of.get(cls)
         ns = cost.get(cal, {}).get(args.waves) if cal else None
+        if cls == "v_cndmask_b32":
+            # the stream of v_cndmask alone reads a VCC nobody wrote and stalls on it (9.7 ns at every occupancy): the
+            # select is priced from the compare + select pair instead: 2 x (ns per instruction of the pair) - v_cmp
+            pair = cost.get("v_cmp_ge_f32 + v_cndmask (2)", {}).get(args.waves)
+            cmp_ = cost.get("v_cmp_ge_f32 -> vcc", {}).get(args.waves)
+            if pair is not None and cmp_ is not None:
+                ns = max(2.0 * pair - cmp_, 0.0)
         per_step = c / steps_per_trip
         if cal:
             valu_per_step += per_step
@@ -157,6 +166,13 @@ def main():
         valu_per_step, total_ns))
     if missing:
         print("(no calibration stream found for: %s)\n" % sorted(set(missing)))
+    if args.json_out:
+        json.dump(dict(kernel="k_blend_grouped<Splat,4>", valu_insts_per_step=valu_per_step, priced_ns_per_step=total_ns,
+                       ns_per_valu_inst_loop_mix=total_ns / valu_per_step, waves_per_simd=args.waves,
+                       classes={k: v / steps_per_trip for k, v in counts.items()},
+                       source="tools/blend_table.py: loop ISA counted by class, each class priced with its own stream of "
+                              "tools/mb/mb_valu.hip (%s)" % os.path.relpath(args.valu_log, ROOT)),
+                  open(args.json_out, "w"), indent=1)
     if pmc.get("SQ_INSTS_VALU") and pmc.get("GRBM_GUI_ACTIVE"):
         insts = pmc["SQ_INSTS_VALU"]
         gui = pmc["GRBM_GUI_ACTIVE"] / 8.0            # cycles of the launch (the counter sums the 8 XCDs)
