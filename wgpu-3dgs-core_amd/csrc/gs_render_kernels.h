@@ -1233,21 +1233,37 @@ __global__ __launch_bounds__(EXP_CHUNK) void k_expand_count(ExpandIO io) {
     uint32_t rp[EXP_COUNT_CHUNKS];
 #pragma unroll
     for (uint32_t c = 0; c < EXP_COUNT_CHUNKS; c++) {
-        if constexpr (RECT32) rp[c] = slot[c] != 0xffffffffu ? ((const uint32_t *)io.rect)[slot[c]] : 0u;
-        else r[c] = slot[c] != 0xffffffffu ? io.rect[slot[c]] : make_uint2(0u, 0u);
+        // no branch around a gather (a load behind a branch gets its own wait, and that wait also covers every
+        // store issued before it): elements past V gather slot 0 and are masked below
+        const uint32_t sl = slot[c] != 0xffffffffu ? slot[c] : 0u;
+        if constexpr (RECT32) rp[c] = ((const uint32_t *)io.rect)[sl];
+        else r[c] = io.rect[sl];
+    }
+#pragma unroll
+    for (uint32_t c = 0; c < EXP_COUNT_CHUNKS; c++) {
+        if constexpr (RECT32) rp[c] = slot[c] != 0xffffffffu ? rp[c] : 0u;
+        else r[c] = slot[c] != 0xffffffffu ? r[c] : make_uint2(0u, 0u);
     }
     const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+    // all stores first, back to back, then the reductions: with each store next to its reduction hipcc put an
+    // s_waitcnt vmcnt(0) behind every one of the eight stores (eight store round trips in a row per thread)
+#pragma unroll
+    for (uint32_t c = 0; c < EXP_COUNT_CHUNKS; c++) {
+        const uint64_t j = (uint64_t)(first_chunk + c) * EXP_CHUNK + threadIdx.x;
+        if constexpr (RECT32) {
+            // unconditional: the array is padded past V by more than a workgroup's span (gs3d.hip reserves
+            // (N + 1024) x 8 bytes for 4-byte entries), and k_pairs_emit masks what it reads past V
+            ((uint32_t *)io.sorted_rect)[j] = rp[c];
+        } else {
+            if (j < v_count) io.sorted_rect[j] = r[c];
+        }
+    }
 #pragma unroll
     for (uint32_t c = 0; c < EXP_COUNT_CHUNKS; c++) {
         const uint64_t j = (uint64_t)(first_chunk + c) * EXP_CHUNK + threadIdx.x;
         uint32_t v;
-        if constexpr (RECT32) {
-            if (j < v_count) ((uint32_t *)io.sorted_rect)[j] = rp[c];
-            v = j < v_count ? (((rp[c] >> 16) & 0xffu) + 1u) * ((rp[c] >> 24) + 1u) : 0u;
-        } else {
-            if (j < v_count) io.sorted_rect[j] = r[c];
-            v = ((r[c].y & 0xffffu) - (r[c].x & 0xffffu)) * ((r[c].y >> 16) - (r[c].x >> 16));
-        }
+        if constexpr (RECT32) v = j < v_count ? (((rp[c] >> 16) & 0xffu) + 1u) * ((rp[c] >> 24) + 1u) : 0u;
+        else v = ((r[c].y & 0xffffu) - (r[c].x & 0xffffu)) * ((r[c].y >> 16) - (r[c].x >> 16));
         v = wave_reduce_add(v);
         if (lane == 0) s_red[c][wid] = v;
     }
