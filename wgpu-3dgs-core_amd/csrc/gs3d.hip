@@ -2527,12 +2527,21 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
         static const int cursor_env = std::getenv("GS3D_CURSOR_KERNEL") ? std::atoi(std::getenv("GS3D_CURSOR_KERNEL")) : -1;
         const bool cursor_kernel = cursor_env >= 0 ? cursor_env != 0 : eo.sb_bound > 256u;
         eo.cursors = cursor_kernel ? (gs::PairCursorRec *)r->cursors.ptr : nullptr;
+        // XCD-aware span order of the gather: XCD x takes C consecutive spans of every group of 8 C, so that its L2
+        // serves part of the gather (neighbours in depth order are often neighbours in the mirror).  Same-box sweep
+        // (gpurun_out/r04q/ab*.log): C = 0 / 16 / 64 / 256 / 1024 -> 58.3 / 53.3 / 49.1 / 54.3 / 90.6 us at 10 M, 261 / 258 /
+        // 231 / 228 / 293 us at 50 M, 12.0 / - / 10.5 / 21 / 26 us at 1 M.  GS3D_EXPAND_XCD=<C> forces, 0 = dispatch order.
+        static const int exp_xcd = std::getenv("GS3D_EXPAND_XCD") ? std::atoi(std::getenv("GS3D_EXPAND_XCD")) : 64;
+        uint32_t count_grid = (exp_grid + gs::EXP_COUNT_CHUNKS - 1) / gs::EXP_COUNT_CHUNKS;
+        eo.xcd_chunk = 0;
+        if (exp_xcd > 0 && count_grid >= 256u) {
+            eo.xcd_chunk = (uint32_t)exp_xcd;
+            count_grid = 8u * eo.xcd_chunk * ((count_grid + 8u * eo.xcd_chunk - 1u) / (8u * eo.xcd_chunk));
+        }
         if (eo.rect32)
-            hipLaunchKernelGGL(gs::k_expand_count<true>, dim3((exp_grid + gs::EXP_COUNT_CHUNKS - 1) / gs::EXP_COUNT_CHUNKS),
-                               dim3(gs::EXP_CHUNK), 0, st, eo);
+            hipLaunchKernelGGL(gs::k_expand_count<true>, dim3(count_grid), dim3(gs::EXP_CHUNK), 0, st, eo);
         else
-            hipLaunchKernelGGL(gs::k_expand_count<false>, dim3((exp_grid + gs::EXP_COUNT_CHUNKS - 1) / gs::EXP_COUNT_CHUNKS),
-                               dim3(gs::EXP_CHUNK), 0, st, eo);
+            hipLaunchKernelGGL(gs::k_expand_count<false>, dim3(count_grid), dim3(gs::EXP_CHUNK), 0, st, eo);
         r->launches++;
         if (cursor_kernel) {
             hipLaunchKernelGGL(gs::k_pairs_cursors, dim3(eo.sb_bound), dim3(gs::EXP_SB), 0, st, eo);

@@ -1185,6 +1185,19 @@ __global__ __launch_bounds__(1024) void k_scan_chunks(ScanJob j0, ScanJob j1) {
 // 64-bit (tile << 32 | depth) key.
 // ---------------------------------------------------------------------------------------------
 
+// Workgroup -> tile of the pass.  The hardware deals consecutive workgroup ids round-robin to the 8
+// XCDs, each with its own L2.  Tile b's run of a digit is followed in memory by tile b + 1's, and the
+// runs are short (16-128 elements): with tiles dealt in order, the two halves of almost every
+// 128-byte line are written through two different L2s and reach HBM as partial lines.  With
+// xcd_chunk = C, XCD x takes C consecutive tiles of every group of 8 C tiles: neighbouring runs meet
+// in one L2, while all XCDs still work on the same region of the output at any time (giving each
+// XCD one contiguous eighth of the pass instead lost more on DRAM page locality than it gained).
+__device__ __forceinline__ uint32_t scatter_tile_of(uint32_t wg, uint32_t xcd_chunk) {
+    if (!xcd_chunk) return wg;
+    const uint32_t slot = wg >> 3;
+    return (slot / xcd_chunk) * 8u * xcd_chunk + (wg & 7u) * xcd_chunk + slot % xcd_chunk;   // may be past the live tiles
+}
+
 constexpr int EXP_CHUNK = 256;   // Gaussians per workgroup in the expansion kernels
 constexpr uint32_t EXP_SB = 128;   // chunks per super-chunk of the expansion's offset sums
 
@@ -1205,6 +1218,7 @@ struct ExpandIO {
     struct PairCursorRec *cursors;   // [capacity / CURSOR_SLOTS + 1] where the pairs of every 1024-slot span start
     uint32_t rect32;                 // rect / sorted_rect hold packed 4-byte rects (rect_pack32)
     uint32_t *flags_dev;             // optional device copy of the frame flags (null: none)
+    uint32_t xcd_chunk;              // k_expand_count: workgroup -> span order (0: dispatch order)
 };
 
 // Expansion, part 1: gather the tile rects into depth order (the only random access of the key
@@ -1220,7 +1234,11 @@ template <bool RECT32>
 __global__ __launch_bounds__(EXP_CHUNK) void k_expand_count(ExpandIO io) {
     __shared__ uint32_t s_red[EXP_COUNT_CHUNKS][4];
     const uint32_t v_count = io.state->visible;
-    const uint32_t first_chunk = blockIdx.x * EXP_COUNT_CHUNKS;
+    // XCD-aware order (io.xcd_chunk, as in the radix passes): consecutive workgroups go round-robin to the 8 XCDs,
+    // each with its own L2; neighbours in depth order are neighbours in space often enough (one 64-byte sector holds
+    // the rects of 16 consecutive mirror slots) that giving one XCD a run of consecutive spans lets its L2 serve part
+    // of the gather
+    const uint32_t first_chunk = scatter_tile_of(blockIdx.x, io.xcd_chunk) * EXP_COUNT_CHUNKS;
     if ((uint64_t)first_chunk * EXP_CHUNK >= v_count) return;
     uint32_t slot[EXP_COUNT_CHUNKS];
 #pragma unroll
@@ -1323,19 +1341,6 @@ struct SortCount {
 // compaction of the visible Gaussians for free: the output of the pass is the dense, stably
 // partitioned (key, slot) list of the V visible ones, and workgroup 0 publishes V.
 constexpr uint32_t SORT_INVALID_KEY = 0xffffffffu;
-
-// Workgroup -> tile of the pass.  The hardware deals consecutive workgroup ids round-robin to the 8
-// XCDs, each with its own L2.  Tile b's run of a digit is followed in memory by tile b + 1's, and the
-// runs are short (16-128 elements): with tiles dealt in order, the two halves of almost every
-// 128-byte line are written through two different L2s and reach HBM as partial lines.  With
-// xcd_chunk = C, XCD x takes C consecutive tiles of every group of 8 C tiles: neighbouring runs meet
-// in one L2, while all XCDs still work on the same region of the output at any time (giving each
-// XCD one contiguous eighth of the pass instead lost more on DRAM page locality than it gained).
-__device__ __forceinline__ uint32_t scatter_tile_of(uint32_t wg, uint32_t xcd_chunk) {
-    if (!xcd_chunk) return wg;
-    const uint32_t slot = wg >> 3;
-    return (slot / xcd_chunk) * 8u * xcd_chunk + (wg & 7u) * xcd_chunk + slot % xcd_chunk;   // may be past the live tiles
-}
 
 // ghist layout: [digit][block] (digit-major, row stride = the grid size) so that the row scan reads
 // contiguous memory.  Tile ids and depth exponents are highly repetitive, so neighbouring lanes
