@@ -649,7 +649,7 @@ __device__ const float k_ln_opacity_byte[256] = {
 // half (shade_one) reads the SH words.  project_one = both, in the order the spec gives.
 template <int SH, int COV>
 __device__ __forceinline__ uint32_t project_geom(const uint32_t *w, const FrameConsts &fc,
-                                                 uint4 rec[3], float d[3]) {
+                                                 uint4 rec[3], float d[3], const float *ln_tab) {
     float p[3] = {u2f(w[0]), u2f(w[1]), u2f(w[2])};
     float pw[4], t[4];
     mat4_mul_point(fc.M, p, pw);
@@ -710,7 +710,9 @@ __device__ __forceinline__ uint32_t project_geom(const uint32_t *w, const FrameC
         const float dd = radius + 16.0f;
         const float err = (3.0e-7f * ((fabsf(qa) + fabsf(qb)) + fabsf(qc))) * (dd * dd);
         if (err <= 0.05f) {
-            const float lim = k_ln_opacity_byte[kop] + 0.1f;
+            // (ln_tab: the workgroup's LDS copy of k_ln_opacity_byte — from global memory this was a dependent
+            // round trip in the middle of every visible Gaussian's projection)
+            const float lim = ln_tab[kop] + 0.1f;
             const float ex = sqrtf(lim / -(qa - (qb * qb) / (4.0f * qc)));
             const float ey = sqrtf(lim / -(qc - (qb * qb) / (4.0f * qa)));
             // tile t holds the pixel centres 16 t + 0.5 ... 16 t + 15.5; NaN extents change nothing
@@ -756,9 +758,9 @@ __device__ __forceinline__ void shade_one(const uint32_t *w, const FrameConsts &
 
 template <int SH, int COV>
 __device__ __forceinline__ uint32_t project_one(const uint32_t *w, const FrameConsts &fc,
-                                                uint4 rec[3]) {
+                                                uint4 rec[3], const float *ln_tab) {
     float d[3];
-    uint32_t cnt = project_geom<SH, COV>(w, fc, rec, d);
+    uint32_t cnt = project_geom<SH, COV>(w, fc, rec, d, ln_tab);
     shade_one<SH>(w, fc, d, rec);
     return cnt;
 }
@@ -798,10 +800,13 @@ __device__ __forceinline__ void pre_begin(const PreOut &io) {
     for (uint32_t i = blockIdx.x * PP_THREADS + threadIdx.x; i < io.zero_words; i += gridDim.x * PP_THREADS)
         io.zero_ptr[i] = 0u;
 }
-// a workgroup that is going to project Gaussians clears its digit histogram first
-__device__ __forceinline__ void pre_hist_clear(uint32_t *s_dhist) {
+// a workgroup that is going to project Gaussians clears its digit histogram first and takes its LDS copy of the
+// ln(opacity byte) table of the rect clip
+__device__ __forceinline__ void pre_hist_clear(uint32_t *s_dhist, float *s_ln) {
 #pragma unroll
     for (int q = 0; q < PRE_HIST_BINS / PP_THREADS; q++) s_dhist[threadIdx.x + q * PP_THREADS] = 0u;
+    static_assert(PP_THREADS == 256, "one table entry per thread");
+    s_ln[threadIdx.x] = k_ln_opacity_byte[threadIdx.x];
     __syncthreads();
 }
 
@@ -857,12 +862,13 @@ __global__ __launch_bounds__(PP_THREADS) void k_preprocess(const uint4 *__restri
                                                            FrameConsts fc, PreOut io) {
     __shared__ uint32_t s_red[8];
     __shared__ uint32_t s_dhist[PRE_HIST_BINS];
+    __shared__ float s_ln[256];
     pre_begin(io);
     if (fc.cull_gain > 0.0f && block_is_culled(io.block_bounds + (uint64_t)blockIdx.x * 8u, fc)) {
         pre_finish_culled(io);
         return;
     }
-    pre_hist_clear(s_dhist);
+    pre_hist_clear(s_dhist, s_ln);
     constexpr int NW = pod_words(SH, COV);
     constexpr int NC = NW / 4;
     const uint32_t base = blockIdx.x * PP_CHUNK;
@@ -889,7 +895,7 @@ __global__ __launch_bounds__(PP_THREADS) void k_preprocess(const uint4 *__restri
                 w[4 * c + 3] = v[c].w;
             }
             uint4 rec[3];
-            const uint32_t cnt = project_one<SH, COV>(w, fc, rec);
+            const uint32_t cnt = project_one<SH, COV>(w, fc, rec, s_ln);
             uint32_t *o = io.recs + (uint64_t)i * REC_WORDS;
             *(u32x4_a4 *)(o) = u32x4_a4{rec[0].x, rec[0].y, rec[0].z, rec[0].w};
             *(u32x4_a4 *)(o + 4) = u32x4_a4{rec[1].x, rec[1].y, rec[1].z, rec[1].w};
@@ -916,6 +922,7 @@ __global__ __launch_bounds__(PP_THREADS) void k_preprocess_banded(const uint4 *_
                                                                   FrameConsts fc, PreOut io) {
     __shared__ uint32_t s_red[8];
     __shared__ uint32_t s_dhist[PRE_HIST_BINS];
+    __shared__ float s_ln[256];
     pre_begin(io);
     uint32_t block = blockIdx.x;
     if (io.block_list) {
@@ -929,7 +936,7 @@ __global__ __launch_bounds__(PP_THREADS) void k_preprocess_banded(const uint4 *_
         pre_finish_culled(io);
         return;
     }
-    pre_hist_clear(s_dhist);
+    pre_hist_clear(s_dhist, s_ln);
     constexpr int NW = pod_words(SH, COV);
     constexpr int NC = NW / 4;
     constexpr int G0 = cov_word0(SH) / 4;                              // first chunk holding covariance words
@@ -1000,7 +1007,7 @@ __global__ __launch_bounds__(PP_THREADS) void k_preprocess_banded(const uint4 *_
             }
             uint4 rec[3];
             float d[3];
-            const uint32_t cnt = project_geom<SH, COV>(w, fc, rec, d);
+            const uint32_t cnt = project_geom<SH, COV>(w, fc, rec, d, s_ln);
             if (cnt) {
                 constexpr int S0 = 1, S1 = G0 - 1;   // SH-only chunks (G0.. were loaded above)
                 if constexpr (S1 >= S0) {
