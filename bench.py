@@ -280,16 +280,19 @@ def stage_models(wl, res):
     # depth sort: pass 0 reads the N dense keys twice and writes V x (4 + 4); pass p > 0 reads its keys for the
     # histogram, keys + slots for the scatter, writes keys + slots; the pass before the last writes 2-byte keys,
     # the last one reads them and writes the slots only
-    depth = n * 4 * 2 + v * ((2 if dpasses == 2 else 4) + 4 if dpasses > 1 else 4)
+    chunk_hist = os.environ.get("GS3D_CHUNK_HIST", "1") != "0"
+    # pass 0: the N dense keys once for the scatter; its histogram sums the chunks' 1 KB rows (1 B per slot) that the
+    # preprocess kernel counted — or reads the N keys once more with GS3D_CHUNK_HIST=0
+    depth = n * 4 + (n if chunk_hist else n * 4) + v * ((2 if dpasses == 2 else 4) + 4 if dpasses > 1 else 4)
     for p in range(1, dpasses):
         kin = 2 if p == dpasses - 1 else 4
         kout = 0 if p == dpasses - 1 else (2 if p == dpasses - 2 else 4)
         depth += v * kin + v * (kin + 4) + v * (kout + 4)
     models = {
-        "preprocess": (n * wl["payload"] + v * 36 + n * 4 + rect_writers * rb,
-                       "read N x payload; write 36-B records of the V visible, 4-B keys of all N, %d-B rects of the %s"
+        "preprocess": (n * wl["payload"] + v * 36 + n * 4 + rect_writers * rb + (n if chunk_hist else 0),
+                       "read N x payload; write 36-B records of the V visible, 4-B keys of all N (+ 1 B per slot of digit histogram), %d-B rects of the %s"
                        % (rb, "V visible" if wl["sh"] != 3 else "N"),),
-        "depth_sort": (depth, "pass 0 reads the N dense keys twice (hist, scatter) and writes V x (key + 4 B); each further "
+        "depth_sort": (depth, "pass 0 reads the N dense keys once (scatter) + 1 B per slot of per-chunk histogram rows and writes V x (key + 4 B); each further "
                               "pass reads its keys (hist) and keys + slots (scatter) and writes them; 2-byte keys into the last pass"),
         "expand": (v * (4 + rb) + v * rb,
                    "k_expand_count: V x (4-B slot + %d-B rect gather) -> V x %d B (the pairs themselves are produced "
