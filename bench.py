@@ -373,6 +373,8 @@ def frame_bytes_object(wl_name, wl, res):
                    implementation_model="sum of the HBM-bound stage_models + W x H x 16 (image); the blend's record "
                                         "gathers are excluded: measured at tens of MB per frame (PMC), not D x 40 B")
     pmc, why = pmc_record("frame_%s" % wl_name)
+    if res.get("per_rank_ms") and len(res["per_rank_ms"]) > 1:
+        pmc, why = None, "PMC traffic was collected for the single-GPU frame"
     if pmc:
         tot = pmc["fetch_bytes"] + pmc["write_bytes"]
         out.update(pmc_frame_traffic_bytes=tot, pmc_frame_fetch_bytes=pmc["fetch_bytes"], pmc_frame_write_bytes=pmc["write_bytes"],
@@ -409,13 +411,21 @@ def pmc_record(key):
     return rec, None
 
 
-def roofline_object(wl_name, wl, res):
+def roofline_object(wl_name, wl, res, world=1):
     """roofline of the preprocess kernel on `wl`: achieved = ALGORITHMIC bytes per launch (payload
-    bytes x Gaussians per launch) / average launch duration (HIP events on the launch stream)."""
+    bytes x Gaussians per launch) / average launch duration (HIP events on the launch stream).
+    world > 1 (rank 0's launch): a rank must read the 44 B of position, colour and covariance of EVERY
+    Gaussian but the SH bytes only of the Gaussians its band shows ("pos + cov traffic stays
+    N x 44 B - the non-scaling term"): algorithmic bytes = N x 44 + V_rank x (payload - 44); the PMC traffic
+    figures (collected on one GPU, whole frame) do not apply and are left out."""
     ms = res["stages_ms"]["preprocess"]
     alg = wl["n"] * wl["payload"]
+    if world > 1:
+        alg = wl["n"] * min(44, wl["payload"]) + res["visible"] * max(wl["payload"] - 44, 0)
     gbs = alg / (ms * 1e-3) / 1e9
     pmc, why = pmc_record("preprocess_%s" % wl_name)
+    if world > 1:
+        pmc, why = None, "PMC traffic was collected for the single-GPU frame; this is rank 0's band of %d" % world
     obj = {
         "bound": "hbm",
         "kernel": "k_preprocess_banded<ShSingle,RotScale,pipelined,nt>" if wl["sh"] != 3 else "k_preprocess<ShNone,RotScale>",
@@ -553,7 +563,7 @@ def compact_line(line, detail_path, limit=3900):
     ro = line.get("roofline")
     if ro:
         keep = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "frac_nocull", "algorithmic_bytes_per_launch",
-                "avg_launch_ms", "fetched_over_required", "physical_traffic_frac", "traffic_note")
+                "avg_launch_ms", "fetched_over_required", "physical_traffic_frac", "traffic_note", "note")
         c["roofline"] = {k: _r(ro[k]) for k in keep if k in ro}
         c["roofline"]["workload"] = "10m" if ro["gaussians"] == 10_000_000 else ro["workload"]
         rw = line.get("roofline_workload")
@@ -753,7 +763,8 @@ def main():
                  "stage_models": stage_models(w, rr), "frame_bytes": frame_bytes_object(name, w, rr)}
             if rr["stages_ms"]:
                 pre = rr["stages_ms"]["preprocess"]
-                d["preprocess_read_frac"] = w["n"] * w["payload"] / (pre * 1e-3) / 1e9 / HBM_PEAK_GBS
+                alg = w["n"] * w["payload"] if world == 1 else w["n"] * min(44, w["payload"]) + rr["visible"] * max(w["payload"] - 44, 0)
+                d["preprocess_read_frac"] = alg / (pre * 1e-3) / 1e9 / HBM_PEAK_GBS    # world > 1: rank 0's band (roofline_object)
             if world > 1:
                 d.update(per_rank_ms=rr["per_rank_ms"], per_rank_ms_min=min(rr["per_rank_ms"]),
                          per_rank_ms_max=max(rr["per_rank_ms"]), render_ms_per_rank=rr["render_ms_per_rank"],
@@ -800,7 +811,10 @@ def main():
                                    "band_plan": res["band_plan"], "skipped_band_flags": res["skipped_band_flags"]}
         if roof is not None:
             roof_wl = WORKLOADS[args.roofline_workload]
-            line["roofline"] = roofline_object(args.roofline_workload, roof_wl, roof)
+            line["roofline"] = roofline_object(args.roofline_workload, roof_wl, roof, world)
+            if world > 1:
+                line["roofline"]["note"] = ("rank 0's band: algorithmic bytes = N x 44 B (geometry of every Gaussian) + "
+                                            "V_rank x 180 B (SH of the band's visible Gaussians)")
             line["roofline_workload"] = summary(roof_wl, roof, args.roofline_workload)
             if nocull is not None:
                 line["roofline_nocull"] = roofline_object("10m-nocull", WORKLOADS["10m-nocull"], nocull)
