@@ -1711,12 +1711,35 @@ static void make_frame_consts(const gs_gaussian_transform_pod *gt, const gs_mode
         static const bool rect32_off = std::getenv("GS3D_RECT32") && std::getenv("GS3D_RECT32")[0] == '0';
         fc.rect32 = !rect32_off && fc.tiles_x <= 256u && fc.tiles_y <= 256u ? 1u : 0u;
     }
-    // block culling gain (see block_is_culled): |W R_m S_m|_F^2 bounds the squared spectral norm of
-    // the linear part whatever the caller's view matrix is; 0.1 % head room for the f32 arithmetic
-    float ws2 = 0.0f;
-    for (int k = 0; k < 9; k++) ws2 += fc.WS[k] * fc.WS[k];
-    fc.cull_gain = 1.001f * fc.size2 * ws2 *
-                   (fc.fx * fc.fx * (1.0f + fc.limx * fc.limx) + fc.fy * fc.fy * (1.0f + fc.limy * fc.limy));
+    // block culling gain (see block_is_culled): size^2 |W R_m S_m|_2^2, the squared SPECTRAL norm of the linear part
+    // whatever the caller's view and model matrices are: the largest eigenvalue of A = (WS)^T (WS), in double by the
+    // closed form for symmetric 3x3 matrices, never above the trace (= the squared Frobenius norm, the bound of rounds
+    // 2-3); 0.1 % head room for the f32 arithmetic.  The Jacobian's norm is taken per block on the device.
+    {
+        double a[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++)
+                for (int k = 0; k < 3; k++) a[i][j] += (double)fc.WS[3 * k + i] * (double)fc.WS[3 * k + j];
+        const double tr = a[0][0] + a[1][1] + a[2][2];
+        double lmax = tr;
+        const double p1 = a[0][1] * a[0][1] + a[0][2] * a[0][2] + a[1][2] * a[1][2];
+        const double q = tr / 3.0;
+        const double p2 = (a[0][0] - q) * (a[0][0] - q) + (a[1][1] - q) * (a[1][1] - q) + (a[2][2] - q) * (a[2][2] - q) + 2.0 * p1;
+        const double pp = std::sqrt(p2 / 6.0);
+        if (pp == 0.0) {
+            lmax = q * (1.0 + 1e-6);          // A = q I (a rotation times a uniform scale: the identity model transform)
+        } else if (pp > 0.0 && std::isfinite(pp)) {
+            double b[3][3];
+            for (int i = 0; i < 3; i++)
+                for (int j = 0; j < 3; j++) b[i][j] = (a[i][j] - (i == j ? q : 0.0)) / pp;
+            double rdet = (b[0][0] * (b[1][1] * b[2][2] - b[1][2] * b[2][1]) - b[0][1] * (b[1][0] * b[2][2] - b[1][2] * b[2][0]) +
+                           b[0][2] * (b[1][0] * b[2][1] - b[1][1] * b[2][0])) / 2.0;
+            rdet = rdet < -1.0 ? -1.0 : (rdet > 1.0 ? 1.0 : rdet);
+            const double l = q + 2.0 * pp * std::cos(std::acos(rdet) / 3.0);
+            if (std::isfinite(l) && l > 0.0 && l <= tr) lmax = l * (1.0 + 1e-6) + 1e-30;
+        }
+        fc.cull_gain = (float)(1.001 * (double)fc.size2 * lmax);
+    }
     if (!(fc.cull_gain > 0.0f) || !(fc.cull_gain < 1e30f)) fc.cull_gain = 0.0f;   // degenerate uniforms: no block culling
 }
 

@@ -390,9 +390,16 @@ __global__ __launch_bounds__(256) void k_repack_planar_scatter(const uint4 *__re
 //   * screen position: x/z and y/z are ratios of affine functions, so over a box in front of the
 //     camera their extremes are attained at corners;
 //   * radius: Sigma' = size^2 (J W R_m S_m) Sigma (..)^T + 0.3 I, so lambda_max(Sigma') <=
-//     size^2 |J|_F^2 |R_m S_m|_F^2 lambda_max(Sigma) + 0.3, with |J|_F^2 <= (fx^2 (1 + limx^2) +
-//     fy^2 (1 + limy^2)) / z^2 because the Jacobian is evaluated at the clamped position; the
-//     spec's lambda (mid + sqrt(max(0.1, ..))) exceeds the true one by at most 0.32 and
+//     size^2 |J|_2^2 |W R_m S_m|_2^2 lambda_max(Sigma) + 0.3 with SPECTRAL norms (round 4; rounds 2-3 used
+//     Frobenius norms and the Jacobian's worst case over the whole image, which inflated the radius bound up
+//     to 4.7 x at the image centre and kept half again as many blocks of a band as needed):
+//       - |W R_m S_m|_2^2: largest eigenvalue of (W S)^T (W S), computed on the host (cull_gain);
+//       - |J|_2^2 = lambda_max(J J^T) / z^2 with J J^T z^2 = [[fx^2 (1 + u^2), fx fy u v], [fx fy u v, fy^2 (1 +
+//         v^2)]], u, v the CLAMPED x/z, y/z: the largest eigenvalue of a PSD 2x2 matrix grows with its diagonal
+//         and with |off-diagonal|, all of which grow with |u|, |v|, so it is bounded by its value at the
+//         block's largest |u|, |v| (corner extremes, cut at limx / limy) and smallest z;
+//       - lambda_max(Sigma) <= min(Frobenius norm, largest absolute row sum) per Gaussian (k_block_bounds).
+//     The spec's lambda (mid + sqrt(max(0.1, ..))) exceeds the true one by at most 0.32 and
 //     radius = ceil(k sqrt(lambda)).  All comparisons carry explicit slack for f32 rounding and
 //     are written so that NaN / inf bounds never cull.
 // ---------------------------------------------------------------------------------------------
@@ -424,6 +431,14 @@ __global__ __launch_bounds__(PP_THREADS) void k_block_bounds(const uint4 *__rest
             gaussian_unpack_cov3d<SH, COV>(w, S);
             float f2 = ((S[0] * S[0] + S[3] * S[3]) + S[5] * S[5]) + 2.0f * ((S[1] * S[1] + S[2] * S[2]) + S[4] * S[4]);
             float f = sqrtf(f2);
+            // two upper bounds of the largest eigenvalue of the (symmetric) covariance: its Frobenius norm and its
+            // largest absolute row sum (Gershgorin); the smaller one is kept.  A NaN in either makes the
+            // comparison false, so f — NaN or not — stays; a NaN f never replaces L below, +inf does.
+            const float g0 = (fabsf(S[0]) + fabsf(S[1])) + fabsf(S[2]);
+            const float g1 = (fabsf(S[1]) + fabsf(S[3])) + fabsf(S[4]);
+            const float g2 = (fabsf(S[2]) + fabsf(S[4])) + fabsf(S[5]);
+            const float gr = fmaxf(fmaxf(g0, g1), g2) * 1.000001f;
+            if (gr < f && !(g0 != g0) && !(g1 != g1) && !(g2 != g2)) f = gr;
             L = f > L ? f : L;                 // NaN never replaces L; +inf does (=> never culled)
 #pragma unroll
             for (int a = 0; a < 3; a++) {
@@ -508,14 +523,20 @@ __device__ __forceinline__ bool block_is_culled(const float *__restrict__ bb, co
     if (z0 - ez >= fc.far_plane) return true;
     if (!(z0 - ez > 0.0f)) return false;          // box reaches the camera plane: x/z is unbounded
     const float zl = fmaxf(z0 - ez, fc.near_plane);
-    const float lam = fc.cull_gain * L / (zl * zl) + 0.7f;
+    const float um = fmaxf(fabsf(u0), fabsf(u1)), vm = fmaxf(fabsf(v0), fabsf(v1));
+    // |J|_2^2 z^2 at the block's largest clamped |x/z|, |y/z| (with their rounding error; see the header comment)
+    const float ub = fminf(um + (ea * (1.0f + um) / zl) * 2.0f + 1e-4f * um, fc.limx);
+    const float vb = fminf(vm + (ea * (1.0f + vm) / zl) * 2.0f + 1e-4f * vm, fc.limy);
+    const float ja = (fc.fx * fc.fx) * (1.0f + ub * ub), jc = (fc.fy * fc.fy) * (1.0f + vb * vb);
+    const float jb = fabsf(fc.fx * fc.fy) * (ub * vb);
+    const float jn = (0.5f * (ja + jc) + sqrtf(0.25f * ((ja - jc) * (ja - jc)) + jb * jb)) * 1.0001f;
+    const float lam = fc.cull_gain * jn * L / (zl * zl) + 0.7f;
     const float r = fc.max_std_dev * sqrtf(lam) * 1.001f + 1.01f;
     if (!(r < 1e30f)) return false;
     const float mxa = fc.fx * u0 + fc.cx, mxb = fc.fx * u1 + fc.cx;
     const float mya = fc.fy * v0 + fc.cy, myb = fc.fy * v1 + fc.cy;
     const float mx0 = fminf(mxa, mxb), mx1 = fmaxf(mxa, mxb), my0 = fminf(mya, myb), my1 = fmaxf(mya, myb);
     // error of x/z: (ea + |x/z| ea) / z, in pixels times the focal length; plus a relative part
-    const float um = fmaxf(fabsf(u0), fabsf(u1)), vm = fmaxf(fabsf(v0), fabsf(v1));
     const float ex = fabsf(fc.fx) * (ea * (1.0f + um) / zl) * 2.0f + 1e-4f * (fabsf(mx0) + fabsf(mx1)) + 0.05f;
     const float ey = fabsf(fc.fy) * (ea * (1.0f + vm) / zl) * 2.0f + 1e-4f * (fabsf(my0) + fabsf(my1)) + 0.05f;
     if (mx1 + ex + r < 0.0f) return true;
