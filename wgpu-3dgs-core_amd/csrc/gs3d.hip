@@ -2242,8 +2242,19 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
     // the other.  On one stream that is stream order; a caller that moves the renderer to ANOTHER
     // stream gets the same guarantee from the previous frame's end-of-frame event (a device-side wait,
     // the host does not block).
-    if (r->have_frame && st != r->last_stream && r->done_valid[r->gen & 1u])
-        GS_HIP(hipStreamWaitEvent(st, r->done[r->gen & 1u], 0));
+    // No event at the end of every frame (round 4: it cost ~4 us of a pipelined 1 M frame).  The event a stream change
+    // needs is recorded on the PREVIOUS stream when the change happens (everything enqueued there is in front of it),
+    // and the capacity history reads the self-validating result blocks (gen stored last, read first and last)
+    // without asking an event first.  GS3D_FRAME_EVENT=1 restores the per-frame event (and the query in front of
+    // every history read).
+    static const bool frame_event = std::getenv("GS3D_FRAME_EVENT") && std::getenv("GS3D_FRAME_EVENT")[0] == '1';
+    if (r->have_frame && st != r->last_stream) {
+        if (!frame_event) {
+            GS_HIP(hipEventRecord(r->done[r->gen & 1u], r->last_stream));
+            r->done_valid[r->gen & 1u] = true;
+        }
+        if (r->done_valid[r->gen & 1u]) GS_HIP(hipStreamWaitEvent(st, r->done[r->gen & 1u], 0));
+    }
     const bool timing = r->timing && r->ev_valid;
     static const char *const k_stage_names[ST_COUNT] = {"gs3d:repack", "gs3d:preprocess", "gs3d:sizing", "gs3d:depth_sort",
                                                         "gs3d:expand", "gs3d:tile_sort", "gs3d:ranges", "gs3d:blend",
@@ -2277,16 +2288,24 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
     uint32_t hist_gen[2] = {0, 0};
     uint32_t hist_v[2] = {0, 0};
     for (int i = 0; i < 2; i++) {
-        if (!r->done_valid[i] || hipEventQuery(r->done[i]) != hipSuccess) continue;
+        if (frame_event) {
+            if (!r->done_valid[i] || hipEventQuery(r->done[i]) != hipSuccess) continue;
+        } else if (!r->done_gen[i]) {
+            continue;
+        }
         const gs::FrameResult &fr = r->results[i];
-        // gen is published last with a system-scope release (publish_result): read it first
-        if (__atomic_load_n(&fr.gen, __ATOMIC_ACQUIRE) != r->done_gen[i] || fr.pairs_total > 0xfffffff0ull) continue;
-        hist_d[i] = fr.pairs_total;
+        // gen is published last with a system-scope release (publish_result): read it first — and once more behind the
+        // fields (a frame two generations on may be overwriting the block while it is read)
+        if (__atomic_load_n(&fr.gen, __ATOMIC_ACQUIRE) != r->done_gen[i]) continue;
+        const uint64_t f_pairs = fr.pairs_total;
+        const uint32_t f_vis = fr.visible;
+        if (__atomic_load_n(&fr.gen, __ATOMIC_ACQUIRE) != r->done_gen[i] || f_pairs > 0xfffffff0ull) continue;
+        hist_d[i] = f_pairs;
         hist_gen[i] = r->done_gen[i];
-        hist_v[i] = fr.visible;
+        hist_v[i] = f_vis;
         // grow when the last measured D leaves less than 1/8 of head room
-        if (fr.pairs_total + fr.pairs_total / 8 > r->pair_capacity && capacity_for(fr.pairs_total) > want_capacity)
-            want_capacity = capacity_for(fr.pairs_total);
+        if (f_pairs + f_pairs / 8 > r->pair_capacity && capacity_for(f_pairs) > want_capacity)
+            want_capacity = capacity_for(f_pairs);
     }
     // A camera that keeps closing in: D grows frame over frame, and this frame is two or three frames
     // ahead of the newest result (frames are pipelined).  Extrapolate the last step three frames ahead
@@ -2353,13 +2372,18 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
         gs_renderer *r;
         hipStream_t st;
         uint32_t gen;
+        bool record;
         ~DoneGuard() {
-            (void)hipEventRecord(r->done[gen & 1u], st);
-            r->done_valid[gen & 1u] = true;
+            if (record) {
+                (void)hipEventRecord(r->done[gen & 1u], st);
+                r->done_valid[gen & 1u] = true;
+            } else {
+                r->done_valid[gen & 1u] = false;      // recorded when (if) the renderer moves to another stream
+            }
             r->done_gen[gen & 1u] = gen;
             r->done_shape[gen & 1u] = r->shape_epoch;
         }
-    } done_guard{r, st, gen};
+    } done_guard{r, st, gen, frame_event};
     gs::FrameState *state = (gs::FrameState *)r->state.ptr;
     gs::FrameResult *result = &r->results[gen & 1u];
     r->n = n;
