@@ -27,6 +27,7 @@ pub const GS_ERR_PAIR_OVERFLOW: gs_status = -23;
 pub const GS_ERR_PLY: gs_status = -24;
 pub const GS_ERR_SPZ: gs_status = -25;
 pub const GS_ERR_PAIR_CAPACITY: gs_status = -26;
+pub const GS_ERR_RANK_ORDER: gs_status = -27;
 
 // enum gs_sh_config (passed as u32)
 pub const GS_SH_SINGLE: u32 = 0;
@@ -276,6 +277,7 @@ extern "C" {
     pub fn gs_device_destroy(dev: *mut gs_device);
     pub fn gs_device_limits(dev: *const gs_device, out: *mut gs_limits) -> gs_status;
     pub fn gs_device_synchronize(dev: *mut gs_device) -> gs_status;
+    pub fn gs_device_fast_rank(dev: *const gs_device) -> i32;
     pub fn gs_stream_create(dev: *mut gs_device, out: *mut *mut gs_stream) -> gs_status;
     pub fn gs_stream_wrap(dev: *mut gs_device, hip_stream: *mut c_void, out: *mut *mut gs_stream) -> gs_status;
     pub fn gs_stream_native(s: *const gs_stream) -> *mut c_void;

@@ -71,7 +71,12 @@ enum {
      * buffers hold (a = pairs, b = capacity).  The frame was SKIPPED: the image was not written (it
      * keeps what it held) rather than blended without its farthest pairs.  The next frame grows the
      * buffers: render again. */
-    GS_ERR_PAIR_CAPACITY = -26
+    GS_ERR_PAIR_CAPACITY = -26,
+    /* gs_renderer_wait_frame: the watchdog of the radix sort's LDS-atomic rank fired in this frame (an order
+     * assumption about returning LDS atomics that the hardware documents do not promise; probed at
+     * gs_device_create and checked by block 0 of every pass).  The frame's blend order may be wrong; the device
+     * has been switched to the ballot-based rank for good: render again. */
+    GS_ERR_RANK_ORDER = -27
 };
 
 /* Thread-local details of the last failing call on this thread.
@@ -275,6 +280,10 @@ gs_status gs_device_create(int32_t hip_ordinal, gs_device **out);
 void gs_device_destroy(gs_device *dev);
 gs_status gs_device_limits(const gs_device *dev, gs_limits *out);
 gs_status gs_device_synchronize(gs_device *dev);
+/* 1 while the radix sorts of this device rank with returning LDS atomics (the order probe of gs_device_create passed
+ * and the per-frame watchdog has not fired: GS_ERR_RANK_ORDER), 0 once they use the ballot-based rank (no reference
+ * item: wgpu has no such primitive) */
+int32_t gs_device_fast_rank(const gs_device *dev);
 gs_status gs_stream_create(gs_device *dev, gs_stream **out);
 /* borrow an existing hipStream_t (e.g. the stream a caller's framework is using) */
 gs_status gs_stream_wrap(gs_device *dev, void *hip_stream, gs_stream **out);
@@ -606,7 +615,8 @@ typedef struct gs_frame_result {
     uint64_t visible;         /* V */
     uint64_t pairs;           /* D (the true count, also when it exceeded the capacity) */
     uint64_t pair_capacity;   /* pairs the renderer's buffers hold */
-    uint32_t flags;           /* bit 0: pair capacity exceeded; bit 1: the frame was skipped (image not written) */
+    uint32_t flags;           /* bit 0: pair capacity exceeded; bit 1: the frame was skipped (image not written);
+                               * bit 2: the rank watchdog fired (GS_ERR_RANK_ORDER) */
     uint32_t launches;        /* kernel launches the frame enqueued (after the repack) */
 } gs_frame_result;
 

@@ -37,6 +37,7 @@ struct PlyError : Error { using Error::Error; };   // std::io::Error of the PLY 
 struct SpzError : Error { using Error::Error; };   // std::io::Error of the SPZ reader
 // gs_renderer_wait_frame: the frame exceeded the pair capacity sized from earlier frames (render again)
 struct PairCapacityError : Error { using Error::Error; uint64_t pairs() const { return a; } uint64_t capacity() const { return b; } };
+struct RankOrderError : Error { using Error::Error; };   // the radix rank watchdog fired: render again
 
 inline void check(gs_status s) {
     if (s == GS_OK) return;
@@ -56,6 +57,7 @@ inline void check(gs_status s) {
     case GS_ERR_PLY: throw PlyError(i);
     case GS_ERR_SPZ: throw SpzError(i);
     case GS_ERR_PAIR_CAPACITY: throw PairCapacityError(i);
+    case GS_ERR_RANK_ORDER: throw RankOrderError(i);
     default: throw Error(i);
     }
 }
@@ -234,6 +236,7 @@ class Device {
     Device(const Device &) = delete;
     Device &operator=(const Device &) = delete;
     gs_limits limits() const { gs_limits l; check(gs_device_limits(h_, &l)); return l; }
+    bool fast_rank() const { return gs_device_fast_rank(h_) != 0; }
     gs_device *raw() const { return h_; }
   private:
     gs_device *h_ = nullptr;

@@ -149,12 +149,18 @@ class PairCapacityError(GsError):
         self.pairs, self.capacity = info.a, info.b
 
 
+class RankOrderError(GsError):
+    """gs_renderer_wait_frame: the watchdog of the radix sort's LDS-atomic rank fired in this frame (its blend
+    order may be wrong).  The device has been switched to the ballot-based rank: render again."""
+    code = -27
+
+
 _ERRORS = {c.code: c for c in (InvalidArgumentError, NoDeviceError, HipError, OutOfMemoryError,
                                GaussiansBufferUpdateError, GaussiansBufferUpdateRangeError,
                                GaussiansBufferTryFromBufferError, FixedSizeBufferWrapperError,
                                ResourceCountMismatch, WorkgroupSizeExceedsDeviceLimit,
                                LossyConfigError, DownloadBufferError, PlyError, SpzError, PairOverflowError,
-                               PairCapacityError)}
+                               PairCapacityError, RankOrderError)}
 
 
 def _check(status):
@@ -581,6 +587,10 @@ class Device:
 
     def synchronize(self):
         _check(_L.gs_device_synchronize(self._h))
+
+    def fast_rank(self):
+        """True while this device's radix sorts rank with returning LDS atomics (gs_device_fast_rank)"""
+        return bool(_L.gs_device_fast_rank(self._h))
 
     def create_stream(self):
         return Stream(self)
@@ -1124,7 +1134,7 @@ class ComputeBundleBuilder:
 # renderer
 # ------------------------------------------------------------------------------------------------
 
-FRAME_FLAG_PAIR_OVERFLOW, FRAME_FLAG_SKIPPED = 1, 2     # gs_frame_result.flags
+FRAME_FLAG_PAIR_OVERFLOW, FRAME_FLAG_SKIPPED, FRAME_FLAG_RANK_FAULT = 1, 2, 4     # gs_frame_result.flags
 STAGE_NAMES = ["repack", "preprocess", "scan", "depth_sort", "expand", "tile_sort", "ranges", "blend", "frame"]
 
 
@@ -1167,7 +1177,7 @@ class Renderer:
                 return None
             try:
                 return self.wait_frame()
-            except PairCapacityError:
+            except (PairCapacityError, RankOrderError):
                 if attempt == 3:
                     raise
 

@@ -106,6 +106,7 @@ SIGNATURES = {
     "gs_device_destroy": (None, [vp]),
     "gs_device_limits": (i32, [vp, vp]),
     "gs_device_synchronize": (i32, [vp]),
+    "gs_device_fast_rank": (i32, [vp]),
     "gs_stream_create": (i32, [vp, vp]),
     "gs_stream_wrap": (i32, [vp, vp, vp]),
     "gs_stream_native": (vp, [vp]),

@@ -93,6 +93,7 @@ extern "C" const char *gs_status_string(gs_status s) {
     case GS_ERR_DOWNLOAD: return "buffer download failed";
     case GS_ERR_PAIR_OVERFLOW: return "more than 2^32 (tile, Gaussian) pairs";
     case GS_ERR_PAIR_CAPACITY: return "pair capacity exceeded; render again";
+    case GS_ERR_RANK_ORDER: return "radix rank watchdog fired; device switched to the ballot-based rank; render again";
     case GS_ERR_PLY: return "PLY read error";
     case GS_ERR_SPZ: return "SPZ read error";
     default: return "unknown";
@@ -326,6 +327,8 @@ extern "C" gs_status gs_device_create(int32_t ordinal, gs_device **out) {
     *out = d;
     return GS_OK;
 }
+
+extern "C" int32_t gs_device_fast_rank(const gs_device *dev) { return dev && dev->lds_atomic_ordered ? 1 : 0; }
 
 extern "C" void gs_device_destroy(gs_device *dev) {
     if (!dev) return;
@@ -1444,6 +1447,7 @@ struct gs_renderer {
     DevArray cull_status;                 // k_block_cull: one (tag << 10 | count) word per group of 256 blocks
     DevArray chunk_hist;                  // [chunks][256] first-digit histogram of every chunk's depth keys (PreOut::chunk_hist)
     bool list_mode = false;               // the last frame's per-slot arrays are in LIST space (k_block_cull ran)
+    bool rank_inject_set = false;         // GS3D_TEST_RANK_FAULT: the watchdog's test hook has been armed
     uint32_t cull_last_gen = 0, cull_last_groups = 0;   // frame / group count of the last k_block_cull (status tags)
     DevArray dkeys[2], dvals[2];          // (depth bits - bias, mirror slot), capacity N
     DevArray tkeys[2], tvals[2];          // (tile id, mirror slot), capacity pair_capacity
@@ -1612,6 +1616,15 @@ extern "C" gs_status gs_renderer_wait_frame(gs_renderer *r, gs_frame_result *out
     if (fr.pairs_total > 0xfffffff0ull)
         return fail(GS_ERR_PAIR_OVERFLOW, r->n, 0, 0,
                     "the frame needs more than 2^32 (tile, Gaussian) pairs; pair indices are 32-bit");
+    if (fr.flags & gs::FRAME_FLAG_RANK_FAULT) {
+        if (r->dev->lds_atomic_ordered) {
+            r->dev->lds_atomic_ordered = false;
+            (void)hipMemset(&((gs::FrameState *)r->state.ptr)->rank_fault, 0, sizeof(uint32_t));   // the stream is idle here
+        }
+        return fail(GS_ERR_RANK_ORDER, 0, 0, 0,
+                    "the LDS-atomic rank of the radix sort returned an out-of-order value in this frame: its blend order "
+                    "may be wrong; the device has been switched to the ballot-based rank: render again");
+    }
     if (fr.flags & gs::FRAME_FLAG_PAIR_OVERFLOW)
         return fail(GS_ERR_PAIR_CAPACITY, fr.pairs_total, r->pair_capacity, 0,
                     "the frame produced %llu (tile, Gaussian) pairs but the pair buffers hold %llu: the frame was "
@@ -1795,6 +1808,11 @@ static void launch_scan_rows(uint32_t rows, hipStream_t st, uint32_t *ghist, uin
                            totals);
 }
 
+// Watchdog word of the LDS-atomic rank for the scatters launched by the current gs_render_frame call (FrameState::
+// rank_fault; null outside a frame: the stand-alone sorts are not watched).  Thread-local instead of one more
+// parameter through five levels of sort templates.
+static thread_local uint32_t *t_rank_fault = nullptr;
+
 // one scatter launch (FAST_RANK chosen by the device probe); KO = type of the keys the pass writes
 template <typename KI, typename KO, int RB, bool COMPACT, int ITEMS>
 static void launch_scatter(const gs_device *dev, hipStream_t st, uint32_t sgrid, const KI *kin, const uint32_t *vin, KO *kout,
@@ -1808,10 +1826,10 @@ static void launch_scatter(const gs_device *dev, hipStream_t st, uint32_t sgrid,
     const uint32_t xr_nt = xr | (nt ? 0x80000000u : 0u);
     if (dev->lds_atomic_ordered)
         hipLaunchKernelGGL((gs::k_sort_scatter<KI, true, RB, COMPACT, ITEMS, KO>), dim3(sgrid), dim3(gs::SORT_THREADS), 0, st, kin, vin,
-                           kout, ko_shift, vout, psc, shift, digit_mask, ghist, totals, cv, vo, pnb, xr_nt);
+                           kout, ko_shift, vout, psc, shift, digit_mask, ghist, totals, cv, vo, pnb, xr_nt, t_rank_fault);
     else
         hipLaunchKernelGGL((gs::k_sort_scatter<KI, false, RB, COMPACT, ITEMS, KO>), dim3(sgrid), dim3(gs::SORT_THREADS), 0, st, kin, vin,
-                           kout, ko_shift, vout, psc, shift, digit_mask, ghist, totals, cv, vo, pnb, xr_nt);
+                           kout, ko_shift, vout, psc, shift, digit_mask, ghist, totals, cv, vo, pnb, xr_nt, (uint32_t *)nullptr);
 }
 
 // one radix pass: histogram -> row scan -> scatter
@@ -2284,6 +2302,7 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
 
     // ---- what the previous frames told us (never blocks: an unfinished frame is simply not consulted) ----
     uint64_t want_capacity = r->pair_capacity;
+    bool rank_fault_seen = false;
     uint64_t hist_d[2] = {0, 0};
     uint32_t hist_gen[2] = {0, 0};
     uint32_t hist_v[2] = {0, 0};
@@ -2299,10 +2318,12 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
         if (__atomic_load_n(&fr.gen, __ATOMIC_ACQUIRE) != r->done_gen[i]) continue;
         const uint64_t f_pairs = fr.pairs_total;
         const uint32_t f_vis = fr.visible;
+        const uint32_t f_flags = fr.flags;
         if (__atomic_load_n(&fr.gen, __ATOMIC_ACQUIRE) != r->done_gen[i] || f_pairs > 0xfffffff0ull) continue;
         hist_d[i] = f_pairs;
         hist_gen[i] = r->done_gen[i];
         hist_v[i] = f_vis;
+        if (f_flags & gs::FRAME_FLAG_RANK_FAULT) rank_fault_seen = true;
         // grow when the last measured D leaves less than 1/8 of head room
         if (f_pairs + f_pairs / 8 > r->pair_capacity && capacity_for(f_pairs) > want_capacity)
             want_capacity = capacity_for(f_pairs);
@@ -2359,6 +2380,28 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
     const uint32_t exp_grid = (n + gs::EXP_CHUNK - 1) / gs::EXP_CHUNK;   // V <= N
     GS_TRY(dev_reserve(r->exp_sums, (size_t)(exp_grid ? exp_grid : 1) * 4));
     GS_TRY(reserve_zeroed(r->state, sizeof(gs::FrameState), st));
+    {
+        // Watchdog of the LDS-atomic rank (scatter_ranked): a completed frame reported a rank that was not the
+        // ballot-based one -> this device sorts with the ballot-based rank from now on, and the flag is cleared in
+        // stream order (the kernels that could set it are no longer launched).
+        gs::FrameState *fs = (gs::FrameState *)r->state.ptr;
+        if (rank_fault_seen && r->dev->lds_atomic_ordered) {
+            r->dev->lds_atomic_ordered = false;
+            GS_HIP(hipMemsetAsync(&fs->rank_fault, 0, sizeof(uint32_t), st));
+        }
+        // GS3D_TEST_RANK_FAULT=1 (tests): the watchdog's expectation is off by one, so it fires in the first frame
+        static const bool inject = std::getenv("GS3D_TEST_RANK_FAULT") && std::getenv("GS3D_TEST_RANK_FAULT")[0] == '1';
+        if (inject && !r->rank_inject_set) {
+            const uint32_t one = 1u;
+            GS_HIP(hipMemcpyAsync(&fs->rank_inject, &one, sizeof(one), hipMemcpyHostToDevice, st));
+            GS_HIP(hipStreamSynchronize(st));      // `one` lives on this stack frame
+            r->rank_inject_set = true;
+        }
+        t_rank_fault = r->dev->lds_atomic_ordered ? &fs->rank_fault : nullptr;
+    }
+    struct RankFaultScope {
+        ~RankFaultScope() { t_rank_fault = nullptr; }
+    } rank_fault_scope;
 
     r->gen++;
     const uint32_t gen = r->gen;

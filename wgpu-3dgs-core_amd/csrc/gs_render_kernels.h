@@ -165,10 +165,15 @@ struct FrameState {
     uint32_t list_blocks;    // length of the block list (k_block_cull), written by the workgroup that drew the last ticket
     uint32_t list_slots;     // = list_blocks * 1024: the preprocess outputs of a list frame live in LIST space, [0, list_slots)
     uint32_t cull_ticket;    // k_block_cull: workgroups take their group of 256 blocks in ticket order; the last ticket resets it
-    uint32_t pad[2];
+    uint32_t rank_fault;     // watchdog of the LDS-atomic rank (scatter_ranked): set when block 0 of a radix pass finds a rank
+                             // that is not the ballot-based one; published with the frame flags, cleared by the host
+    uint32_t rank_inject;    // test hook (GS3D_TEST_RANK_FAULT=1): added to the expected rank, so the watchdog fires
 };
 constexpr uint32_t FRAME_FLAG_PAIR_OVERFLOW = 1u;   // D exceeded the pair capacity
 constexpr uint32_t FRAME_FLAG_SKIPPED = 2u;         // ... so the frame was skipped: the image was NOT written
+constexpr uint32_t FRAME_FLAG_RANK_FAULT = 4u;      // the LDS-atomic rank's order assumption failed in a pass of this (or, for the
+                                                    // tile sort, of the previous) frame: blend order possibly wrong; the host
+                                                    // switches the device to the ballot-based rank
 
 // pinned host memory, one per frame parity; written by workgroup 0 of k_pairs_emit
 struct FrameResult {
@@ -1635,7 +1640,7 @@ __device__ __forceinline__ void scatter_ranked(ScatterShared<K, RB, ITEMS> &sh, 
                                                uint32_t *__restrict__ vals_out, uint32_t shift, uint32_t digit_mask,
                                                const uint32_t *__restrict__ ghist,
                                                const uint32_t *__restrict__ digit_totals,
-                                               uint32_t *__restrict__ visible_out) {
+                                               uint32_t *__restrict__ visible_out, uint32_t *rank_fault = nullptr) {
     constexpr int R = 1 << RB;
     constexpr int DPT = R / SORT_THREADS;        // digits per thread: thread t owns digits [t*DPT, t*DPT+DPT)
     auto &s_wave_hist = sh.wave_hist;
@@ -1650,6 +1655,23 @@ __device__ __forceinline__ void scatter_ranked(ScatterShared<K, RB, ITEMS> &sh, 
         for (int k = 0; k < ITEMS; k++) {
             uint32_t d = (uint32_t)(key[k] >> shift) & digit_mask;
             if (!COMPACT || (uint32_t)key[k] != SORT_INVALID_KEY) rank[k] = atomicAdd(&s_wave_hist[wid][d], 1u);
+        }
+        // Watchdog of the bet: block 0 of every pass checks its first round against the ballot-based
+        // rank — the wave's counters start at zero, so the rank of a live lane must be the number of live lanes below
+        // it holding the same digit.  A mismatch sets FrameState.rank_fault; the frame result carries it to the host,
+        // which switches the device to the ballot-based rank for good.  (A probe at gs_device_create cannot see a
+        // violation that only shows under the frame's real access pattern; rounds 2-3 shipped the bet unguarded.)
+        if (rank_fault && block == 0u) {
+            const uint32_t d0 = (uint32_t)(key[0] >> shift) & digit_mask;
+            const bool live0 = !COMPACT || (uint32_t)key[0] != SORT_INVALID_KEY;
+            uint64_t peers = __ballot(live0);
+#pragma unroll
+            for (int b = 0; b < RB; b++) {
+                const uint64_t m = __ballot((d0 >> b) & 1u);
+                peers &= ((d0 >> b) & 1u) ? m : ~m;
+            }
+            const bool bad = live0 && rank[0] != mbcnt(peers) + rank_fault[1];
+            if (__any(bad) && (threadIdx.x & 63u) == 0u) atomicOr(rank_fault, 1u);
         }
     } else {
 #pragma unroll
@@ -1790,7 +1812,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
     uint32_t *__restrict__ vals_out, SortCount sc, uint32_t shift, uint32_t digit_mask,
     const uint32_t *__restrict__ ghist, const uint32_t *__restrict__ digit_totals,
     const uint32_t *__restrict__ chunk_vis, uint32_t *__restrict__ visible_out, uint32_t num_tiles,
-    uint32_t xcd_chunk_nt) {
+    uint32_t xcd_chunk_nt, uint32_t *rank_fault) {
     constexpr int TILE = SORT_THREADS * ITEMS;
     __shared__ ScatterShared<K, RB, ITEMS> sh;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
@@ -1854,7 +1876,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
         }
     }
     scatter_ranked<K, FAST_RANK, RB, COMPACT, ITEMS, KO>(sh, key, val, in_tile, block, num_tiles, keys_out, ko_shift, vals_out,
-                                                         shift, digit_mask, ghist, digit_totals, visible_out);
+                                                         shift, digit_mask, ghist, digit_totals, visible_out, rank_fault);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2003,7 +2025,7 @@ __global__ __launch_bounds__(EXP_SB) void k_pairs_cursors(ExpandIO io) {
         const uint32_t over = d > (uint64_t)io.capacity ? (FRAME_FLAG_PAIR_OVERFLOW | FRAME_FLAG_SKIPPED) : 0u;
         io.state->pairs = over ? io.capacity : (uint32_t)d;
         io.state->overflow = over ? 1u : 0u;
-        publish_result(io.result, v_count, d, over, io.gen, io.flags_dev);
+        publish_result(io.result, v_count, d, over | (io.state->rank_fault ? FRAME_FLAG_RANK_FAULT : 0u), io.gen, io.flags_dev);
     }
     if (v == 0ull) return;
     const uint64_t p = s_before[0] + s_before[1] + (wid ? s_wave0 : 0ull) + incl - v;   // pairs in front of chunk c
@@ -2224,7 +2246,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_pairs_emit(ExpandIO io, uint32
             const uint32_t over = d > (uint64_t)io.capacity ? (FRAME_FLAG_PAIR_OVERFLOW | FRAME_FLAG_SKIPPED) : 0u;
             io.state->pairs = count;
             io.state->overflow = over ? 1u : 0u;
-            publish_result(io.result, v_count, d, over, io.gen, io.flags_dev);
+            publish_result(io.result, v_count, d, over | (io.state->rank_fault ? FRAME_FLAG_RANK_FAULT : 0u), io.gen, io.flags_dev);
         }
     }
     if ((uint64_t)block * TILE >= count) return;      // the same D in every wave: block-uniform
