@@ -223,8 +223,8 @@ def run_workload(gs, synth, torch, dist, dev, stream, rank, world, wl, steps, wa
     else:
         skipped_bands = [int(r.wait_frame().flags)]
     if any(skipped_bands):
-        raise RuntimeError("bench.py: a frame was skipped (pair capacity exceeded, per-band flags %s): the timed "
-                           "region did not render every frame" % skipped_bands)
+        raise RuntimeError("bench.py: a frame was skipped or flagged (per-band flags %s; bit 0/1 = pair capacity exceeded / "
+                           "skipped, bit 2 = radix rank watchdog): the timed region did not render every frame" % skipped_bands)
     checksum = float(img[:H].double().sum().item())
     visible, pairs = int(st.visible), int(st.pairs)
     if world > 1:   # totals over the bands
