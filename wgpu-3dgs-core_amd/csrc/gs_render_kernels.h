@@ -2041,13 +2041,39 @@ constexpr int GEN_PER = 4;                    // Gaussians per lane per batch (c
 constexpr int GEN_BATCH = WAVE * GEN_PER;     // = EXP_CHUNK: a batch is one chunk of the count kernel
 static_assert(GEN_BATCH == EXP_CHUNK, "the cursor hands out chunk starts");
 
-template <typename K, int NSLOTS>
+// per Gaussian of the batch: first slot (signed, relative to the wave's first), id, tile id of the rect origin, rect
+// width.  PACKED (rect_pack32: width <= 256, origin < 2^22): 12 bytes instead of 16 — with the staging below a
+// workgroup of k_pairs_emit then needs 38 KB of LDS instead of 52, four per CU instead of three (the kernel is
+// bound by the latency of its dependent loads times its occupancy, NOTES.md Part II).
+template <bool PACKED>
+struct PairGenTab {
+    uint4 rec[GEN_BATCH];
+    __device__ __forceinline__ void put(uint32_t i, uint32_t start, uint32_t gid, uint32_t origin, uint32_t w) {
+        rec[i] = make_uint4(start, gid, origin, w);
+    }
+    __device__ __forceinline__ uint4 get(uint32_t i) const { return rec[i]; }
+};
+template <>
+struct PairGenTab<true> {
+    uint2 so[GEN_BATCH];               // first slot, origin | (width - 1) << 24
+    uint32_t gid[GEN_BATCH];
+    __device__ __forceinline__ void put(uint32_t i, uint32_t start, uint32_t g, uint32_t origin, uint32_t w) {
+        so[i] = make_uint2(start, origin | ((w - 1u) << 24));
+        gid[i] = g;
+    }
+    __device__ __forceinline__ uint4 get(uint32_t i) const {
+        const uint2 a = so[i];
+        return make_uint4(a.x, gid[i], a.y & 0xffffffu, (a.y >> 24) + 1u);
+    }
+};
+
+template <typename K, int NSLOTS, bool RECT32>
 struct PairGenShared {                 // LDS private to one wave
-    uint32_t vals[NSLOTS + GEN_BATCH]; // output staging (Gaussian id per slot); until a slot is produced it holds
+    uint32_t vals[NSLOTS];             // output staging (Gaussian id per slot); until a slot is produced it holds
                                        // the marker: 1 + batch index of the Gaussian whose first pair it is, 0 = none
+                                       // (markers and groups stay below hi <= n_slots <= NSLOTS, a multiple of 256)
     K keys[NSLOTS];                    // output staging (tile id per slot)
-    uint4 tab[GEN_BATCH];              // per Gaussian of the batch: first slot (signed, relative to the wave's
-                                       // first), id, tile id of the rect origin, rect width
+    PairGenTab<RECT32> tab;
 };
 
 // The wave produces its output slots [0, n_slots) (absolute: o0 + slot) into sh.keys / sh.vals and
@@ -2059,13 +2085,14 @@ struct PairGenShared {                 // LDS private to one wave
 // terminates.
 template <typename K, int NSLOTS, bool RECT32, typename Count>
 __device__ __forceinline__ void pair_generate(const ExpandIO &io, uint32_t v_count, uint64_t o0, uint32_t n_slots,
-                                              const PairCursor &cur, uint32_t lane, PairGenShared<K, NSLOTS> &sh,
+                                              const PairCursor &cur, uint32_t lane, PairGenShared<K, NSLOTS, RECT32> &sh,
                                               Count count) {
     static_assert(sizeof(K) == 2 || sizeof(K) == 4, "tile keys are u16 or u32");
+    static_assert(NSLOTS % GEN_BATCH == 0, "whole groups of 256 slots");
     {
         uint4 *z = (uint4 *)sh.vals;
 #pragma unroll
-        for (uint32_t q0 = 0; q0 < (NSLOTS + GEN_BATCH) / 4; q0 += WAVE) z[q0 + lane] = make_uint4(0u, 0u, 0u, 0u);
+        for (uint32_t q0 = 0; q0 < NSLOTS / 4; q0 += WAVE) z[q0 + lane] = make_uint4(0u, 0u, 0u, 0u);
     }
     // slots relative to o0 from here on: the chunk in front of o0 holds < 2^30 pairs, a batch < 2^30
     int32_t rel = (int32_t)(int64_t)(cur.prefix - o0);      // <= 0: first slot of the batch
@@ -2125,7 +2152,7 @@ __device__ __forceinline__ void pair_generate(const ExpandIO &io, uint32_t v_cou
 #pragma unroll
             for (int k = 0; k < GEN_PER; k++) {
                 const uint32_t idx = GEN_PER * lane + k;
-                sh.tab[idx] = make_uint4((uint32_t)start, g[k], origin[k], w[k] ? w[k] : 1u);
+                sh.tab.put(idx, (uint32_t)start, g[k], origin[k], w[k] ? w[k] : 1u);
                 if (cnt[k] != 0u) {
                     if (start <= lo) last = idx + 1u;
                     else if (start < hi) sh.vals[start] = idx + 1u;
@@ -2161,7 +2188,7 @@ __device__ __forceinline__ void pair_generate(const ExpandIO &io, uint32_t v_cou
 #pragma unroll
                 for (int k = 0; k < GEN_PER; k++) {
                     own = m[k] > own ? m[k] : own;
-                    ot[k] = sh.tab[own - 1u];
+                    ot[k] = sh.tab.get(own - 1u);
                 }
 #pragma unroll
                 for (int k = 0; k < GEN_PER; k++) {
@@ -2214,10 +2241,12 @@ __global__ __launch_bounds__(SORT_THREADS) void k_pairs_emit(ExpandIO io, uint32
     constexpr uint32_t TILE = SORT_THREADS * ITEMS;
     constexpr uint32_t NSLOTS = ITEMS * WAVE;
     constexpr int R = 1 << RB;
-    constexpr int COPIES = 2048 / R;
+    // two copies of the histogram (lanes alternate): neighbouring slots of a lane are neighbouring tiles, and the
+    // Gaussians of one wave instruction are neighbours in depth, not in space — same-address adds are rare
+    constexpr int COPIES = 512 / R > 1 ? 512 / R : 1;
     constexpr int DPT = R / SORT_THREADS;
     __shared__ uint32_t s_hist[COPIES][R];
-    __shared__ PairGenShared<K, NSLOTS> s_gen[4];
+    __shared__ PairGenShared<K, NSLOTS, RECT32> s_gen[4];
     const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
     const uint32_t v_count = io.state->visible;
     const uint32_t block = scatter_tile_of(blockIdx.x, xcd_chunk);   // as the scatter and the histograms
@@ -2258,7 +2287,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_pairs_emit(ExpandIO io, uint32
     if (o0 < count) {
         const uint32_t n_slots = count - o0 < (uint64_t)NSLOTS ? (uint32_t)(count - o0) : NSLOTS;
         uint32_t *hist = s_hist[threadIdx.x & (uint32_t)(COPIES - 1)];
-        PairGenShared<K, NSLOTS> &sh = s_gen[wid];
+        PairGenShared<K, NSLOTS, RECT32> &sh = s_gen[wid];
         pair_generate<K, NSLOTS, RECT32>(io, v_count, o0, n_slots, cur, lane, sh,
                          [&](uint32_t tile) { atomicAdd(&hist[tile & digit_mask], 1u); });
         // the wave's slots leave in whole 16-byte vectors (o0 is a multiple of NSLOTS: aligned)
