@@ -18,7 +18,7 @@ SUBSET = "synthetic_small or emission or capacity_overflow or edge_cases or wide
 @pytest.mark.parametrize("env", [{"GS3D_CURSOR_KERNEL": "1", "GS3D_RANGES_IN_BLEND": "1"}, {"GS3D_DISABLE_FAST_RANK": "1"},
                                  {"GS3D_BLEND_GROUPS": "1", "GS3D_RANGES_IN_BLEND": "1"}, {"GS3D_RECT_V1": "1"}, {"GS3D_SPATIAL_ORDER": "0"},
                                  {"GS3D_XCD_REMAP": "0", "GS3D_EVENT_FENCE": "1", "GS3D_FRAME_EVENT": "1", "GS3D_NT_LOADS": "1", "GS3D_BLOCK_LIST": "1", "GS3D_NT_SCATTER": "1",
-                                  "GS3D_RANGES_SEARCH": "1", "GS3D_RANGES_IN_BLEND": "0"},
+                                  "GS3D_RANGES_SEARCH": "1", "GS3D_RANGES_IN_BLEND": "0", "GS3D_DEPTH_SORT_LARGE": "1"},
                                  {"GS3D_PRE_PIPELINE": "0", "GS3D_SCAN_ROWS_SMALL": "0", "GS3D_NT_LOADS": "0", "GS3D_BLOCK_LIST": "0",
                                   "GS3D_NT_SCATTER": "0", "GS3D_RANGES_SEARCH": "0", "GS3D_RANGES_IN_BLEND": "0", "GS3D_CHUNK_HIST": "0", "GS3D_EXPAND_XCD": "0"}],
                          ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))

@@ -1971,6 +1971,11 @@ static gs_status run_sort_rb(const gs_device *dev, void *const keys[2], void *co
         // twice as many workgroups per CU (10 M: emit + tile sort 376 -> 358 us); 8-bit digits (4K: 15
         // bits = 8 + 7) keep 8192-key tiles (848 vs 875 us with the small ones).
         bool large = bound >= (4u << 20);
+        if (sizeof(K) == 4) {
+            // GS3D_DEPTH_SORT_LARGE=0/1 forces 4096- / 8192-key tiles for 32-bit keys (A/B runs)
+            static const int force32 = std::getenv("GS3D_DEPTH_SORT_LARGE") ? std::atoi(std::getenv("GS3D_DEPTH_SORT_LARGE")) : -1;
+            if (force32 >= 0) large = force32 != 0;
+        }
         if (sizeof(K) == 2) {
             const uint32_t passes = (end_bit + RB - 1) / RB;
             large = passes ? (end_bit + passes - 1) / passes > 7u : false;
