@@ -62,6 +62,18 @@ __global__ __launch_bounds__(256) void k_scan_small(uint32_t *tab, uint32_t nb, 
     if (r < R) scan_row<false>(tab, nb, r, lane, totals);
 }
 
+// A with the row length read from DEVICE memory first (the product's kernels learn V and D that way: the counts never
+// return to the host inside a frame) — one more dependent round trip in front of the row loads
+__global__ __launch_bounds__(256) void k_write_dev(uint32_t *tab, const uint32_t *nb_dev, uint32_t salt) {
+    const uint32_t nb = *nb_dev;
+    if (blockIdx.x < nb) write_column(tab, nb, salt);
+}
+__global__ __launch_bounds__(256) void k_scan_small_dev(uint32_t *tab, const uint32_t *nb_dev, uint32_t *totals) {
+    const uint32_t nb = *nb_dev;
+    const uint32_t lane = threadIdx.x & 63u, r = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (r < R) scan_row<false>(tab, nb, r, lane, totals);
+}
+
 // B: the workgroup that draws the last ticket scans everything
 __global__ __launch_bounds__(256) void k_write_last_scans(uint32_t *tab, uint32_t nb, uint32_t salt, uint32_t *totals,
                                                           uint32_t *ticket) {
@@ -117,7 +129,26 @@ int main(int argc, char **argv) {
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
     const uint32_t sizes[] = {64, 173, 245};
+    uint32_t *nb_dev;
+    CK(hipMalloc(&nb_dev, 4));
     for (uint32_t nb : sizes) {
+        // the same pair with the row length in device memory, written by a kernel-ordered copy like V and D are
+        {
+            CK(hipMemcpyAsync(nb_dev, &nb, 4, hipMemcpyHostToDevice, st));
+            CK(hipStreamSynchronize(st));
+            for (int rep = 0; rep < 2; rep++) {
+                CK(hipEventRecord(e0, st));
+                for (int i = 0; i < iters; i++) {
+                    hipLaunchKernelGGL(k_write_dev, dim3(nb), dim3(256), 0, st, tab, nb_dev, (uint32_t)i);
+                    hipLaunchKernelGGL(k_scan_small_dev, dim3(R / 4), dim3(256), 0, st, tab, nb_dev, totals);
+                }
+                CK(hipEventRecord(e1, st));
+                CK(hipStreamSynchronize(st));
+                float ms = 0;
+                CK(hipEventElapsedTime(&ms, e0, e1));
+                if (rep) printf("NB %3u: two kernels, row length from device memory %6.2f us\n", nb, ms * 1e3 / iters);
+            }
+        }
         std::vector<uint32_t> ref((size_t)R * nb), got((size_t)R * nb), rt(R), gt(R);
         double us[4] = {0, 0, 0, 0};
         bool same[4] = {true, true, true, true};
