@@ -12,6 +12,21 @@
 #include "../../wgpu-3dgs-core_amd/csrc/gs_render_kernels.h"
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
+// What a frame does between two launches of the same small kernel, in two kernels: ~200 MB streamed through the L2s,
+// and 64 KB of straight-line code through every CU's instruction cache.
+__global__ __launch_bounds__(256) void k_thrash_data(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+__global__ __launch_bounds__(64) void k_thrash_code(float *out, float seed) {
+    float a = seed + threadIdx.x, b = 1.0f;
+#pragma unroll
+    for (int i = 0; i < 8192; i++) {           // 2 x 8192 VALU instructions with literal operands: ~128 KB of code
+        a = a * (1.0f + i * 1e-7f) + b;
+        b = b * 0.999f + (float)i;
+    }
+    if (a == 12345.678f) out[0] = a + b;      // never true: keeps the chain alive
+}
+
 int main(int argc, char **argv) {
     const int iters = argc > 1 ? atoi(argv[1]) : 300;
     const uint32_t n = 708615, RB = 9, ITEMS = 16, TILE = 256 * ITEMS, R = 1u << RB;
@@ -53,14 +68,39 @@ int main(int argc, char **argv) {
                            (const uint32_t *)ghist, (const uint32_t *)totals, (const uint32_t *)nullptr, (uint32_t *)nullptr, nb, 0u,
                            (uint32_t *)nullptr);
     };
-    double us[3];
+    uint4 *ta, *tb;
+    const size_t n16 = (96u << 20) / 16;
+    CK(hipMalloc(&ta, n16 * 16));
+    CK(hipMalloc(&tb, n16 * 16));
+    CK(hipMemset(ta, 1, n16 * 16));
+    float *fout;
+    CK(hipMalloc(&fout, 4));
+    const bool cold = argc > 2 && atoi(argv[2]) != 0;
+    auto thrash = [&] {
+        hipLaunchKernelGGL(k_thrash_data, dim3(2048), dim3(256), 0, st, (const uint4 *)ta, tb, n16);
+        hipLaunchKernelGGL(k_thrash_code, dim3(512), dim3(64), 0, st, fout, 1.0f);
+    };
+    double us[4];
     for (int rep = 0; rep < 2; rep++)
-        for (int variant = 0; variant < 3; variant++) {
+        for (int variant = cold ? -1 : 0; variant < 3; variant++) {
             auto run = [&] {
-                hist();
+                if (cold) thrash();
+                if (variant >= 0) hist();
                 if (variant >= 1) scan();
                 if (variant >= 2) scatter();
             };
+            if (variant < 0) {
+                for (int i = 0; i < 5; i++) run();
+                CK(hipStreamSynchronize(st));
+                CK(hipEventRecord(e0, st));
+                for (int i = 0; i < iters; i++) run();
+                CK(hipEventRecord(e1, st));
+                CK(hipStreamSynchronize(st));
+                float ms = 0;
+                CK(hipEventElapsedTime(&ms, e0, e1));
+                us[3] = ms * 1e3 / iters;
+                continue;
+            }
             for (int i = 0; i < 20; i++) run();
             CK(hipStreamSynchronize(st));
             CK(hipEventRecord(e0, st));
@@ -69,7 +109,9 @@ int main(int argc, char **argv) {
             CK(hipStreamSynchronize(st));
             float ms = 0;
             CK(hipEventElapsedTime(&ms, e0, e1));
-            us[variant] = ms * 1e3 / iters;
+            us[variant] = ms * 1e3 / iters - (cold ? us[3] : 0.0);
+            if (rep && variant == 2 && cold)
+                printf("COLD (192 MB copied + 128 KB of code run between passes, %.1f us, subtracted): ", us[3]);
             if (rep && variant == 2)
                 printf("708 615 keys, %u tiles: hist %.2f us | + scan %.2f us | + scatter %.2f us | pass %.2f us "
                        "(frame's kernel trace: 5.05 + 4.70 + 9.14 = 18.89)\n", nb, us[0], us[1] - us[0], us[2] - us[1], us[2]);
