@@ -231,37 +231,75 @@ def run_workload(gs, synth, torch, dist, dev, stream, rank, world, wl, steps, wa
         t = torch.tensor([pairs], dtype=torch.float64, device="cuda")
         dist.all_reduce(t)
         pairs = int(t.item())
-    # Throughput with TWO frames in flight (single GPU): a second renderer (its own scratch buffers) on a
-    # second stream takes every other frame, so the latency-bound sort chain of frame i + 1 fills the gaps
-    # of frame i's VALU-bound blend.  Reported beside `value`, never as `value`: a frame's latency does
-    # not change.  Both images are checked against the single-stream frame.
+    # Frames in flight (single GPU): F renderers (each its own scratch buffers) on F streams of F different
+    # priorities take the frames in turn, so that the latency-bound sort chain of frame i + 1 runs under the
+    # VALU-bound blend of frame i.  Different priorities because HIP gives each priority level its own hardware
+    # queues while streams of one priority may share a queue — under torch they do, and then nothing overlaps
+    # (kernel trace: one Queue_Id for both streams; 0.327 ms per frame with or without the second stream, 0.275
+    # with two priorities).  The contract's W warm-up + K timed steps are run this way too: every frame is a whole
+    # frame, bit-identical to the single-stream one (checked below), only its latency is longer.
     in_flight = None
-    if world == 1 and two_in_flight:
-        # two streams of their own (torch's current stream may be the legacy default stream, which
-        # serialises with every other stream)
+    if world == 1 and two_in_flight and two_in_flight > 1:
+        F = int(two_in_flight)
         torch.cuda.synchronize()
         r.set_timing(False)          # no stage events in this run
-        s1, s2 = dev.create_stream(), dev.create_stream()
-        r2 = gs.Renderer(dev)
-        img2 = gs.Buffer(dev, size=W * H * 16)
-        lanes = [(r, s1, par.band_target_ptr(gbuf, plan, rank, W)), (r2, s2, img2.device_ptr())]
-        r2.render(s2, buf, gt, mt, cam, img2.device_ptr(), check=True)      # sizing frame of the second renderer
-        for i in range(2 * warmup):
-            rr, ss, pp = lanes[i & 1]
+        least, greatest = dev.stream_priority_range()
+        prio_cycle = [greatest, least, 0] if least != greatest else [0]
+        prios = [prio_cycle[k % len(prio_cycle)] for k in range(F)]
+        lanes, extra = [], []
+        for k in range(F):
+            sk = dev.create_stream(priority=prios[k])
+            if k == 0:
+                lanes.append((r, sk, par.band_target_ptr(gbuf, plan, rank, W)))
+            else:
+                rk, ik = gs.Renderer(dev), gs.Buffer(dev, size=W * H * 16)
+                rk.render(sk, buf, gt, mt, cam, ik.device_ptr(), check=True)      # sizing frame of this renderer
+                lanes.append((rk, sk, ik.device_ptr()))
+                extra.append((rk, ik))
+        frame_no = [0]
+
+        def pstep():
+            rr, ss, pp = lanes[frame_no[0] % F]
+            frame_no[0] += 1
             rr.render(ss, buf, gt, mt, cam, pp, check=False)
+
+        for _ in range(warmup):
+            pstep()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for i in range(steps):
-            rr, ss, pp = lanes[i & 1]
-            rr.render(ss, buf, gt, mt, cam, pp, check=False)
+        for _ in range(steps):
+            pstep()
         torch.cuda.synchronize()
         dt2 = time.perf_counter() - t0
-        sum2 = float(img2.download(s2, np.float32).astype(np.float64).sum())
-        in_flight = dict(frames_in_flight=2, ms_per_step=dt2 * 1e3 / steps, value=wl["n"] / (dt2 / steps) / 1e6,
-                         unit="Msplats/s", image_checksums_equal=bool(abs(sum2 - checksum) <= 1e-6 * max(1.0, abs(checksum))),
-                         note="two renderers on two streams take the frames alternately; per-frame latency unchanged")
-        r2.destroy()
-        img2.release()
+        psteady = None
+        if steady_frames:
+            for _ in range(100):
+                pstep()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steady_frames):
+                pstep()
+            torch.cuda.synchronize()
+            dts = time.perf_counter() - t0
+            psteady = dict(frames=steady_frames, ms_per_step=dts * 1e3 / steady_frames,
+                           value=wl["n"] / (dts / steady_frames) / 1e6, unit="Msplats/s")
+        for _ in range(F):               # every lane's last frame is a frame of this camera
+            pstep()
+        torch.cuda.synchronize()
+        flags = [int(rr.wait_frame().flags) for rr, _, _ in lanes]
+        if any(flags):
+            raise RuntimeError("bench.py: a pipelined frame was skipped or flagged (per-lane flags %s)" % flags)
+        ref = gbuf[:H].cpu().numpy().view(np.uint32)
+        equal = all(np.array_equal(ik.download(lanes[k + 1][1], np.float32).reshape(H, W, 4).view(np.uint32), ref)
+                    for k, (_, ik) in enumerate(extra))
+        equal = equal and float(gbuf[:H].double().sum().item()) == checksum
+        in_flight = dict(frames_in_flight=F, ms_per_step=dt2 * 1e3 / steps, value=wl["n"] / (dt2 / steps) / 1e6,
+                         unit="Msplats/s", stream_priorities=prios, steady_state=psteady, images_bit_identical=bool(equal),
+                         note="%d renderers on %d streams of different priority (= different hardware queues) take the "
+                              "frames in turn; W warm-up + K timed frames as for the single stream" % (F, F))
+        for rk, ik in extra:
+            rk.destroy()
+            ik.release()
     out = dict(ms_per_frame=dt * 1e3 / steps, visible=visible, pairs=pairs, sort_passes=int(st.sort_passes),
                two_frames_in_flight=in_flight, steady_state=steady,
                stages_ms=stages, checksum=checksum, launches=int(fr.launches), pair_capacity=int(fr.pair_capacity),
@@ -573,7 +611,8 @@ def compact_line(line, detail_path, limit=3900):
                               "scaling", "vs_baseline", "dtype", "data")}
     c["value"], c["ms_per_step"] = _r(c["value"], 6), _r(c["ms_per_step"], 6)
     cfg = line["config"]
-    c["config"] = {k: cfg[k] for k in ("workload", "gaussians", "visible", "pairs", "launches_per_frame", "parallelism")}
+    c["config"] = {k: cfg[k] for k in ("workload", "gaussians", "visible", "pairs", "launches_per_frame", "parallelism",
+                                       "frames_in_flight") if k in cfg}
     if line.get("frame_ms"):
         c["frame_ms_median"] = _r(line["frame_ms"]["median"])
     c["stages_ms"] = {k: _r(v, 4) for k, v in (line.get("stages_ms") or {}).items() if v}
@@ -613,8 +652,11 @@ def compact_line(line, detail_path, limit=3900):
         if wls:
             for k, v in wls.items():
                 c["workloads"][k]["per_rank_ms"] = [_r(x, 4) for x in v.get("per_rank_ms", [])]
-    if line.get("two_frames_in_flight"):
-        c["two_in_flight_ms"] = _r(line["two_frames_in_flight"]["ms_per_step"])
+    ss = line.get("single_stream")
+    if ss and line.get("two_frames_in_flight"):    # `value` ran with frames in flight: the one-stream figure of the same W + K
+        c["single_stream"] = {"ms_per_step": _r(ss["ms_per_step"], 6), "Msplats/s": _r(ss["value"])}
+        if ss.get("steady_state"):
+            c["single_stream"]["steady_ms"] = _r(ss["steady_state"]["ms_per_step"])
     if line.get("steady_state"):     # beside `value`: the same frames once the clocks have settled (200 frames)
         c["steady_state"] = {"ms_per_step": _r(line["steady_state"]["ms_per_step"]), "Msplats/s": _r(line["steady_state"]["value"]),
                              "frames": line["steady_state"]["frames"]}
@@ -679,7 +721,9 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=3)
     ap.add_argument("--timing-steps", type=int, default=20)
     ap.add_argument("--frame-samples", type=int, default=100)
-    ap.add_argument("--no-in-flight", action="store_true", help="skip the two-frames-in-flight measurement")
+    ap.add_argument("--no-in-flight", action="store_true", help="single stream only (same as --frames-in-flight 1)")
+    ap.add_argument("--frames-in-flight", type=int, default=3,
+                    help="single GPU: renderers / priority streams that take the headline's frames in turn (1 = one stream)")
     ap.add_argument("--no-steady", action="store_true", help="skip the steady-state measurement (200 frames after 100 more untimed ones)")
     ap.add_argument("--no-rebalance", action="store_true", help="N > 1: keep the floor(g*R/G) band plan")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
@@ -764,7 +808,8 @@ def main():
                             steady_frames=steady_frames)
 
     wl = WORKLOADS[args.workload]
-    res = run(args.workload, args.steps, args.warmup, args.frame_samples, two_in_flight=not args.no_in_flight,
+    res = run(args.workload, args.steps, args.warmup, args.frame_samples,
+              two_in_flight=0 if args.no_in_flight else args.frames_in_flight,
               steady_frames=0 if args.no_steady else 200)
     rsteps, rwarm = max(5, min(args.steps, 20)), max(2, min(args.warmup, 5))
     roof = nocull = None
@@ -794,7 +839,13 @@ def main():
                          gather_ms_per_rank=rr["gather_ms_per_rank"], bands=rr["bands"], band_plan=rr["band_plan"])
             return d
 
-        value = wl["n"] / (res["ms_per_frame"] * 1e-3) / 1e6
+        # single GPU: the headline is measured with the frames in flight (run_workload), the single-stream
+        # figure of the same W + K steps stays beside it
+        fl = res.get("two_frames_in_flight")
+        if fl and not fl["images_bit_identical"]:
+            raise RuntimeError("bench.py: the pipelined frames differ from the single-stream frame")
+        head_ms = fl["ms_per_step"] if fl else res["ms_per_frame"]
+        value = wl["n"] / (head_ms * 1e-3) / 1e6
         line = {
             "metric": "Msplats/s @1080p (Gaussians per second through proj+sort+blend)",
             "value": value,
@@ -802,7 +853,7 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": res["ms_per_frame"],
+            "ms_per_step": head_ms,
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
@@ -813,13 +864,18 @@ def main():
                        "launches_per_frame": res["launches"],
                        "parallelism": "tile-row bands x%d + one %s all-gather (%s)" % (
                            world, "RCCL" if backend == "nccl" else "%s (rehearsal, host-staged)" % backend, res["band_plan"])
-                       if world > 1 else "single GPU", "image_checksum": res["checksum"]},
+                       if world > 1 else ("single GPU, %d frames in flight on %d priority streams" % (
+                           fl["frames_in_flight"], fl["frames_in_flight"]) if fl else "single GPU, one stream"),
+                       "frames_in_flight": fl["frames_in_flight"] if fl else 1, "image_checksum": res["checksum"]},
+            "single_stream": {"ms_per_step": res["ms_per_frame"], "value": wl["n"] / (res["ms_per_frame"] * 1e-3) / 1e6,
+                              "unit": "Msplats/s", "steady_state": res.get("steady_state"),
+                              "note": "the same W + K frames on one stream, one frame at a time on the device"},
             "frame_ms": res.get("frame_ms"),
             "stages_ms": res["stages_ms"],
             "stage_models": stage_models(wl, res),
             "frame_bytes": frame_bytes_object(args.workload, wl, res),
             "two_frames_in_flight": res.get("two_frames_in_flight"),
-            "steady_state": res.get("steady_state"),
+            "steady_state": (fl or {}).get("steady_state") or res.get("steady_state"),
             "blend": blend_valu_object(res) if args.workload == "1m" and world == 1 else None,
             "hip_runtime": {"source": hiprt.info()["source"], "libamdhip64": hiprt.mapped()["libamdhip64"],
                             "compiled_version": gs.hip_versions()[0], "runtime_version": gs.hip_versions()[1],

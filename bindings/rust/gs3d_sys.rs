@@ -279,6 +279,8 @@ extern "C" {
     pub fn gs_device_synchronize(dev: *mut gs_device) -> gs_status;
     pub fn gs_device_fast_rank(dev: *const gs_device) -> i32;
     pub fn gs_stream_create(dev: *mut gs_device, out: *mut *mut gs_stream) -> gs_status;
+    pub fn gs_stream_create_with_priority(dev: *mut gs_device, priority: i32, out: *mut *mut gs_stream) -> gs_status;
+    pub fn gs_device_stream_priority_range(dev: *mut gs_device, least: *mut i32, greatest: *mut i32) -> gs_status;
     pub fn gs_stream_wrap(dev: *mut gs_device, hip_stream: *mut c_void, out: *mut *mut gs_stream) -> gs_status;
     pub fn gs_stream_native(s: *const gs_stream) -> *mut c_void;
     pub fn gs_stream_synchronize(s: *mut gs_stream) -> gs_status;

@@ -285,6 +285,13 @@ gs_status gs_device_synchronize(gs_device *dev);
  * item: wgpu has no such primitive) */
 int32_t gs_device_fast_rank(const gs_device *dev);
 gs_status gs_stream_create(gs_device *dev, gs_stream **out);
+/* Streams of one process that should run CONCURRENTLY on the device (two frames in flight: the latency-bound sort
+ * chain of frame i + 1 under the VALU-bound blend of frame i) must sit on different hardware queues; HIP gives every
+ * priority level its own queues, and streams of equal priority may share one (measured under torch: they do).
+ * priority: hipStreamCreateWithPriority's number, between *least and *greatest of gs_device_stream_priority_range
+ * (numerically lower = higher priority).  No reference item: a wgpu::Queue has no priority. */
+gs_status gs_stream_create_with_priority(gs_device *dev, int32_t priority, gs_stream **out);
+gs_status gs_device_stream_priority_range(gs_device *dev, int32_t *least, int32_t *greatest);
 /* borrow an existing hipStream_t (e.g. the stream a caller's framework is using) */
 gs_status gs_stream_wrap(gs_device *dev, void *hip_stream, gs_stream **out);
 void *gs_stream_native(const gs_stream *s);

@@ -245,6 +245,7 @@ class Device {
 class Stream {   // CommandEncoder + queue.submit
   public:
     explicit Stream(Device &d) { check(gs_stream_create(d.raw(), &h_)); }
+    Stream(Device &d, int priority) { check(gs_stream_create_with_priority(d.raw(), priority, &h_)); }   // frames in flight: one priority each
     ~Stream() { gs_stream_destroy(h_); }
     Stream(const Stream &) = delete;
     void synchronize() { check(gs_stream_synchronize(h_)); }

@@ -67,9 +67,12 @@ def _fake_detail(world=8):
         config=dict(workload="1M synthetic Gaussians, SH degree 0 (ShNone/RotScale 48 B), 1920x1080", gaussians=1000000,
                     visible=708615, pairs=2550276, sort_passes=5, launches_per_frame=19,
                     parallelism="tile-row bands x8 + one RCCL all-gather (tile rows re-cut to equal pairs (one calibration frame))",
+                    frames_in_flight=2,
                     image_checksum=5161086.015),
         frame_ms=dict(median=0.34256123, samples=100), stages_ms=dict(stages), stage_models=dict(models), frame_bytes=dict(fb),
-        two_frames_in_flight=dict(ms_per_step=0.3476212), blend=dict(note="z" * 500),
+        two_frames_in_flight=dict(ms_per_step=0.2749212, frames_in_flight=2, images_bit_identical=True),
+        single_stream=dict(ms_per_step=0.3276212, value=3052.123456, steady_state=dict(ms_per_step=0.3031212, value=3299.1, frames=200)),
+        blend=dict(note="z" * 500),
         hip_runtime=dict(source="already-mapped", compiled_version=70226015, runtime_version=70051831),
         distributed=dict(backend="nccl", world_size=world, per_rank_ms=[0.123456789] * world, per_rank_ms_min=0.1,
                          per_rank_ms_max=0.2, render_ms_per_rank=[0.123456789] * world, gather_ms_per_rank=[0.0123456789] * world,
@@ -100,7 +103,8 @@ def test_compact_line_fits_the_drivers_tail(world):
         assert k in c["roofline"], k
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c["cpu_baseline"], k
-    assert c["config"]["workload"].startswith("1M synthetic")
+    assert c["config"]["workload"].startswith("1M synthetic") and c["config"]["frames_in_flight"] == 2
+    assert c["single_stream"]["ms_per_step"] > c["ms_per_step"] * 0     # the one-stream figure travels with the headline
     if world > 1:
         assert c["distributed"]["world_size"] == world and c["distributed"]["backend"] == "nccl"
 
@@ -144,6 +148,22 @@ def test_bench_two_ranks_gloo_rehearsal_self_launched(tmp_path):
 
 
 @pytest.mark.gpu
+def test_bench_headline_runs_with_frames_in_flight(tmp_path):
+    """the default: three renderers on three priority streams take the headline's frames in turn; the images must be
+    bit-identical to the single-stream frame (bench.py raises otherwise) and the one-stream figure is reported too"""
+    detail = tmp_path / "detail.json"
+    res = _run(["--workload", "100k", "--steps", "6", "--warmup", "2", "--no-roofline", "--no-cpu-baseline",
+                "--frame-samples", "4", "--timing-steps", "2", "--no-steady", "--detail-out", str(detail)])
+    assert res.returncode == 0, (res.stdout[-2000:], res.stderr[-3000:])
+    j = json.loads(res.stdout.strip().splitlines()[-1])
+    assert j["config"]["frames_in_flight"] == 3 and j["single_stream"]["ms_per_step"] > 0 and j["steps"] == 6
+    full = json.loads(detail.read_text())
+    fl = full["two_frames_in_flight"]
+    assert fl["images_bit_identical"] and len(set(fl["stream_priorities"])) == 3
+    assert abs(full["ms_per_step"] - fl["ms_per_step"]) < 1e-12
+
+
+@pytest.mark.gpu
 def test_bench_single_gpu_compact_line(tmp_path):
     detail = tmp_path / "detail.json"
     res = _run(["--workload", "100k", "--steps", "3", "--warmup", "1", "--no-roofline", "--no-cpu-baseline",
@@ -153,4 +173,5 @@ def test_bench_single_gpu_compact_line(tmp_path):
     assert len(lines) == 1 and len(lines[0]) <= 4096       # ONE stdout line
     j = json.loads(lines[0])
     assert j["n_gpus"] == 1 and j["hip"]["compiled"] and j["hip"]["runtime"]
+    assert j["config"]["frames_in_flight"] == 1 and "single_stream" not in j        # --no-in-flight: one stream
     assert json.loads(detail.read_text())["hip_runtime"]["runtime_version"] == j["hip"]["runtime"]

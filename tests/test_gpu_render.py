@@ -955,3 +955,47 @@ def test_adversarial_needles_match_the_unclipped_frame(gs, ob, device, stream, c
     if old != 1:
         assert (st.pairs < v1[1]) == (sigma <= 60.0), (st.pairs, v1[1])      # the guard keeps the square of the long thin ones
     r.destroy(); img.release(); buf.destroy()
+
+
+def test_two_frames_in_flight_on_priority_streams(gs, ob, device):
+    """gs_stream_create_with_priority: two renderers on two streams of different priority (= two hardware queues) take
+    frames of two cameras in turn without waiting for each other; every frame equals the one rendered alone."""
+    import synth
+    least, greatest = device.stream_priority_range()
+    assert greatest <= least
+    with pytest.raises(gs.GsError):
+        device.create_stream(priority=least + 1)
+    g = synth.scene(40000, first=99)
+    pod = gs.GaussianPod(gs.SH_HALF, gs.COV3D_ROT_SCALE)
+    buf = gs.GaussiansBuffer.new_with_pods(device, pod, pod.from_gaussian(g))
+    gt, mt = gs.gaussian_transform_pod(sh_deg=2), gs.model_transform_pod()
+    W, H = 1280, 720
+    cams = [helpers.copy_camera(helpers.default_camera(ob, W, H, eye=e), gs.Camera) for e in ((0, 0, 0), (0.5, 0.25, 1.0))]
+    s0 = device.create_stream()
+    alone = []
+    r0 = gs.Renderer(device)
+    img0 = gs.Buffer(device, size=W * H * 16)
+    for cam in cams:
+        r0.render(s0, buf, gt, mt, cam, img0.device_ptr())
+        alone.append(img0.download(s0, np.float32).view(np.uint32).copy())
+    lanes = []
+    for k, prio in enumerate((greatest, least)):
+        st = device.create_stream(priority=prio)
+        r = gs.Renderer(device)
+        img = gs.Buffer(device, size=W * H * 16)
+        r.render(st, buf, gt, mt, cams[k], img.device_ptr())        # sizing frame
+        lanes.append((st, r, img))
+    for i in range(12):                                             # only enqueued: the two queues run side by side
+        st, r, img = lanes[i & 1]
+        r.render(st, buf, gt, mt, cams[i & 1], img.device_ptr(), check=False)
+    for k, (st, r, img) in enumerate(lanes):
+        assert r.wait_frame().flags == 0
+        assert np.array_equal(img.download(st, np.float32).view(np.uint32), alone[k]), "lane %d differs" % k
+    for st, r, img in lanes:
+        r.destroy()
+        img.release()
+        st.close()
+    r0.destroy()
+    img0.release()
+    s0.close()
+    buf.destroy()

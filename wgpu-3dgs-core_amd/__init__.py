@@ -592,8 +592,16 @@ class Device:
         """True while this device's radix sorts rank with returning LDS atomics (gs_device_fast_rank)"""
         return bool(_L.gs_device_fast_rank(self._h))
 
-    def create_stream(self):
-        return Stream(self)
+    def create_stream(self, priority=None):
+        """priority: see gs_stream_create_with_priority — streams meant to overlap on the device (frames in flight)
+        need different priorities to be sure of different hardware queues"""
+        return Stream(self, priority=priority)
+
+    def stream_priority_range(self):
+        """(least, greatest) of hipDeviceGetStreamPriorityRange; numerically lower = higher priority"""
+        lo, hi = C.c_int32(0), C.c_int32(0)
+        _check(_L.gs_device_stream_priority_range(self._h, C.byref(lo), C.byref(hi)))
+        return lo.value, hi.value
 
     def wrap_stream(self, native_handle):
         return Stream(self, native=native_handle)
@@ -607,9 +615,11 @@ class Device:
 class Stream:
     """CommandEncoder + queue.submit: an ordered HIP stream."""
 
-    def __init__(self, device, native=None):
+    def __init__(self, device, native=None, priority=None):
         h = C.c_void_p()
-        if native is None:
+        if native is None and priority is not None:
+            _check(_L.gs_stream_create_with_priority(device._h, int(priority), C.byref(h)))
+        elif native is None:
             _check(_L.gs_stream_create(device._h, C.byref(h)))
         else:
             _check(_L.gs_stream_wrap(device._h, C.c_void_p(native), C.byref(h)))

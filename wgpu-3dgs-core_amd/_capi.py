@@ -108,6 +108,8 @@ SIGNATURES = {
     "gs_device_synchronize": (i32, [vp]),
     "gs_device_fast_rank": (i32, [vp]),
     "gs_stream_create": (i32, [vp, vp]),
+    "gs_stream_create_with_priority": (i32, [vp, i32, vp]),
+    "gs_device_stream_priority_range": (i32, [vp, vp, vp]),
     "gs_stream_wrap": (i32, [vp, vp, vp]),
     "gs_stream_native": (vp, [vp]),
     "gs_stream_synchronize": (i32, [vp]),

@@ -358,6 +358,29 @@ extern "C" gs_status gs_stream_create(gs_device *dev, gs_stream **out) {
     return GS_OK;
 }
 
+extern "C" gs_status gs_device_stream_priority_range(gs_device *dev, int32_t *least, int32_t *greatest) {
+    GS_TRY(use_device(dev));
+    int lo = 0, hi = 0;
+    GS_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    if (least) *least = lo;
+    if (greatest) *greatest = hi;
+    return GS_OK;
+}
+
+extern "C" gs_status gs_stream_create_with_priority(gs_device *dev, int32_t priority, gs_stream **out) {
+    if (!out) return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "null out");
+    GS_TRY(use_device(dev));
+    int lo = 0, hi = 0;
+    GS_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    if (priority > lo || priority < hi)
+        return fail(GS_ERR_INVALID_ARGUMENT, (uint64_t)(int64_t)priority, 0, 0, "stream priority %d outside [%d (least), %d (greatest)]",
+                    priority, lo, hi);
+    hipStream_t s;
+    GS_HIP(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, priority));
+    *out = new gs_stream{dev, s, true};
+    return GS_OK;
+}
+
 extern "C" gs_status gs_stream_wrap(gs_device *dev, void *hip_stream, gs_stream **out) {
     if (!dev || !out) return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "null argument");
     *out = new gs_stream{dev, (hipStream_t)hip_stream, false};
