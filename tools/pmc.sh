@@ -5,7 +5,7 @@ TAG=$1; WL=$2; CTRS=$3; STEPS=${4:-3}
 OUT=$PWD/gpurun_out/pmc_${TAG}_${WL}
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-CMD="python3 $PWD/bench.py --workload $WL --no-roofline --no-cpu-baseline --steps $STEPS --warmup 1 --timing-steps 0"
+CMD="python3 $PWD/bench.py --workload $WL --no-roofline --no-cpu-baseline --steps $STEPS --warmup 1 --timing-steps 0 --frames-in-flight 1"
 cd /tmp
 rocprofv3 --pmc $CTRS --output-format csv -d "$OUT/pmc" -o pmc -- $CMD > "$OUT/pmc.log" 2>&1 || { tail -20 "$OUT/pmc.log"; exit 1; }
 cd - > /dev/null

@@ -107,7 +107,7 @@ with open("%s/%s_bench_default_agreement.txt" % (out, tag), "w") as f:
         if key in b:
             f.write("  %-11s bench %.4f ms   rocprofv3 %.4f ms over %d launches (min %.4f, max %.4f)\n" % (
                 wl, b[key]["avg_launch_ms"], sum(g) / len(g), len(g), min(g), max(g)))
-    f.write("other processes on the same box (--kernel-trace --stats of `bench.py --workload <wl> --no-roofline`, %s_<wl>_summary.md;\n" % tag)
+    f.write("other processes on the same box (--kernel-trace --stats of `bench.py --workload <wl> --no-roofline --frames-in-flight 1`, %s_<wl>_summary.md;\n" % tag)
     f.write("a fresh process places its buffers anew, which moves this HBM-bound kernel by a few per cent):\n")
     for key, wl in (("roofline", "10m"), ("roofline_nocull", "10m-nocull")):
         if ("preprocess_%s" % wl) in pmc:
