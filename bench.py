@@ -243,25 +243,18 @@ def run_workload(gs, synth, torch, dist, dev, stream, rank, world, wl, steps, wa
         F = int(two_in_flight)
         torch.cuda.synchronize()
         r.set_timing(False)          # no stage events in this run
-        least, greatest = dev.stream_priority_range()
-        prio_cycle = [greatest, least, 0] if least != greatest else [0]
-        prios = [prio_cycle[k % len(prio_cycle)] for k in range(F)]
-        lanes, extra = [], []
-        for k in range(F):
-            sk = dev.create_stream(priority=prios[k])
-            if k == 0:
-                lanes.append((r, sk, par.band_target_ptr(gbuf, plan, rank, W)))
-            else:
-                rk, ik = gs.Renderer(dev), gs.Buffer(dev, size=W * H * 16)
-                rk.render(sk, buf, gt, mt, cam, ik.device_ptr(), check=True)      # sizing frame of this renderer
-                lanes.append((rk, sk, ik.device_ptr()))
-                extra.append((rk, ik))
+        ring = gs.FrameRing(dev, F)
+        prios = ring.priorities
+        targets = [par.band_target_ptr(gbuf, plan, rank, W)]
+        extra = [gs.Buffer(dev, size=W * H * 16) for _ in range(F - 1)]
+        targets += [b.device_ptr() for b in extra]
+        for k in range(F):               # the sizing frame of every lane's renderer (blocking once each)
+            ring.render(buf, gt, mt, cam, targets[k], check=True)
         frame_no = [0]
 
         def pstep():
-            rr, ss, pp = lanes[frame_no[0] % F]
             frame_no[0] += 1
-            rr.render(ss, buf, gt, mt, cam, pp, check=False)
+            ring.render(buf, gt, mt, cam, targets[(frame_no[0] - 1) % F])
 
         for _ in range(warmup):
             pstep()
@@ -286,20 +279,20 @@ def run_workload(gs, synth, torch, dist, dev, stream, rank, world, wl, steps, wa
         for _ in range(F):               # every lane's last frame is a frame of this camera
             pstep()
         torch.cuda.synchronize()
-        flags = [int(rr.wait_frame().flags) for rr, _, _ in lanes]
+        flags = [int(fr_.flags) for fr_ in ring.wait()]
         if any(flags):
             raise RuntimeError("bench.py: a pipelined frame was skipped or flagged (per-lane flags %s)" % flags)
         ref = gbuf[:H].cpu().numpy().view(np.uint32)
-        equal = all(np.array_equal(ik.download(lanes[k + 1][1], np.float32).reshape(H, W, 4).view(np.uint32), ref)
-                    for k, (_, ik) in enumerate(extra))
+        equal = all(np.array_equal(b.download(ring.streams[k + 1], np.float32).reshape(H, W, 4).view(np.uint32), ref)
+                    for k, b in enumerate(extra))
         equal = equal and float(gbuf[:H].double().sum().item()) == checksum
         in_flight = dict(frames_in_flight=F, ms_per_step=dt2 * 1e3 / steps, value=wl["n"] / (dt2 / steps) / 1e6,
                          unit="Msplats/s", stream_priorities=prios, steady_state=psteady, images_bit_identical=bool(equal),
                          note="%d renderers on %d streams of different priority (= different hardware queues) take the "
                               "frames in turn; W warm-up + K timed frames as for the single stream" % (F, F))
-        for rk, ik in extra:
-            rk.destroy()
-            ik.release()
+        ring.close()
+        for b in extra:
+            b.release()
     out = dict(ms_per_frame=dt * 1e3 / steps, visible=visible, pairs=pairs, sort_passes=int(st.sort_passes),
                two_frames_in_flight=in_flight, steady_state=steady,
                stages_ms=stages, checksum=checksum, launches=int(fr.launches), pair_capacity=int(fr.pair_capacity),

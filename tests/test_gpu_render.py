@@ -995,6 +995,21 @@ def test_two_frames_in_flight_on_priority_streams(gs, ob, device):
         r.destroy()
         img.release()
         st.close()
+    # the same through FrameRing: three lanes, frames of the two cameras in turn, one target per lane
+    ring = gs.FrameRing(device, 3)
+    assert len(ring) == 3 and len(set(ring.priorities)) == (3 if least - greatest >= 2 else len(set(ring.priorities)))
+    imgs = [gs.Buffer(device, size=W * H * 16) for _ in range(3)]
+    last_cam = [None] * 3
+    for i in range(15):
+        lane = ring.render(buf, gt, mt, cams[i & 1], imgs[i % 3].device_ptr())
+        assert lane == i % 3
+        last_cam[lane] = i & 1
+    assert all(fr.flags == 0 for fr in ring.wait())
+    for k in range(3):
+        assert np.array_equal(imgs[k].download(ring.streams[k], np.float32).view(np.uint32), alone[last_cam[k]]), "ring lane %d" % k
+    ring.close()
+    for b in imgs:
+        b.release()
     r0.destroy()
     img0.release()
     s0.close()

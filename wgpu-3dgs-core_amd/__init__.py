@@ -1225,6 +1225,50 @@ class Renderer:
             self._h = None
 
 
+class FrameRing:
+    """Frames in flight: `frames` renderers, each on a stream of its own PRIORITY, take the frames in turn
+    (what a viewer with double / triple buffering does).  A frame is a chain of dependent kernels — latency-bound
+    in its sorts, VALU-bound in its blend — so the frames of different renderers overlap on the device, provided
+    their streams sit on different hardware queues: HIP keeps separate queues per priority level, streams of one
+    priority may share a queue (gs_stream_create_with_priority).  Every frame is the frame its renderer would
+    have rendered alone; only the order in which the device works on them changes.  No reference item (the
+    viewer owns the frame loop)."""
+
+    def __init__(self, device, frames=3):
+        least, greatest = device.stream_priority_range()
+        cycle = [greatest, least, 0] if least != greatest else [0]
+        self.priorities = [cycle[k % len(cycle)] for k in range(max(1, int(frames)))]
+        self.streams = [device.create_stream(priority=p) for p in self.priorities]
+        self.renderers = [Renderer(device) for _ in self.streams]
+        self._next = 0
+
+    def __len__(self):
+        return len(self.renderers)
+
+    def render(self, gaussians, gaussian_transform, model_transform, camera, rgba_device_ptr, band=None, check=False):
+        """enqueues one frame on the next lane; returns the lane's index (its stream: `streams[lane]`)"""
+        lane = self._next % len(self.renderers)
+        self._next += 1
+        self.renderers[lane].render(self.streams[lane], gaussians, gaussian_transform, model_transform, camera,
+                                    rgba_device_ptr, band=band, check=check)
+        return lane
+
+    def wait(self):
+        """blocks until every lane's last frame has completed; their FrameResults (raises as wait_frame does)"""
+        return [r.wait_frame() for r in self.renderers]
+
+    def synchronize(self):
+        for s in self.streams:
+            s.synchronize()
+
+    def close(self):
+        for r in self.renderers:
+            r.destroy()
+        for s in self.streams:
+            s.close()
+        self.renderers, self.streams = [], []
+
+
 def sort_pairs_u64(device, stream, keys, values, end_bit=64):
     """Device radix sort of host arrays (stable LSD on key bits [0, end_bit)); returns copies."""
     k = np.ascontiguousarray(keys, dtype=np.uint64).copy()
