@@ -71,7 +71,7 @@ def _camera(gs, wl):
 
 
 def run_workload(gs, synth, torch, dist, dev, stream, rank, world, wl, steps, warmup, timing_steps,
-                 frame_samples, rebalance=True, two_in_flight=False, steady_frames=0):
+                 frame_samples, rebalance=True, frames_in_flight=0, steady_frames=0):
     """Times `steps` pipelined frames between barriers (max over ranks), then `frame_samples`
     individually event-timed frames (median / min / p95), then a short run with HIP-event stage
     timing.  Returns a dict (rank-0 view; per-rank numbers where world > 1)."""
@@ -239,8 +239,8 @@ def run_workload(gs, synth, torch, dist, dev, stream, rank, world, wl, steps, wa
     # with two priorities).  The contract's W warm-up + K timed steps are run this way too: every frame is a whole
     # frame, bit-identical to the single-stream one (checked below), only its latency is longer.
     in_flight = None
-    if world == 1 and two_in_flight and two_in_flight > 1:
-        F = int(two_in_flight)
+    if world == 1 and frames_in_flight and frames_in_flight > 1:
+        F = int(frames_in_flight)
         torch.cuda.synchronize()
         r.set_timing(False)          # no stage events in this run
         ring = gs.FrameRing(dev, F)
@@ -294,7 +294,7 @@ def run_workload(gs, synth, torch, dist, dev, stream, rank, world, wl, steps, wa
         for b in extra:
             b.release()
     out = dict(ms_per_frame=dt * 1e3 / steps, visible=visible, pairs=pairs, sort_passes=int(st.sort_passes),
-               two_frames_in_flight=in_flight, steady_state=steady,
+               in_flight_run=in_flight, steady_state=steady,
                stages_ms=stages, checksum=checksum, launches=int(fr.launches), pair_capacity=int(fr.pair_capacity),
                per_rank_ms=per_rank, render_ms_per_rank=render_ms, gather_ms_per_rank=gather_ms,
                bands=plan.bands, band_plan=plan_kind, skipped_band_flags=skipped_bands)
@@ -646,7 +646,7 @@ def compact_line(line, detail_path, limit=3900):
             for k, v in wls.items():
                 c["workloads"][k]["per_rank_ms"] = [_r(x, 4) for x in v.get("per_rank_ms", [])]
     ss = line.get("single_stream")
-    if ss and line.get("two_frames_in_flight"):    # `value` ran with frames in flight: the one-stream figure of the same W + K
+    if ss and line.get("in_flight_run"):    # `value` ran with frames in flight: the one-stream figure of the same W + K
         c["single_stream"] = {"ms_per_step": _r(ss["ms_per_step"], 6), "Msplats/s": _r(ss["value"])}
         if ss.get("steady_state"):
             c["single_stream"]["steady_ms"] = _r(ss["steady_state"]["ms_per_step"])
@@ -795,14 +795,14 @@ def main():
     assert tstream.cuda_stream != 0
     stream = dev.wrap_stream(tstream.cuda_stream)
 
-    def run(name, steps, warmup, samples, two_in_flight=False, steady_frames=0):
+    def run(name, steps, warmup, samples, frames_in_flight=0, steady_frames=0):
         return run_workload(gs, synth, torch, dist, dev, stream, rank, world, WORKLOADS[name], steps, warmup,
-                            args.timing_steps, samples, rebalance=not args.no_rebalance, two_in_flight=two_in_flight,
+                            args.timing_steps, samples, rebalance=not args.no_rebalance, frames_in_flight=frames_in_flight,
                             steady_frames=steady_frames)
 
     wl = WORKLOADS[args.workload]
     res = run(args.workload, args.steps, args.warmup, args.frame_samples,
-              two_in_flight=0 if args.no_in_flight else args.frames_in_flight,
+              frames_in_flight=0 if args.no_in_flight else args.frames_in_flight,
               steady_frames=0 if args.no_steady else 200)
     rsteps, rwarm = max(5, min(args.steps, 20)), max(2, min(args.warmup, 5))
     roof = nocull = None
@@ -834,7 +834,7 @@ def main():
 
         # single GPU: the headline is measured with the frames in flight (run_workload), the single-stream
         # figure of the same W + K steps stays beside it
-        fl = res.get("two_frames_in_flight")
+        fl = res.get("in_flight_run")
         if fl and not fl["images_bit_identical"]:
             raise RuntimeError("bench.py: the pipelined frames differ from the single-stream frame")
         head_ms = fl["ms_per_step"] if fl else res["ms_per_frame"]
@@ -867,7 +867,7 @@ def main():
             "stages_ms": res["stages_ms"],
             "stage_models": stage_models(wl, res),
             "frame_bytes": frame_bytes_object(args.workload, wl, res),
-            "two_frames_in_flight": res.get("two_frames_in_flight"),
+            "in_flight_run": res.get("in_flight_run"),
             "steady_state": (fl or {}).get("steady_state") or res.get("steady_state"),
             "blend": blend_valu_object(res) if args.workload == "1m" and world == 1 else None,
             "hip_runtime": {"source": hiprt.info()["source"], "libamdhip64": hiprt.mapped()["libamdhip64"],

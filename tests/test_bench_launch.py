@@ -70,7 +70,7 @@ def _fake_detail(world=8):
                     frames_in_flight=2,
                     image_checksum=5161086.015),
         frame_ms=dict(median=0.34256123, samples=100), stages_ms=dict(stages), stage_models=dict(models), frame_bytes=dict(fb),
-        two_frames_in_flight=dict(ms_per_step=0.2749212, frames_in_flight=2, images_bit_identical=True),
+        in_flight_run=dict(ms_per_step=0.2749212, frames_in_flight=2, images_bit_identical=True),
         single_stream=dict(ms_per_step=0.3276212, value=3052.123456, steady_state=dict(ms_per_step=0.3031212, value=3299.1, frames=200)),
         blend=dict(note="z" * 500),
         hip_runtime=dict(source="already-mapped", compiled_version=70226015, runtime_version=70051831),
@@ -158,7 +158,7 @@ def test_bench_headline_runs_with_frames_in_flight(tmp_path):
     j = json.loads(res.stdout.strip().splitlines()[-1])
     assert j["config"]["frames_in_flight"] == 3 and j["single_stream"]["ms_per_step"] > 0 and j["steps"] == 6
     full = json.loads(detail.read_text())
-    fl = full["two_frames_in_flight"]
+    fl = full["in_flight_run"]
     assert fl["images_bit_identical"] and len(set(fl["stream_priorities"])) == 3
     assert abs(full["ms_per_step"] - fl["ms_per_step"]) < 1e-12
 
