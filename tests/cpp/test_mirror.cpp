@@ -167,6 +167,24 @@ int main() {
         auto decoded = SpzGaussians::read_from(spz_bytes.data(), spz_bytes.size()).iter_gaussian();
         REQUIRE(from_spz.len() == 15 && from_spz.download(s) == G::from_gaussians(decoded));
     }
+    {   // frames in flight: a second renderer on a stream of another priority (its own hardware queue) renders the
+        // same frame while the first one's stream is busy with it again; both equal the frame rendered alone
+        int32_t least = 0, greatest = 0;
+        REQUIRE(gs_device_stream_priority_range(dev.raw(), &least, &greatest) == GS_OK && greatest <= least);
+        gs_stream *bad = nullptr;
+        REQUIRE(gs_stream_create_with_priority(dev.raw(), least + 1, &bad) == GS_ERR_INVALID_ARGUMENT);
+        Stream s2(dev, greatest);
+        Buffer img2(dev, (size_t)cam.width * cam.height * 16);
+        Renderer r2(dev);
+        r2.render(s2, rbuf, gt, mt, cam, (float *)img2.device_ptr());
+        REQUIRE(r2.wait_frame().flags == 0);
+        for (int i = 0; i < 4; i++) {
+            r.render(s, rbuf, gt, mt, cam, (float *)img.device_ptr());
+            r2.render(s2, rbuf, gt, mt, cam, (float *)img2.device_ptr());
+        }
+        REQUIRE(r.wait_frame().flags == 0 && r2.wait_frame().flags == 0);
+        REQUIRE(img2.download<float>(s2) == px && img.download<float>(s) == px);
+    }
     double sum = 0; for (float v : px) sum += v;
     REQUIRE(st.gaussians == 15 && std::isfinite(sum));
     std::printf("cpp mirror OK: visible %llu pairs %llu checksum %.6f\n", (unsigned long long)st.visible, (unsigned long long)st.pairs, sum);
