@@ -136,6 +136,71 @@ def run_workload(gs, synth, torch, dist, dev, stream, rank, world, wl, steps, wa
     if world > 1:
         pipe[0] = par.FramePipeline(torch, dist, plan, rank, W, "cuda")
         band_flags[0] = torch.zeros(world, dtype=torch.int32, device="cuda")
+    # Frames in flight (single GPU): F renderers (each its own scratch buffers) on F streams of F different
+    # priorities take the frames in turn, so that the latency-bound sort chain of frame i + 1 runs under the
+    # VALU-bound blend of frame i.  Different priorities because HIP gives each priority level its own hardware
+    # queues while streams of one priority may share a queue — under torch they do, and then nothing overlaps
+    # (kernel trace: one Queue_Id for both streams; 0.327 ms per frame with or without the second stream, 0.275
+    # with two priorities).  The contract's W warm-up + K timed steps are run this way FIRST, straight after the
+    # sizing frames like the single-stream region used to be (so that the two are not told apart by how long the GPU
+    # has been busy); every frame is a whole frame, bit-identical to the single-stream one (checked at the end).
+    ring, dt2 = None, None
+    if world == 1 and frames_in_flight and frames_in_flight > 1:
+        F = int(frames_in_flight)
+        ring = gs.FrameRing(dev, F)
+        targets = [par.band_target_ptr(gbuf, plan, rank, W)]
+        extra = [gs.Buffer(dev, size=W * H * 16) for _ in range(F - 1)]
+        targets += [b.device_ptr() for b in extra]
+        for k in range(F):               # the sizing frame of every lane's renderer (blocking once each)
+            ring.render(buf, gt, mt, cam, targets[k], check=True)
+        frame_no = [0]
+
+        def pstep():
+            frame_no[0] += 1
+            ring.render(buf, gt, mt, cam, targets[(frame_no[0] - 1) % F])
+
+        for _ in range(warmup):
+            pstep()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            pstep()
+        torch.cuda.synchronize()
+        dt2 = time.perf_counter() - t0
+
+        def finish_in_flight():
+            psteady = None
+            if steady_frames:
+                for _ in range(100):
+                    pstep()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(steady_frames):
+                    pstep()
+                torch.cuda.synchronize()
+                dts = time.perf_counter() - t0
+                psteady = dict(frames=steady_frames, ms_per_step=dts * 1e3 / steady_frames,
+                               value=wl["n"] / (dts / steady_frames) / 1e6, unit="Msplats/s")
+            for _ in range(F):               # every lane's last frame is a frame of this camera
+                pstep()
+            torch.cuda.synchronize()
+            flags = [int(fr_.flags) for fr_ in ring.wait()]
+            if any(flags):
+                raise RuntimeError("bench.py: a pipelined frame was skipped or flagged (per-lane flags %s)" % flags)
+            ref = gbuf[:H].cpu().numpy().view(np.uint32)
+            equal = all(np.array_equal(b.download(ring.streams[k + 1], np.float32).reshape(H, W, 4).view(np.uint32), ref)
+                        for k, b in enumerate(extra))
+            equal = equal and float(gbuf[:H].double().sum().item()) == checksum
+            res = dict(frames_in_flight=F, ms_per_step=dt2 * 1e3 / steps, value=wl["n"] / (dt2 / steps) / 1e6,
+                       unit="Msplats/s", stream_priorities=ring.priorities, steady_state=psteady,
+                       images_bit_identical=bool(equal), measured="first: W warm-up + K timed frames straight after the sizing frames",
+                       note="%d renderers on %d streams of different priority (= different hardware queues) take the "
+                            "frames in turn; W warm-up + K timed frames as for the single stream" % (F, F))
+            ring.close()
+            for b in extra:
+                b.release()
+            return res
+
     for _ in range(warmup):
         step()
     sync_all()
@@ -231,68 +296,7 @@ def run_workload(gs, synth, torch, dist, dev, stream, rank, world, wl, steps, wa
         t = torch.tensor([pairs], dtype=torch.float64, device="cuda")
         dist.all_reduce(t)
         pairs = int(t.item())
-    # Frames in flight (single GPU): F renderers (each its own scratch buffers) on F streams of F different
-    # priorities take the frames in turn, so that the latency-bound sort chain of frame i + 1 runs under the
-    # VALU-bound blend of frame i.  Different priorities because HIP gives each priority level its own hardware
-    # queues while streams of one priority may share a queue — under torch they do, and then nothing overlaps
-    # (kernel trace: one Queue_Id for both streams; 0.327 ms per frame with or without the second stream, 0.275
-    # with two priorities).  The contract's W warm-up + K timed steps are run this way too: every frame is a whole
-    # frame, bit-identical to the single-stream one (checked below), only its latency is longer.
-    in_flight = None
-    if world == 1 and frames_in_flight and frames_in_flight > 1:
-        F = int(frames_in_flight)
-        torch.cuda.synchronize()
-        r.set_timing(False)          # no stage events in this run
-        ring = gs.FrameRing(dev, F)
-        prios = ring.priorities
-        targets = [par.band_target_ptr(gbuf, plan, rank, W)]
-        extra = [gs.Buffer(dev, size=W * H * 16) for _ in range(F - 1)]
-        targets += [b.device_ptr() for b in extra]
-        for k in range(F):               # the sizing frame of every lane's renderer (blocking once each)
-            ring.render(buf, gt, mt, cam, targets[k], check=True)
-        frame_no = [0]
-
-        def pstep():
-            frame_no[0] += 1
-            ring.render(buf, gt, mt, cam, targets[(frame_no[0] - 1) % F])
-
-        for _ in range(warmup):
-            pstep()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            pstep()
-        torch.cuda.synchronize()
-        dt2 = time.perf_counter() - t0
-        psteady = None
-        if steady_frames:
-            for _ in range(100):
-                pstep()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(steady_frames):
-                pstep()
-            torch.cuda.synchronize()
-            dts = time.perf_counter() - t0
-            psteady = dict(frames=steady_frames, ms_per_step=dts * 1e3 / steady_frames,
-                           value=wl["n"] / (dts / steady_frames) / 1e6, unit="Msplats/s")
-        for _ in range(F):               # every lane's last frame is a frame of this camera
-            pstep()
-        torch.cuda.synchronize()
-        flags = [int(fr_.flags) for fr_ in ring.wait()]
-        if any(flags):
-            raise RuntimeError("bench.py: a pipelined frame was skipped or flagged (per-lane flags %s)" % flags)
-        ref = gbuf[:H].cpu().numpy().view(np.uint32)
-        equal = all(np.array_equal(b.download(ring.streams[k + 1], np.float32).reshape(H, W, 4).view(np.uint32), ref)
-                    for k, b in enumerate(extra))
-        equal = equal and float(gbuf[:H].double().sum().item()) == checksum
-        in_flight = dict(frames_in_flight=F, ms_per_step=dt2 * 1e3 / steps, value=wl["n"] / (dt2 / steps) / 1e6,
-                         unit="Msplats/s", stream_priorities=prios, steady_state=psteady, images_bit_identical=bool(equal),
-                         note="%d renderers on %d streams of different priority (= different hardware queues) take the "
-                              "frames in turn; W warm-up + K timed frames as for the single stream" % (F, F))
-        ring.close()
-        for b in extra:
-            b.release()
+    in_flight = finish_in_flight() if ring is not None else None
     out = dict(ms_per_frame=dt * 1e3 / steps, visible=visible, pairs=pairs, sort_passes=int(st.sort_passes),
                in_flight_run=in_flight, steady_state=steady,
                stages_ms=stages, checksum=checksum, launches=int(fr.launches), pair_capacity=int(fr.pair_capacity),
