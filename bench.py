@@ -64,6 +64,16 @@ def upload_scene(gs, synth, dev, stream, wl, chunk=1_000_000):
     return pod, buf
 
 
+def par_nccl_options(dist):
+    """ProcessGroupNCCL.Options with the collective's stream on the high-priority queues (None if this torch has none)"""
+    try:
+        opts = dist.ProcessGroupNCCL.Options()
+        opts.is_high_priority_stream = True
+        return opts
+    except Exception:
+        return None
+
+
 def _camera(gs, wl):
     eye = wl.get("eye", DEFAULT_EYE)
     return gs.camera_look_at(eye, (eye[0], eye[1], eye[2] - 1.0), (0, 1, 0), float(np.deg2rad(60.0)),
@@ -776,7 +786,10 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            # RCCL's stream on the HIGH-priority queues: the frames are rendered on a stream of the default priority,
+            # and two streams of one priority may share a hardware queue — the all-gather of frame i
+            # would then sit in front of the kernels of frame i + 1 instead of running beside them
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local), pg_options=par_nccl_options(dist))
         else:
             dist.init_process_group(args.backend)
         backend = dist.get_backend()

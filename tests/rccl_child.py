@@ -50,7 +50,9 @@ def main():
     torch.cuda.set_device(0)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    opts = dist.ProcessGroupNCCL.Options()       # as bench.py does: RCCL's stream on the high-priority queues, so that
+    opts.is_high_priority_stream = True          # it cannot share a hardware queue with the render stream
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0), pg_options=opts)
     assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
 
     W, H, N = 1280, 720, 200_000

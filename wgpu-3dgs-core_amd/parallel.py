@@ -36,7 +36,11 @@ Streams: launch on a dedicated non-default stream (`torch.cuda.Stream()`, wrappe
 `Device.wrap_stream(s.cuda_stream)` and made current with `torch.cuda.stream(s)` around the calls of
 this module): RCCL orders its own stream behind the CURRENT stream when a collective is issued and
 `work.wait()` makes the CURRENT stream wait for it; the legacy null stream would serialise with every
-other stream of the device and defeat the overlap `FramePipeline` exists for.
+other stream of the device and defeat the overlap `FramePipeline` exists for.  Give RCCL's stream a priority of
+its own as well (`ProcessGroupNCCL.Options().is_high_priority_stream = True`, bench.py): HIP keeps separate hardware
+queues per priority level, while two streams of ONE priority may share a queue — the all-gather would then sit in
+front of the next frame's kernels instead of running beside them (measured on one GPU with two render streams:
+no overlap at all until they had different priorities).
 """
 import numpy as np
 
