@@ -114,14 +114,26 @@ def run_workload(gs, synth, torch, dist, dev, stream, rank, world, wl, steps, wa
         torch.bitwise_or(band_flags[0], pipe[0].flags(i), out=band_flags[0])
         return img
 
+    # N > 1, frames in flight inside the rank: a band is a chain of small dependent kernels, so the rank's frames are
+    # taken in turn by renderers on streams of different priority (parallel.lanes; 1 M / 8 ranks on one GPU: 0.162 ->
+    # 0.076 ms per band with three, `tools/band_bench.py --frames-in-flight`); begin / render / submit run on the
+    # lane's stream, the exchange is ordered behind it, finish on the main stream
+    rank_lanes = [None]
+
     def step():
         if world == 1:
             render()
             return gbuf
         i = count[0]
         count[0] += 1
-        r.render(stream, buf, gt, mt, cam, pipe[0].begin(i, r), band=plan.bands[rank], check=False)
-        pipe[0].submit(i)
+        if rank_lanes[0]:
+            rr, gs_s, ts = rank_lanes[0][i % len(rank_lanes[0])]
+            with torch.cuda.stream(ts):
+                rr.render(gs_s, buf, gt, mt, cam, pipe[0].begin(i, rr), band=plan.bands[rank], check=False)
+                pipe[0].submit(i)
+        else:
+            r.render(stream, buf, gt, mt, cam, pipe[0].begin(i, r), band=plan.bands[rank], check=False)
+            pipe[0].submit(i)
         return finish(i - 1) if i else None
 
     def sync_all():
@@ -144,7 +156,13 @@ def run_workload(gs, synth, torch, dist, dev, stream, rank, world, wl, steps, wa
         plan_kind = "tile rows re-cut to equal pairs (one calibration frame)"
     fr = render(check=True)          # sizes the pair buffers for this band (blocking once)
     if world > 1:
-        pipe[0] = par.FramePipeline(torch, dist, plan, rank, W, "cuda")
+        nl = max(1, min(int(frames_in_flight or 1), 2))
+        if nl > 1:
+            rank_lanes[0] = par.lanes(torch, gs, dev, nl, first_renderer=r)
+            for rr, gs_s, ts in rank_lanes[0][1:]:      # the sizing frame of every further renderer (blocking once each)
+                rr.render(gs_s, buf, gt, mt, cam, par.band_target_ptr(gbuf, plan, rank, W), band=plan.bands[rank], check=True)
+            torch.cuda.synchronize()
+        pipe[0] = par.FramePipeline(torch, dist, plan, rank, W, "cuda", depth=nl + 1)
         band_flags[0] = torch.zeros(world, dtype=torch.int32, device="cuda")
     # Frames in flight (single GPU): F renderers (each its own scratch buffers) on F streams of F different
     # priorities take the frames in turn, so that the latency-bound sort chain of frame i + 1 runs under the
@@ -290,11 +308,21 @@ def run_workload(gs, synth, torch, dist, dev, stream, rank, world, wl, steps, wa
     if world > 1:
         img = finish(count[0] - 1)               # the frame just submitted, exchanged and assembled
     sync_all()
+    if world > 1:
+        # the pipelined frame (lanes, three gather buffers, async exchange) against the same frame rendered and
+        # exchanged synchronously on the main stream: bit for bit, on every rank
+        img = img.clone()
+        plain = par.render_sharded(dist, torch, gbuf, plan, rank, W,
+                                   lambda band, ptr: r.render(stream, buf, gt, mt, cam, ptr, band=band, check=False),
+                                   renderer=r, check=True)
+        if plain is None or not torch.equal(plain[:H].view(torch.int32), img[:H].view(torch.int32)):
+            raise RuntimeError("bench.py: the pipelined N-GPU frame differs from the synchronously exchanged one (rank %d)" % rank)
     # no frame of this run may have been skipped (pair capacity): on one GPU the renderer's last result says
     # so, on N the OR of the flags words that travelled with every band of every finished frame
     if world > 1:
         skipped_bands = [int(x) for x in band_flags[0].cpu().tolist()]
-        r.set_frame_flags_target(None)
+        for rr in [r] + [l[0] for l in (rank_lanes[0] or [])[1:]]:
+            rr.set_frame_flags_target(None)
     else:
         skipped_bands = [int(r.wait_frame().flags)]
     if any(skipped_bands):
@@ -316,7 +344,11 @@ def run_workload(gs, synth, torch, dist, dev, stream, rank, world, wl, steps, wa
         out["frame_ms"] = dict(samples=len(samples), median=samples[len(samples) // 2], min=samples[0],
                                p95=samples[min(len(samples) - 1, int(0.95 * len(samples)))], max=samples[-1],
                                timer="hipEvent pairs around single frames on the launch stream")
+    for rr, gs_s, _ in (rank_lanes[0] or [])[1:]:
+        rr.destroy()
     r.destroy()
+    for _, gs_s, _ in (rank_lanes[0] or []):
+        gs_s.close()
     buf.destroy()
     del gbuf
     return out

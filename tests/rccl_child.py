@@ -119,7 +119,35 @@ def main():
         assert after is not None, "the frame after a skipped one must be rendered"
         after = after.clone()
         pipe2.drain()
+        # frames in flight INSIDE the rank (bench.py --gpus N): two renderers on priority streams take the frames in
+        # turn; begin / render / submit on the lane's stream, finish here on stream `s`; three gather buffers, the
+        # forced RCCL collective ordered behind the lane, the next writer of a buffer behind its reader
+        lanes = par.lanes(torch, gs, dev, 2)
+        assert len(lanes) == 2 and lanes[0][1].native() != lanes[1][1].native()
+        pipe3 = par.FramePipeline(torch, dist, plan, 0, W, "cuda", depth=3, force_collective=True)
+        for b in pipe3.bufs:
+            b.fill_(float("nan"))
+        rounds = 3                                   # every buffer and every lane is reused several times
+        got_lanes = []
+        for j in range(rounds * frames):
+            rr, gs_s, ts = lanes[j % 2]
+            with torch.cuda.stream(ts):
+                rr.render(gs_s, buf, gt, mt, cams[j % frames], pipe3.begin(j, rr), band=plan.bands[0], check=False)
+                pipe3.submit(j)
+            if j:
+                prev = pipe3.finish(j - 1, check=True)
+                assert prev is not None
+                got_lanes.append(prev.clone())
+        got_lanes.append(pipe3.finish(rounds * frames - 1, check=True).clone())
+        pipe3.drain()
     s.synchronize()
+    torch.cuda.synchronize()
+    have_lanes = [hashlib.sha256(np.ascontiguousarray(t[:H].cpu().numpy()).tobytes()).hexdigest() for t in got_lanes]
+    assert have_lanes == [want[j % frames] for j in range(rounds * frames)], "frames of the lanes differ: %s" % (
+        [a == want[j % frames] for j, a in enumerate(have_lanes)],)
+    for rr, gs_s, _ in lanes:
+        rr.destroy()
+        gs_s.close()
     assert skipped is None and skip_flags == 3, (skipped is None, skip_flags)
     r.render(own, buf, gt_big, mt, cams[0], img.device_ptr())
     want_big = hashlib.sha256(img.download(own, np.float32).tobytes()).hexdigest()
@@ -132,7 +160,7 @@ def main():
     dist.barrier()
     dist.destroy_process_group()
     print(json.dumps({"ok": True, "order": order, "frames": frames, "backend": "nccl", "world_size": 1,
-                      "work_handle": sorted(kinds), "skipped_frame_dropped": True, "hip_runtime": hiprt.info()["source"],
+                      "work_handle": sorted(kinds), "skipped_frame_dropped": True, "lanes_frames": len(have_lanes), "hip_runtime": hiprt.info()["source"],
                       "libamdhip64": mapped["libamdhip64"], "libhsa": mapped["libhsa-runtime64"],
                       "torch": torch.__version__, "hip": torch.version.hip}), flush=True)
 

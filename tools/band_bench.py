@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--which", type=int, default=-1, help="rank whose band is rendered (-1 = middle)")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--morton", action="store_true", help="experiment: upload the scene in Morton order of the positions")
+    ap.add_argument("--frames-in-flight", type=int, default=0,
+                    help="also time the band with this many renderers on priority streams taking the frames in turn (FrameRing)")
     args = ap.parse_args()
     import torch  # noqa: F401  (device memory for the frame, as in bench.py)
     import synth
@@ -63,6 +65,22 @@ def main():
         r.render(stream, buf, gt, mt, cam, img.device_ptr(), band=band, check=False)
     stream.synchronize()
     ms = (time.perf_counter() - t0) * 1e3 / args.steps
+    ms_ring = None
+    if args.frames_in_flight > 1:
+        ring = gs.FrameRing(dev, args.frames_in_flight)
+        imgs = [gs.Buffer(dev, size=max(padded, H) * W * 16) for _ in range(len(ring))]
+        for k in range(len(ring)):
+            ring.render(buf, gt, mt, cam, imgs[k].device_ptr(), band=band, check=True)
+        for i in range(100):
+            ring.render(buf, gt, mt, cam, imgs[i % len(ring)].device_ptr(), band=band)
+        ring.synchronize()
+        t0 = time.perf_counter()
+        for i in range(200):
+            ring.render(buf, gt, mt, cam, imgs[i % len(ring)].device_ptr(), band=band)
+        ring.synchronize()
+        ms_ring = (time.perf_counter() - t0) * 1e3 / 200
+        assert all(fr.flags == 0 for fr in ring.wait())
+        ring.close()
     r.set_timing(True)
     r.reset_stats()
     for _ in range(args.steps):
@@ -70,6 +88,8 @@ def main():
     st = r.stats()
     stages = {n: round(st.stage_ms[i] / max(st.timed_frames, 1), 4) for i, n in enumerate(gs.STAGE_NAMES)}
     print(json.dumps(dict(workload=args.workload, ranks=args.ranks, band=band, ms_per_frame=round(ms, 4),
+                          ms_per_frame_in_flight=None if ms_ring is None else round(ms_ring, 4),
+                          frames_in_flight=args.frames_in_flight,
                           visible=int(st.visible), pairs=int(st.pairs), stages_ms=stages,
                           forced=os.environ.get("GS3D_FORCE_BANDED"))))
 

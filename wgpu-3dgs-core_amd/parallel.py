@@ -180,6 +180,11 @@ class FramePipeline:
         pipe.submit(i)                 # start the exchange of frame i
         image = pipe.finish(i - 1)     # the complete previous frame (orders the caller's stream behind its exchange)
 
+    begin / render / submit may run on another stream than finish (several renderers on priority streams taking the
+    frames in turn, `lanes()` below: a rank's band is a chain of small dependent kernels, and three of them in flight
+    cost 0.076 ms per frame instead of 0.162 at 1 M / 8 ranks): the exchange is ordered behind the stream that is
+    current at submit, the buffer's next writer behind the stream that consumed it.
+
     A band that overflowed its pair capacity is skipped on the device; its flags word travels with the
     band.  `finish(i, check=True)` reads the G words back (one small device-to-host copy: a presenting
     viewer synchronises here anyway) and returns None when ANY rank skipped — every rank sees the same
@@ -195,6 +200,9 @@ class FramePipeline:
         self.bufs = [allocate_gather(torch, plan, width, device) for _ in range(depth)]
         self.work = [None] * depth          # exchange in flight on each buffer
         self.frame = [None] * depth         # frame number each buffer holds
+        self.reader = [None] * depth        # stream on which finish() / flags() last read each buffer
+        self.submitted = [None] * depth     # event behind everything submit() enqueued on ITS stream (the render, and
+                                            # — gloo rehearsals — the staged copies of the other ranks' bands)
 
     def _slot(self, i):
         return i % len(self.bufs)
@@ -203,10 +211,28 @@ class FramePipeline:
         if self.work[k] is not None:
             self.work[k].wait()             # stream-level: the current stream waits, the host does not
             self.work[k] = None
+        if self.submitted[k] is not None:
+            self.torch.cuda.current_stream().wait_event(self.submitted[k])     # (a no-op on the stream that submitted)
+
+    def _note_reader(self, k):
+        # frames may be rendered on other streams than the one that consumes them (frames in flight on priority
+        # streams): remember who read the buffer, so that its next writer can be ordered behind that stream
+        if self.bufs[k].device.type != "cpu":
+            self.reader[k] = self.torch.cuda.current_stream()
 
     def begin(self, i, renderer=None):
         k = self._slot(i)
         self._wait(k)                       # the buffer's previous exchange must have read and written it
+        rd = self.reader[k]
+        if rd is not None:
+            # ... and whoever consumed that frame (assemble's copy, the flags OR) must be done reading: everything the
+            # reader's stream has been given so far — the views finish() / flags() handed out are used right away
+            cur = self.torch.cuda.current_stream()
+            if rd != cur:
+                ev = self.torch.cuda.Event()
+                ev.record(rd)
+                cur.wait_event(ev)
+            self.reader[k] = None
         self.frame[k] = i
         if renderer is not None:
             renderer.set_frame_flags_target(flags_ptr(self.bufs[k], self.plan, self.rank, self.width))
@@ -216,18 +242,24 @@ class FramePipeline:
         k = self._slot(i)
         assert self.frame[k] == i
         self.work[k] = gather_bands(self.dist, self.bufs[k], self.plan, self.rank, async_op=True, force=self.force)
+        self.submitted[k] = None
+        if self.bufs[k].device.type != "cpu":
+            self.submitted[k] = self.torch.cuda.Event()
+            self.submitted[k].record(self.torch.cuda.current_stream())
 
     def flags(self, i):
         """device tensor [G] of frame i's per-band flags (valid once its exchange has been waited for)"""
         k = self._slot(i)
         assert self.frame[k] == i, "frame %d is no longer in the pipeline" % i
         self._wait(k)
+        self._note_reader(k)
         return frame_flags(self.torch, self.bufs[k], self.plan)
 
     def finish(self, i, check=False):
         k = self._slot(i)
         assert self.frame[k] == i, "frame %d is no longer in the pipeline" % i
         self._wait(k)
+        self._note_reader(k)
         if check and bool((frame_flags(self.torch, self.bufs[k], self.plan) != 0).any().item()):
             return None                     # some band was skipped: drop the frame on every rank
         return assemble(self.torch, self.bufs[k], self.plan)
@@ -235,6 +267,23 @@ class FramePipeline:
     def drain(self):
         for k in range(len(self.bufs)):
             self._wait(k)
+
+
+def lanes(torch, gs, device, count, first_renderer=None, priorities=None):
+    """`count` (renderer, gs stream, torch stream) triples for frames in flight inside one rank: the streams are
+    created with DIFFERENT priorities (gs_stream_create_with_priority: different hardware queues) and handed to torch
+    as external streams, so that `with torch.cuda.stream(lane[2])` makes RCCL and FramePipeline order themselves behind
+    the lane.  Default priorities: default and least — the greatest is left to RCCL's stream
+    (ProcessGroupNCCL.Options.is_high_priority_stream)."""
+    least, greatest = device.stream_priority_range()
+    if priorities is None:
+        priorities = [0, least] if least != greatest else [0]
+    out = []
+    for k in range(max(1, min(int(count), len(priorities)))):
+        s = device.create_stream(priority=priorities[k])
+        out.append((first_renderer if (k == 0 and first_renderer is not None) else gs.Renderer(device), s,
+                    torch.cuda.ExternalStream(s.native())))
+    return out
 
 
 def render_sharded(dist, torch, buf, plan, rank, width, render_band, renderer=None, check=True):
