@@ -339,7 +339,8 @@ def run_workload(gs, synth, torch, dist, dev, stream, rank, world, wl, steps, wa
                in_flight_run=in_flight, steady_state=steady,
                stages_ms=stages, checksum=checksum, launches=int(fr.launches), pair_capacity=int(fr.pair_capacity),
                per_rank_ms=per_rank, render_ms_per_rank=render_ms, gather_ms_per_rank=gather_ms,
-               bands=plan.bands, band_plan=plan_kind, skipped_band_flags=skipped_bands)
+               bands=plan.bands, band_plan=plan_kind, skipped_band_flags=skipped_bands,
+               rank_lanes=len(rank_lanes[0]) if rank_lanes[0] else 1)
     if samples:
         out["frame_ms"] = dict(samples=len(samples), median=samples[len(samples) // 2], min=samples[0],
                                p95=samples[min(len(samples) - 1, int(0.95 * len(samples)))], max=samples[-1],
@@ -904,11 +905,13 @@ def main():
             "config": {"workload": wl["label"], "gaussians": wl["n"], "visible": res["visible"],
                        "pairs": res["pairs"], "sort_passes": res["sort_passes"],
                        "launches_per_frame": res["launches"],
-                       "parallelism": "tile-row bands x%d + one %s all-gather (%s)" % (
-                           world, "RCCL" if backend == "nccl" else "%s (rehearsal, host-staged)" % backend, res["band_plan"])
+                       "parallelism": "tile-row bands x%d + one %s all-gather (%s), %d frames in flight per rank" % (
+                           world, "RCCL" if backend == "nccl" else "%s (rehearsal, host-staged)" % backend, res["band_plan"],
+                           res.get("rank_lanes", 1))
                        if world > 1 else ("single GPU, %d frames in flight on %d priority streams" % (
                            fl["frames_in_flight"], fl["frames_in_flight"]) if fl else "single GPU, one stream"),
-                       "frames_in_flight": fl["frames_in_flight"] if fl else 1, "image_checksum": res["checksum"]},
+                       "frames_in_flight": fl["frames_in_flight"] if fl else res.get("rank_lanes", 1),
+                       "image_checksum": res["checksum"]},
             "single_stream": {"ms_per_step": res["ms_per_frame"], "value": wl["n"] / (res["ms_per_frame"] * 1e-3) / 1e6,
                               "unit": "Msplats/s", "steady_state": res.get("steady_state"),
                               "note": "the same W + K frames on one stream, one frame at a time on the device"},

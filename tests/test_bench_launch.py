@@ -141,6 +141,7 @@ def test_bench_two_ranks_gloo_rehearsal_self_launched(tmp_path):
     assert len(last) <= 4096
     j = json.loads(last)
     assert j["n_gpus"] == 2 and j["value"] > 0 and j["steps"] == 3 and j["warmup"] == 1
+    assert j["config"]["frames_in_flight"] == 2 and "2 frames in flight per rank" in j["config"]["parallelism"]
     d = j["distributed"]
     assert d["backend"] == "gloo" and d["world_size"] == 2 and len(d["per_rank_ms"]) == 2 and len(d["bands"]) == 2
     full = json.loads(detail.read_text())
