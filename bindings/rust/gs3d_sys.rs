@@ -241,6 +241,17 @@ pub struct gs_frame_result {
     pub launches: u32,
 }
 
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct gs_sort_info {
+    pub depth_msd: u32,
+    pub depth_bucket_max: u32,
+    pub bucket_capacity: u32,
+    pub tile_msd: u32,
+    pub tile_bucket_max: u32,
+    pub reserved: [u32; 3],
+}
+
 #[link(name = "gs3d_hip")]
 extern "C" {
     pub fn gs_last_error(out: *mut gs_error_info);
@@ -349,6 +360,8 @@ extern "C" {
     pub fn gs_renderer_stats(r: *mut gs_renderer, out: *mut gs_frame_stats) -> gs_status;
     pub fn gs_render_frame(r: *mut gs_renderer, s: *mut gs_stream, gaussians: *mut gs_gaussians_buffer, gaussian_transform: *const gs_gaussian_transform_pod, model_transform: *const gs_model_transform_pod, camera: *const gs_camera, band_ty0: u32, band_ty1: u32, rgba_out_device: *mut f32) -> gs_status;
     pub fn gs_renderer_wait_frame(r: *mut gs_renderer, out: *mut gs_frame_result) -> gs_status;
+    pub fn gs_renderer_sort_info(r: *mut gs_renderer, out: *mut gs_sort_info) -> gs_status;
+    pub fn gs_renderer_set_sort_mode(r: *mut gs_renderer, depth_msd: i32, tile_msd: i32) -> gs_status;
     pub fn gs_renderer_download_projected(r: *mut gs_renderer, proj_out: *mut gs_projected, tiles_touched_out: *mut u32, n: usize) -> gs_status;
     pub fn gs_renderer_download_sorted(r: *mut gs_renderer, keys_out: *mut u64, idx_out: *mut u32, capacity: u64, pairs_out: *mut u64) -> gs_status;
     pub fn gs_renderer_download_ranges(r: *mut gs_renderer, ranges_out: *mut u32, num_tiles: usize) -> gs_status;

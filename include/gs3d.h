@@ -632,6 +632,24 @@ typedef struct gs_frame_result {
  * `out` may be NULL. */
 gs_status gs_renderer_wait_frame(gs_renderer *r, gs_frame_result *out);
 
+/* How the last frame sorted (blocking like gs_renderer_stats; no reference item: the sorts are the viewer's).  The depth
+ * sort runs MSD-first — one scatter on the top 9 bits of the depth key, then one workgroup per bucket finishes the low
+ * bits on its CU — while the buckets fit (`bucket_capacity` elements), and as LSD passes while they do not; the renderer
+ * chooses per frame from the bucket sizes the previous frames reported.  Both produce the same order. */
+typedef struct gs_sort_info {
+    uint32_t depth_msd;          /* 1: MSD-first depth sort in the last frame, 0: LSD passes */
+    uint32_t depth_bucket_max;   /* largest top-digit bucket the last frame saw (its own report) */
+    uint32_t bucket_capacity;    /* elements a bucket may hold for the on-CU path (larger ones take a slow in-kernel fallback) */
+    uint32_t tile_msd;           /* the same for the tile sort */
+    uint32_t tile_bucket_max;
+    uint32_t reserved[3];
+} gs_sort_info;
+gs_status gs_renderer_sort_info(gs_renderer *r, gs_sort_info *out);
+/* Pins the choice for the following frames: 1 MSD-first, 0 LSD passes, -1 the renderer chooses (default; the
+ * environment variables GS3D_DEPTH_MSD / GS3D_TILE_MSD = 0 / 1 pin it for every renderer of the process).  A pinned
+ * MSD-first sort stays correct whatever the bucket sizes (oversized buckets take the in-kernel fallback). */
+gs_status gs_renderer_set_sort_mode(gs_renderer *r, int32_t depth_msd, int32_t tile_msd);
+
 /* Parity taps on the last frame (blocking).  Sizes: N records / N counts; D keys / D indices;
  * tiles_x*tiles_y*2 ranges. */
 gs_status gs_renderer_download_projected(gs_renderer *r, gs_projected *proj_out,

@@ -461,6 +461,8 @@ class Renderer {
     // PairCapacityError when it exceeded the pair capacity (the next frame has larger buffers)
     gs_frame_result wait_frame() { gs_frame_result fr; check(gs_renderer_wait_frame(h_, &fr)); return fr; }
     gs_frame_stats stats() { gs_frame_stats st; check(gs_renderer_stats(h_, &st)); return st; }
+    gs_sort_info sort_info() { gs_sort_info si; check(gs_renderer_sort_info(h_, &si)); return si; }
+    void set_sort_mode(int32_t depth_msd, int32_t tile_msd = -1) { check(gs_renderer_set_sort_mode(h_, depth_msd, tile_msd)); }
     // sharded frames: a DEVICE word that receives every following frame's flags in stream order (nullptr: off)
     void set_frame_flags_target(uint32_t *device_word) { check(gs_renderer_set_frame_flags_target(h_, device_word)); }
   private:

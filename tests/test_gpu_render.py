@@ -17,10 +17,12 @@ pytestmark = pytest.mark.gpu
 RGBA_TOL = 1e-4  # BASELINE.json north_star: <= 1e-4 per channel
 
 
-def _render_gpu(gs, device, stream, pod, pods, gt, mt, cam, band=None, renderer=None):
+def _render_gpu(gs, device, stream, pod, pods, gt, mt, cam, band=None, renderer=None, sort_mode=None):
     buf = gs.GaussiansBuffer.new_with_pods(device, pod, pods)
     img = gs.Buffer(device, size=cam.height * cam.width * 16)
     r = renderer or gs.Renderer(device)
+    if sort_mode is not None:
+        r.set_sort_mode(*sort_mode)        # (depth, tile): 1 MSD-first, 0 LSD passes, -1 the renderer chooses
     r.render(stream, buf, gt, mt, cam, img.device_ptr(), band=band)
     stream.synchronize()
     rgba = img.download(stream, np.float32).reshape(cam.height, cam.width, 4)
@@ -51,7 +53,7 @@ def _oracle_frame(ob, sh, cov, pods, ogt, omt, ocam, band=None, order=None):
 
 
 def _compare_frame(gs, ob, device, stream, sh, cov, gaussians, W, H, gt_kw=None, mt_kw=None,
-                   cam_kw=None, band=None, check_image_exact=True):
+                   cam_kw=None, band=None, check_image_exact=True, sort_mode=None, info=None):
     gt_kw, mt_kw, cam_kw = gt_kw or {}, mt_kw or {}, cam_kw or {}
     pod = gs.GaussianPod(sh, cov)
     pods = pod.from_gaussian(gaussians)
@@ -66,7 +68,9 @@ def _compare_frame(gs, ob, device, stream, sh, cov, gaussians, W, H, gt_kw=None,
     cam = helpers.copy_camera(ocam, gs.Camera)
     assert bytes(gt) == bytes(ogt) and bytes(mt) == bytes(omt)
 
-    r, buf, img, rgba = _render_gpu(gs, device, stream, pod, pods, gt, mt, cam, band)
+    r, buf, img, rgba = _render_gpu(gs, device, stream, pod, pods, gt, mt, cam, band, sort_mode=sort_mode)
+    if info is not None:
+        info.append(r.sort_info())
     order = _mirror_order(ob, buf, stream, sh, cov, pods)
     o_proj, o_tiles, o_keys, o_idx, o_skeys, o_sidx, o_ranges, o_rgba = _oracle_frame(
         ob, sh, cov, pods, ogt, omt, ocam, band, order=order)
@@ -197,9 +201,10 @@ def _depth_bits(near, far):
     return (fb - nb).bit_length() if fb > nb else 0
 
 
-@pytest.mark.parametrize("planes", [(0.001, 100.0), (5.0, 20.0), (0.0, 1000.0), (9.99, 10.02)])
+@pytest.mark.parametrize("msd", [0, 1])
+@pytest.mark.parametrize("planes", [(0.001, 100.0), (5.0, 20.0), (0.0, 1000.0), (9.99, 10.02), (0.1, 100.0)])
 @pytest.mark.parametrize("case", ["same_depth", "two_depths", "wide_range", "narrow_range"])
-def test_depth_key_ranges(gs, ob, device, stream, case, planes):
+def test_depth_key_ranges(gs, ob, device, stream, case, planes, msd):
     """The depth sort's pass count comes from the camera's near / far planes alone (no read-back of
     the scene's depth range inside a frame): 9-bit digits when they save a pass (19-27 bits), 8-bit
     digits otherwise; scenes with all-equal, two-valued, wide and narrow depth distributions must
@@ -223,13 +228,21 @@ def test_depth_key_ranges(gs, ob, device, stream, case, planes):
     else:
         g["pos"][:, 2] = (-mid * (1.0 - rng.random(len(g)) * 1e-4)).astype(np.float32)
         g["pos"][:, :2] *= mid / 14.0
+    info = []
     st = _compare_frame(gs, ob, device, stream, gs.SH_NONE, gs.COV3D_ROT_SCALE, g, 640, 360,
-                        gt_kw=dict(sh_deg=0), cam_kw=dict(near=near, far=far))
+                        gt_kw=dict(sh_deg=0), cam_kw=dict(near=near, far=far), sort_mode=(msd, 0), info=info)
     assert st.visible > 100
     tile_passes = 2   # 40 x 23 = 920 tiles -> 10 bits -> 5 + 5
     bits = _depth_bits(near, far)
     p8, p9 = -(-bits // 8), -(-bits // 9)
     assert st.sort_passes - tile_passes == min(p8, p9), (st.sort_passes, bits)
+    # MSD-first (round 5: a scatter on the top 9 bits + one workgroup per bucket) exists for 10..27 key bits; pinned
+    # it is taken, and in either mode the frame reports its largest top-digit bucket
+    assert info[0].depth_msd == (1 if msd and 9 < bits <= 27 else 0), (bits, info[0].depth_msd)
+    if bits > 9:
+        assert 0 < info[0].depth_bucket_max <= st.visible
+        if case == "same_depth":
+            assert info[0].depth_bucket_max == st.visible       # every key in one bucket
 
 
 @pytest.mark.parametrize("seed", [1, 2, 3])

@@ -20,7 +20,7 @@ import ctypes as C
 import numpy as np
 
 from . import _capi
-from ._capi import Camera, FrameResult, FrameStats, GaussianTransformPod, Limits, ModelTransformPod
+from ._capi import Camera, FrameResult, FrameStats, GaussianTransformPod, Limits, ModelTransformPod, SortInfo
 
 _L = _capi.load()
 
@@ -1171,6 +1171,16 @@ class Renderer:
         st = FrameStats()
         _check(_L.gs_renderer_stats(self._h, C.byref(st)))
         return st
+
+    def sort_info(self):
+        """gs_renderer_sort_info: how the last frame sorted (MSD-first or LSD passes, largest bucket)."""
+        si = SortInfo()
+        _check(_L.gs_renderer_sort_info(self._h, C.byref(si)))
+        return si
+
+    def set_sort_mode(self, depth_msd=-1, tile_msd=-1):
+        """gs_renderer_set_sort_mode: 1 MSD-first, 0 LSD passes, -1 the renderer chooses (default)."""
+        _check(_L.gs_renderer_set_sort_mode(self._h, int(depth_msd), int(tile_msd)))
 
     def render(self, stream, gaussians, gaussian_transform, model_transform, camera,
                rgba_device_ptr, band=None, check=True):

@@ -47,6 +47,11 @@ class FrameResult(C.Structure):
                 ("flags", u32), ("launches", u32)]
 
 
+class SortInfo(C.Structure):
+    _fields_ = [("depth_msd", u32), ("depth_bucket_max", u32), ("bucket_capacity", u32), ("tile_msd", u32),
+                ("tile_bucket_max", u32), ("reserved", u32 * 3)]
+
+
 class BundleDesc(C.Structure):
     _fields_ = [("label", C.c_char_p), ("kernel", i32), ("sh", i32), ("cov", i32),
                 ("bind_group_count", u32), ("bindings_per_group", C.POINTER(u32)),
@@ -179,6 +184,8 @@ SIGNATURES = {
     "gs_renderer_set_frame_flags_target": (i32, [vp, vp]),
     "gs_renderer_stats": (i32, [vp, vp]),
     "gs_renderer_wait_frame": (i32, [vp, vp]),
+    "gs_renderer_sort_info": (i32, [vp, vp]),
+    "gs_renderer_set_sort_mode": (i32, [vp, i32, i32]),
     "gs_render_frame": (i32, [vp, vp, vp, vp, vp, vp, u32, u32, vp]),
     "gs_renderer_download_projected": (i32, [vp, vp, vp, sz]),
     "gs_renderer_download_sorted": (i32, [vp, vp, vp, u64, vp]),

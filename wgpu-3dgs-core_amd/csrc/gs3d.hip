@@ -251,7 +251,10 @@ struct gs_device {
     int ordinal;
     gs_limits limits;
     hipStream_t internal;  // for blocking helper work
-    bool lds_atomic_ordered;   // probe result: returning LDS atomics hand out lane-ordered values
+    // probe result: returning LDS atomics hand out lane-ordered values.  Written by any renderer of the device whose rank
+    // watchdog fired (gs_render_frame / gs_renderer_wait_frame, possibly from different host threads) and read once per
+    // frame (t_rank_fault) and by the stand-alone sorts: atomic, relaxed — it only ever goes from true to false.
+    std::atomic<bool> lds_atomic_ordered{false};
 };
 
 struct gs_stream {
@@ -328,7 +331,7 @@ extern "C" gs_status gs_device_create(int32_t ordinal, gs_device **out) {
     return GS_OK;
 }
 
-extern "C" int32_t gs_device_fast_rank(const gs_device *dev) { return dev && dev->lds_atomic_ordered ? 1 : 0; }
+extern "C" int32_t gs_device_fast_rank(const gs_device *dev) { return dev && dev->lds_atomic_ordered.load() ? 1 : 0; }
 
 extern "C" void gs_device_destroy(gs_device *dev) {
     if (!dev) return;
@@ -1471,6 +1474,13 @@ struct gs_renderer {
     DevArray chunk_hist;                  // [chunks][256] first-digit histogram of every chunk's depth keys (PreOut::chunk_hist)
     bool list_mode = false;               // the last frame's per-slot arrays are in LIST space (k_block_cull ran)
     bool rank_inject_set = false;         // GS3D_TEST_RANK_FAULT: the watchdog's test hook has been armed
+    // Depth sort of the frame: MSD-first (one scatter on the top digit + k_bucket_sort) or the LSD passes.  The choice
+    // follows the largest top-digit bucket the last frames reported (FrameResult::depth_bucket_max): MSD-first while
+    // the buckets fit a workgroup's registers, LSD while they do not; a shape's first frame guesses from N.
+    bool depth_msd = false;               // mode of the last frame
+    uint32_t depth_bucket_seen = 0;       // newest reported bucket size the mode was chosen from (diagnostic)
+    bool tile_msd = false;                // the tile sort of the last frame was MSD-first
+    int depth_msd_req = -1, tile_msd_req = -1;   // gs_renderer_set_sort_mode: -1 = the renderer chooses
     uint32_t cull_last_gen = 0, cull_last_groups = 0;   // frame / group count of the last k_block_cull (status tags)
     DevArray dkeys[2], dvals[2];          // (depth bits - bias, mirror slot), capacity N
     DevArray tkeys[2], tvals[2];          // (tile id, mirror slot), capacity pair_capacity
@@ -1640,10 +1650,11 @@ extern "C" gs_status gs_renderer_wait_frame(gs_renderer *r, gs_frame_result *out
         return fail(GS_ERR_PAIR_OVERFLOW, r->n, 0, 0,
                     "the frame needs more than 2^32 (tile, Gaussian) pairs; pair indices are 32-bit");
     if (fr.flags & gs::FRAME_FLAG_RANK_FAULT) {
-        if (r->dev->lds_atomic_ordered) {
-            r->dev->lds_atomic_ordered = false;
-            (void)hipMemset(&((gs::FrameState *)r->state.ptr)->rank_fault, 0, sizeof(uint32_t));   // the stream is idle here
-        }
+        // The device drops to the ballot-based rank, and THIS renderer's watchdog word is cleared whether or not it was
+        // this renderer that flipped the switch: with several renderers on one device (FrameRing, parallel.lanes) the
+        // second one to report used to find the switch already off, keep its word set, and flag every later frame.
+        r->dev->lds_atomic_ordered.store(false);
+        (void)hipMemset(&((gs::FrameState *)r->state.ptr)->rank_fault, 0, sizeof(uint32_t));   // the stream is idle here
         return fail(GS_ERR_RANK_ORDER, 0, 0, 0,
                     "the LDS-atomic rank of the radix sort returned an out-of-order value in this frame: its blend order "
                     "may be wrong; the device has been switched to the ballot-based rank: render again");
@@ -1672,6 +1683,30 @@ extern "C" gs_status gs_renderer_stats(gs_renderer *r, gs_frame_stats *out) {
     out->timed_frames = r->timed_frames;
     static_assert(ST_COUNT <= 12, "gs_frame_stats.stage_ms too small");
     for (int i = 0; i < ST_COUNT; i++) out->stage_ms[i] = r->stage_ms[i];
+    return GS_OK;
+}
+
+extern "C" gs_status gs_renderer_sort_info(gs_renderer *r, gs_sort_info *out) {
+    if (!r || !out) return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "null argument");
+    GS_TRY(use_device(r->dev));
+    std::memset(out, 0, sizeof(*out));
+    out->bucket_capacity = gs::BKT_CAP;
+    if (!r->have_frame) return GS_OK;
+    GS_HIP(hipStreamSynchronize(r->last_stream));
+    const gs::FrameResult &fr = last_result(r);
+    out->depth_msd = r->depth_msd ? 1u : 0u;
+    out->depth_bucket_max = fr.gen == r->gen ? fr.depth_bucket_max : 0u;
+    out->tile_msd = r->tile_msd ? 1u : 0u;
+    out->tile_bucket_max = r->state.ptr ? 0u : 0u;
+    return GS_OK;
+}
+
+extern "C" gs_status gs_renderer_set_sort_mode(gs_renderer *r, int32_t depth_msd, int32_t tile_msd) {
+    if (!r) return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "null renderer");
+    if (depth_msd < -1 || depth_msd > 1 || tile_msd < -1 || tile_msd > 1)
+        return fail(GS_ERR_INVALID_ARGUMENT, (uint64_t)(int64_t)depth_msd, (uint64_t)(int64_t)tile_msd, 0, "sort modes are -1, 0 or 1");
+    r->depth_msd_req = depth_msd;
+    r->tile_msd_req = tile_msd;
     return GS_OK;
 }
 
@@ -1835,6 +1870,13 @@ static void launch_scan_rows(uint32_t rows, hipStream_t st, uint32_t *ghist, uin
 // rank_fault; null outside a frame: the stand-alone sorts are not watched).  Thread-local instead of one more
 // parameter through five levels of sort templates.
 static thread_local uint32_t *t_rank_fault = nullptr;
+// ... and what else the frame hands its scatters the same way: the watchdog's sample of this frame (gs::k_sort_scatter:
+// tile = watch mod live tiles, round = (watch / live tiles) mod ITEMS; the frame generation, so that every position is
+// visited over a few hundred frames), and the word that receives the largest top-digit bucket of the depth sort
+// (only the LSD sort's LAST pass gets it: t_top_pass).
+static thread_local uint32_t t_watch = 0;
+static thread_local uint32_t *t_bucket_max = nullptr;
+static thread_local bool t_top_pass = false;
 
 // one scatter launch (FAST_RANK chosen by the device probe); KO = type of the keys the pass writes
 template <typename KI, typename KO, int RB, bool COMPACT, int ITEMS>
@@ -1847,12 +1889,16 @@ static void launch_scatter(const gs_device *dev, hipStream_t st, uint32_t sgrid,
     static const int nt_env = std::getenv("GS3D_NT_SCATTER") ? std::atoi(std::getenv("GS3D_NT_SCATTER")) : -1;
     const bool nt = !COMPACT && (nt_env >= 0 ? nt_env != 0 : (uint64_t)psc.count * (sizeof(KI) + 4u) > (32ull << 20));
     const uint32_t xr_nt = xr | (nt ? 0x80000000u : 0u);
-    if (dev->lds_atomic_ordered)
+    uint32_t *bmax = t_top_pass ? t_bucket_max : nullptr;
+    if (t_rank_fault)      // (null outside a frame and once the device has dropped to the ballot-based rank)
         hipLaunchKernelGGL((gs::k_sort_scatter<KI, true, RB, COMPACT, ITEMS, KO>), dim3(sgrid), dim3(gs::SORT_THREADS), 0, st, kin, vin,
-                           kout, ko_shift, vout, psc, shift, digit_mask, ghist, totals, cv, vo, pnb, xr_nt, t_rank_fault);
+                           kout, ko_shift, vout, psc, shift, digit_mask, ghist, totals, cv, vo, pnb, xr_nt, t_rank_fault, t_watch, bmax);
+    else if (dev->lds_atomic_ordered.load(std::memory_order_relaxed))
+        hipLaunchKernelGGL((gs::k_sort_scatter<KI, true, RB, COMPACT, ITEMS, KO>), dim3(sgrid), dim3(gs::SORT_THREADS), 0, st, kin, vin,
+                           kout, ko_shift, vout, psc, shift, digit_mask, ghist, totals, cv, vo, pnb, xr_nt, (uint32_t *)nullptr, 0u, bmax);
     else
         hipLaunchKernelGGL((gs::k_sort_scatter<KI, false, RB, COMPACT, ITEMS, KO>), dim3(sgrid), dim3(gs::SORT_THREADS), 0, st, kin, vin,
-                           kout, ko_shift, vout, psc, shift, digit_mask, ghist, totals, cv, vo, pnb, xr_nt, (uint32_t *)nullptr);
+                           kout, ko_shift, vout, psc, shift, digit_mask, ghist, totals, cv, vo, pnb, xr_nt, (uint32_t *)nullptr, 0u, bmax);
 }
 
 // one radix pass: histogram -> row scan -> scatter
@@ -1882,6 +1928,8 @@ static void launch_pass(const gs_device *dev, hipStream_t st, uint32_t sgrid, co
     launch_scatter<KI, KO, RB, COMPACT, ITEMS>(dev, st, sgrid, kin, vin, kout, ko_shift, vout, psc, shift, digit_mask,
                                                (const uint32_t *)ghist.ptr, (const uint32_t *)digit_totals.ptr, cv, vo, pnb, xr);
 }
+
+static uint32_t xcd_span_for(uint32_t pnb, uint32_t &sgrid);
 
 template <typename K, int RB, int ITEMS>
 static gs_status run_sort_items(const gs_device *dev, void *const keys[2], void *const vals[2], DevArray &ghist,
@@ -1919,15 +1967,9 @@ static gs_status run_sort_items(const gs_device *dev, void *const keys[2], void 
         // XCD-aware tile order in the scatter (see scatter_tile_of): XCD x takes `xr` consecutive tiles
         // of every group of 8 * xr.  xr grows with the number of tiles (a group must stay a small part
         // of the pass) between 4 and 64.  GS3D_XCD_REMAP=0 disables, GS3D_XCD_REMAP_C=<n> forces a size.
-        static const bool remap_on = !(std::getenv("GS3D_XCD_REMAP") && std::getenv("GS3D_XCD_REMAP")[0] == '0');
-        static const int remap_c = std::getenv("GS3D_XCD_REMAP_C") ? std::atoi(std::getenv("GS3D_XCD_REMAP_C")) : 0;
-        uint32_t xr = 0;
-        if (remap_on && pnb >= 256u) {
-            xr = 4u;
-            while (xr < 64u && xr * 2u * 256u <= pnb) xr *= 2u;
-            if (remap_c > 1) xr = (uint32_t)remap_c;
-        }
-        const uint32_t sgrid = xr ? 8u * xr * ((pnb + 8u * xr - 1u) / (8u * xr)) : pnb;
+        uint32_t sgrid = 0;
+        const uint32_t xr = xcd_span_for(pnb, sgrid);
+        t_top_pass = compact != nullptr && p == passes - 1;   // the depth sort's pass on its top digit reports the largest bucket
         if (source && p == 0) {
             // the pairs come from the depth-ordered rects: k_pairs_emit writes this pass's input
             // (keys[side] / vals[side]) and its histogram at once
@@ -1976,8 +2018,69 @@ static gs_status run_sort_items(const gs_device *dev, void *const keys[2], void 
         shift += bits;
         side ^= 1;
     }
+    t_top_pass = false;
     GS_HIP(hipGetLastError());
     result_side = side;
+    return GS_OK;
+}
+
+// XCD-aware tile order of a radix pass over `pnb` tiles (see run_sort_items): the span factor and the padded grid
+static uint32_t xcd_span_for(uint32_t pnb, uint32_t &sgrid) {
+    static const bool remap_on = !(std::getenv("GS3D_XCD_REMAP") && std::getenv("GS3D_XCD_REMAP")[0] == '0');
+    static const int remap_c = std::getenv("GS3D_XCD_REMAP_C") ? std::atoi(std::getenv("GS3D_XCD_REMAP_C")) : 0;
+    uint32_t xr = 0;
+    if (remap_on && pnb >= 256u) {
+        xr = 4u;
+        while (xr < 64u && xr * 2u * 256u <= pnb) xr *= 2u;
+        if (remap_c > 1) xr = (uint32_t)remap_c;
+    }
+    sgrid = xr ? 8u * xr * ((pnb + 8u * xr - 1u) / (8u * xr)) : pnb;
+    return xr;
+}
+
+// The frame's depth sort, MSD-first (round 5; gs_render_kernels.h, "Bucket sort"): ONE compacting scatter pass on the TOP
+// 9 bits of the depth key — its histogram summed from the rows the preprocess kernel counted — then one workgroup per
+// bucket sorts the remaining low bits on its CU and writes the final order to vals[0].  4 launches instead of 9; right
+// when the buckets fit a workgroup (up to ~1-2 M visible Gaussians spread in depth), which the caller decides from the
+// bucket sizes the last frames reported.  `scratch_*`: two passes of the chunked fallback (oversized buckets).
+template <int ITEMS>
+static gs_status run_depth_msd_items(gs_renderer *r, hipStream_t st, const SortCompact &cp, uint32_t dbits, uint32_t top_range,
+                                     void *scratch_keys, void *scratch_vals, uint32_t *bucket_max, uint32_t &passes_out) {
+    constexpr int RB = gs::RADIX_BITS_MAX;
+    constexpr uint32_t R = 1u << RB, TILE = (uint32_t)(gs::SORT_THREADS * ITEMS);
+    const gs_device *dev = r->dev;
+    const uint32_t low_bits = dbits - (uint32_t)RB;
+    const uint32_t pnb = (uint32_t)(((uint64_t)cp.dense_count + TILE - 1) / TILE);
+    GS_TRY(dev_reserve(r->ghist, (size_t)pnb * R * 4));
+    GS_TRY(dev_reserve(r->digit_totals, R * 4));
+    uint32_t sgrid = 0;
+    const uint32_t xr = xcd_span_for(pnb, sgrid);
+    const gs::SortCount psc{cp.dense_count, cp.dense_count_dev};
+    launch_pass<uint32_t, uint32_t, RB, true, ITEMS>(dev, st, sgrid, cp.dense_keys, (const uint32_t *)nullptr, (uint32_t *)r->dkeys[1].ptr, 0u,
+                                                     (uint32_t *)r->dvals[1].ptr, psc, low_bits, R - 1u, r->ghist, r->digit_totals,
+                                                     cp.chunk_vis, cp.visible_out, pnb, xr, cp.chunk_hist);
+    gs::BucketSortIO io;
+    io.totals = (const uint32_t *)r->digit_totals.ptr;
+    io.nb = top_range < R ? top_range : R;          // digits past the far plane's cannot occur (their totals are zero)
+    io.keys_in = r->dkeys[1].ptr;
+    io.vals_in = (const uint32_t *)r->dvals[1].ptr;
+    io.keys_tmp = scratch_keys;
+    io.vals_tmp = (uint32_t *)scratch_vals;
+    io.keys_out = nullptr;                          // nobody reads the sorted depth keys
+    io.vals_out = (uint32_t *)r->dvals[0].ptr;
+    io.low_bits = low_bits;
+    io.bucket_max = bucket_max;
+    io.ranges = nullptr;
+    io.num_tiles = 0;
+    io.rank_fault = t_rank_fault;
+    io.watch = t_watch;
+    if (t_rank_fault || dev->lds_atomic_ordered.load(std::memory_order_relaxed))
+        hipLaunchKernelGGL((gs::k_bucket_sort<uint32_t, RB, true>), dim3(io.nb), dim3(gs::BKT_THREADS), 0, st, io);
+    else
+        hipLaunchKernelGGL((gs::k_bucket_sort<uint32_t, RB, false>), dim3(io.nb), dim3(gs::BKT_THREADS), 0, st, io);
+    GS_HIP(hipGetLastError());
+    r->launches += 4;
+    passes_out = 1u + (low_bits + RB - 1u) / RB;
     return GS_OK;
 }
 
@@ -2334,6 +2437,7 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
     uint64_t hist_d[2] = {0, 0};
     uint32_t hist_gen[2] = {0, 0};
     uint32_t hist_v[2] = {0, 0};
+    uint32_t hist_bmax[2] = {0, 0};
     for (int i = 0; i < 2; i++) {
         if (frame_event) {
             if (!r->done_valid[i] || hipEventQuery(r->done[i]) != hipSuccess) continue;
@@ -2347,10 +2451,12 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
         const uint64_t f_pairs = fr.pairs_total;
         const uint32_t f_vis = fr.visible;
         const uint32_t f_flags = fr.flags;
+        const uint32_t f_bmax = fr.depth_bucket_max;
         if (__atomic_load_n(&fr.gen, __ATOMIC_ACQUIRE) != r->done_gen[i] || f_pairs > 0xfffffff0ull) continue;
         hist_d[i] = f_pairs;
         hist_gen[i] = r->done_gen[i];
         hist_v[i] = f_vis;
+        hist_bmax[i] = f_bmax;
         if (f_flags & gs::FRAME_FLAG_RANK_FAULT) rank_fault_seen = true;
         // grow when the last measured D leaves less than 1/8 of head room
         if (f_pairs + f_pairs / 8 > r->pair_capacity && capacity_for(f_pairs) > want_capacity)
@@ -2413,8 +2519,9 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
         // ballot-based one -> this device sorts with the ballot-based rank from now on, and the flag is cleared in
         // stream order (the kernels that could set it are no longer launched).
         gs::FrameState *fs = (gs::FrameState *)r->state.ptr;
-        if (rank_fault_seen && r->dev->lds_atomic_ordered) {
-            r->dev->lds_atomic_ordered = false;
+        if (rank_fault_seen) {
+            // (the word is this renderer's own and is cleared whoever switched the device: see gs_renderer_wait_frame)
+            r->dev->lds_atomic_ordered.store(false);
             GS_HIP(hipMemsetAsync(&fs->rank_fault, 0, sizeof(uint32_t), st));
         }
         // GS3D_TEST_RANK_FAULT=1 (tests): the watchdog's expectation is off by one, so it fires in the first frame
@@ -2425,14 +2532,26 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
             GS_HIP(hipStreamSynchronize(st));      // `one` lives on this stack frame
             r->rank_inject_set = true;
         }
-        t_rank_fault = r->dev->lds_atomic_ordered ? &fs->rank_fault : nullptr;
+        // read ONCE per frame: every scatter of the frame ranks the same way, whatever another renderer's thread does
+        t_rank_fault = r->dev->lds_atomic_ordered.load() ? &fs->rank_fault : nullptr;
+        t_bucket_max = &fs->depth_bucket_max;
+        t_top_pass = false;
     }
     struct RankFaultScope {
-        ~RankFaultScope() { t_rank_fault = nullptr; }
+        ~RankFaultScope() {
+            t_rank_fault = nullptr;
+            t_bucket_max = nullptr;
+            t_top_pass = false;
+        }
     } rank_fault_scope;
 
     r->gen++;
     const uint32_t gen = r->gen;
+    {
+        // the rank watchdog's sample of this frame (GS3D_TEST_RANK_WATCH=<n> pins it: tests)
+        static const char *watch_env = std::getenv("GS3D_TEST_RANK_WATCH");
+        t_watch = watch_env ? (uint32_t)std::strtoul(watch_env, nullptr, 10) : gen;
+    }
     // From here on kernels of this frame may be in the stream.  Whatever way the function is left — also
     // through GS_TRY / GS_HIP after an allocation or launch failure — the end-of-frame event of this
     // generation is recorded behind them, so the next frame on ANOTHER stream waits for exactly these
@@ -2474,6 +2593,33 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
     const uint32_t dbits = far_bits > near_bits ? bit_length(far_bits - near_bits) : 0u;
     r->key_bias = near_bits;
     const uint32_t tile_bits = bit_length(num_tiles ? num_tiles - 1 : 0);
+
+    // ---- which depth sort (gs_renderer::depth_msd) ----
+    // MSD-first needs a top digit of 9 bits and at most two bucket passes below it: 10..27 key bits (the bench's planes,
+    // 0.1 / 100, give 27); with fewer or more bits the LSD passes stand.
+    const uint32_t msd_low_bits = dbits > (uint32_t)gs::RADIX_BITS_MAX ? dbits - (uint32_t)gs::RADIX_BITS_MAX : 0u;
+    const bool msd_possible = n != 0 && dbits > (uint32_t)gs::RADIX_BITS_MAX && msd_low_bits <= 2u * (uint32_t)gs::RADIX_BITS_MAX;
+    bool depth_msd = false;
+    if (msd_possible) {
+        static const int msd_env = std::getenv("GS3D_DEPTH_MSD") ? std::atoi(std::getenv("GS3D_DEPTH_MSD")) : -1;
+        const int newer = hist_gen[0] > hist_gen[1] ? 0 : 1;
+        const int pinned = r->depth_msd_req >= 0 ? r->depth_msd_req : msd_env;
+        if (pinned >= 0) {
+            depth_msd = pinned != 0;
+        } else if (!sizing && hist_gen[newer] && r->done_shape[newer] == r->shape_epoch && hist_bmax[newer]) {
+            // hysteresis: leave MSD-first when a bucket no longer fits the register path, come back below 7/8 of it
+            const uint32_t b = hist_bmax[newer];
+            r->depth_bucket_seen = b;
+            depth_msd = r->depth_msd ? b <= gs::BKT_CAP : b <= gs::BKT_CAP - gs::BKT_CAP / 8u;
+        } else if (sizing) {
+            // no report yet: the buckets of a scene this small probably fit (and if not, the bucket kernel's chunked path
+            // still sorts them correctly, and the report of this very frame corrects the choice)
+            depth_msd = n <= (4u << 20);
+        } else {
+            depth_msd = r->depth_msd;      // frames in flight between the sizing frame and its report: keep the guess
+        }
+    }
+    r->depth_msd = depth_msd;
 
     gs::TileKeys tile_keys{nullptr, nullptr, 0u, 0u};   // null keys: the blend reads its ranges from the range array
     if (n == 0) {
@@ -2529,7 +2675,8 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
         po.key_bias = near_bits;
         po.block_bounds = (const float *)g->block_bounds;
         po.chunk_hist = (uint32_t *)r->chunk_hist.ptr;
-        po.digit_mask = first_digit_mask(dbits, depth_radix_bits(dbits));
+        po.digit_mask = depth_msd ? (1u << gs::RADIX_BITS_MAX) - 1u : first_digit_mask(dbits, depth_radix_bits(dbits));
+        po.digit_shift = depth_msd ? msd_low_bits : 0u;
         po.block_list = nullptr;
         po.block_count = nullptr;
         // Block list (k_block_cull): one thread per block tests it, the survivors are handed to the first
@@ -2613,7 +2760,18 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
             cp.dense_count_dev = r->list_mode ? &state->list_slots : nullptr;   // list frame: only the surviving blocks' slots
             cp.chunk_hist = (const uint32_t *)r->chunk_hist.ptr;
             const gs::SortCount dc{n, &state->visible};
-            if (depth_radix_bits(dbits) == (uint32_t)gs::RADIX_BITS_MAX)
+            if (depth_msd) {
+                // scratch of the bucket kernel's chunked path: the LSD sort's side 0 keys and the (not yet written)
+                // depth-ordered rects — the dense keys themselves stay intact for the parity taps
+                const uint32_t top_range = ((far_bits - near_bits) >> msd_low_bits) + 1u;
+                if (n >= (4u << 20))
+                    GS_TRY((run_depth_msd_items<gs::SortCfg<uint32_t>::ITEMS_LARGE>(r, st, cp, dbits, top_range, r->dkeys[0].ptr,
+                                                                                  r->sorted_rect.ptr, &state->depth_bucket_max, dpasses)));
+                else
+                    GS_TRY((run_depth_msd_items<gs::SortCfg<uint32_t>::ITEMS>(r, st, cp, dbits, top_range, r->dkeys[0].ptr,
+                                                                            r->sorted_rect.ptr, &state->depth_bucket_max, dpasses)));
+                dside = 0;
+            } else if (depth_radix_bits(dbits) == (uint32_t)gs::RADIX_BITS_MAX)
                 GS_TRY((run_sort_rb<uint32_t, gs::RADIX_BITS_MAX>(r->dev, k2, v2, r->ghist, r->digit_totals, dc, dbits, &cp,
                                                                   st, dside, dpasses, r->launches)));
             else

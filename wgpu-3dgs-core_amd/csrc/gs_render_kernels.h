@@ -168,6 +168,8 @@ struct FrameState {
     uint32_t rank_fault;     // watchdog of the LDS-atomic rank (scatter_ranked): set when block 0 of a radix pass finds a rank
                              // that is not the ballot-based one; published with the frame flags, cleared by the host
     uint32_t rank_inject;    // test hook (GS3D_TEST_RANK_FAULT=1): added to the expected rank, so the watchdog fires
+    uint32_t depth_bucket_max;   // largest top-digit bucket of the depth sort (k_bucket_sort, or the LSD sort's last pass)
+    uint32_t tile_bucket_max;    // the same for the tile sort (k_bucket_sort)
 };
 constexpr uint32_t FRAME_FLAG_PAIR_OVERFLOW = 1u;   // D exceeded the pair capacity
 constexpr uint32_t FRAME_FLAG_SKIPPED = 2u;         // ... so the frame was skipped: the image was NOT written
@@ -181,7 +183,8 @@ struct FrameResult {
     uint32_t flags;
     uint64_t pairs_total;    // true D, also when it exceeded the capacity
     uint32_t gen;            // frame generation this result belongs to
-    uint32_t pad[3];
+    uint32_t depth_bucket_max;   // FrameState::depth_bucket_max: feeds the host's choice of the depth sort (MSD-first / LSD)
+    uint32_t pad[2];
 };
 
 // One thread publishes a frame's result to pinned host memory.  `gen` goes LAST, behind a
@@ -189,7 +192,7 @@ struct FrameResult {
 // event created with hipEventDisableSystemFence, then a read) and finds the expected generation
 // also finds that generation's counts.
 __device__ __forceinline__ void publish_result(FrameResult *r, uint32_t visible, uint64_t pairs_total, uint32_t flags,
-                                               uint32_t gen, uint32_t *flags_dev = nullptr) {
+                                               uint32_t gen, uint32_t *flags_dev = nullptr, uint32_t depth_bucket_max = 0u) {
     // optional copy of the flags in DEVICE memory (gs_renderer_set_frame_flags_target): a sharded frame
     // carries it inside its band's gather chunk, so every rank learns from the one all-gather whether
     // any band was skipped
@@ -197,6 +200,7 @@ __device__ __forceinline__ void publish_result(FrameResult *r, uint32_t visible,
     r->visible = visible;
     r->pairs_total = pairs_total;
     r->flags = flags;
+    r->depth_bucket_max = depth_bucket_max;
     __hip_atomic_store(&r->gen, gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
@@ -818,6 +822,7 @@ struct PreOut {
                                      // Counted here, where the keys sit in registers: the compacting pass's histogram
                                      // kernel then sums 1 KB rows instead of re-reading 4 KB of keys per chunk.
     uint32_t digit_mask;
+    uint32_t digit_shift;            // 0: the LSD sort's lowest digit; the MSD-first sort counts its TOP digit (key >> shift)
 };
 constexpr int PRE_HIST_BINS = 1 << 9;   // RADIX_BITS_MAX bins
 
@@ -928,7 +933,7 @@ __global__ __launch_bounds__(PP_THREADS) void k_preprocess(const uint4 *__restri
             o[8] = rec[2].x;
             const uint32_t key = cnt ? rec[2].y - io.key_bias : 0xffffffffu;
             io.depth[i] = key;
-            if (cnt) atomicAdd(&s_dhist[key & io.digit_mask], 1u);
+            if (cnt) atomicAdd(&s_dhist[(key >> io.digit_shift) & io.digit_mask], 1u);
             if (fc.rect32) ((uint32_t *)io.rect)[i] = cnt ? rect_pack32(rec[2].z, rec[2].w) : 0u;
             else io.rect[i] = cnt ? make_uint2(rec[2].z, rec[2].w) : make_uint2(0u, 0u);
             local += cnt;
@@ -1063,7 +1068,7 @@ __global__ __launch_bounds__(PP_THREADS) void k_preprocess_banded(const uint4 *_
             }
             if (cnt) {
                 key = rec[2].y - io.key_bias;
-                atomicAdd(&s_dhist[key & io.digit_mask], 1u);
+                atomicAdd(&s_dhist[(key >> io.digit_shift) & io.digit_mask], 1u);
             }
             local += cnt;
             local_vis += cnt ? 1u : 0u;
@@ -1640,7 +1645,8 @@ __device__ __forceinline__ void scatter_ranked(ScatterShared<K, RB, ITEMS> &sh, 
                                                uint32_t *__restrict__ vals_out, uint32_t shift, uint32_t digit_mask,
                                                const uint32_t *__restrict__ ghist,
                                                const uint32_t *__restrict__ digit_totals,
-                                               uint32_t *__restrict__ visible_out, uint32_t *rank_fault = nullptr) {
+                                               uint32_t *__restrict__ visible_out, uint32_t *rank_fault = nullptr,
+                                               uint32_t watch_round = 0u, uint32_t *bucket_max_out = nullptr) {
     constexpr int R = 1 << RB;
     constexpr int DPT = R / SORT_THREADS;        // digits per thread: thread t owns digits [t*DPT, t*DPT+DPT)
     auto &s_wave_hist = sh.wave_hist;
@@ -1656,22 +1662,29 @@ __device__ __forceinline__ void scatter_ranked(ScatterShared<K, RB, ITEMS> &sh, 
             uint32_t d = (uint32_t)(key[k] >> shift) & digit_mask;
             if (!COMPACT || (uint32_t)key[k] != SORT_INVALID_KEY) rank[k] = atomicAdd(&s_wave_hist[wid][d], 1u);
         }
-        // Watchdog of the bet: block 0 of every pass checks its first round against the ballot-based
-        // rank — the wave's counters start at zero, so the rank of a live lane must be the number of live lanes below
-        // it holding the same digit.  A mismatch sets FrameState.rank_fault; the frame result carries it to the host,
-        // which switches the device to the ballot-based rank for good.  (A probe at gs_device_create cannot see a
-        // violation that only shows under the frame's real access pattern; rounds 2-3 shipped the bet unguarded.)
-        if (rank_fault && block == 0u) {
-            const uint32_t d0 = (uint32_t)(key[0] >> shift) & digit_mask;
-            const bool live0 = !COMPACT || (uint32_t)key[0] != SORT_INVALID_KEY;
-            uint64_t peers = __ballot(live0);
+        // Watchdog of the bet.  What the bet claims is the order INSIDE one wave instruction: the
+        // lanes that hit one counter receive consecutive values in lane order, i.e. rank = (value the lowest such lane
+        // got) + (number of such lanes below me).  ONE workgroup of every pass (the caller picks it from the frame
+        // generation and hands it the word: every tile is sampled over a few hundred frames, not just tile 0 as in
+        // round 4) checks exactly that for ONE of its rounds (`watch_round`, likewise rotating) against the ballot.
+        // A mismatch sets FrameState.rank_fault; the frame result carries it to the host, which switches the device
+        // to the ballot-based rank for good.  (rank_fault[1]: test hook, makes the expectation wrong.)
+        if (rank_fault) {
 #pragma unroll
-            for (int b = 0; b < RB; b++) {
-                const uint64_t m = __ballot((d0 >> b) & 1u);
-                peers &= ((d0 >> b) & 1u) ? m : ~m;
+            for (int k = 0; k < ITEMS; k++) {
+                if ((uint32_t)k != watch_round) continue;      // uniform: static register indexing
+                const uint32_t dk = (uint32_t)(key[k] >> shift) & digit_mask;
+                const bool livek = !COMPACT || (uint32_t)key[k] != SORT_INVALID_KEY;
+                uint64_t peers = __ballot(livek);
+#pragma unroll
+                for (int b = 0; b < RB; b++) {
+                    const uint64_t m = __ballot((dk >> b) & 1u);
+                    peers &= ((dk >> b) & 1u) ? m : ~m;
+                }
+                const uint32_t first = (uint32_t)__shfl((int)rank[k], peers ? (int)__builtin_ctzll(peers) : 0, WAVE);
+                const bool bad = livek && rank[k] != first + mbcnt(peers) + rank_fault[1];
+                if (__any(bad) && (threadIdx.x & 63u) == 0u) atomicOr(rank_fault, 1u);
             }
-            const bool bad = live0 && rank[0] != mbcnt(peers) + rank_fault[1];
-            if (__any(bad) && (threadIdx.x & 63u) == 0u) atomicOr(rank_fault, 1u);
         }
     } else {
 #pragma unroll
@@ -1749,6 +1762,20 @@ __device__ __forceinline__ void scatter_ranked(ScatterShared<K, RB, ITEMS> &sh, 
         }
         if constexpr (COMPACT)
             if (block == 0 && tid == 0) *visible_out = all;     // V = everything the pass ranked
+        // the LSD sort's pass on the TOP digit reports the largest digit total = the largest bucket an MSD-first
+        // sort of these keys would hand to k_bucket_sort (the host's choice between the two, gs3d.hip)
+        if (bucket_max_out && block == 0u) {
+            uint32_t m = 0;
+#pragma unroll
+            for (int q = 0; q < DPT; q++) m = tot[q] > m ? tot[q] : m;
+            m = wave_reduce_max(m);
+            if ((tid & 63u) == 0u) s_scan[wid] = m;
+            __syncthreads();
+            if (tid == 0u) {
+                const uint32_t a = s_scan[0] > s_scan[1] ? s_scan[0] : s_scan[1], b = s_scan[2] > s_scan[3] ? s_scan[2] : s_scan[3];
+                *bucket_max_out = a > b ? a : b;
+            }
+        }
     }
     __syncthreads();
 
@@ -1812,7 +1839,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
     uint32_t *__restrict__ vals_out, SortCount sc, uint32_t shift, uint32_t digit_mask,
     const uint32_t *__restrict__ ghist, const uint32_t *__restrict__ digit_totals,
     const uint32_t *__restrict__ chunk_vis, uint32_t *__restrict__ visible_out, uint32_t num_tiles,
-    uint32_t xcd_chunk_nt, uint32_t *rank_fault) {
+    uint32_t xcd_chunk_nt, uint32_t *rank_fault, uint32_t watch, uint32_t *bucket_max_out) {
     constexpr int TILE = SORT_THREADS * ITEMS;
     __shared__ ScatterShared<K, RB, ITEMS> sh;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
@@ -1875,8 +1902,393 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
             val[k] = ok ? vals_in[tile_base + e] : 0u;
         }
     }
+    // the watchdog's sample of this pass: tile (watch mod live tiles), round (watch / live tiles) mod ITEMS
+    uint32_t *rf = rank_fault && block == watch % live_tiles ? rank_fault : (uint32_t *)nullptr;
     scatter_ranked<K, FAST_RANK, RB, COMPACT, ITEMS, KO>(sh, key, val, in_tile, block, num_tiles, keys_out, ko_shift, vals_out,
-                                                         shift, digit_mask, ghist, digit_totals, visible_out, rank_fault);
+                                                         shift, digit_mask, ghist, digit_totals, visible_out, rf,
+                                                         (watch / live_tiles) % (uint32_t)ITEMS, bucket_max_out);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Bucket sort: the second half of an MSD-first sort (round 5).  A scatter pass on the TOP digit (its
+// histogram comes for free: the preprocess kernel / k_pairs_emit count it while the keys sit in
+// registers) leaves the elements partitioned into at most 512 buckets, each contiguous and in input
+// order; one 1024-thread workgroup per bucket then sorts its bucket on the remaining low bits
+// entirely on the CU — keys and values in registers, one returning LDS atomic per key and pass for
+// the rank (as in scatter_ranked), one exchange through LDS per pass — and writes the final order.
+// No global histogram, no row scan and no trip through HBM for the low digits: the LSD sort's
+// 3 x (histogram, row scan, scatter) become (histogram sum, row scan, scatter, bucket sort), 9
+// dependent launches -> 4 at 1 M Gaussians.
+// A bucket of up to BKT_CAP = 30 720 elements takes the register path.  A larger one (depths that
+// collapse into a few top digits: a wall seen head-on, `narrow_range`, `same_depth`) is still sorted
+// correctly, by the same workgroup in chunks through global scratch (bucket_sort_chunked: two sweeps
+// per pass, one workgroup's bandwidth) — the device never needs the host to notice.  The host does
+// notice, one or two frames later (FrameResult::depth_bucket_max), and goes back to the LSD passes
+// while buckets do not fit.
+// ---------------------------------------------------------------------------------------------
+constexpr int BKT_THREADS = 1024;
+constexpr int BKT_WAVES = BKT_THREADS / WAVE;
+constexpr int BKT_ITEMS_MAX = 30;
+constexpr uint32_t BKT_CAP = (uint32_t)BKT_THREADS * BKT_ITEMS_MAX;   // elements of the register path
+constexpr int BKT_CHUNK_ITEMS = 16;                                     // chunked path: 16 384 elements per step
+
+struct BucketSortIO {
+    const uint32_t *totals;     // [nb] bucket sizes = digit totals of the scatter pass that made the buckets
+    uint32_t nb;                // buckets (<= BKT_THREADS) = grid size
+    const void *keys_in;        // [count] keys after the top-digit scatter (u32, or u16 tile ids)
+    const uint32_t *vals_in;
+    void *keys_tmp;             // scratch of the chunked path when two passes are left (in -> tmp -> out)
+    uint32_t *vals_tmp;
+    void *keys_out;             // may be null: nobody reads the sorted keys (depth sort)
+    uint32_t *vals_out;
+    uint32_t low_bits;          // key bits [0, low_bits) are still unsorted; <= 2 * RB
+    uint32_t *bucket_max;       // may be null: receives the largest bucket size (workgroup 0)
+    uint32_t *ranges;           // may be null: per-tile [start, end) (tile sort: tile = bucket << low_bits | low digit)
+    uint32_t num_tiles;
+    uint32_t *rank_fault;       // may be null: watchdog word of the LDS-atomic rank (FrameState::rank_fault, [1] = test hook)
+    uint32_t watch;             // which (bucket, round) the watchdog samples this frame (frame generation)
+};
+
+template <int RB>
+struct BucketShared {
+    static constexpr int R = 1 << RB;
+    uint32_t wave_hist[BKT_WAVES][R];   // per-wave digit counters, then each wave's base per digit
+    uint32_t xbuf[BKT_CAP];             // exchange buffer of the register path
+    uint32_t dbase[R];                  // chunked path: running output offset of every digit
+    uint32_t scan[BKT_WAVES];
+    uint32_t bcast[4];
+};
+
+// exclusive scan over the 1024 threads of a bucket workgroup; ends with `smem` reusable
+__device__ __forceinline__ uint32_t block_exclusive_scan_1024(uint32_t v, uint32_t *smem, uint32_t &total) {
+    const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+    const uint32_t inc = wave_inclusive_scan(v, lane);
+    if (lane == 63u) smem[wid] = inc;
+    __syncthreads();
+    uint32_t wave_off = 0, tot = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < (uint32_t)BKT_WAVES; k++) {
+        const uint32_t x = smem[k];
+        if (k < wid) wave_off += x;
+        tot += x;
+    }
+    total = tot;
+    __syncthreads();
+    return wave_off + inc - v;
+}
+
+// Stable rank of the wave's ITEMS x 64 elements inside their digit: element (k, lane) precedes (k', lane') when
+// k < k' or k == k' and lane < lane'.  `hist` is the wave's private row of counters, zero on entry; element
+// (k, lane) is live when k * 64 + lane < nlive (dead elements are neither counted nor ranked); its digit is
+// (key[k] >> shift) & mask — recomputed where needed instead of kept: the register path holds 28 keys, 28 values
+// and 28 ranks per lane as it is.
+template <int RB, int ITEMS, bool FAST_RANK>
+__device__ __forceinline__ void bucket_rank(uint32_t *hist, const uint32_t (&key)[ITEMS], uint32_t shift, uint32_t mask,
+                                            uint32_t nlive, uint32_t (&rank)[ITEMS], uint32_t *rank_fault) {
+    const uint32_t lane = threadIdx.x & 63u;
+    if constexpr (FAST_RANK) {
+#pragma unroll
+        for (int k = 0; k < ITEMS; k++)
+            if (k * WAVE + lane < nlive) rank[k] = atomicAdd(&hist[(key[k] >> shift) & mask], 1u);
+        // the bet's watchdog (scatter_ranked): the bucket the frame generation picks checks round 0 of every wave and
+        // pass — the round whose expected value needs no second set of counters — against the ballot-based rank
+        if (rank_fault) {
+            const uint32_t d0 = (key[0] >> shift) & mask;
+            const bool live0 = lane < nlive;
+            uint64_t peers = __ballot(live0);
+#pragma unroll
+            for (int b = 0; b < RB; b++) {
+                const uint64_t m = __ballot((d0 >> b) & 1u);
+                peers &= ((d0 >> b) & 1u) ? m : ~m;
+            }
+            const bool bad = live0 && rank[0] != mbcnt(peers) + rank_fault[1];
+            if (__any(bad) && lane == 0u) atomicOr(rank_fault, 1u);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < ITEMS; k++) {
+            const uint32_t d = (key[k] >> shift) & mask;
+            const bool live = k * WAVE + lane < nlive;
+            uint64_t peers = __ballot(live);
+#pragma unroll
+            for (int b = 0; b < RB; b++) {
+                const uint64_t m = __ballot((d >> b) & 1u);
+                peers &= ((d >> b) & 1u) ? m : ~m;
+            }
+            const uint32_t before = mbcnt(peers);
+            const uint32_t old = hist[d];
+            rank[k] = old + before;
+            __builtin_amdgcn_wave_barrier();
+            if (live && before == 0u) hist[d] = old + (uint32_t)__popcll(peers);
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+// digit widths balanced over the passes, as run_sort_items does (18 bits -> 9 + 9, 11 -> 6 + 5)
+__device__ __forceinline__ uint32_t bucket_pass_bits(uint32_t low_bits, uint32_t shift, uint32_t passes, uint32_t p) {
+    return (low_bits - shift + (passes - p) - 1u) / (passes - p);
+}
+
+// per-tile ranges of a tile sort's last pass: thread `digit` holds its digit's offset and count inside the bucket
+__device__ __forceinline__ void bucket_ranges(const BucketSortIO &io, uint32_t bucket, uint32_t start, uint32_t digit,
+                                              uint32_t base, uint32_t tot) {
+    const uint32_t tile = (bucket << io.low_bits) | digit;
+    if (tot != 0u && tile < io.num_tiles) {
+        io.ranges[2u * tile] = start + base;
+        io.ranges[2u * tile + 1u] = start + base + tot;
+    }
+}
+
+// counts of the 16 waves -> every wave's base per digit (in place); returns through `base` / `tot` the digit's
+// offset inside the bucket's order of this pass and its count, for the thread that owns the digit (tid < R);
+// `dbase` (chunked path): running offsets carried from chunk to chunk instead of a scan.  Barriers inside.
+template <int RB, bool RUNNING>
+__device__ __forceinline__ void bucket_wave_bases(BucketShared<RB> &sh, uint32_t &base, uint32_t &tot) {
+    constexpr int R = 1 << RB;
+    const uint32_t tid = threadIdx.x;
+    uint32_t c[BKT_WAVES];
+    tot = 0;
+    if (tid < (uint32_t)R) {
+#pragma unroll
+        for (int w = 0; w < BKT_WAVES; w++) {
+            c[w] = sh.wave_hist[w][tid];
+            tot += c[w];
+        }
+    }
+    if constexpr (RUNNING) {
+        base = tid < (uint32_t)R ? sh.dbase[tid] : 0u;
+    } else {
+        uint32_t all;
+        base = block_exclusive_scan_1024(tid < (uint32_t)R ? tot : 0u, sh.scan, all);
+    }
+    if (tid < (uint32_t)R) {
+        uint32_t run = base;
+#pragma unroll
+        for (int w = 0; w < BKT_WAVES; w++) {
+            sh.wave_hist[w][tid] = run;
+            run += c[w];
+        }
+        if constexpr (RUNNING) sh.dbase[tid] = run;
+    }
+    __syncthreads();
+}
+
+// The register path: the whole bucket (size <= 1024 * ITEMS) lives in the workgroup's registers; wave w owns
+// elements [w * ITEMS * 64, (w + 1) * ITEMS * 64), round k of a wave 64 consecutive ones.  Only the KEYS travel: what
+// is sorted is (remaining key bits, position in the bucket), and the values are gathered once at the end through the
+// sorted positions (the bucket's values are 4 bytes x size, L2-resident: the top-digit scatter has just written
+// them).  Pass 1 of 2 drops the digit it has sorted and packs (next digit << 15 | position) into one word — a
+// position needs 15 bits, BKT_CAP <= 2^15 — so a lane holds ITEMS keys and ITEMS ranks and nothing else (with the
+// values in registers too the 28-item instantiation spilled 4.6 KB per lane), and a pass is ONE exchange through LDS.
+template <typename K, int RB, int ITEMS, bool FAST_RANK>
+__device__ __forceinline__ void bucket_sort_fast(BucketShared<RB> &sh, const BucketSortIO &io, uint32_t bucket,
+                                                 uint32_t start, uint32_t size, uint32_t *rank_fault) {
+    constexpr int R = 1 << RB;
+    static_assert(BKT_CAP <= (1u << 15) && RB + 15 <= 32, "(digit << 15 | position) in one word");
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
+    const uint32_t wave_off = wid * (uint32_t)(ITEMS * WAVE);
+    const uint32_t nlive = size > wave_off ? size - wave_off : 0u;     // live elements of this wave (the rest is padding)
+    const K *kin = (const K *)io.keys_in + start;
+    const uint32_t *vin = io.vals_in + start;
+    K *kout = io.keys_out ? (K *)io.keys_out + start : (K *)nullptr;
+    uint32_t *vout = io.vals_out + start;
+    const uint32_t passes = (io.low_bits + RB - 1) / RB;    // 0, 1 or 2
+    if (passes == 0u) {   // the top digit was the whole key: the bucket is in its final order
+#pragma unroll
+        for (int k = 0; k < ITEMS; k++) {
+            const uint32_t i = k * BKT_THREADS + tid;
+            if (i < size) {
+                vout[i] = vin[i];
+                if (kout) kout[i] = kin[i];
+            }
+        }
+        if (io.ranges && tid == 0u) bucket_ranges(io, bucket, start, 0u, 0u, size);
+        return;
+    }
+    uint32_t key[ITEMS], rank[ITEMS];
+    // (no branch around a load: a load behind a branch gets its own wait; element 0 exists, size > 0)
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) key[k] = (uint32_t)kin[k * WAVE + lane < nlive ? wave_off + k * WAVE + lane : 0u];
+    // one counting pass over the registers: ranks, wave bases, final place of every element in `rank`
+    auto pass = [&](uint32_t shift, uint32_t mask, bool ranges) {
+#pragma unroll
+        for (int q = 0; q < BKT_WAVES * R / BKT_THREADS; q++) (&sh.wave_hist[0][0])[tid + q * BKT_THREADS] = 0u;
+        __syncthreads();
+        bucket_rank<RB, ITEMS, FAST_RANK>(sh.wave_hist[wid], key, shift, mask, nlive, rank, rank_fault);
+        __syncthreads();
+        uint32_t base, tot;
+        bucket_wave_bases<RB, false>(sh, base, tot);
+        if (ranges && tid < (uint32_t)R) bucket_ranges(io, bucket, start, tid, base, tot);
+        // all LDS reads of the batch first, then what depends on them (scatter_ranked's note on hipcc's chains)
+#pragma unroll
+        for (int k = 0; k < ITEMS; k++) rank[k] += sh.wave_hist[wid][(key[k] >> shift) & mask];
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    const uint32_t bits1 = bucket_pass_bits(io.low_bits, 0u, passes, 0u), bits2 = io.low_bits - bits1;
+    pass(0u, (1u << bits1) - 1u, passes == 1u && io.ranges != nullptr);     // (ranges: the tile sort, one pass by contract)
+    // what an element still needs: its position in the input bucket and, if a pass follows, that pass's digit
+    const uint32_t mask2 = (1u << bits2) - 1u;
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++)
+        if (k * WAVE + lane < nlive) sh.xbuf[rank[k]] = (((key[k] >> bits1) & mask2) << 15) | (wave_off + k * WAVE + lane);
+    __syncthreads();
+    if (passes == 2u) {
+#pragma unroll
+        for (int k = 0; k < ITEMS; k++) key[k] = sh.xbuf[k * WAVE + lane < nlive ? wave_off + k * WAVE + lane : 0u];
+        __syncthreads();
+        pass(15u, mask2, false);
+#pragma unroll
+        for (int k = 0; k < ITEMS; k++)
+            if (k * WAVE + lane < nlive) sh.xbuf[rank[k]] = key[k];
+        __syncthreads();
+    }
+    // xbuf[i] (low 15 bits) = position in the INPUT bucket of the element that belongs at place i: gather
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) {
+        const uint32_t i = k * BKT_THREADS + tid;
+        rank[k] = sh.xbuf[i < size ? i : 0u] & 0x7fffu;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) key[k] = vin[rank[k]];
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) {
+        const uint32_t i = k * BKT_THREADS + tid;
+        if (i < size) vout[i] = key[k];
+    }
+    if (kout) {
+#pragma unroll
+        for (int k = 0; k < ITEMS; k++) {
+            const uint32_t i = k * BKT_THREADS + tid;
+            if (i < size) kout[i] = kin[rank[k]];
+        }
+    }
+}
+
+// The chunked path: a bucket of any size, by one workgroup, through global memory.  Per pass: sweep 1 counts the
+// digits of the whole bucket, sweep 2 walks the bucket in order, 16 384 elements at a time, ranks each chunk like
+// the register path and writes every element to its final place of the pass (running per-digit offsets in LDS).
+// Slow — one CU's bandwidth, scattered stores — and only ever a fallback (see the section comment).
+template <typename K, int RB, bool FAST_RANK>
+__device__ __forceinline__ void bucket_sort_chunked(BucketShared<RB> &sh, const BucketSortIO &io, uint32_t bucket,
+                                                    uint32_t start, uint32_t size) {
+    constexpr int R = 1 << RB;
+    constexpr int ITEMS = BKT_CHUNK_ITEMS;
+    constexpr uint32_t CH = (uint32_t)BKT_THREADS * ITEMS;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
+    const uint32_t wave_off = wid * (uint32_t)(ITEMS * WAVE);
+    const uint32_t passes = (io.low_bits + RB - 1) / RB;   // <= 2 (host)
+    if (passes == 0u) {
+        for (uint32_t i = tid; i < size; i += BKT_THREADS) {
+            io.vals_out[start + i] = io.vals_in[start + i];
+            if (io.keys_out) ((K *)io.keys_out)[start + i] = ((const K *)io.keys_in)[start + i];
+        }
+        if (io.ranges && tid == 0u) bucket_ranges(io, bucket, start, 0u, 0u, size);
+        return;
+    }
+    uint32_t shift = 0;
+    for (uint32_t p = 0; p < passes; p++) {
+        const uint32_t bits = bucket_pass_bits(io.low_bits, shift, passes, p);
+        const uint32_t mask = (1u << bits) - 1u;
+        const bool last = p + 1u == passes;
+        const K *src_k = (p == 0u ? (const K *)io.keys_in : (const K *)io.keys_tmp) + start;
+        const uint32_t *src_v = (p == 0u ? io.vals_in : (const uint32_t *)io.vals_tmp) + start;
+        K *dst_k = last ? (io.keys_out ? (K *)io.keys_out + start : (K *)nullptr) : (K *)io.keys_tmp + start;
+        uint32_t *dst_v = (last ? io.vals_out : io.vals_tmp) + start;
+        // sweep 1: digit counts of the bucket
+        if (tid < (uint32_t)R) sh.dbase[tid] = 0u;
+        __syncthreads();
+        for (uint32_t c0 = 0; c0 < size; c0 += CH) {
+#pragma unroll
+            for (int k = 0; k < ITEMS; k++) {
+                const uint32_t e = c0 + k * BKT_THREADS + tid;
+                if (e < size) atomicAdd(&sh.dbase[((uint32_t)src_k[e] >> shift) & mask], 1u);
+            }
+        }
+        __syncthreads();
+        {
+            const uint32_t tot = tid < (uint32_t)R ? sh.dbase[tid] : 0u;
+            uint32_t all;
+            const uint32_t base = block_exclusive_scan_1024(tot, sh.scan, all);
+            if (tid < (uint32_t)R) {
+                sh.dbase[tid] = base;
+                if (last && io.ranges) bucket_ranges(io, bucket, start, tid, base, tot);
+            }
+        }
+        __syncthreads();
+        // sweep 2: stable placement, chunk by chunk
+        for (uint32_t c0 = 0; c0 < size; c0 += CH) {
+#pragma unroll
+            for (int q = 0; q < BKT_WAVES * R / BKT_THREADS; q++) (&sh.wave_hist[0][0])[tid + q * BKT_THREADS] = 0u;
+            __syncthreads();
+            const uint32_t w0 = c0 + wave_off;
+            const uint32_t nlive = size > w0 ? size - w0 : 0u;
+            uint32_t key[ITEMS], val[ITEMS], rank[ITEMS];
+#pragma unroll
+            for (int k = 0; k < ITEMS; k++) {
+                const uint32_t e = k * WAVE + lane < nlive ? w0 + k * WAVE + lane : 0u;
+                key[k] = (uint32_t)src_k[e];
+                val[k] = src_v[e];
+            }
+            bucket_rank<RB, ITEMS, FAST_RANK>(sh.wave_hist[wid], key, shift, mask, nlive, rank, nullptr);
+            __syncthreads();
+            {
+                uint32_t base, tot;
+                bucket_wave_bases<RB, true>(sh, base, tot);
+            }
+#pragma unroll
+            for (int k = 0; k < ITEMS; k++) {
+                if (k * WAVE + lane < nlive) {
+                    const uint32_t dst = sh.wave_hist[wid][(key[k] >> shift) & mask] + rank[k];
+                    if (dst_k) dst_k[dst] = (K)key[k];
+                    dst_v[dst] = val[k];
+                }
+            }
+            __syncthreads();
+        }
+        shift += bits;
+        // (the next pass reads what this one wrote: the barrier above orders the workgroup's own global accesses)
+    }
+}
+
+template <typename K, int RB, bool FAST_RANK>
+__global__ __launch_bounds__(BKT_THREADS) void k_bucket_sort(BucketSortIO io) {
+    static_assert(RB >= 6 && RB <= 9, "16 waves clear 16 x 2^RB counters with whole rounds of 1024 threads; 512 digit threads");
+    __shared__ BucketShared<RB> sh;
+    const uint32_t tid = threadIdx.x, bucket = blockIdx.x;
+    // bucket start = sum of the sizes in front of it; the same scan counts the non-empty buckets in front (high half)
+    const uint32_t t = tid < io.nb ? io.totals[tid] : 0u;
+    uint32_t all, nz_all;
+    const uint32_t excl = block_exclusive_scan_1024(t, sh.scan, all);
+    const uint32_t nz_excl = block_exclusive_scan_1024(t != 0u ? 1u : 0u, sh.scan, nz_all);
+    if (tid == bucket) {
+        sh.bcast[0] = t;
+        sh.bcast[1] = excl;
+        sh.bcast[2] = nz_excl;
+    }
+    if (bucket == 0u && io.bucket_max) {
+        const uint32_t m = wave_reduce_max(t);
+        if ((tid & 63u) == 0u) sh.wave_hist[0][tid >> 6] = m;
+        __syncthreads();
+        if (tid == 0u) {
+            uint32_t mm = 0;
+#pragma unroll
+            for (int w = 0; w < BKT_WAVES; w++) mm = sh.wave_hist[0][w] > mm ? sh.wave_hist[0][w] : mm;
+            *io.bucket_max = mm;
+        }
+    }
+    __syncthreads();
+    const uint32_t size = sh.bcast[0], start = sh.bcast[1], nz_index = sh.bcast[2];
+    __syncthreads();
+    if (size == 0u) return;
+    // the watchdog samples one NON-EMPTY bucket per frame, the next one every frame
+    uint32_t *rf = io.rank_fault && nz_index == io.watch % nz_all ? io.rank_fault : (uint32_t *)nullptr;
+    if (size <= 4u * BKT_THREADS) bucket_sort_fast<K, RB, 4, FAST_RANK>(sh, io, bucket, start, size, rf);
+    else if (size <= 8u * BKT_THREADS) bucket_sort_fast<K, RB, 8, FAST_RANK>(sh, io, bucket, start, size, rf);
+    else if (size <= 16u * BKT_THREADS) bucket_sort_fast<K, RB, 16, FAST_RANK>(sh, io, bucket, start, size, rf);
+    else if (size <= BKT_CAP) bucket_sort_fast<K, RB, BKT_ITEMS_MAX, FAST_RANK>(sh, io, bucket, start, size, rf);
+    else bucket_sort_chunked<K, RB, FAST_RANK>(sh, io, bucket, start, size);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2025,7 +2437,8 @@ __global__ __launch_bounds__(EXP_SB) void k_pairs_cursors(ExpandIO io) {
         const uint32_t over = d > (uint64_t)io.capacity ? (FRAME_FLAG_PAIR_OVERFLOW | FRAME_FLAG_SKIPPED) : 0u;
         io.state->pairs = over ? io.capacity : (uint32_t)d;
         io.state->overflow = over ? 1u : 0u;
-        publish_result(io.result, v_count, d, over | (io.state->rank_fault ? FRAME_FLAG_RANK_FAULT : 0u), io.gen, io.flags_dev);
+        publish_result(io.result, v_count, d, over | (io.state->rank_fault ? FRAME_FLAG_RANK_FAULT : 0u), io.gen, io.flags_dev,
+                           io.state->depth_bucket_max);
     }
     if (v == 0ull) return;
     const uint64_t p = s_before[0] + s_before[1] + (wid ? s_wave0 : 0ull) + incl - v;   // pairs in front of chunk c
@@ -2275,7 +2688,8 @@ __global__ __launch_bounds__(SORT_THREADS) void k_pairs_emit(ExpandIO io, uint32
             const uint32_t over = d > (uint64_t)io.capacity ? (FRAME_FLAG_PAIR_OVERFLOW | FRAME_FLAG_SKIPPED) : 0u;
             io.state->pairs = count;
             io.state->overflow = over ? 1u : 0u;
-            publish_result(io.result, v_count, d, over | (io.state->rank_fault ? FRAME_FLAG_RANK_FAULT : 0u), io.gen, io.flags_dev);
+            publish_result(io.result, v_count, d, over | (io.state->rank_fault ? FRAME_FLAG_RANK_FAULT : 0u), io.gen, io.flags_dev,
+                           io.state->depth_bucket_max);
         }
     }
     if ((uint64_t)block * TILE >= count) return;      // the same D in every wave: block-uniform
