@@ -296,6 +296,10 @@ gs_status gs_device_stream_priority_range(gs_device *dev, int32_t *least, int32_
 gs_status gs_stream_wrap(gs_device *dev, void *hip_stream, gs_stream **out);
 void *gs_stream_native(const gs_stream *s);
 gs_status gs_stream_synchronize(gs_stream *s);
+/* Lifetime: a renderer whose newest frame was enqueued on `s` stays usable — gs_stream_destroy records that frame's end
+ * event on the stream before it goes, and later frames / waits of the renderer are ordered behind the event, not the
+ * stream.  A WRAPPED stream (gs_stream_wrap) must therefore be handed to gs_stream_destroy BEFORE the caller destroys
+ * the hipStream_t it wraps. */
 void gs_stream_destroy(gs_stream *s);
 
 /* ------------------------------------------------------------------------------------------ */
@@ -633,7 +637,7 @@ typedef struct gs_frame_result {
 gs_status gs_renderer_wait_frame(gs_renderer *r, gs_frame_result *out);
 
 /* How the last frame sorted (blocking like gs_renderer_stats; no reference item: the sorts are the viewer's).  The depth
- * sort runs MSD-first — one scatter on the top 9 bits of the depth key, then one workgroup per bucket finishes the low
+ * sort runs MSD-first — one scatter on the top 10 bits of the depth key, then one workgroup per bucket finishes the low
  * bits on its CU — while the buckets fit (`bucket_capacity` elements), and as LSD passes while they do not; the renderer
  * chooses per frame from the bucket sizes the previous frames reported.  Both produce the same order. */
 typedef struct gs_sort_info {

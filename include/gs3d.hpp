@@ -8,6 +8,7 @@
 #include <cstdint>
 #include <cstring>
 #include <initializer_list>
+#include <memory>
 #include <optional>
 #include <stdexcept>
 #include <string>
@@ -467,6 +468,52 @@ class Renderer {
     void set_frame_flags_target(uint32_t *device_word) { check(gs_renderer_set_frame_flags_target(h_, device_word)); }
   private:
     gs_renderer *h_ = nullptr;
+};
+
+// Frames in flight (no reference item: the viewer owns the frame loop; the seam is src/compute_bundle.rs:196-198 —
+// dispatch only records, the caller owns the submission order).  `frames` renderers, each on a stream of its own
+// PRIORITY, take the frames in turn: what a viewer with double / triple buffering does.  A frame is a chain of
+// dependent kernels, latency-bound in its sorts and VALU-bound in its blend, so frames of different renderers overlap
+// on the device when their streams sit on different hardware queues.  HIP keeps separate queues per priority LEVEL and
+// may put streams of one level on one queue — observed, not promised: where the lanes share a queue they run one after
+// the other and the ring costs what one stream costs.  Every frame is the frame its renderer would
+// have rendered alone.  Presentation in order: render() returns the lane, wait(lane) blocks until THAT lane's newest
+// frame is complete (lanes complete out of order when frames differ in cost).
+class FrameRing {
+  public:
+    explicit FrameRing(Device &d, size_t frames = 3) {
+        int32_t least = 0, greatest = 0;
+        check(gs_device_stream_priority_range(d.raw(), &least, &greatest));
+        const int32_t cycle3[3] = {greatest, least, 0};
+        if (frames == 0) frames = 1;
+        for (size_t k = 0; k < frames; k++) {
+            const int32_t prio = least != greatest ? cycle3[k % 3] : 0;
+            priorities_.push_back(prio);
+            streams_.push_back(std::make_unique<Stream>(d, (int)prio));
+            renderers_.push_back(std::make_unique<Renderer>(d));
+        }
+    }
+    size_t size() const { return renderers_.size(); }
+    // enqueues one frame on the next lane and returns the lane (its stream: stream(lane))
+    template <class G>
+    size_t render(GaussiansBuffer<G> &g, const gs_gaussian_transform_pod &gt, const gs_model_transform_pod &mt, const gs_camera &cam,
+                  float *rgba_device, uint32_t band_ty0 = 0, uint32_t band_ty1 = 0xffffffffu) {
+        const size_t lane = next_++ % renderers_.size();
+        renderers_[lane]->render(*streams_[lane], g, gt, mt, cam, rgba_device, band_ty0, band_ty1);
+        return lane;
+    }
+    // blocks until the newest frame of `lane` is complete; throws as Renderer::wait_frame does
+    gs_frame_result wait(size_t lane) { return renderers_.at(lane)->wait_frame(); }
+    void synchronize() { for (auto &s : streams_) s->synchronize(); }
+    Stream &stream(size_t lane) { return *streams_.at(lane); }
+    Renderer &renderer(size_t lane) { return *renderers_.at(lane); }
+    int32_t priority(size_t lane) const { return priorities_.at(lane); }
+  private:
+    // (renderers are destroyed before their streams: gs_renderer_destroy synchronises the stream of its last frame)
+    std::vector<std::unique_ptr<Stream>> streams_;
+    std::vector<std::unique_ptr<Renderer>> renderers_;
+    std::vector<int32_t> priorities_;
+    size_t next_ = 0;
 };
 
 // HIP version of the headers the library was compiled with / of the runtime / of the driver it runs on

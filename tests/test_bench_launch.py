@@ -35,6 +35,16 @@ def test_self_launch_two_ranks_gloo_launch_check():
     assert j["distributed"] == {"backend": "gloo", "world_size": 2}
 
 
+def test_self_launch_eight_ranks_gloo_launch_check():
+    """The command the driver types on the 8-GPU node, as far as a machine without GPUs can take it:
+    eight ranks come up under the self-started launcher, join one group and rank 0's line comes back."""
+    res = _run(["--gpus", "8", "--backend", "gloo", "--launch-check"])
+    assert res.returncode == 0, res.stderr[-3000:]
+    j = json.loads(res.stdout.strip().splitlines()[-1])
+    assert j["launch_check"] and j["self_launched"]
+    assert j["distributed"] == {"backend": "gloo", "world_size": 8}
+
+
 def test_world_size_mismatch_is_refused():
     env = dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"], cwd=ROOT,

@@ -1,4 +1,4 @@
-"""The frame's depth sort, MSD-first (round 5): one compacting scatter on the top 9 bits of the depth
+"""The frame's depth sort, MSD-first (round 5): one compacting scatter on the top 10 bits of the depth
 key, then one workgroup per bucket finishes the low bits on its CU (gs::k_bucket_sort).  Against the oracle and
 against the LSD passes, on the register path (buckets up to `bucket_capacity`), on the chunked in-kernel fallback
 (larger buckets: depths that collapse into a few top digits) and through the renderer's own choice between the two
@@ -53,13 +53,13 @@ def test_bucket_sizes_across_the_register_path_variants(gs, ob, device, stream):
     n = sum(sizes)
     g = synth.scene(n, first=99)
     rng = np.random.default_rng(17)
-    # top digit = (bits(z) - bits(near)) >> 18 with 27 key bits (near 0.1, far 100): slab i fills digit 110 + i (z in
-    # 1.03 .. 1.6) with random low 18 bits — the camera sits at the origin and looks down -z, so the view depth IS z
+    # top digit = (bits(z) - bits(near)) >> 17 with 27 key bits (near 0.1, far 100): slab i fills digit 220 + i (z in
+    # 1.03 .. 1.3) with random low 17 bits — the camera sits at the origin and looks down -z, so the view depth IS z
     near_bits = int(np.float32(0.1).view(np.uint32))
     zb = np.empty(n, dtype=np.uint32)
     o = 0
     for i, m in enumerate(sizes):
-        zb[o:o + m] = near_bits + ((110 + i) << 18) + rng.integers(0, 1 << 18, m, dtype=np.uint32)
+        zb[o:o + m] = near_bits + ((220 + i) << 17) + rng.integers(0, 1 << 17, m, dtype=np.uint32)
         o += m
     z = zb.view(np.float32)
     assert z.min() > 1.0 and z.max() < 2.0
@@ -104,4 +104,69 @@ def test_renderer_chooses_from_the_reported_buckets(gs, ob, device, stream):
     assert modes["wall"][0][-1] == 0, modes                                          # the wall was noticed
     assert modes["spread"][1][-1] == 1, modes                                        # and the way back
     r.destroy()
+    img.release()
+
+
+# ---- the tile sort, MSD-first: k_pairs_emit counts the top 10 bits of the tile id, one scatter, k_bucket_sort finishes
+# ---- the 2^(bits - 10) tiles of every bucket and writes the tile ranges ----
+
+@pytest.mark.parametrize("size,expect", [((1280, 720), 1), ((1920, 1080), 1), ((4000, 2200), 1), ((640, 360), 0), ((4112, 4100), 0)])
+@pytest.mark.parametrize("tile_msd", [0, 1])
+def test_tile_sort_modes_match_the_oracle(gs, ob, device, stream, size, expect, tile_msd):
+    """12 / 13 / 16 tile-id bits take the MSD-first tile sort when pinned; 10 bits (nothing left below the top digit) and
+    more than 65536 tiles (u32 tile ids) stay with the LSD passes whatever is pinned.  Keys, indices, RANGES (written by
+    the bucket kernel) and the image against the oracle."""
+    import synth
+    g = synth.scene(20000, first=808)
+    g["scale"] *= 2.0
+    info = []
+    st = _compare_frame(gs, ob, device, stream, gs.SH_NONE, gs.COV3D_ROT_SCALE, g, size[0], size[1], gt_kw=dict(sh_deg=0),
+                        sort_mode=(-1, tile_msd), info=info)
+    assert info[0].tile_msd == (tile_msd and expect)
+    if info[0].tile_msd:
+        assert 0 < info[0].tile_bucket_max <= st.pairs
+
+
+def test_tile_buckets_beyond_the_register_path(gs, ob, device, stream):
+    """50 000 large splats on a small part of the screen: single 8-tile buckets hold far more pairs than the register
+    path takes (30 720) — the bucket kernel's chunked path, and the ranges it writes, must match the oracle."""
+    import synth
+    g = synth.scene(50000, first=4711)
+    g["pos"][:, 0] *= 0.03
+    g["pos"][:, 1] *= 0.03
+    info = []
+    st = _compare_frame(gs, ob, device, stream, gs.SH_NONE, gs.COV3D_ROT_SCALE, g, 1920, 1080, gt_kw=dict(sh_deg=0),
+                        sort_mode=(-1, 1), info=info)
+    assert info[0].tile_msd == 1 and info[0].tile_bucket_max > info[0].bucket_capacity, (info[0].tile_bucket_max, st.pairs)
+
+
+def test_renderer_leaves_the_msd_tile_sort_when_buckets_overflow(gs, ob, device, stream):
+    """With the renderer allowed to choose the MSD-first tile sort (GS3D_TILE_MSD_AUTO=1; off by default: at 1 M it is
+    5 us slower than the LSD passes): the dense scene above starts MSD-first (few pairs in all), reports its oversized
+    bucket one frame late, and the renderer continues with the LSD passes; every frame is the oracle's image."""
+    import os
+    import synth
+    if os.environ.get("GS3D_TILE_MSD_AUTO") != "1":
+        pytest.skip("the renderer does not choose the MSD-first tile sort by itself (GS3D_TILE_MSD_AUTO=1 enables)")
+    g = synth.scene(50000, first=4711)
+    g["pos"][:, 0] *= 0.03
+    g["pos"][:, 1] *= 0.03
+    pod = gs.GaussianPod(gs.SH_NONE, gs.COV3D_ROT_SCALE)
+    pods = pod.from_gaussian(g)
+    gt, mt = gs.gaussian_transform_pod(1.0, 0, 0, False, 3.0), gs.model_transform_pod()
+    cam = helpers.default_camera(gs, 1920, 1080)
+    buf = gs.GaussiansBuffer.new_with_pods(device, pod, pods)
+    img = gs.Buffer(device, size=cam.height * cam.width * 16)
+    r = gs.Renderer(device)
+    o_rgba = _oracle_frame(ob, pod.sh, pod.cov, pods, ob.gaussian_transform(sh_deg=0), ob.model_transform(),
+                           helpers.copy_camera(cam, ob.Camera), order=_mirror_order(ob, buf, stream, pod.sh, pod.cov, pods))[-1]
+    seq = []
+    for i in range(6):
+        r.render(stream, buf, gt, mt, cam, img.device_ptr())
+        seq.append(r.sort_info().tile_msd)
+        rgba = img.download(stream, np.float32).reshape(cam.height, cam.width, 4)
+        assert np.array_equal(rgba.view(np.uint32), o_rgba.view(np.uint32)), (i, seq)
+    assert seq[0] == 1 and seq[-1] == 0 and seq[-2] == 0, seq
+    for h in (r, buf):
+        h.destroy()
     img.release()

@@ -1,6 +1,7 @@
 """The radix sorts rank with returning LDS atomics when the order probe of gs_device_create passes
-(DESIGN.md §4.4).  The probe is a bet on an undocumented property, so every frame re-checks it: block 0
-of every radix pass compares the ranks the atomics handed out with the ballot-based ones.  A mismatch
+(DESIGN.md §4.4).  The probe is a bet on an undocumented property, so every frame re-checks it: one workgroup
+of every radix pass (and one bucket of the bucket sort) — a different one every frame — compares the ranks the atomics
+handed out in one of its rounds with the ballot-based ones.  A mismatch
 reaches the host as gs_frame_result.flags bit 2 / GS_ERR_RANK_ORDER, the device falls back to the
 ballot-based rank and the frame is rendered again.
 
@@ -119,14 +120,57 @@ def test_child_pipelined_frames_switch_without_a_wait(gs, ob, device, stream):
     flags_word.release()
 
 
+@pytest.mark.skipif(not ARMED, reason="runs in the child process of test_watchdog_children (GS3D_TEST_RANK_FAULT=1)")
+def test_child_ring_of_three_recovers_on_every_lane(gs, ob, device, stream):
+    """Several renderers on one device (FrameRing, parallel.lanes) with a faulted frame in flight on EACH: the first
+    one to report switches the device; the others must still clear their own watchdog word (round 4 left it set for
+    good: every later frame of those lanes carried the flag and wait_frame raised forever — ADVICE r04)."""
+    if os.environ.get("GS3D_DISABLE_FAST_RANK"):
+        pytest.skip("the LDS-atomic rank is switched off: nothing to watch")
+    dev = gs.Device(device.ordinal)
+    assert dev.fast_rank()
+    pod, pods, o, p = _scene(gs, ob, n=12000, W=640, H=360)
+    buf = gs.GaussiansBuffer.new_with_pods(dev, pod, pods)
+    ring = gs.FrameRing(dev, 3)
+    imgs = [gs.Buffer(dev, size=p[2].height * p[2].width * 16) for _ in range(3)]
+    for k in range(3):                       # one armed frame in flight per lane before anybody looks
+        ring.render(buf, p[0], p[1], p[2], imgs[k].device_ptr(), check=False)
+    faults = 0
+    for r in ring.renderers:
+        try:
+            r.wait_frame()
+        except gs.RankOrderError:
+            faults += 1
+    assert faults == 3 and not dev.fast_rank()
+    for rnd in range(3):
+        for k in range(3):
+            ring.render(buf, p[0], p[1], p[2], imgs[k].device_ptr(), check=False)
+        res = ring.wait()                    # raises if any lane still carries the flag
+        assert all(fr.flags == 0 for fr in res), (rnd, [fr.flags for fr in res])
+    want = _oracle_image(gs, ob, buf, ring.streams[0], pods, o).view(np.uint32)
+    for k in range(3):
+        rgba = imgs[k].download(ring.streams[k], np.float32).reshape(p[2].height, p[2].width, 4)
+        assert np.array_equal(rgba.view(np.uint32), want), k
+    ring.close()
+    buf.destroy()
+    for im in imgs:
+        im.release()
+
+
 @pytest.mark.skipif(ARMED, reason="this is the child")
-def test_watchdog_children():
-    env = dict(os.environ, GS3D_TEST_RANK_FAULT="1")
+@pytest.mark.parametrize("extra", [{}, {"GS3D_TEST_RANK_WATCH": "1234567"}, {"GS3D_DEPTH_MSD": "0", "GS3D_TEST_RANK_WATCH": "3"}],
+                         ids=["watch=generation", "watch=1234567", "lsd-watch=3"])
+def test_watchdog_children(extra):
+    """The armed cases, each set in a child process: with the watchdog's sample following the frame generation (frame 1:
+    tile 1 of every pass, never tile 0), pinned to an arbitrary tile / round (GS3D_TEST_RANK_WATCH: tile = n mod live
+    tiles, round = (n / live tiles) mod keys per lane — round 4 only ever looked at tile 0, round 0), and with the depth
+    sort's LSD passes instead of the MSD-first sort (whose bucket kernel carries its own check)."""
+    env = dict(os.environ, GS3D_TEST_RANK_FAULT="1", **extra)
     res = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu",
                           "-k", "child", "-p", "no:cacheprovider"], cwd=ROOT, env=env, stdout=subprocess.PIPE,
                          stderr=subprocess.STDOUT, text=True, timeout=600)
     assert res.returncode == 0, res.stdout[-3000:]
-    assert "3 passed" in res.stdout or "skipped" in res.stdout, res.stdout[-1000:]
+    assert "4 passed" in res.stdout, res.stdout[-1000:]       # (a child that skipped its cases is a failure)
 
 
 @pytest.mark.skipif(ARMED, reason="this is the child")

@@ -235,11 +235,13 @@ def test_depth_key_ranges(gs, ob, device, stream, case, planes, msd):
     tile_passes = 2   # 40 x 23 = 920 tiles -> 10 bits -> 5 + 5
     bits = _depth_bits(near, far)
     p8, p9 = -(-bits // 8), -(-bits // 9)
-    assert st.sort_passes - tile_passes == min(p8, p9), (st.sort_passes, bits)
-    # MSD-first (round 5: a scatter on the top 9 bits + one workgroup per bucket) exists for 10..27 key bits; pinned
-    # it is taken, and in either mode the frame reports its largest top-digit bucket
-    assert info[0].depth_msd == (1 if msd and 9 < bits <= 27 else 0), (bits, info[0].depth_msd)
-    if bits > 9:
+    # MSD-first (round 5: a scatter on the top 10 bits + one workgroup per bucket for the low bits, at most 2 x 9)
+    # exists for 11..28 key bits; pinned it is taken, and in either mode the frame reports its largest top-digit bucket
+    is_msd = 1 if msd and 10 < bits <= 28 else 0
+    assert info[0].depth_msd == is_msd, (bits, info[0].depth_msd)
+    want = 1 - (-(bits - 10) // 9) if is_msd else min(p8, p9)
+    assert st.sort_passes - tile_passes == want, (st.sort_passes, bits)
+    if bits > 10:
         assert 0 < info[0].depth_bucket_max <= st.visible
         if case == "same_depth":
             assert info[0].depth_bucket_max == st.visible       # every key in one bucket

@@ -125,7 +125,7 @@ def test_sharded_frame_equals_single_rank(tmp_path, world, balanced):
         assert np.array_equal(np.load(os.path.join(str(tmp_path), "bands%d.npy" % r)), bands0)   # same plan everywhere
 
 
-def _pipeline_worker(rank, world, port, height, width, out_dir):
+def _pipeline_worker(rank, world, port, height, width, out_dir, balanced=False):
     sys.path[:0] = [ROOT, os.path.join(ROOT, "tools")]
     import torch
     import torch.distributed as dist
@@ -133,6 +133,13 @@ def _pipeline_worker(rank, world, port, height, width, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     par = _par()
     plan = par.BandPlan(height, world)
+    if balanced:
+        # every rank re-cuts the same plan from the same (exchanged) per-row cost: heavy centre rows
+        ty = np.arange(plan.tiles_y)
+        cost = torch.from_numpy(100.0 + 2000.0 * np.exp(-((ty - 0.5 * plan.tiles_y) / (0.18 * plan.tiles_y)) ** 2)) / world
+        dist.all_reduce(cost)
+        plan = plan.rebalanced(cost.numpy())
+        np.save(os.path.join(out_dir, "pbands%d.npy" % rank), np.array(plan.bands))
     pipe = par.FramePipeline(torch, dist, plan, rank, width, "cpu")
     y0, y1 = plan.pixel_rows(rank)
     images = []
@@ -191,3 +198,31 @@ def test_frame_pipeline_keeps_frames_apart(tmp_path, world):
             if i == 3:
                 want[:] = 0.0          # dropped on every rank: one band was skipped (its flags word travelled with it)
             assert np.array_equal(got[i], want), (rank, i)
+
+
+@pytest.mark.parametrize("balanced", [False, True])
+def test_eight_ranks_on_the_4k_geometry(tmp_path, balanced):
+    """First-contact insurance for the 8-GPU node: BASELINE config 4's geometry — 2160 rows = 135 tile
+    rows over 8 ranks, bands of 16 / 17 tile rows (or re-cut to equal cost) — through FramePipeline with gloo: five
+    pipelined frames, one band skipped in frame 3 and that frame dropped on all 8 ranks."""
+    import torch.multiprocessing as mp
+    par = _par()
+    world, height, width = 8, 2160, 5
+    base = par.BandPlan(height, world)
+    assert sorted(b - a for a, b in base.bands) == [16] + [17] * 7 and base.bands[-1][1] == 135
+    port = _free_port()
+    mp.spawn(_pipeline_worker, args=(world, port, height, width, str(tmp_path), balanced), nprocs=world, join=True)
+    for rank in range(world):
+        got = np.load(os.path.join(str(tmp_path), "pipe%d.npy" % rank))
+        assert got.shape == (5, height, width, 4)
+        for i in range(5):
+            want = (1000 * i + np.arange(height, dtype=np.float32))[:, None, None] * np.ones((1, width, 4), np.float32)
+            if i == 3:
+                want[:] = 0.0
+            assert np.array_equal(got[i], want), (rank, i)
+    if balanced:
+        bands = [np.load(os.path.join(str(tmp_path), "pbands%d.npy" % r)) for r in range(world)]
+        assert all(np.array_equal(b, bands[0]) for b in bands)                    # one plan on every rank
+        rows = bands[0][:, 1] - bands[0][:, 0]
+        assert bands[0][0, 0] == 0 and bands[0][-1, 1] == 135 and (rows > 0).all()
+        assert rows[3] < 17 and rows[0] > 17, rows                                # thin bands where the rows are heavy

@@ -1,0 +1,106 @@
+// What does a dependent kernel boundary cost behind a kernel that has just WRITTEN B bytes?  (the
+// frame's small kernels take ~2 us longer in the frame's trace than alone; MI355X_MICROARCH.md prices a boundary at
+// 1.45-1.9 us "+ B / 6 TB/s when the predecessor leaves B bytes dirty".)
+// Chain on one stream: k_store<MODE>(B bytes, scatter-shaped: 16 B per lane, workgroups spread over the buffer) ->
+// k_probe -> k_probe.  Every workgroup stamps s_memrealtime (100 MHz, one counter for the chip) when it starts and
+// when it ends; the gap "last store workgroup ended -> first probe workgroup started" is the boundary behind B dirty
+// bytes, "probe 1 ended -> probe 2 started" the clean boundary beside it.  Store modes: plain, nt, sc1 (write-through at
+// agent scope), sc0 sc1.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tools/mb/mb_boundary tools/mb/mb_boundary.hip
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+struct Stamps {
+    unsigned long long first_start, last_end;
+};
+
+__device__ __forceinline__ void stamp_start(Stamps *s) {
+    if (threadIdx.x == 0) atomicMin(&s->first_start, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+}
+__device__ __forceinline__ void stamp_end(Stamps *s) {
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(&s->last_end, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_store(uint4 *__restrict__ dst, size_t n16, uint32_t seed, Stamps *s) {
+    stamp_start(s);
+    const uint4 v = make_uint4(seed, seed + 1u, seed + 2u, threadIdx.x);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) {
+        uint4 *p = dst + i;
+        if constexpr (MODE == 0) *p = v;
+        else if constexpr (MODE == 1) {
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            __builtin_nontemporal_store(u32x4{v.x, v.y, v.z, v.w}, (u32x4 *)p);
+        }
+        else {
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 w = {v.x, v.y, v.z, v.w};
+            if constexpr (MODE == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(w) : "memory");
+            else asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(w) : "memory");
+        }
+    }
+    stamp_end(s);
+}
+
+// a small dependent kernel of the frame's shape: 174 workgroups, reads 16 KB each from a buffer nobody writes
+__global__ __launch_bounds__(256) void k_probe(const uint4 *__restrict__ src, uint32_t *__restrict__ out, Stamps *s) {
+    stamp_start(s);
+    uint4 a = src[(size_t)blockIdx.x * 1024 + threadIdx.x], b = src[(size_t)blockIdx.x * 1024 + 256 + threadIdx.x];
+    if ((a.x ^ b.y) == 0x12345u) out[blockIdx.x] = a.z;      // never true
+    stamp_end(s);
+}
+
+int main(int argc, char **argv) {
+    const int iters = argc > 1 ? atoi(argv[1]) : 200;
+    hipStream_t st;
+    CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    uint4 *dst, *src;
+    uint32_t *out;
+    const size_t cap = 64u << 20;
+    CK(hipMalloc(&dst, cap));
+    CK(hipMalloc(&src, 174 * 16384));
+    CK(hipMemset(src, 0, 174 * 16384));
+    CK(hipMalloc(&out, 4096));
+    Stamps *stamps;      // [iters][3]
+    CK(hipMalloc(&stamps, (size_t)iters * 3 * sizeof(Stamps)));
+    std::vector<Stamps> h((size_t)iters * 3), init((size_t)iters * 3);
+    for (auto &x : init) { x.first_start = ~0ull; x.last_end = 0ull; }
+    const char *names[4] = {"plain", "nt", "sc1", "sc0 sc1"};
+    printf("%-8s %8s | %9s %9s %9s | %9s\n", "stores", "B", "store us", "gap dirty", "gap clean", "extra");
+    for (size_t bytes : {(size_t)0, (size_t)1 << 20, (size_t)4 << 20, (size_t)16 << 20, (size_t)64 << 20}) {
+        for (int mode = 0; mode < 4; mode++) {
+            CK(hipMemcpy(stamps, init.data(), init.size() * sizeof(Stamps), hipMemcpyHostToDevice));
+            const size_t n16 = bytes / 16;
+            const uint32_t grid = 1024;
+            for (int i = 0; i < iters; i++) {
+                Stamps *s = stamps + (size_t)i * 3;
+                switch (mode) {
+                case 0: hipLaunchKernelGGL(k_store<0>, dim3(grid), dim3(256), 0, st, dst, n16, (uint32_t)i, s); break;
+                case 1: hipLaunchKernelGGL(k_store<1>, dim3(grid), dim3(256), 0, st, dst, n16, (uint32_t)i, s); break;
+                case 2: hipLaunchKernelGGL(k_store<2>, dim3(grid), dim3(256), 0, st, dst, n16, (uint32_t)i, s); break;
+                default: hipLaunchKernelGGL(k_store<3>, dim3(grid), dim3(256), 0, st, dst, n16, (uint32_t)i, s); break;
+                }
+                hipLaunchKernelGGL(k_probe, dim3(174), dim3(256), 0, st, (const uint4 *)src, out, s + 1);
+                hipLaunchKernelGGL(k_probe, dim3(174), dim3(256), 0, st, (const uint4 *)src, out, s + 2);
+            }
+            CK(hipStreamSynchronize(st));
+            CK(hipMemcpy(h.data(), stamps, h.size() * sizeof(Stamps), hipMemcpyDeviceToHost));
+            std::vector<double> store_us, gap_dirty, gap_clean;
+            for (int i = iters / 4; i < iters; i++) {
+                const Stamps *s = &h[(size_t)i * 3];
+                store_us.push_back((double)(s[0].last_end - s[0].first_start) * 0.01);
+                gap_dirty.push_back((double)((long long)s[1].first_start - (long long)s[0].last_end) * 0.01);
+                gap_clean.push_back((double)((long long)s[2].first_start - (long long)s[1].last_end) * 0.01);
+            }
+            auto med = [](std::vector<double> &v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
+            const double a = med(store_us), b = med(gap_dirty), c = med(gap_clean);
+            printf("%-8s %5zu MB | %9.2f %9.2f %9.2f | %+9.2f\n", names[mode], bytes >> 20, a, b, c, b - c);
+        }
+    }
+    return 0;
+}

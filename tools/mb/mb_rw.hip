@@ -52,6 +52,19 @@ __global__ __launch_bounds__(256) void k_rw(const uint4* __restrict__ planar, ui
                 out[b] = r0; out[b + 1024] = r1; out[b + 2048] = r2;
             }
             if (MODE == 7) { out4[i] = r2.y; out8[i] = make_uint2(r2.z, r2.w); }
+            // round 5: today's outputs with the packed rect — 36 B record + 4 B key + 4 B rect — against
+            // a 32-byte record (two aligned 16-byte stores, never straddling a 128-byte line) + key + rect + a 1-byte
+            // opacity plane
+            if (MODE == 8) {
+                uint32_t* o = (uint32_t*)out + (uint64_t)i * 9;
+                typedef uint32_t u4a __attribute__((ext_vector_type(4), aligned(4)));
+                *(u4a*)o = u4a{r0.x, r0.y, r0.z, r0.w}; *(u4a*)(o + 4) = u4a{r1.x, r1.y, r1.z, r1.w}; o[8] = r2.x;
+                out4[i] = r2.y; ((uint32_t*)out8)[i] = r2.z;
+            }
+            if (MODE == 9) {
+                out[2ull * i] = r0; out[2ull * i + 1] = r1;
+                out4[i] = r2.y; ((uint32_t*)out8)[i] = r2.z; ((uint8_t*)out8)[4ull * n + i] = (uint8_t)r2.x;
+            }
         }
     }
     if (MODE == 4) {
@@ -93,6 +106,10 @@ int main() {
     run<5, false, true>("W5 nt stores", 48, planar, n, out, out4, out8, sums);
     run<5, true, true>("W5 nt loads + nt stores", 48, planar, n, out, out4, out8, sums);
     run<7, true, false>("W7 nt loads", 12, planar, n, out, out4, out8, sums);
+    run<8, true>("W8 36 B AoS + 4 B + 4 B (round 4/5), nt loads", 44, planar, n, out, out4, out8, sums);
+    run<9, true>("W9 32 B AoS + 4 B + 4 B + 1 B, nt loads", 41, planar, n, out, out4, out8, sums);
+    run<8, true>("W8 again", 44, planar, n, out, out4, out8, sums);
+    run<9, true>("W9 again", 41, planar, n, out, out4, out8, sums);
     run<0>("W0 no writes (again)", 0, planar, n, out, out4, out8, sums);
     return 0;
 }

@@ -9,6 +9,7 @@
 #include <hip/hiprtc.h>
 
 #include <atomic>
+#include <mutex>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -255,6 +256,10 @@ struct gs_device {
     // watchdog fired (gs_render_frame / gs_renderer_wait_frame, possibly from different host threads) and read once per
     // frame (t_rank_fault) and by the stand-alone sorts: atomic, relaxed — it only ever goes from true to false.
     std::atomic<bool> lds_atomic_ordered{false};
+    // renderers of this device: gs_stream_destroy records the end-of-frame event of those whose last frame sits on the
+    // stream that is going away (the event is otherwise recorded lazily, when the renderer moves to another stream)
+    std::mutex renderers_mu;
+    std::vector<struct gs_renderer *> renderers;
 };
 
 struct gs_stream {
@@ -399,8 +404,15 @@ extern "C" gs_status gs_stream_synchronize(gs_stream *s) {
     return GS_OK;
 }
 
+static void renderers_leave_stream(gs_device *dev, hipStream_t st);
+
 extern "C" void gs_stream_destroy(gs_stream *s) {
     if (!s) return;
+    // A renderer whose last frame was enqueued on this stream records its end-of-frame event lazily, on the stream, when
+    // it moves elsewhere (gs_render_frame): do that now, while the handle is alive.  This holds for wrapped streams too
+    // (gs_stream_wrap): destroy the gs_stream BEFORE the hipStream_t it wraps.
+    (void)hipSetDevice(s->dev->ordinal);
+    renderers_leave_stream(s->dev, s->s);
     if (s->owned) {
         (void)hipSetDevice(s->dev->ordinal);
         (void)hipStreamDestroy(s->s);
@@ -1481,6 +1493,8 @@ struct gs_renderer {
     uint32_t depth_bucket_seen = 0;       // newest reported bucket size the mode was chosen from (diagnostic)
     bool tile_msd = false;                // the tile sort of the last frame was MSD-first
     int depth_msd_req = -1, tile_msd_req = -1;   // gs_renderer_set_sort_mode: -1 = the renderer chooses
+    uint64_t tile_msd_fail_d = 0;         // pair count at which the MSD-first tile sort last reported an oversized bucket (0: never)
+    bool state_tile_bmax_dirty = false;   // FrameState::tile_bucket_max holds a value of an MSD-first frame
     uint32_t cull_last_gen = 0, cull_last_groups = 0;   // frame / group count of the last k_block_cull (status tags)
     DevArray dkeys[2], dvals[2];          // (depth bits - bias, mirror slot), capacity N
     DevArray tkeys[2], tvals[2];          // (tile id, mirror slot), capacity pair_capacity
@@ -1506,6 +1520,7 @@ struct gs_renderer {
     uint32_t *flags_target = nullptr;     // device word that receives every frame's flags (gs_renderer_set_frame_flags_target)
     hipStream_t last_stream;
     bool have_frame;                      // last_stream is meaningful (the null stream is a valid stream)
+    bool last_stream_gone = false;        // ... but has been destroyed since (gs_stream_destroy recorded done[gen & 1] on it)
     gs_buffer *last_order;   // mirror order of the last frame's buffer (null = index order), for the taps
     // timing
     bool timing;
@@ -1515,6 +1530,25 @@ struct gs_renderer {
     double stage_ms[ST_COUNT];
     uint32_t timed_frames;
 };
+
+// gs_stream_destroy: the end-of-frame event of every renderer whose last frame is on `st` is recorded now, and the
+// renderer remembers that the stream is gone (it must not be touched again: waits go through the event).
+static void renderers_leave_stream(gs_device *dev, hipStream_t st) {
+    std::lock_guard<std::mutex> lock(dev->renderers_mu);
+    for (gs_renderer *r : dev->renderers) {
+        if (!r->have_frame || r->last_stream_gone || r->last_stream != st) continue;
+        r->done_valid[r->gen & 1u] = hipEventRecord(r->done[r->gen & 1u], st) == hipSuccess;
+        r->last_stream_gone = true;
+    }
+    (void)hipGetLastError();
+}
+
+// host wait for the renderer's last frame: its stream, or — the stream was destroyed — its end-of-frame event
+static hipError_t sync_last_frame(gs_renderer *r) {
+    if (!r->have_frame) return hipSuccess;
+    if (!r->last_stream_gone) return hipStreamSynchronize(r->last_stream);
+    return r->done_valid[r->gen & 1u] ? hipEventSynchronize(r->done[r->gen & 1u]) : hipSuccess;
+}
 
 extern "C" gs_status gs_renderer_create(gs_device *dev, gs_renderer **out) {
     if (!out) return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "null out");
@@ -1559,6 +1593,10 @@ extern "C" gs_status gs_renderer_create(gs_device *dev, gs_renderer **out) {
     r->ev_pending = false;
     r->timed_frames = 0;
     for (int i = 0; i < ST_COUNT; i++) r->stage_ms[i] = 0.0;
+    {
+        std::lock_guard<std::mutex> lock(dev->renderers_mu);
+        dev->renderers.push_back(r);
+    }
     *out = r;
     return GS_OK;
 }
@@ -1566,7 +1604,17 @@ extern "C" gs_status gs_renderer_create(gs_device *dev, gs_renderer **out) {
 extern "C" void gs_renderer_destroy(gs_renderer *r) {
     if (!r) return;
     (void)hipSetDevice(r->dev->ordinal);
-    if (r->have_frame) (void)hipStreamSynchronize(r->last_stream);   // kernels of the last frame write pinned memory
+    {
+        std::lock_guard<std::mutex> lock(r->dev->renderers_mu);
+        auto &v = r->dev->renderers;
+        for (size_t i = 0; i < v.size(); i++)
+            if (v[i] == r) {
+                v[i] = v.back();
+                v.pop_back();
+                break;
+            }
+    }
+    (void)sync_last_frame(r);   // kernels of the last frame write pinned memory
     DevArray *arrs[] = {&r->recs, &r->depth, &r->rect, &r->sorted_rect, &r->exp_sums, &r->cursors, &r->chunk_tiles, &r->chunk_vis,
                         &r->state, &r->zero_region, &r->scan_tmp, &r->block_list, &r->cull_status, &r->chunk_hist, &r->dkeys[0], &r->dkeys[1], &r->dvals[0],
                         &r->dvals[1], &r->tkeys[0], &r->tkeys[1], &r->tvals[0], &r->tvals[1], &r->ghist,
@@ -1633,7 +1681,7 @@ extern "C" gs_status gs_renderer_wait_frame(gs_renderer *r, gs_frame_result *out
     GS_TRY(use_device(r->dev));
     if (out) std::memset(out, 0, sizeof(*out));
     if (!r->have_frame) return GS_OK;       // no frame yet
-    GS_HIP(hipStreamSynchronize(r->last_stream));
+    GS_HIP(sync_last_frame(r));
     const gs::FrameResult &fr = last_result(r);
     if (out) {
         out->gaussians = r->n;
@@ -1670,7 +1718,7 @@ extern "C" gs_status gs_renderer_wait_frame(gs_renderer *r, gs_frame_result *out
 extern "C" gs_status gs_renderer_stats(gs_renderer *r, gs_frame_stats *out) {
     if (!r || !out) return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "null argument");
     GS_TRY(use_device(r->dev));
-    if (r->have_frame) GS_HIP(hipStreamSynchronize(r->last_stream));
+    GS_HIP(sync_last_frame(r));
     GS_TRY(collect_timing(r));
     std::memset(out, 0, sizeof(*out));
     const gs::FrameResult &fr = last_result(r);
@@ -1692,12 +1740,13 @@ extern "C" gs_status gs_renderer_sort_info(gs_renderer *r, gs_sort_info *out) {
     std::memset(out, 0, sizeof(*out));
     out->bucket_capacity = gs::BKT_CAP;
     if (!r->have_frame) return GS_OK;
-    GS_HIP(hipStreamSynchronize(r->last_stream));
+    GS_HIP(sync_last_frame(r));
     const gs::FrameResult &fr = last_result(r);
     out->depth_msd = r->depth_msd ? 1u : 0u;
     out->depth_bucket_max = fr.gen == r->gen ? fr.depth_bucket_max : 0u;
     out->tile_msd = r->tile_msd ? 1u : 0u;
-    out->tile_bucket_max = r->state.ptr ? 0u : 0u;
+    if (r->tile_msd && r->state.ptr)      // (the result block carries the PREVIOUS frame's: read this frame's from the device)
+        GS_HIP(hipMemcpy(&out->tile_bucket_max, &((gs::FrameState *)r->state.ptr)->tile_bucket_max, sizeof(uint32_t), hipMemcpyDeviceToHost));
     return GS_OK;
 }
 
@@ -1906,7 +1955,7 @@ template <typename KI, typename KO, int RB, bool COMPACT, int ITEMS>
 static void launch_pass(const gs_device *dev, hipStream_t st, uint32_t sgrid, const KI *kin, const uint32_t *vin, KO *kout,
                         uint32_t ko_shift, uint32_t *vout, gs::SortCount psc, uint32_t shift, uint32_t digit_mask, DevArray &ghist,
                         DevArray &digit_totals, const uint32_t *cv, uint32_t *vo, uint32_t pnb, uint32_t xr,
-                        const uint32_t *chunk_hist = nullptr) {
+                        const uint32_t *chunk_hist = nullptr, uint32_t chunk_hist_words = (uint32_t)gs::PP_THREADS) {
     constexpr uint32_t R = 1u << RB;
     constexpr int TILE = gs::SORT_THREADS * ITEMS;
     // GS3D_CHUNK_HIST=0: the compacting pass counts its histogram from the keys again (A/B, tests)
@@ -1916,7 +1965,7 @@ static void launch_pass(const gs_device *dev, hipStream_t st, uint32_t sgrid, co
         if (chunk_hist && !chunk_hist_off) {
             // the preprocess kernel counted this digit per chunk: sum the chunks' rows instead of re-reading the keys
             hipLaunchKernelGGL((gs::k_sort_hist_chunks<RB, ITEMS>), dim3(sgrid), dim3(gs::SORT_THREADS), 0, st, chunk_hist, psc,
-                               digit_mask, (uint32_t *)ghist.ptr, cv, pnb, xr);
+                               digit_mask, (uint32_t *)ghist.ptr, cv, pnb, xr, chunk_hist_words);
             summed = true;
         }
     }
@@ -1978,10 +2027,10 @@ static gs_status run_sort_items(const gs_device *dev, void *const keys[2], void 
                 src.tvals = (uint32_t *)vals[side];
                 if (sizeof(K) == 2 && src.rect32)
                     hipLaunchKernelGGL((gs::k_pairs_emit<K, RB, ITEMS, sizeof(K) == 2>), dim3(sgrid), dim3(gs::SORT_THREADS), 0, st,
-                                       src, digit_mask, (uint32_t *)ghist.ptr, (K *)keys[side], pnb, xr);
+                                       src, digit_mask, (uint32_t *)ghist.ptr, (K *)keys[side], pnb, xr, 0u);
                 else
                     hipLaunchKernelGGL((gs::k_pairs_emit<K, RB, ITEMS, false>), dim3(sgrid), dim3(gs::SORT_THREADS), 0, st, src,
-                                       digit_mask, (uint32_t *)ghist.ptr, (K *)keys[side], pnb, xr);
+                                       digit_mask, (uint32_t *)ghist.ptr, (K *)keys[side], pnb, xr, 0u);
                 launch_scan_rows<(int)TILE>(digit_mask + 1u, st, (uint32_t *)ghist.ptr, pnb, psc, (uint32_t *)digit_totals.ptr);
                 launch_scatter<K, K, RB, false, ITEMS>(dev, st, sgrid, kin, vin, kout, 0u, vout, psc, shift, digit_mask,
                                                        (const uint32_t *)ghist.ptr, (const uint32_t *)digit_totals.ptr, cv, vo, pnb, xr);
@@ -2039,14 +2088,14 @@ static uint32_t xcd_span_for(uint32_t pnb, uint32_t &sgrid) {
 }
 
 // The frame's depth sort, MSD-first (round 5; gs_render_kernels.h, "Bucket sort"): ONE compacting scatter pass on the TOP
-// 9 bits of the depth key — its histogram summed from the rows the preprocess kernel counted — then one workgroup per
+// 10 bits of the depth key — its histogram summed from the rows the preprocess kernel counted — then one workgroup per
 // bucket sorts the remaining low bits on its CU and writes the final order to vals[0].  4 launches instead of 9; right
 // when the buckets fit a workgroup (up to ~1-2 M visible Gaussians spread in depth), which the caller decides from the
 // bucket sizes the last frames reported.  `scratch_*`: two passes of the chunked fallback (oversized buckets).
 template <int ITEMS>
 static gs_status run_depth_msd_items(gs_renderer *r, hipStream_t st, const SortCompact &cp, uint32_t dbits, uint32_t top_range,
                                      void *scratch_keys, void *scratch_vals, uint32_t *bucket_max, uint32_t &passes_out) {
-    constexpr int RB = gs::RADIX_BITS_MAX;
+    constexpr int RB = gs::MSD_TOP_BITS, RBL = gs::RADIX_BITS_MAX;     // top digit 10 bits; two bucket passes of up to 9 below it
     constexpr uint32_t R = 1u << RB, TILE = (uint32_t)(gs::SORT_THREADS * ITEMS);
     const gs_device *dev = r->dev;
     const uint32_t low_bits = dbits - (uint32_t)RB;
@@ -2058,7 +2107,7 @@ static gs_status run_depth_msd_items(gs_renderer *r, hipStream_t st, const SortC
     const gs::SortCount psc{cp.dense_count, cp.dense_count_dev};
     launch_pass<uint32_t, uint32_t, RB, true, ITEMS>(dev, st, sgrid, cp.dense_keys, (const uint32_t *)nullptr, (uint32_t *)r->dkeys[1].ptr, 0u,
                                                      (uint32_t *)r->dvals[1].ptr, psc, low_bits, R - 1u, r->ghist, r->digit_totals,
-                                                     cp.chunk_vis, cp.visible_out, pnb, xr, cp.chunk_hist);
+                                                     cp.chunk_vis, cp.visible_out, pnb, xr, cp.chunk_hist, R / 2u);
     gs::BucketSortIO io;
     io.totals = (const uint32_t *)r->digit_totals.ptr;
     io.nb = top_range < R ? top_range : R;          // digits past the far plane's cannot occur (their totals are zero)
@@ -2075,12 +2124,67 @@ static gs_status run_depth_msd_items(gs_renderer *r, hipStream_t st, const SortC
     io.rank_fault = t_rank_fault;
     io.watch = t_watch;
     if (t_rank_fault || dev->lds_atomic_ordered.load(std::memory_order_relaxed))
-        hipLaunchKernelGGL((gs::k_bucket_sort<uint32_t, RB, true>), dim3(io.nb), dim3(gs::BKT_THREADS), 0, st, io);
+        hipLaunchKernelGGL((gs::k_bucket_sort<uint32_t, RBL, gs::BKT_THREADS, true>), dim3(io.nb), dim3(gs::BKT_THREADS), 0, st, io);
     else
-        hipLaunchKernelGGL((gs::k_bucket_sort<uint32_t, RB, false>), dim3(io.nb), dim3(gs::BKT_THREADS), 0, st, io);
+        hipLaunchKernelGGL((gs::k_bucket_sort<uint32_t, RBL, gs::BKT_THREADS, false>), dim3(io.nb), dim3(gs::BKT_THREADS), 0, st, io);
     GS_HIP(hipGetLastError());
     r->launches += 4;
-    passes_out = 1u + (low_bits + RB - 1u) / RB;
+    passes_out = 1u + (low_bits + RBL - 1u) / RBL;
+    return GS_OK;
+}
+
+// The frame's tile sort, MSD-first (u16 tile ids, more than 1024 tiles): k_pairs_emit counts the TOP 10 bits of the tile id
+// while it writes the pairs, one scatter pass partitions them into buckets of 2^low_bits consecutive tiles (each in depth
+// order), and k_bucket_sort finishes every bucket with one counting pass on the low bits — which also yields the tiles'
+// [start, end) ranges: no second histogram / row scan / scatter and no range kernel, 4 launches instead of 7.  Result on
+// side 0 (keys too: the parity tap rebuilds the 64-bit keys from them).
+template <int ITEMS>
+static gs_status run_tile_msd_items(gs_renderer *r, hipStream_t st, const gs::ExpandIO &eo, gs::SortCount tc, uint32_t tile_bits,
+                                    uint32_t num_tiles, uint32_t *ranges, uint32_t *bucket_max, uint32_t &passes_out) {
+    constexpr int RB = gs::MSD_TOP_BITS, RBL = 6;        // top digit 10 bits; up to 6 bits (65536 tiles) left for the buckets
+    constexpr uint32_t R = 1u << RB, TILE = (uint32_t)(gs::SORT_THREADS * ITEMS);
+    const gs_device *dev = r->dev;
+    const uint32_t low_bits = tile_bits - (uint32_t)RB;
+    const uint32_t pnb = (uint32_t)(((uint64_t)tc.count + TILE - 1) / TILE);
+    GS_TRY(dev_reserve(r->ghist, (size_t)pnb * R * 4));
+    GS_TRY(dev_reserve(r->digit_totals, R * 4));
+    uint32_t sgrid = 0;
+    const uint32_t xr = xcd_span_for(pnb, sgrid);
+    gs::ExpandIO src = eo;
+    src.tvals = (uint32_t *)r->tvals[0].ptr;
+    if (src.rect32)
+        hipLaunchKernelGGL((gs::k_pairs_emit<uint16_t, RB, ITEMS, true>), dim3(sgrid), dim3(gs::SORT_THREADS), 0, st, src, R - 1u,
+                           (uint32_t *)r->ghist.ptr, (uint16_t *)r->tkeys[0].ptr, pnb, xr, low_bits);
+    else
+        hipLaunchKernelGGL((gs::k_pairs_emit<uint16_t, RB, ITEMS, false>), dim3(sgrid), dim3(gs::SORT_THREADS), 0, st, src, R - 1u,
+                           (uint32_t *)r->ghist.ptr, (uint16_t *)r->tkeys[0].ptr, pnb, xr, low_bits);
+    launch_scan_rows<(int)TILE>(R, st, (uint32_t *)r->ghist.ptr, pnb, tc, (uint32_t *)r->digit_totals.ptr);
+    launch_scatter<uint16_t, uint16_t, RB, false, ITEMS>(dev, st, sgrid, (const uint16_t *)r->tkeys[0].ptr, (const uint32_t *)r->tvals[0].ptr,
+                                                         (uint16_t *)r->tkeys[1].ptr, 0u, (uint32_t *)r->tvals[1].ptr, tc, low_bits, R - 1u,
+                                                         (const uint32_t *)r->ghist.ptr, (const uint32_t *)r->digit_totals.ptr,
+                                                         (const uint32_t *)nullptr, (uint32_t *)nullptr, pnb, xr);
+    gs::BucketSortIO io;
+    io.totals = (const uint32_t *)r->digit_totals.ptr;
+    io.nb = ((num_tiles - 1u) >> low_bits) + 1u;
+    io.keys_in = r->tkeys[1].ptr;
+    io.vals_in = (const uint32_t *)r->tvals[1].ptr;
+    io.keys_tmp = nullptr;                          // one pass: the chunked path needs no scratch
+    io.vals_tmp = nullptr;
+    io.keys_out = r->tkeys[0].ptr;
+    io.vals_out = (uint32_t *)r->tvals[0].ptr;
+    io.low_bits = low_bits;
+    io.bucket_max = bucket_max;
+    io.ranges = ranges;
+    io.num_tiles = num_tiles;
+    io.rank_fault = t_rank_fault;
+    io.watch = t_watch;
+    if (t_rank_fault || dev->lds_atomic_ordered.load(std::memory_order_relaxed))
+        hipLaunchKernelGGL((gs::k_bucket_sort<uint16_t, RBL, gs::BKT_THREADS_SMALL, true>), dim3(io.nb), dim3(gs::BKT_THREADS_SMALL), 0, st, io);
+    else
+        hipLaunchKernelGGL((gs::k_bucket_sort<uint16_t, RBL, gs::BKT_THREADS_SMALL, false>), dim3(io.nb), dim3(gs::BKT_THREADS_SMALL), 0, st, io);
+    GS_HIP(hipGetLastError());
+    r->launches += 4;
+    passes_out = low_bits ? 2u : 1u;
     return GS_OK;
 }
 
@@ -2397,8 +2501,10 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
     // without asking an event first.  GS3D_FRAME_EVENT=1 restores the per-frame event (and the query in front of
     // every history read).
     static const bool frame_event = std::getenv("GS3D_FRAME_EVENT") && std::getenv("GS3D_FRAME_EVENT")[0] == '1';
-    if (r->have_frame && st != r->last_stream) {
-        if (!frame_event) {
+    if (r->have_frame && (st != r->last_stream || r->last_stream_gone)) {
+        // (a stream that has been destroyed since recorded the event on its way out: gs_stream_destroy; a new stream may
+        // have received the old handle's value, hence the flag and not the comparison alone)
+        if (!frame_event && !r->last_stream_gone) {
             GS_HIP(hipEventRecord(r->done[r->gen & 1u], r->last_stream));
             r->done_valid[r->gen & 1u] = true;
         }
@@ -2437,7 +2543,7 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
     uint64_t hist_d[2] = {0, 0};
     uint32_t hist_gen[2] = {0, 0};
     uint32_t hist_v[2] = {0, 0};
-    uint32_t hist_bmax[2] = {0, 0};
+    uint32_t hist_bmax[2] = {0, 0}, hist_tmax[2] = {0, 0};
     for (int i = 0; i < 2; i++) {
         if (frame_event) {
             if (!r->done_valid[i] || hipEventQuery(r->done[i]) != hipSuccess) continue;
@@ -2451,12 +2557,13 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
         const uint64_t f_pairs = fr.pairs_total;
         const uint32_t f_vis = fr.visible;
         const uint32_t f_flags = fr.flags;
-        const uint32_t f_bmax = fr.depth_bucket_max;
+        const uint32_t f_bmax = fr.depth_bucket_max, f_tmax = fr.tile_bucket_max;
         if (__atomic_load_n(&fr.gen, __ATOMIC_ACQUIRE) != r->done_gen[i] || f_pairs > 0xfffffff0ull) continue;
         hist_d[i] = f_pairs;
         hist_gen[i] = r->done_gen[i];
         hist_v[i] = f_vis;
         hist_bmax[i] = f_bmax;
+        hist_tmax[i] = f_tmax;
         if (f_flags & gs::FRAME_FLAG_RANK_FAULT) rank_fault_seen = true;
         // grow when the last measured D leaves less than 1/8 of head room
         if (f_pairs + f_pairs / 8 > r->pair_capacity && capacity_for(f_pairs) > want_capacity)
@@ -2505,7 +2612,7 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
     GS_TRY(dev_reserve(r->sorted_rect, (nn + 1024) * 8));   // padded: k_pairs_emit reads whole batches
     GS_TRY(dev_reserve(r->chunk_tiles, nc * 4));
     GS_TRY(dev_reserve(r->chunk_vis, nc * 4));
-    GS_TRY(dev_reserve(r->chunk_hist, nc * (size_t)gs::PP_THREADS * 4));
+    GS_TRY(dev_reserve(r->chunk_hist, nc * (size_t)(gs::PRE_HIST_BINS / 2) * 4));
     GS_TRY(dev_reserve(r->scan_tmp, nc * 4));
     for (int i = 0; i < 2; i++) {
         GS_TRY(dev_reserve(r->dkeys[i], nn * 4));
@@ -2581,6 +2688,7 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
     r->tiles_y = fc.tiles_y;
     r->rect32 = fc.rect32 != 0u;
     r->last_stream = st;
+    r->last_stream_gone = false;
     r->have_frame = true;
     r->launches = 0;
     r->list_mode = false;
@@ -2595,10 +2703,10 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
     const uint32_t tile_bits = bit_length(num_tiles ? num_tiles - 1 : 0);
 
     // ---- which depth sort (gs_renderer::depth_msd) ----
-    // MSD-first needs a top digit of 9 bits and at most two bucket passes below it: 10..27 key bits (the bench's planes,
+    // MSD-first needs a top digit of 10 bits and at most two bucket passes (of 9) below it: 11..28 key bits (the bench's planes,
     // 0.1 / 100, give 27); with fewer or more bits the LSD passes stand.
-    const uint32_t msd_low_bits = dbits > (uint32_t)gs::RADIX_BITS_MAX ? dbits - (uint32_t)gs::RADIX_BITS_MAX : 0u;
-    const bool msd_possible = n != 0 && dbits > (uint32_t)gs::RADIX_BITS_MAX && msd_low_bits <= 2u * (uint32_t)gs::RADIX_BITS_MAX;
+    const uint32_t msd_low_bits = dbits > (uint32_t)gs::MSD_TOP_BITS ? dbits - (uint32_t)gs::MSD_TOP_BITS : 0u;
+    const bool msd_possible = n != 0 && dbits > (uint32_t)gs::MSD_TOP_BITS && msd_low_bits <= 2u * (uint32_t)gs::RADIX_BITS_MAX;
     bool depth_msd = false;
     if (msd_possible) {
         static const int msd_env = std::getenv("GS3D_DEPTH_MSD") ? std::atoi(std::getenv("GS3D_DEPTH_MSD")) : -1;
@@ -2675,8 +2783,9 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
         po.key_bias = near_bits;
         po.block_bounds = (const float *)g->block_bounds;
         po.chunk_hist = (uint32_t *)r->chunk_hist.ptr;
-        po.digit_mask = depth_msd ? (1u << gs::RADIX_BITS_MAX) - 1u : first_digit_mask(dbits, depth_radix_bits(dbits));
+        po.digit_mask = depth_msd ? (1u << gs::MSD_TOP_BITS) - 1u : first_digit_mask(dbits, depth_radix_bits(dbits));
         po.digit_shift = depth_msd ? msd_low_bits : 0u;
+        po.hist_words = depth_msd ? (1u << gs::MSD_TOP_BITS) / 2u : (uint32_t)gs::PP_THREADS;
         po.block_list = nullptr;
         po.block_count = nullptr;
         // Block list (k_block_cull): one thread per block tests it, the survivors are handed to the first
@@ -2830,7 +2939,43 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
         int tside = 0;
         uint32_t tpasses = 0;
         const gs::SortCount tc{capacity, &state->pairs};
-        {
+        // Which tile sort (gs_renderer::tile_msd).  MSD-first needs u16 tile ids with more than 10 bits; its buckets are
+        // 2^(bits - 10) consecutive tiles, so what decides is the pair count: up to an average of a quarter of the register
+        // path's capacity per bucket it is tried, and a frame that reports a bucket beyond the capacity (FrameResult::
+        // tile_bucket_max, one frame late) sends the renderer back to the LSD passes until the pair count has dropped by
+        // a quarter below the count that failed.
+        bool tile_msd = false;
+        if (!wide && tile_bits > (uint32_t)gs::MSD_TOP_BITS && capacity != 0u) {
+            static const int tmsd_env = std::getenv("GS3D_TILE_MSD") ? std::atoi(std::getenv("GS3D_TILE_MSD")) : -1;
+            const int pinned = r->tile_msd_req >= 0 ? r->tile_msd_req : tmsd_env;
+            const int newer = hist_gen[0] > hist_gen[1] ? 0 : 1;
+            // pairs this frame is expected to hold: the newest report of this shape, else what sized the buffers
+            const uint64_t d_est = !sizing && hist_gen[newer] && r->done_shape[newer] == r->shape_epoch ? hist_d[newer]
+                                                                                                         : (uint64_t)capacity * 4u / 5u;
+            if (!sizing && hist_gen[newer] && r->done_shape[newer] == r->shape_epoch && hist_tmax[newer] > gs::BKT_CAP_SMALL)
+                r->tile_msd_fail_d = d_est ? d_est : 1u;
+            if (sizing) r->tile_msd_fail_d = 0;
+            // Measured at 1 M (gpurun_out/r05c/kt_1m.txt): the 1020 buckets of ~2 500 pairs cost the bucket kernel 22 us (one
+            // 1024-thread workgroup with 157 KB of LDS per bucket: four rounds of workgroups whose fixed costs dominate) and
+            // the 10-bit first pass 6 us more than the 7-bit one — 60 us against the LSD sort's 55.  So the renderer does
+            // not choose it by itself (GS3D_TILE_MSD_AUTO=1 lets it); pinned, it is exact (tests/test_gpu_msd_sort.py).
+            static const bool tile_auto = std::getenv("GS3D_TILE_MSD_AUTO") && std::getenv("GS3D_TILE_MSD_AUTO")[0] == '1';
+            if (pinned >= 0)
+                tile_msd = pinned != 0;
+            else
+                tile_msd = tile_auto && d_est <= (uint64_t)gs::BKT_CAP_SMALL * 256u &&
+                           (r->tile_msd_fail_d == 0 || d_est < r->tile_msd_fail_d - r->tile_msd_fail_d / 4u);
+        }
+        r->tile_msd = tile_msd;
+        if (tile_msd) {
+            t_bucket_max = nullptr;
+            if (tile_bits > (uint32_t)gs::MSD_TOP_BITS + 6u) return fail(GS_ERR_INVALID_ARGUMENT, tile_bits, 0, 0, "tile id bits");
+            GS_TRY((run_tile_msd_items<gs::SortCfg<uint16_t>::ITEMS>(r, st, eo, tc, tile_bits, num_tiles, zero, &state->tile_bucket_max,
+                                                                          tpasses)));
+            tside = 0;
+        } else {
+            // (a frame whose tile sort is LSD reports no bucket size: the next result must not carry a stale one)
+            if (r->state_tile_bmax_dirty) GS_HIP(hipMemsetAsync(&state->tile_bucket_max, 0, sizeof(uint32_t), st));
             void *k2[2] = {r->tkeys[0].ptr, r->tkeys[1].ptr};
             void *v2[2] = {r->tvals[0].ptr, r->tvals[1].ptr};
             const gs::ExpandIO *src = &eo;
@@ -2841,8 +2986,9 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
                 GS_TRY((run_sort_rb<uint16_t, gs::RADIX_BITS>(r->dev, k2, v2, r->ghist, r->digit_totals, tc, tile_bits, nullptr,
                                                               st, tside, tpasses, r->launches, src)));
         }
+        r->state_tile_bmax_dirty = tile_msd;
         mark(ST_RANGES);
-        // Tile ranges, three ways.  (1) One pass over the sorted keys (k_tile_ranges).  (2) A 32-ary search per tile
+        // Tile ranges, three ways (the MSD-first tile sort has written them already: k_bucket_sort).  (1) One pass over the sorted keys (k_tile_ranges).  (2) A 32-ary search per tile
         // (k_tile_ranges_search) once reading every key again costs more than a few dependent probes per tile: from
         // a pair capacity of 8 M (GS3D_RANGES_SEARCH=0/1 forces).  (3) The same search run by the blend workgroups
         // themselves (blend_tile_range_wg): no launch in front of the blend, but a workgroup that waits for its
@@ -2854,7 +3000,9 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
         const bool ranges_in_blend = in_blend_env >= 0 ? in_blend_env != 0 : num_tiles > 16384u;
         static const int ranges_env = std::getenv("GS3D_RANGES_SEARCH") ? std::atoi(std::getenv("GS3D_RANGES_SEARCH")) : -1;
         const bool ranges_search = ranges_env >= 0 ? ranges_env != 0 : capacity >= (8u << 20);
-        if (capacity && ranges_in_blend) {
+        if (tile_msd) {
+            // nothing to do
+        } else if (capacity && ranges_in_blend) {
             tile_keys.keys = r->tkeys[tside].ptr;
             tile_keys.count_dev = &state->pairs;
             tile_keys.count_bound = capacity;
@@ -2910,7 +3058,7 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
 
 static gs_status download_sync(gs_renderer *r, void *dst, const void *src, size_t bytes) {
     if (!bytes) return GS_OK;
-    GS_HIP(hipStreamSynchronize(r->last_stream));
+    GS_HIP(sync_last_frame(r));
     hipError_t e = hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost);
     if (e != hipSuccess)
         return fail(GS_ERR_DOWNLOAD, (uint64_t)e, 0, 0, "download failed: %s", hipGetErrorString(e));
@@ -3022,7 +3170,7 @@ extern "C" gs_status gs_renderer_download_sorted(gs_renderer *r, uint64_t *keys_
                                                  uint64_t capacity, uint64_t *pairs_out) {
     if (!r) return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "null renderer");
     GS_TRY(use_device(r->dev));
-    if (r->have_frame) GS_HIP(hipStreamSynchronize(r->last_stream));
+    GS_HIP(sync_last_frame(r));
     uint64_t d = r->have_frame ? last_result(r).pairs_total : 0;
     if (d > r->pair_capacity) d = r->pair_capacity;     // an overflowed frame only holds this many
     if (pairs_out) *pairs_out = d;

@@ -184,7 +184,9 @@ struct FrameResult {
     uint64_t pairs_total;    // true D, also when it exceeded the capacity
     uint32_t gen;            // frame generation this result belongs to
     uint32_t depth_bucket_max;   // FrameState::depth_bucket_max: feeds the host's choice of the depth sort (MSD-first / LSD)
-    uint32_t pad[2];
+    uint32_t tile_bucket_max;    // FrameState::tile_bucket_max as the PREVIOUS frame of the renderer left it (the tile sort
+                                 // runs behind the kernel that publishes this block); 0 = that frame's tile sort was LSD
+    uint32_t pad[1];
 };
 
 // One thread publishes a frame's result to pinned host memory.  `gen` goes LAST, behind a
@@ -192,7 +194,8 @@ struct FrameResult {
 // event created with hipEventDisableSystemFence, then a read) and finds the expected generation
 // also finds that generation's counts.
 __device__ __forceinline__ void publish_result(FrameResult *r, uint32_t visible, uint64_t pairs_total, uint32_t flags,
-                                               uint32_t gen, uint32_t *flags_dev = nullptr, uint32_t depth_bucket_max = 0u) {
+                                               uint32_t gen, uint32_t *flags_dev = nullptr, uint32_t depth_bucket_max = 0u,
+                                               uint32_t tile_bucket_max = 0u) {
     // optional copy of the flags in DEVICE memory (gs_renderer_set_frame_flags_target): a sharded frame
     // carries it inside its band's gather chunk, so every rank learns from the one all-gather whether
     // any band was skipped
@@ -201,6 +204,7 @@ __device__ __forceinline__ void publish_result(FrameResult *r, uint32_t visible,
     r->pairs_total = pairs_total;
     r->flags = flags;
     r->depth_bucket_max = depth_bucket_max;
+    r->tile_bucket_max = tile_bucket_max;
     __hip_atomic_store(&r->gen, gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
@@ -817,14 +821,17 @@ struct PreOut {
                                      // (ties of the depth sort break the same way), and everything behind this kernel — the
                                      // compacting depth pass, its histogram, the sizing scan — walks list_slots, not N.
     const uint32_t *block_count;
-    uint32_t *chunk_hist;            // [chunks][256] words: histogram of the chunk's keys on the FIRST digit of the depth
-                                     // sort (low `digit_mask` bits), two 16-bit counts per word (a chunk holds <= 1024 keys).
+    uint32_t *chunk_hist;            // [chunks][hist_words] words: histogram of the chunk's keys on the FIRST digit of the depth
+                                     // sort ((key >> digit_shift) & digit_mask), two 16-bit counts per word (a chunk holds <= 1024 keys).
                                      // Counted here, where the keys sit in registers: the compacting pass's histogram
                                      // kernel then sums 1 KB rows instead of re-reading 4 KB of keys per chunk.
     uint32_t digit_mask;
     uint32_t digit_shift;            // 0: the LSD sort's lowest digit; the MSD-first sort counts its TOP digit (key >> shift)
+    uint32_t hist_words;             // words per chunk row: 256 (512 bins: the LSD sort's digits) or 512 (1024 bins: the
+                                     // MSD-first sort's 10-bit top digit)
 };
-constexpr int PRE_HIST_BINS = 1 << 9;   // RADIX_BITS_MAX bins
+constexpr int MSD_TOP_BITS = 10;              // top digit of the MSD-first sorts: 1024 buckets
+constexpr int PRE_HIST_BINS = 1 << MSD_TOP_BITS;
 
 // this workgroup's share of the per-frame clear job
 __device__ __forceinline__ void pre_begin(const PreOut &io) {
@@ -857,8 +864,12 @@ __device__ __forceinline__ void pre_finish(const PreOut &io, uint32_t block, uin
         io.chunk_vis[block] = (s_red[4] + s_red[5]) + (s_red[6] + s_red[7]);
     }
     // the chunk's digit histogram (every LDS atomic of the workgroup is behind the barrier above): 1 KB, coalesced
-    static_assert(PRE_HIST_BINS == 2 * PP_THREADS, "two bins per thread");
-    io.chunk_hist[(uint64_t)block * PP_THREADS + threadIdx.x] = s_dhist[2u * threadIdx.x] | (s_dhist[2u * threadIdx.x + 1u] << 16);
+    static_assert(PRE_HIST_BINS == 4 * PP_THREADS, "up to two words = four bins per thread");
+    io.chunk_hist[(uint64_t)block * io.hist_words + threadIdx.x] = s_dhist[2u * threadIdx.x] | (s_dhist[2u * threadIdx.x + 1u] << 16);
+    if (io.hist_words > (uint32_t)PP_THREADS) {
+        const uint32_t t = threadIdx.x + PP_THREADS;
+        io.chunk_hist[(uint64_t)block * io.hist_words + t] = s_dhist[2u * t] | (s_dhist[2u * t + 1u] << 16);
+    }
 }
 
 // whole block provably invisible: nothing is read, nothing is written but the two chunk scalars
@@ -1490,31 +1501,39 @@ template <int RB, int ITEMS>
 __global__ __launch_bounds__(SORT_THREADS) void k_sort_hist_chunks(const uint32_t *__restrict__ chunk_hist, SortCount sc,
                                                                    uint32_t digit_mask, uint32_t *__restrict__ ghist,
                                                                    const uint32_t *__restrict__ chunk_vis, uint32_t num_blocks,
-                                                                   uint32_t xcd_chunk) {
+                                                                   uint32_t xcd_chunk, uint32_t hist_words) {
     constexpr uint32_t TILE = SORT_THREADS * ITEMS;
     constexpr uint32_t C = TILE / PP_CHUNK;
     constexpr uint32_t R = 1u << RB;
+    constexpr uint32_t WPT = R > 2u * SORT_THREADS ? R / (2u * SORT_THREADS) : 1u;   // words of a chunk's row per thread (2 bins each)
     static_assert(TILE % PP_CHUNK == 0 && SORT_THREADS == PP_THREADS && R <= (uint32_t)PRE_HIST_BINS, "whole chunks per tile");
     const uint32_t count = sc.get();
     const uint32_t block = scatter_tile_of(blockIdx.x, xcd_chunk);
     if ((uint64_t)block * TILE >= count) return;
     const uint32_t chunk0 = block * C;
     const uint32_t live = (uint32_t)(((uint64_t)count - (uint64_t)block * TILE + PP_CHUNK - 1) / PP_CHUNK);   // chunks of this tile that hold slots
-    uint32_t w[C];
+    uint32_t w[WPT][C];
     bool ok[C];
 #pragma unroll
     for (uint32_t c = 0; c < C; c++) ok[c] = c < live && chunk_vis[chunk0 + (c < live ? c : 0u)] != 0u;
 #pragma unroll
-    for (uint32_t c = 0; c < C; c++) w[c] = chunk_hist[(uint64_t)(chunk0 + (ok[c] ? c : 0u)) * SORT_THREADS + threadIdx.x];
-    uint32_t lo = 0, hi = 0;
+    for (uint32_t q = 0; q < WPT; q++)
 #pragma unroll
-    for (uint32_t c = 0; c < C; c++) {
-        lo += ok[c] ? w[c] & 0xffffu : 0u;
-        hi += ok[c] ? w[c] >> 16 : 0u;
-    }
-    if (2u * threadIdx.x <= digit_mask) {     // live rows only (k_sort_hist); the mask is 2^b - 1: row 2t + 1 is live with row 2t
-        ghist[(uint64_t)(2u * threadIdx.x) * num_blocks + block] = lo;
-        if (digit_mask) ghist[(uint64_t)(2u * threadIdx.x + 1u) * num_blocks + block] = hi;
+        for (uint32_t c = 0; c < C; c++)
+            w[q][c] = chunk_hist[(uint64_t)(chunk0 + (ok[c] ? c : 0u)) * hist_words + q * SORT_THREADS + threadIdx.x];
+#pragma unroll
+    for (uint32_t q = 0; q < WPT; q++) {
+        uint32_t lo = 0, hi = 0;
+#pragma unroll
+        for (uint32_t c = 0; c < C; c++) {
+            lo += ok[c] ? w[q][c] & 0xffffu : 0u;
+            hi += ok[c] ? w[q][c] >> 16 : 0u;
+        }
+        const uint32_t d = 2u * (q * SORT_THREADS + threadIdx.x);
+        if (d <= digit_mask) {     // live rows only (k_sort_hist); the mask is 2^b - 1: row d + 1 is live with row d
+            ghist[(uint64_t)d * num_blocks + block] = lo;
+            if (digit_mask) ghist[(uint64_t)(d + 1u) * num_blocks + block] = hi;
+        }
     }
 }
 
@@ -1912,7 +1931,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
 // ---------------------------------------------------------------------------------------------
 // Bucket sort: the second half of an MSD-first sort (round 5).  A scatter pass on the TOP digit (its
 // histogram comes for free: the preprocess kernel / k_pairs_emit count it while the keys sit in
-// registers) leaves the elements partitioned into at most 512 buckets, each contiguous and in input
+// registers) leaves the elements partitioned into at most 1024 buckets, each contiguous and in input
 // order; one 1024-thread workgroup per bucket then sorts its bucket on the remaining low bits
 // entirely on the CU — keys and values in registers, one returning LDS atomic per key and pass for
 // the rank (as in scatter_ranked), one exchange through LDS per pass — and writes the final order.
@@ -1926,15 +1945,36 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
 // notice, one or two frames later (FrameResult::depth_bucket_max), and goes back to the LSD passes
 // while buckets do not fit.
 // ---------------------------------------------------------------------------------------------
-constexpr int BKT_THREADS = 1024;
-constexpr int BKT_WAVES = BKT_THREADS / WAVE;
-constexpr int BKT_ITEMS_MAX = 30;
-constexpr uint32_t BKT_CAP = (uint32_t)BKT_THREADS * BKT_ITEMS_MAX;   // elements of the register path
-constexpr int BKT_CHUNK_ITEMS = 16;                                     // chunked path: 16 384 elements per step
+// Diagnostic build only (tools/mb/mb_bucket.hip defines GS3D_BKT_STAMPS): s_memrealtime (100 MHz) at the phase boundaries of the
+// register path, written by thread 0 of every bucket to a buffer nothing else reads.  Absent from the product.
+#ifdef GS3D_BKT_STAMPS
+#define GS_BKT_STAMP(io, bucket, i)                                                                  \
+    do {                                                                                              \
+        if (threadIdx.x == 0u && (io).stamps) (io).stamps[(bucket) * 16u + (i)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#else
+#define GS_BKT_STAMP(io, bucket, i) do { } while (0)
+#endif
+
+// Two workgroup shapes (template parameter T = threads).  T = 1024, 30 keys per lane: few, large buckets — the depth
+// sort, where the largest bucket is the critical path and wants a whole CU.  T = 256, 32 keys per lane: many small
+// buckets — the tile sort's ~1000 buckets of a few thousand pairs, where a workgroup's fixed costs (clearing and
+// scanning its counters, barriers) dominate and four workgroups per CU hide them (33 KB of LDS instead of 157).
+constexpr int BKT_THREADS = 1024;          // the large shape: gs_sort_info::bucket_capacity refers to it
+constexpr int BKT_THREADS_SMALL = 256;
+template <int T> struct BucketCfg {
+    static_assert(T == 1024 || T == 256, "workgroup shapes of k_bucket_sort");
+    static constexpr int THREADS = T, WAVES = T / WAVE;
+    static constexpr int ITEMS_MAX = T == 1024 ? 30 : 32;
+    static constexpr uint32_t CAP = (uint32_t)T * ITEMS_MAX;      // elements of the register path
+    static constexpr int CHUNK_ITEMS = 16;                         // chunked path: 16 T elements per step
+};
+constexpr uint32_t BKT_CAP = BucketCfg<BKT_THREADS>::CAP;
+constexpr uint32_t BKT_CAP_SMALL = BucketCfg<BKT_THREADS_SMALL>::CAP;
 
 struct BucketSortIO {
     const uint32_t *totals;     // [nb] bucket sizes = digit totals of the scatter pass that made the buckets
-    uint32_t nb;                // buckets (<= BKT_THREADS) = grid size
+    uint32_t nb;                // buckets (<= BKT_THREADS = 1024: the 10-bit top digit) = grid size
     const void *keys_in;        // [count] keys after the top-digit scatter (u32, or u16 tile ids)
     const uint32_t *vals_in;
     void *keys_tmp;             // scratch of the chunked path when two passes are left (in -> tmp -> out)
@@ -1947,27 +1987,31 @@ struct BucketSortIO {
     uint32_t num_tiles;
     uint32_t *rank_fault;       // may be null: watchdog word of the LDS-atomic rank (FrameState::rank_fault, [1] = test hook)
     uint32_t watch;             // which (bucket, round) the watchdog samples this frame (frame generation)
+#ifdef GS3D_BKT_STAMPS
+    unsigned long long *stamps; // [nb][16]
+#endif
 };
 
-template <int RB>
+template <int RB, int T>
 struct BucketShared {
     static constexpr int R = 1 << RB;
-    uint32_t wave_hist[BKT_WAVES][R];   // per-wave digit counters, then each wave's base per digit
-    uint32_t xbuf[BKT_CAP];             // exchange buffer of the register path
-    uint32_t dbase[R];                  // chunked path: running output offset of every digit
-    uint32_t scan[BKT_WAVES];
+    uint32_t wave_hist[BucketCfg<T>::WAVES][R];   // per-wave digit counters, then each wave's base per digit
+    uint32_t xbuf[BucketCfg<T>::CAP];             // exchange buffer of the register path
+    uint32_t dbase[R];                            // chunked path: running output offset of every digit
+    uint32_t scan[BucketCfg<T>::WAVES];
     uint32_t bcast[4];
 };
 
-// exclusive scan over the 1024 threads of a bucket workgroup; ends with `smem` reusable
-__device__ __forceinline__ uint32_t block_exclusive_scan_1024(uint32_t v, uint32_t *smem, uint32_t &total) {
+// exclusive scan over the T threads of a bucket workgroup; ends with `smem` reusable
+template <int T>
+__device__ __forceinline__ uint32_t block_exclusive_scan_t(uint32_t v, uint32_t *smem, uint32_t &total) {
     const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
     const uint32_t inc = wave_inclusive_scan(v, lane);
     if (lane == 63u) smem[wid] = inc;
     __syncthreads();
     uint32_t wave_off = 0, tot = 0;
 #pragma unroll
-    for (uint32_t k = 0; k < (uint32_t)BKT_WAVES; k++) {
+    for (uint32_t k = 0; k < (uint32_t)(T / WAVE); k++) {
         const uint32_t x = smem[k];
         if (k < wid) wave_off += x;
         tot += x;
@@ -2043,15 +2087,16 @@ __device__ __forceinline__ void bucket_ranges(const BucketSortIO &io, uint32_t b
 // counts of the 16 waves -> every wave's base per digit (in place); returns through `base` / `tot` the digit's
 // offset inside the bucket's order of this pass and its count, for the thread that owns the digit (tid < R);
 // `dbase` (chunked path): running offsets carried from chunk to chunk instead of a scan.  Barriers inside.
-template <int RB, bool RUNNING>
-__device__ __forceinline__ void bucket_wave_bases(BucketShared<RB> &sh, uint32_t &base, uint32_t &tot) {
-    constexpr int R = 1 << RB;
+template <int RB, int T, bool RUNNING>
+__device__ __forceinline__ void bucket_wave_bases(BucketShared<RB, T> &sh, uint32_t &base, uint32_t &tot) {
+    constexpr int R = 1 << RB, WAVES = BucketCfg<T>::WAVES;
+    static_assert(R <= T, "one thread per digit");
     const uint32_t tid = threadIdx.x;
-    uint32_t c[BKT_WAVES];
+    uint32_t c[WAVES];
     tot = 0;
     if (tid < (uint32_t)R) {
 #pragma unroll
-        for (int w = 0; w < BKT_WAVES; w++) {
+        for (int w = 0; w < WAVES; w++) {
             c[w] = sh.wave_hist[w][tid];
             tot += c[w];
         }
@@ -2060,12 +2105,12 @@ __device__ __forceinline__ void bucket_wave_bases(BucketShared<RB> &sh, uint32_t
         base = tid < (uint32_t)R ? sh.dbase[tid] : 0u;
     } else {
         uint32_t all;
-        base = block_exclusive_scan_1024(tid < (uint32_t)R ? tot : 0u, sh.scan, all);
+        base = block_exclusive_scan_t<T>(tid < (uint32_t)R ? tot : 0u, sh.scan, all);
     }
     if (tid < (uint32_t)R) {
         uint32_t run = base;
 #pragma unroll
-        for (int w = 0; w < BKT_WAVES; w++) {
+        for (int w = 0; w < WAVES; w++) {
             sh.wave_hist[w][tid] = run;
             run += c[w];
         }
@@ -2081,11 +2126,11 @@ __device__ __forceinline__ void bucket_wave_bases(BucketShared<RB> &sh, uint32_t
 // them).  Pass 1 of 2 drops the digit it has sorted and packs (next digit << 15 | position) into one word — a
 // position needs 15 bits, BKT_CAP <= 2^15 — so a lane holds ITEMS keys and ITEMS ranks and nothing else (with the
 // values in registers too the 28-item instantiation spilled 4.6 KB per lane), and a pass is ONE exchange through LDS.
-template <typename K, int RB, int ITEMS, bool FAST_RANK>
-__device__ __forceinline__ void bucket_sort_fast(BucketShared<RB> &sh, const BucketSortIO &io, uint32_t bucket,
+template <typename K, int RB, int T, int ITEMS, bool FAST_RANK>
+__device__ __forceinline__ void bucket_sort_fast(BucketShared<RB, T> &sh, const BucketSortIO &io, uint32_t bucket,
                                                  uint32_t start, uint32_t size, uint32_t *rank_fault) {
-    constexpr int R = 1 << RB;
-    static_assert(BKT_CAP <= (1u << 15) && RB + 15 <= 32, "(digit << 15 | position) in one word");
+    constexpr int R = 1 << RB, WAVES = BucketCfg<T>::WAVES;
+    static_assert(BucketCfg<T>::CAP <= (1u << 15) && RB + 15 <= 32, "(digit << 15 | position) in one word");
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
     const uint32_t wave_off = wid * (uint32_t)(ITEMS * WAVE);
     const uint32_t nlive = size > wave_off ? size - wave_off : 0u;     // live elements of this wave (the rest is padding)
@@ -2097,7 +2142,7 @@ __device__ __forceinline__ void bucket_sort_fast(BucketShared<RB> &sh, const Buc
     if (passes == 0u) {   // the top digit was the whole key: the bucket is in its final order
 #pragma unroll
         for (int k = 0; k < ITEMS; k++) {
-            const uint32_t i = k * BKT_THREADS + tid;
+            const uint32_t i = k * T + tid;
             if (i < size) {
                 vout[i] = vin[i];
                 if (kout) kout[i] = kin[i];
@@ -2107,18 +2152,23 @@ __device__ __forceinline__ void bucket_sort_fast(BucketShared<RB> &sh, const Buc
         return;
     }
     uint32_t key[ITEMS], rank[ITEMS];
+    GS_BKT_STAMP(io, bucket, 0);
     // (no branch around a load: a load behind a branch gets its own wait; element 0 exists, size > 0)
 #pragma unroll
     for (int k = 0; k < ITEMS; k++) key[k] = (uint32_t)kin[k * WAVE + lane < nlive ? wave_off + k * WAVE + lane : 0u];
     // one counting pass over the registers: ranks, wave bases, final place of every element in `rank`
-    auto pass = [&](uint32_t shift, uint32_t mask, bool ranges) {
+    auto pass = [&](uint32_t shift, uint32_t mask, bool ranges, uint32_t stamp0) {
+        (void)stamp0;
 #pragma unroll
-        for (int q = 0; q < BKT_WAVES * R / BKT_THREADS; q++) (&sh.wave_hist[0][0])[tid + q * BKT_THREADS] = 0u;
+        for (int q = 0; q < WAVES * R / T; q++) (&sh.wave_hist[0][0])[tid + q * T] = 0u;
         __syncthreads();
+        GS_BKT_STAMP(io, bucket, stamp0);
         bucket_rank<RB, ITEMS, FAST_RANK>(sh.wave_hist[wid], key, shift, mask, nlive, rank, rank_fault);
         __syncthreads();
+        GS_BKT_STAMP(io, bucket, stamp0 + 1u);
         uint32_t base, tot;
-        bucket_wave_bases<RB, false>(sh, base, tot);
+        bucket_wave_bases<RB, T, false>(sh, base, tot);
+        GS_BKT_STAMP(io, bucket, stamp0 + 2u);
         if (ranges && tid < (uint32_t)R) bucket_ranges(io, bucket, start, tid, base, tot);
         // all LDS reads of the batch first, then what depends on them (scatter_ranked's note on hipcc's chains)
 #pragma unroll
@@ -2126,42 +2176,73 @@ __device__ __forceinline__ void bucket_sort_fast(BucketShared<RB> &sh, const Buc
         __builtin_amdgcn_sched_barrier(0);
     };
     const uint32_t bits1 = bucket_pass_bits(io.low_bits, 0u, passes, 0u), bits2 = io.low_bits - bits1;
-    pass(0u, (1u << bits1) - 1u, passes == 1u && io.ranges != nullptr);     // (ranges: the tile sort, one pass by contract)
+    pass(0u, (1u << bits1) - 1u, passes == 1u && io.ranges != nullptr, 1u);     // (ranges: the tile sort, one pass by contract)
     // what an element still needs: its position in the input bucket and, if a pass follows, that pass's digit
     const uint32_t mask2 = (1u << bits2) - 1u;
 #pragma unroll
     for (int k = 0; k < ITEMS; k++)
         if (k * WAVE + lane < nlive) sh.xbuf[rank[k]] = (((key[k] >> bits1) & mask2) << 15) | (wave_off + k * WAVE + lane);
     __syncthreads();
+    GS_BKT_STAMP(io, bucket, 4);
     if (passes == 2u) {
 #pragma unroll
         for (int k = 0; k < ITEMS; k++) key[k] = sh.xbuf[k * WAVE + lane < nlive ? wave_off + k * WAVE + lane : 0u];
         __syncthreads();
-        pass(15u, mask2, false);
+        pass(15u, mask2, false, 5u);
 #pragma unroll
         for (int k = 0; k < ITEMS; k++)
             if (k * WAVE + lane < nlive) sh.xbuf[rank[k]] = key[k];
         __syncthreads();
     }
-    // xbuf[i] (low 15 bits) = position in the INPUT bucket of the element that belongs at place i: gather
+    GS_BKT_STAMP(io, bucket, 8);
+    // xbuf[i] (low 15 bits) = position in the INPUT bucket of the element that belongs at place i.  The values follow
+    // through LDS: read coalesced, parked at their input positions, picked up by the sorted positions, written
+    // coalesced.  (Gathering them from global memory by position — 64 different sectors per wave instruction — made
+    // this kernel three times slower: 33 us for a 21 000-key bucket.)
 #pragma unroll
     for (int k = 0; k < ITEMS; k++) {
-        const uint32_t i = k * BKT_THREADS + tid;
+        const uint32_t i = k * T + tid;
         rank[k] = sh.xbuf[i < size ? i : 0u] & 0x7fffu;
     }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int k = 0; k < ITEMS; k++) key[k] = vin[rank[k]];
 #pragma unroll
     for (int k = 0; k < ITEMS; k++) {
-        const uint32_t i = k * BKT_THREADS + tid;
+        const uint32_t i = k * T + tid;
+        key[k] = vin[i < size ? i : 0u];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) {
+        const uint32_t i = k * T + tid;
+        if (i < size) sh.xbuf[i] = key[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) key[k] = sh.xbuf[rank[k]];
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) {
+        const uint32_t i = k * T + tid;
         if (i < size) vout[i] = key[k];
     }
-    if (kout) {
+    GS_BKT_STAMP(io, bucket, 9);
+    if (kout) {     // the sorted keys likewise (the tile sort: its parity tap rebuilds the 64-bit keys from them)
 #pragma unroll
         for (int k = 0; k < ITEMS; k++) {
-            const uint32_t i = k * BKT_THREADS + tid;
-            if (i < size) kout[i] = kin[rank[k]];
+            const uint32_t i = k * T + tid;
+            key[k] = (uint32_t)kin[i < size ? i : 0u];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < ITEMS; k++) {
+            const uint32_t i = k * T + tid;
+            if (i < size) sh.xbuf[i] = key[k];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < ITEMS; k++) key[k] = sh.xbuf[rank[k]];
+#pragma unroll
+        for (int k = 0; k < ITEMS; k++) {
+            const uint32_t i = k * T + tid;
+            if (i < size) kout[i] = (K)key[k];
         }
     }
 }
@@ -2170,17 +2251,17 @@ __device__ __forceinline__ void bucket_sort_fast(BucketShared<RB> &sh, const Buc
 // digits of the whole bucket, sweep 2 walks the bucket in order, 16 384 elements at a time, ranks each chunk like
 // the register path and writes every element to its final place of the pass (running per-digit offsets in LDS).
 // Slow — one CU's bandwidth, scattered stores — and only ever a fallback (see the section comment).
-template <typename K, int RB, bool FAST_RANK>
-__device__ __forceinline__ void bucket_sort_chunked(BucketShared<RB> &sh, const BucketSortIO &io, uint32_t bucket,
+template <typename K, int RB, int T, bool FAST_RANK>
+__device__ __forceinline__ void bucket_sort_chunked(BucketShared<RB, T> &sh, const BucketSortIO &io, uint32_t bucket,
                                                     uint32_t start, uint32_t size) {
-    constexpr int R = 1 << RB;
-    constexpr int ITEMS = BKT_CHUNK_ITEMS;
-    constexpr uint32_t CH = (uint32_t)BKT_THREADS * ITEMS;
+    constexpr int R = 1 << RB, WAVES = BucketCfg<T>::WAVES;
+    constexpr int ITEMS = BucketCfg<T>::CHUNK_ITEMS;
+    constexpr uint32_t CH = (uint32_t)T * ITEMS;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
     const uint32_t wave_off = wid * (uint32_t)(ITEMS * WAVE);
     const uint32_t passes = (io.low_bits + RB - 1) / RB;   // <= 2 (host)
     if (passes == 0u) {
-        for (uint32_t i = tid; i < size; i += BKT_THREADS) {
+        for (uint32_t i = tid; i < size; i += T) {
             io.vals_out[start + i] = io.vals_in[start + i];
             if (io.keys_out) ((K *)io.keys_out)[start + i] = ((const K *)io.keys_in)[start + i];
         }
@@ -2202,7 +2283,7 @@ __device__ __forceinline__ void bucket_sort_chunked(BucketShared<RB> &sh, const 
         for (uint32_t c0 = 0; c0 < size; c0 += CH) {
 #pragma unroll
             for (int k = 0; k < ITEMS; k++) {
-                const uint32_t e = c0 + k * BKT_THREADS + tid;
+                const uint32_t e = c0 + k * T + tid;
                 if (e < size) atomicAdd(&sh.dbase[((uint32_t)src_k[e] >> shift) & mask], 1u);
             }
         }
@@ -2210,7 +2291,7 @@ __device__ __forceinline__ void bucket_sort_chunked(BucketShared<RB> &sh, const 
         {
             const uint32_t tot = tid < (uint32_t)R ? sh.dbase[tid] : 0u;
             uint32_t all;
-            const uint32_t base = block_exclusive_scan_1024(tot, sh.scan, all);
+            const uint32_t base = block_exclusive_scan_t<T>(tot, sh.scan, all);
             if (tid < (uint32_t)R) {
                 sh.dbase[tid] = base;
                 if (last && io.ranges) bucket_ranges(io, bucket, start, tid, base, tot);
@@ -2220,7 +2301,7 @@ __device__ __forceinline__ void bucket_sort_chunked(BucketShared<RB> &sh, const 
         // sweep 2: stable placement, chunk by chunk
         for (uint32_t c0 = 0; c0 < size; c0 += CH) {
 #pragma unroll
-            for (int q = 0; q < BKT_WAVES * R / BKT_THREADS; q++) (&sh.wave_hist[0][0])[tid + q * BKT_THREADS] = 0u;
+            for (int q = 0; q < WAVES * R / T; q++) (&sh.wave_hist[0][0])[tid + q * T] = 0u;
             __syncthreads();
             const uint32_t w0 = c0 + wave_off;
             const uint32_t nlive = size > w0 ? size - w0 : 0u;
@@ -2235,7 +2316,7 @@ __device__ __forceinline__ void bucket_sort_chunked(BucketShared<RB> &sh, const 
             __syncthreads();
             {
                 uint32_t base, tot;
-                bucket_wave_bases<RB, true>(sh, base, tot);
+                bucket_wave_bases<RB, T, true>(sh, base, tot);
             }
 #pragma unroll
             for (int k = 0; k < ITEMS; k++) {
@@ -2252,29 +2333,49 @@ __device__ __forceinline__ void bucket_sort_chunked(BucketShared<RB> &sh, const 
     }
 }
 
-template <typename K, int RB, bool FAST_RANK>
-__global__ __launch_bounds__(BKT_THREADS) void k_bucket_sort(BucketSortIO io) {
-    static_assert(RB >= 6 && RB <= 9, "16 waves clear 16 x 2^RB counters with whole rounds of 1024 threads; 512 digit threads");
-    __shared__ BucketShared<RB> sh;
+template <typename K, int RB, int T, bool FAST_RANK>
+__global__ __launch_bounds__(T) void k_bucket_sort(BucketSortIO io) {
+    constexpr int WAVES = BucketCfg<T>::WAVES;
+    constexpr uint32_t PER = 1024u / (uint32_t)T;      // totals per thread: the top digit has at most 1024 values
+    static_assert(RB >= 6 && RB <= 9 && (WAVES << RB) % T == 0 && (1 << RB) <= T,
+                  "the waves' counters are cleared with whole rounds of T threads; one thread per digit");
+    __shared__ BucketShared<RB, T> sh;
     const uint32_t tid = threadIdx.x, bucket = blockIdx.x;
-    // bucket start = sum of the sizes in front of it; the same scan counts the non-empty buckets in front (high half)
-    const uint32_t t = tid < io.nb ? io.totals[tid] : 0u;
+    // bucket start = sum of the sizes in front of it; the same walk counts the non-empty buckets in front
+    uint32_t v[PER], mine = 0, mine_nz = 0;
+#pragma unroll
+    for (uint32_t q = 0; q < PER; q++) {
+        const uint32_t i = tid * PER + q;
+        v[q] = i < io.nb ? io.totals[i] : 0u;
+        mine += v[q];
+        mine_nz += v[q] != 0u ? 1u : 0u;
+    }
     uint32_t all, nz_all;
-    const uint32_t excl = block_exclusive_scan_1024(t, sh.scan, all);
-    const uint32_t nz_excl = block_exclusive_scan_1024(t != 0u ? 1u : 0u, sh.scan, nz_all);
-    if (tid == bucket) {
-        sh.bcast[0] = t;
-        sh.bcast[1] = excl;
-        sh.bcast[2] = nz_excl;
+    uint32_t excl = block_exclusive_scan_t<T>(mine, sh.scan, all);
+    uint32_t nz_excl = block_exclusive_scan_t<T>(mine_nz, sh.scan, nz_all);
+    if (tid == bucket / PER) {
+#pragma unroll
+        for (uint32_t q = 0; q < PER; q++) {
+            if (q == bucket % PER) {
+                sh.bcast[0] = v[q];
+                sh.bcast[1] = excl;
+                sh.bcast[2] = nz_excl;
+            }
+            excl += v[q];
+            nz_excl += v[q] != 0u ? 1u : 0u;
+        }
     }
     if (bucket == 0u && io.bucket_max) {
-        const uint32_t m = wave_reduce_max(t);
+        uint32_t m = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < PER; q++) m = v[q] > m ? v[q] : m;
+        m = wave_reduce_max(m);
         if ((tid & 63u) == 0u) sh.wave_hist[0][tid >> 6] = m;
         __syncthreads();
         if (tid == 0u) {
             uint32_t mm = 0;
 #pragma unroll
-            for (int w = 0; w < BKT_WAVES; w++) mm = sh.wave_hist[0][w] > mm ? sh.wave_hist[0][w] : mm;
+            for (int w = 0; w < WAVES; w++) mm = sh.wave_hist[0][w] > mm ? sh.wave_hist[0][w] : mm;
             *io.bucket_max = mm;
         }
     }
@@ -2284,11 +2385,11 @@ __global__ __launch_bounds__(BKT_THREADS) void k_bucket_sort(BucketSortIO io) {
     if (size == 0u) return;
     // the watchdog samples one NON-EMPTY bucket per frame, the next one every frame
     uint32_t *rf = io.rank_fault && nz_index == io.watch % nz_all ? io.rank_fault : (uint32_t *)nullptr;
-    if (size <= 4u * BKT_THREADS) bucket_sort_fast<K, RB, 4, FAST_RANK>(sh, io, bucket, start, size, rf);
-    else if (size <= 8u * BKT_THREADS) bucket_sort_fast<K, RB, 8, FAST_RANK>(sh, io, bucket, start, size, rf);
-    else if (size <= 16u * BKT_THREADS) bucket_sort_fast<K, RB, 16, FAST_RANK>(sh, io, bucket, start, size, rf);
-    else if (size <= BKT_CAP) bucket_sort_fast<K, RB, BKT_ITEMS_MAX, FAST_RANK>(sh, io, bucket, start, size, rf);
-    else bucket_sort_chunked<K, RB, FAST_RANK>(sh, io, bucket, start, size);
+    if (size <= 4u * T) bucket_sort_fast<K, RB, T, 4, FAST_RANK>(sh, io, bucket, start, size, rf);
+    else if (size <= 8u * T) bucket_sort_fast<K, RB, T, 8, FAST_RANK>(sh, io, bucket, start, size, rf);
+    else if (size <= 16u * T) bucket_sort_fast<K, RB, T, 16, FAST_RANK>(sh, io, bucket, start, size, rf);
+    else if (size <= BucketCfg<T>::CAP) bucket_sort_fast<K, RB, T, BucketCfg<T>::ITEMS_MAX, FAST_RANK>(sh, io, bucket, start, size, rf);
+    else bucket_sort_chunked<K, RB, T, FAST_RANK>(sh, io, bucket, start, size);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2438,7 +2539,7 @@ __global__ __launch_bounds__(EXP_SB) void k_pairs_cursors(ExpandIO io) {
         io.state->pairs = over ? io.capacity : (uint32_t)d;
         io.state->overflow = over ? 1u : 0u;
         publish_result(io.result, v_count, d, over | (io.state->rank_fault ? FRAME_FLAG_RANK_FAULT : 0u), io.gen, io.flags_dev,
-                           io.state->depth_bucket_max);
+                           io.state->depth_bucket_max, io.state->tile_bucket_max);
     }
     if (v == 0ull) return;
     const uint64_t p = s_before[0] + s_before[1] + (wid ? s_wave0 : 0ull) + incl - v;   // pairs in front of chunk c
@@ -2650,7 +2751,7 @@ __device__ __forceinline__ void pair_generate(const ExpandIO &io, uint32_t v_cou
 template <typename K, int RB, int ITEMS, bool RECT32 = false>
 __global__ __launch_bounds__(SORT_THREADS) void k_pairs_emit(ExpandIO io, uint32_t digit_mask,
                                                              uint32_t *__restrict__ ghist, K *__restrict__ tkeys,
-                                                             uint32_t num_blocks, uint32_t xcd_chunk) {
+                                                             uint32_t num_blocks, uint32_t xcd_chunk, uint32_t digit_shift) {
     constexpr uint32_t TILE = SORT_THREADS * ITEMS;
     constexpr uint32_t NSLOTS = ITEMS * WAVE;
     constexpr int R = 1 << RB;
@@ -2689,7 +2790,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_pairs_emit(ExpandIO io, uint32
             io.state->pairs = count;
             io.state->overflow = over ? 1u : 0u;
             publish_result(io.result, v_count, d, over | (io.state->rank_fault ? FRAME_FLAG_RANK_FAULT : 0u), io.gen, io.flags_dev,
-                           io.state->depth_bucket_max);
+                           io.state->depth_bucket_max, io.state->tile_bucket_max);
         }
     }
     if ((uint64_t)block * TILE >= count) return;      // the same D in every wave: block-uniform
@@ -2703,7 +2804,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_pairs_emit(ExpandIO io, uint32
         uint32_t *hist = s_hist[threadIdx.x & (uint32_t)(COPIES - 1)];
         PairGenShared<K, NSLOTS, RECT32> &sh = s_gen[wid];
         pair_generate<K, NSLOTS, RECT32>(io, v_count, o0, n_slots, cur, lane, sh,
-                         [&](uint32_t tile) { atomicAdd(&hist[tile & digit_mask], 1u); });
+                         [&](uint32_t tile) { atomicAdd(&hist[(tile >> digit_shift) & digit_mask], 1u); });
         // the wave's slots leave in whole 16-byte vectors (o0 is a multiple of NSLOTS: aligned)
         uint32_t *vout = io.tvals + o0;
         K *kout = tkeys + o0;

@@ -201,6 +201,7 @@ class FramePipeline:
         self.work = [None] * depth          # exchange in flight on each buffer
         self.frame = [None] * depth         # frame number each buffer holds
         self.reader = [None] * depth        # stream on which finish() / flags() last read each buffer
+        self.gathered = [None] * depth      # event recorded by the first stream that waited for the buffer's exchange
         self.submitted = [None] * depth     # event behind everything submit() enqueued on ITS stream (the render, and
                                             # — gloo rehearsals — the staged copies of the other ranks' bands)
 
@@ -211,6 +212,13 @@ class FramePipeline:
         if self.work[k] is not None:
             self.work[k].wait()             # stream-level: the current stream waits, the host does not
             self.work[k] = None
+            if self.bufs[k].device.type != "cpu":
+                # the handle is gone after this: a LATER reader on another stream (flags(i) here, finish(i) there)
+                # must still be ordered behind the collective, not just behind the render — it waits for this event
+                self.gathered[k] = self.torch.cuda.Event()
+                self.gathered[k].record(self.torch.cuda.current_stream())
+        elif self.gathered[k] is not None:
+            self.torch.cuda.current_stream().wait_event(self.gathered[k])     # (a no-op on the stream that recorded it)
         if self.submitted[k] is not None:
             self.torch.cuda.current_stream().wait_event(self.submitted[k])     # (a no-op on the stream that submitted)
 
@@ -243,6 +251,7 @@ class FramePipeline:
         assert self.frame[k] == i
         self.work[k] = gather_bands(self.dist, self.bufs[k], self.plan, self.rank, async_op=True, force=self.force)
         self.submitted[k] = None
+        self.gathered[k] = None
         if self.bufs[k].device.type != "cpu":
             self.submitted[k] = self.torch.cuda.Event()
             self.submitted[k].record(self.torch.cuda.current_stream())
