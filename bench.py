@@ -652,7 +652,7 @@ def compact_line(line, detail_path, limit=3900):
     c["value"], c["ms_per_step"] = _r(c["value"], 6), _r(c["ms_per_step"], 6)
     cfg = line["config"]
     c["config"] = {k: cfg[k] for k in ("workload", "gaussians", "visible", "pairs", "launches_per_frame", "parallelism",
-                                       "frames_in_flight") if k in cfg}
+                                       "frames_in_flight", "renderer_scratch_copies") if k in cfg}
     if line.get("frame_ms"):
         c["frame_ms_median"] = _r(line["frame_ms"]["median"])
     c["stages_ms"] = {k: _r(v, 4) for k, v in (line.get("stages_ms") or {}).items() if v}
@@ -890,7 +890,10 @@ def main():
         head_ms = fl["ms_per_step"] if fl else res["ms_per_frame"]
         value = wl["n"] / (head_ms * 1e-3) / 1e6
         line = {
-            "metric": "Msplats/s @1080p (Gaussians per second through proj+sort+blend)",
+            # what `value` times is in the metric's own name: with F > 1 frames in flight it is the THROUGHPUT of
+            # F renderers taking the frames in turn, not one frame at a time; `single_stream` beside it is the latter
+            "metric": "Msplats/s @1080p (Gaussians per second through proj+sort+blend%s)" % (
+                "; %d frames in flight on %d priority streams" % (fl["frames_in_flight"], fl["frames_in_flight"]) if fl and world == 1 else ""),
             "value": value,
             "unit": "Msplats/s",
             "n_gpus": world,
@@ -911,6 +914,8 @@ def main():
                        if world > 1 else ("single GPU, %d frames in flight on %d priority streams" % (
                            fl["frames_in_flight"], fl["frames_in_flight"]) if fl else "single GPU, one stream"),
                        "frames_in_flight": fl["frames_in_flight"] if fl else res.get("rank_lanes", 1),
+                       # every lane is a renderer of its own: per-slot outputs, sort and pair buffers once per lane
+                       "renderer_scratch_copies": fl["frames_in_flight"] if fl else res.get("rank_lanes", 1),
                        "image_checksum": res["checksum"]},
             "single_stream": {"ms_per_step": res["ms_per_frame"], "value": wl["n"] / (res["ms_per_frame"] * 1e-3) / 1e6,
                               "unit": "Msplats/s", "steady_state": res.get("steady_state"),

@@ -646,13 +646,20 @@ typedef struct gs_sort_info {
     uint32_t bucket_capacity;    /* elements a bucket may hold for the on-CU path (larger ones take a slow in-kernel fallback) */
     uint32_t tile_msd;           /* the same for the tile sort */
     uint32_t tile_bucket_max;
-    uint32_t reserved[3];
+    uint32_t tile_masks;         /* 1: the last frame dropped unreachable tiles from small rects (tile rect version 4), 0: version 3 */
+    uint32_t reserved[2];
 } gs_sort_info;
 gs_status gs_renderer_sort_info(gs_renderer *r, gs_sort_info *out);
 /* Pins the choice for the following frames: 1 MSD-first, 0 LSD passes, -1 the renderer chooses (default; the
  * environment variables GS3D_DEPTH_MSD / GS3D_TILE_MSD = 0 / 1 pin it for every renderer of the process).  A pinned
  * MSD-first sort stays correct whatever the bucket sizes (oversized buckets take the in-kernel fallback). */
 gs_status gs_renderer_set_sort_mode(gs_renderer *r, int32_t depth_msd, int32_t tile_msd);
+/* Tile rect version 4 (no reference item): rects of at most 3 x 3 tiles lose the tiles their splat cannot
+ * reach — 5 % fewer (tile, Gaussian) pairs, the same image.  The test costs the preprocess kernel ~120 instructions per
+ * Gaussian: hidden where that kernel waits for HBM, a net loss where it does not (50 M x 144 B: +3 %), so by default (-1)
+ * it is on for records of 200 bytes or more (f32 SH) in scenes beyond the 256 MiB Infinity Cache; 1 / 0 pin it
+ * (GS3D_TILE_MASKS=0/1 pins it for every renderer of the process). */
+gs_status gs_renderer_set_tile_masks(gs_renderer *r, int32_t mode);
 
 /* Parity taps on the last frame (blocking).  Sizes: N records / N counts; D keys / D indices;
  * tiles_x*tiles_y*2 ranges. */

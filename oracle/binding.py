@@ -117,9 +117,9 @@ def lib():
     L.gso_exp.restype = f32
     L.gso_exp.argtypes = [f32]
     L.gso_camera_look_at.argtypes = [vp, vp, vp, f32, u32, u32, f32, f32, vp]
-    L.gso_preprocess.argtypes = [i32, i32, vp, sz, vp, vp, vp, u32, u32, vp, vp]
+    L.gso_preprocess.argtypes = [i32, i32, vp, sz, vp, vp, vp, u32, u32, vp, vp, vp]
     L.gso_build_keys.restype = C.c_uint64
-    L.gso_build_keys.argtypes = [vp, vp, sz, u32, vp, vp]
+    L.gso_build_keys.argtypes = [vp, vp, vp, sz, u32, vp, vp]
     L.gso_sort_pairs.argtypes = [vp, vp, C.c_uint64]
     L.gso_tile_ranges.argtypes = [vp, C.c_uint64, u32, vp]
     L.gso_blend.argtypes = [vp, vp, vp, vp, u32, u32, vp]
@@ -132,7 +132,9 @@ def lib():
     L.gso_set_rect_version.argtypes = [i32]
     L.gso_rect_version.restype = i32
     # the product's A/B switch GS3D_RECT_V1=1 (spec version 1 of the tile rect) selects the matching oracle
-    L.gso_set_rect_version(1 if os.environ.get("GS3D_RECT_V1") == "1" else 3)
+    # the product's switches (tests run oracle and product under the same environment): GS3D_RECT_V1=1 keeps the
+    # radius square, GS3D_TILE_MASKS=0 stops at version 3 (no exact tile test for small rects)
+    L.gso_set_rect_version(1 if os.environ.get("GS3D_RECT_V1") == "1" else 3 if os.environ.get("GS3D_TILE_MASKS") == "0" else 4)
     _lib = L
     return L
 
@@ -214,15 +216,24 @@ def camera_look_at(eye, target, up, vfov_rad, width, height, near=0.1, far=100.0
     return cam
 
 
+class TilesTouched(np.ndarray):
+    """tiles touched per Gaussian (uint32) + `.rows`: the tile row codes of rect version 4 (uint16 per Gaussian, 0 =
+    the whole rect), which build_keys needs to enumerate the tiles that remain of a small rect"""
+
+    def __array_finalize__(self, obj):
+        self.rows = getattr(obj, "rows", None)
+
+
 def preprocess(sh, cov, pods, gt, mt, cam, band=None):
     pods = np.ascontiguousarray(pods, dtype=np.uint8)
     n = len(pods) // pod_size(sh, cov)
     tiles_y = (cam.height + 15) // 16
     b0, b1 = band if band is not None else (0, tiles_y)
     proj = np.zeros(n, dtype=PROJECTED_DTYPE)
-    tiles = np.zeros(n, dtype=np.uint32)
+    tiles = np.zeros(n, dtype=np.uint32).view(TilesTouched)
+    tiles.rows = np.zeros(n, dtype=np.uint16)
     lib().gso_preprocess(sh, cov, _p(pods), n, C.byref(gt), C.byref(mt), C.byref(cam), b0, b1,
-                         _p(proj), _p(tiles))
+                         _p(proj), _p(tiles), _p(tiles.rows))
     return proj, tiles
 
 
@@ -243,11 +254,17 @@ def build_keys(proj, tiles, tiles_x, order=None):
     idx = np.zeros(max(d, 1), dtype=np.uint32)
     fn = lib().gso_build_keys_ordered
     fn.restype = C.c_uint64
-    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
     if order is not None:
         order = np.ascontiguousarray(order, dtype=np.uint32)
         assert len(order) == len(proj)
-    d2 = fn(_p(proj), _p(tiles), len(proj), tiles_x, _p(keys), _p(idx), _p(order) if order is not None else None)
+    rows = getattr(tiles, "rows", None)
+    if rows is not None:
+        rows = np.ascontiguousarray(rows, dtype=np.uint16)
+        assert len(rows) == len(proj)
+    tiles = np.ascontiguousarray(tiles, dtype=np.uint32)
+    d2 = fn(_p(proj), _p(tiles), _p(rows) if rows is not None else None, len(proj), tiles_x, _p(keys), _p(idx),
+            _p(order) if order is not None else None)
     assert d2 == d
     return keys[:d], idx[:d]
 

@@ -728,8 +728,11 @@ static inline float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, 
 /* version of the tile-rect definition.  1 = the radius square; 2 (default) = the
  * radius square clipped, in display mode Splat, to the bounding box of the region where the splat can
  * reach alpha >= 1/255.  Both versions produce the same image: version 2 only drops (tile, Gaussian)
- * pairs that contribute to no pixel.  Version 1 is kept so that the version-1 goldens stay checkable. */
-static int g_rect_version = 3;
+ * pairs that contribute to no pixel.  Version 1 is kept so that the version-1 goldens stay checkable.
+ * Version 3 guards the clip against the blend's own rounding.  Version 4 (round 5) adds the exact tile test for
+ * rects of at most 3 x 3 tiles: tiles whose pixel-centre box the region {power >= -(ln k + 0.1)} does not reach are
+ * dropped from the rect (a per-Gaussian row code says which remain).  Every version produces the same image. */
+static int g_rect_version = 4;
 void gso_set_rect_version(int v) { g_rect_version = v; }
 int gso_rect_version(void) { return g_rect_version; }
 
@@ -783,6 +786,7 @@ typedef struct {
     int no_sh0;
     int clip_rect; /* DESIGN.md §3.3, second step of the rect (display mode Splat only) */
     int clip_guard; /* version 3: no clip where the blend's own rounding error could exceed half the head room */
+    int tile_masks; /* version 4: exact tile test for rects of at most 3 x 3 tiles */
 } frame_consts;
 
 static void make_frame_consts(const gso_gaussian_transform *gt, const gso_model_transform *mt,
@@ -810,12 +814,61 @@ static void make_frame_consts(const gso_gaussian_transform *gt, const gso_model_
     fc->no_sh0 = (int)gso_transform_no_sh0(flags);
     fc->clip_rect = gso_transform_display_mode(flags) == 0u && g_rect_version >= 2;
     fc->clip_guard = g_rect_version >= 3;
+    fc->tile_masks = g_rect_version >= 4;
+}
+
+/* DESIGN.md §3.3, third step (version 4).  Maximum over t in [lo, hi] of the concave parabola q2 t^2 + q1 t + q0 whose
+ * vertex the caller hands in as `tv` (= -q1 / (2 q2), computed as ratio * d: ONE division per Gaussian and direction). */
+static inline float parabola_max(float q2, float q1, float q0, float tv, float lo, float hi) {
+    float t = clampf(tv, lo, hi);
+    return (q2 * t + q1) * t + q0;
+}
+
+/* Can the corner tile (tx, ty) of a small rect be dropped?  power(d) = qa dx^2 + qb dx dy + qc dy^2, d = mean - pixel, is
+ * concave with its maximum 0 at the mean.  Only a box that lies diagonally off the mean (the mean's x outside its x range
+ * AND the mean's y outside its y range) is examined: there the maximum over the box sits on the two edges that face the
+ * mean (moving from any point of the box towards the mean never lowers a concave function that peaks at the mean), one
+ * clamped parabola each; the tile goes iff both stay below nlim.  Every other tile is kept without a look (keeping a
+ * tile is always safe).  NaN: kept. */
+static int corner_dropped(float mx, float my, float qa, float qb, float qc, float ry, float rx, uint32_t tx, uint32_t ty,
+                          float nlim) {
+    float x0 = (float)(16u * tx) + 0.5f, y0 = (float)(16u * ty) + 0.5f;
+    float dxl = mx - (x0 + 15.0f), dxh = mx - x0, dyl = my - (y0 + 15.0f), dyh = my - y0;
+    int in_x = dxl <= 0.0f && dxh >= 0.0f, in_y = dyl <= 0.0f && dyh >= 0.0f;
+    if (in_x || in_y) return 0;
+    float dx = dxh < 0.0f ? dxh : dxl, dy = dyh < 0.0f ? dyh : dyl;
+    float m0 = parabola_max(qc, qb * dx, (qa * dx) * dx, ry * dx, dyl, dyh);
+    float m1 = parabola_max(qa, qb * dy, (qc * dy) * dy, rx * dy, dxl, dxh);
+    return fmaxf(m0, m1) < nlim;
+}
+
+/* Row code of a rect of w x h tiles, 2 <= w, h <= 3, whose CORNER tiles may go: 4 bits per row, (first kept column) |
+ * (kept columns) << 2; returns the number of tiles kept. */
+static uint32_t tile_rows(float mx, float my, float qa, float qb, float qc, uint32_t tx0, uint32_t ty0, uint32_t w,
+                          uint32_t h, float nlim, uint32_t *code_out) {
+    /* along the edge dx = const the exponent peaks at dy = ry dx, along dy = const at dx = rx dy */
+    const float ry = (-0.5f * qb) / qc, rx = (-0.5f * qb) / qa;
+    uint32_t code = 0, count = 0;
+    for (uint32_t j = 0; j < h; j++) {
+        uint32_t first = 0, last = w - 1u;
+        if (j == 0u || j == h - 1u) {
+            if (corner_dropped(mx, my, qa, qb, qc, ry, rx, tx0, ty0 + j, nlim)) first = 1u;
+            if (corner_dropped(mx, my, qa, qb, qc, ry, rx, tx0 + w - 1u, ty0 + j, nlim)) last = w - 2u;
+        }
+        uint32_t cnt = last + 1u > first ? last + 1u - first : 0u;      /* (w = 2 with both corners gone: an empty row) */
+        if (!cnt) first = 0u;
+        code |= (first | (cnt << 2)) << (4u * j);
+        count += cnt;
+    }
+    *code_out = code;
+    return count;
 }
 
 /* DESIGN.md §3.3. Returns tiles touched (0 = culled). */
 static uint32_t project_one(int sh, int cov, const uint8_t *pod, const frame_consts *fc,
                             const gso_camera *cam, uint32_t tiles_x, uint32_t band_ty0,
-                            uint32_t band_ty1, gso_projected *out) {
+                            uint32_t band_ty1, gso_projected *out, uint16_t *rows_out) {
+    *rows_out = 0;
     float p[3] = {ld_f32(pod), ld_f32(pod + 4), ld_f32(pod + 8)};
     float pw[4], t[4];
     mat4_mul_point(fc->M, p, pw);
@@ -864,6 +917,8 @@ static uint32_t project_one(int sh, int cov, const uint8_t *pod, const frame_con
     float fy1 = clampf(floorf((my + radius) * 0.0625f) + 1.0f, lo_y, hi_y);
     /* the record's quadratic form: power(dx, dy) = qa dx^2 + qb dx dy + qc dy^2 */
     float qa = -0.5f * (cc * inv), qb = cb * inv, qc = -0.5f * (ca * inv);
+    int masks_ok = 0;
+    float mask_lim = 0.0f;
     if (fc->clip_rect) {
         /* DESIGN.md §3.3, second step: bounding box of {power >= -(ln k + 0.1)}; tile t holds the
          * pixel centres 16 t + 0.5 ... 16 t + 15.5; a NaN extent leaves the rect as it is */
@@ -885,10 +940,28 @@ static uint32_t project_one(int sh, int cov, const uint8_t *pod, const frame_con
             fx1 = fminf(fx1, floorf(((mx + ex) - 0.5f) * 0.0625f) + 1.0f);
             fy0 = fmaxf(fy0, floorf(((my - ey) - 15.5f) * 0.0625f) + 1.0f);
             fy1 = fminf(fy1, floorf(((my + ey) - 0.5f) * 0.0625f) + 1.0f);
+            /* version 4: the tile test evaluates `power` itself, so it claims only half of what is left of the
+             * head room: E <= 0.025 (a NaN E: no test) */
+            if (fc->tile_masks && fc->clip_guard && err <= 0.025f) {
+                masks_ok = 1;
+                mask_lim = lim;
+            }
         }
     }
     if (!(fx1 > fx0) || !(fy1 > fy0)) return 0;
     uint32_t tx0 = (uint32_t)fx0, tx1 = (uint32_t)fx1, ty0 = (uint32_t)fy0, ty1 = (uint32_t)fy1;
+    uint32_t count = (tx1 - tx0) * (ty1 - ty0);
+    if (masks_ok && tx1 - tx0 >= 2u && tx1 - tx0 <= 3u && ty1 - ty0 >= 2u && ty1 - ty0 <= 3u) {
+        /* version 4: the corner tiles of a small rect that the clip region does not reach are dropped; a rect that keeps
+         * all of its tiles stays a plain rect (row code 0), one that keeps none is culled */
+        uint32_t code;
+        uint32_t kept = tile_rows(mx, my, qa, qb, qc, tx0, ty0, tx1 - tx0, ty1 - ty0, -mask_lim, &code);
+        if (kept == 0u) return 0;
+        if (kept != count) {
+            count = kept;
+            *rows_out = (uint16_t)(0x8000u | code);
+        }
+    }
 
     /* colour (x1): direction in model space */
     float dw[3] = {pw[0] - cam->pos[0], pw[1] - cam->pos[1], pw[2] - cam->pos[2]};
@@ -916,12 +989,12 @@ static uint32_t project_one(int sh, int cov, const uint8_t *pod, const frame_con
     out->ty0 = (uint16_t)ty0;
     out->tx1 = (uint16_t)tx1;
     out->ty1 = (uint16_t)ty1;
-    return (tx1 - tx0) * (ty1 - ty0);
+    return count;
 }
 
 void gso_preprocess(int sh, int cov, const void *pods, size_t n, const gso_gaussian_transform *gt,
                     const gso_model_transform *mt, const gso_camera *cam, uint32_t band_ty0,
-                    uint32_t band_ty1, gso_projected *proj, uint32_t *tiles_touched) {
+                    uint32_t band_ty1, gso_projected *proj, uint32_t *tiles_touched, uint16_t *tile_rows_out) {
     frame_consts fc;
     make_frame_consts(gt, mt, cam, &fc);
     size_t stride = gso_pod_size(sh, cov);
@@ -931,11 +1004,13 @@ void gso_preprocess(int sh, int cov, const void *pods, size_t n, const gso_gauss
     for (long i = 0; i < (long)n; i++) {
         gso_projected rec;
         memset(&rec, 0, sizeof(rec));
+        uint16_t rows = 0;
         uint32_t cnt = project_one(sh, cov, base + (size_t)i * stride, &fc, cam, tiles_x, band_ty0,
-                                   band_ty1, &rec);
+                                   band_ty1, &rec, &rows);
         if (!cnt) memset(&rec, 0, sizeof(rec));
         proj[i] = rec;
         tiles_touched[i] = cnt;
+        if (tile_rows_out) tile_rows_out[i] = cnt ? rows : 0;
     }
 }
 
@@ -943,8 +1018,8 @@ void gso_preprocess(int sh, int cov, const void *pods, size_t n, const gso_gauss
 /* pairs are emitted in the buffer's mirror order (`order[slot]` = Gaussian index;
  * NULL = index order), and the sort is stable, so pairs with exactly equal (tile, depth) keys keep
  * that order. */
-uint64_t gso_build_keys_ordered(const gso_projected *proj, const uint32_t *tiles_touched, size_t n,
-                                uint32_t tiles_x, uint64_t *keys, uint32_t *idx, const uint32_t *order) {
+uint64_t gso_build_keys_ordered(const gso_projected *proj, const uint32_t *tiles_touched, const uint16_t *tile_rows_in,
+                                size_t n, uint32_t tiles_x, uint64_t *keys, uint32_t *idx, const uint32_t *order) {
     if (!keys) {   /* count only */
         uint64_t d = 0;
         for (size_t i = 0; i < n; i++) d += tiles_touched[i];
@@ -966,20 +1041,34 @@ uint64_t gso_build_keys_ordered(const gso_projected *proj, const uint32_t *tiles
         const gso_projected *p = &proj[i];
         uint32_t depth_bits = f2u(p->depth);
         uint64_t o = off[slot];
-        for (uint32_t ty = p->ty0; ty < p->ty1; ty++)
-            for (uint32_t tx = p->tx0; tx < p->tx1; tx++) {
-                keys[o] = ((uint64_t)(ty * tiles_x + tx) << 32) | depth_bits;
-                idx[o] = (uint32_t)i;
-                o++;
+        const uint32_t rows = tile_rows_in ? tile_rows_in[i] : 0u;
+        if (rows & 0x8000u) {
+            /* version 4: a small rect with dropped tiles — per row the columns [first, first + cnt) */
+            for (uint32_t j = 0; j < (uint32_t)(p->ty1 - p->ty0); j++) {
+                const uint32_t first = (rows >> (4u * j)) & 3u, cnt = (rows >> (4u * j + 2u)) & 3u;
+                for (uint32_t c = 0; c < cnt; c++) {
+                    keys[o] = ((uint64_t)((p->ty0 + j) * tiles_x + p->tx0 + first + c) << 32) | depth_bits;
+                    idx[o] = (uint32_t)i;
+                    o++;
+                }
             }
+        } else {
+            for (uint32_t ty = p->ty0; ty < p->ty1; ty++)
+                for (uint32_t tx = p->tx0; tx < p->tx1; tx++) {
+                    keys[o] = ((uint64_t)(ty * tiles_x + tx) << 32) | depth_bits;
+                    idx[o] = (uint32_t)i;
+                    o++;
+                }
+        }
+        if (o != off[slot + 1]) abort();   /* tiles_touched and the row code disagree */
     }
     free(off);
     return d;
 }
 
-uint64_t gso_build_keys(const gso_projected *proj, const uint32_t *tiles_touched, size_t n,
+uint64_t gso_build_keys(const gso_projected *proj, const uint32_t *tiles_touched, const uint16_t *tile_rows_in, size_t n,
                         uint32_t tiles_x, uint64_t *keys, uint32_t *idx) {
-    return gso_build_keys_ordered(proj, tiles_touched, n, tiles_x, keys, idx, NULL);
+    return gso_build_keys_ordered(proj, tiles_touched, tile_rows_in, n, tiles_x, keys, idx, NULL);
 }
 
 /* DESIGN.md §3.4a — the spatial mirror order: 30-bit Morton code of the position quantised to 10
@@ -1196,15 +1285,16 @@ uint64_t gso_render_ordered(int sh, int cov, const void *pods, size_t n, const g
     uint32_t tiles_x = (cam->width + 15u) / 16u, tiles_y = (cam->height + 15u) / 16u;
     gso_projected *proj = (gso_projected *)malloc((n ? n : 1) * sizeof(gso_projected));
     uint32_t *tt = (uint32_t *)malloc((n ? n : 1) * sizeof(uint32_t));
+    uint16_t *rows = (uint16_t *)malloc((n ? n : 1) * sizeof(uint16_t));
     double t0 = now_s();
-    gso_preprocess(sh, cov, pods, n, gt, mt, cam, band_ty0, band_ty1, proj, tt);
+    gso_preprocess(sh, cov, pods, n, gt, mt, cam, band_ty0, band_ty1, proj, tt, rows);
     double t1 = now_s();
-    uint64_t d = gso_build_keys_ordered(proj, tt, n, tiles_x, NULL, NULL, order);
+    uint64_t d = gso_build_keys_ordered(proj, tt, rows, n, tiles_x, NULL, NULL, order);
     uint64_t vis = 0;
     for (size_t i = 0; i < n; i++) vis += tt[i] != 0;
     uint64_t *keys = (uint64_t *)malloc((d ? d : 1) * sizeof(uint64_t));
     uint32_t *idx = (uint32_t *)malloc((d ? d : 1) * sizeof(uint32_t));
-    gso_build_keys_ordered(proj, tt, n, tiles_x, keys, idx, order);
+    gso_build_keys_ordered(proj, tt, rows, n, tiles_x, keys, idx, order);
     double t2 = now_s();
     gso_sort_pairs(keys, idx, d);
     double t3 = now_s();
@@ -1226,6 +1316,7 @@ uint64_t gso_render_ordered(int sh, int cov, const void *pods, size_t n, const g
     if (visible_out) *visible_out = vis;
     free(proj);
     free(tt);
+    free(rows);
     free(keys);
     free(idx);
     free(ranges);

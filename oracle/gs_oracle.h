@@ -158,15 +158,19 @@ void gso_camera_look_at(const float eye[3], const float target[3], const float u
                         float vfov_rad, uint32_t width, uint32_t height, float near_plane,
                         float far_plane, gso_camera *out);
 /* tiles are 16x16; band = [band_ty0, band_ty1) tile rows owned by this shard */
+/* tile_rows (may be NULL; rect version 4): per Gaussian 0 = every tile of the record's rect, or
+ * 0x8000 | row code for a rect of at most 3 x 3 tiles some of whose tiles the splat cannot reach — 4 bits per tile
+ * row: (first kept column) | (kept columns) << 2; tiles_touched counts the kept tiles */
 void gso_preprocess(int sh, int cov, const void *pods, size_t n, const gso_gaussian_transform *gt,
                     const gso_model_transform *mt, const gso_camera *cam, uint32_t band_ty0,
-                    uint32_t band_ty1, gso_projected *proj, uint32_t *tiles_touched);
-/* keys/idx must hold sum(tiles_touched) entries; returns that sum */
-uint64_t gso_build_keys(const gso_projected *proj, const uint32_t *tiles_touched, size_t n,
+                    uint32_t band_ty1, gso_projected *proj, uint32_t *tiles_touched, uint16_t *tile_rows);
+/* keys/idx must hold sum(tiles_touched) entries; returns that sum.  tile_rows as gso_preprocess wrote it (NULL only
+ * for frames without dropped tiles: the function aborts when a count and its rect disagree) */
+uint64_t gso_build_keys(const gso_projected *proj, const uint32_t *tiles_touched, const uint16_t *tile_rows, size_t n,
                         uint32_t tiles_x, uint64_t *keys, uint32_t *idx);
 /* same, emitting in mirror order: order[slot] = Gaussian index (NULL = index order); DESIGN.md §3.4 */
-uint64_t gso_build_keys_ordered(const gso_projected *proj, const uint32_t *tiles_touched, size_t n,
-                                uint32_t tiles_x, uint64_t *keys, uint32_t *idx, const uint32_t *order);
+uint64_t gso_build_keys_ordered(const gso_projected *proj, const uint32_t *tiles_touched, const uint16_t *tile_rows,
+                                size_t n, uint32_t tiles_x, uint64_t *keys, uint32_t *idx, const uint32_t *order);
 /* the spatial mirror order of DESIGN.md §3.4a (30-bit Morton code of the position, ties by index) */
 void gso_spatial_order(const void *pods, size_t n, size_t pod_bytes, uint32_t *order);
 void gso_sort_pairs(uint64_t *keys, uint32_t *idx, uint64_t d);

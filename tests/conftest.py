@@ -10,6 +10,12 @@ for p in (ROOT, os.path.join(ROOT, "tools")):
         sys.path.insert(0, p)
 
 
+# Tile rect version 4 is the oracle's default; the product turns it on by itself only for scenes large
+# enough that its test is free (gs_renderer_set_tile_masks), so the parity tests pin it for the whole process — product and
+# oracle binding read the same variable (GS3D_TILE_MASKS=0 runs both on version 3).
+os.environ.setdefault("GS3D_TILE_MASKS", "1")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

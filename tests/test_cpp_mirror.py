@@ -54,10 +54,10 @@ def test_cpp_fullsize_on_the_runtime_the_library_is_built_for(name):
     """under Python the product runs on the HIP runtime bundled with the torch
     wheel (ROCm 7.0.x) while it is compiled against /opt/rocm's 7.2 headers.  This test renders the
     BASELINE workloads WITHOUT Python or torch in the process — the runtime is the one the library's
-    RUNPATH names — and requires the oracle's frame hashes (tests/golden/fullsize_v2.json), for the
+    RUNPATH names — and requires the oracle's frame hashes (tests/golden/fullsize_v3.json), for the
     spatial and the index mirror order."""
     import json
-    g = json.load(open(os.path.join(ROOT, "tests", "golden", "fullsize_v2.json")))[name]
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "fullsize_v3.json")))[name]
     exe = os.path.join(ROOT, "build", "test_fullsize")
     if not os.path.exists(exe):
         sys.path.insert(0, ROOT)

@@ -1,6 +1,6 @@
 """GPU parity at BASELINE.json's full sizes.  The oracle is too slow to run inside the GPU suite
 at 10 M Gaussians, so these tests use (1) frame / scene hashes the oracle produced offline
-(tests/golden/fullsize_v2.json, generator: tests/golden/make_golden_fullsize.py) — the HIP path is
+(tests/golden/fullsize_v3.json, generators: tests/golden/make_golden_fullsize.py and _v3.py) — the HIP path is
 specified bit-exact, so equal sha256 == equal frames — and (2) size-independent properties of the
 intermediate results: sortedness and stability (in mirror order) of the (tile, depth) pairs, the pair multiset being
 exactly the rect expansion of the projected records, tile ranges partitioning [0, D), idempotence,
@@ -17,11 +17,16 @@ import helpers
 pytestmark = pytest.mark.gpu
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-GOLD = json.load(open(os.path.join(HERE, "golden", "fullsize_v2.json")))
+# fullsize_v3.json: the frames of fullsize_v2.json (same hashes) with the visible / pair counts of rect version 4 (round 5:
+# small rects lose the tiles their splat cannot reach); the older versions' counts ride along for the A/B switches
+GOLD = json.load(open(os.path.join(HERE, "golden", "fullsize_v3.json")))
 if os.environ.get("GS3D_RECT_V1") == "1":
     # the A/B switch of DESIGN.md §3.3: version 1 of the tile rect — same frames, the version-1 counts
     for _g in GOLD.values():
         _g["visible"], _g["pairs"] = _g["visible_rect_v1"], _g["pairs_rect_v1"]
+elif os.environ.get("GS3D_TILE_MASKS") == "0":
+    for _g in GOLD.values():
+        _g["visible"], _g["pairs"] = _g["visible_rect_v3"], _g["pairs_rect_v3"]
 
 
 def _upload(gs, device, stream, g, step=1_000_000):
@@ -77,7 +82,14 @@ def _check_intermediates(gs, r, g, cam, order):
     p = proj[idx]     # rect in tile units, exclusive max
     assert bool(((tx >= p["tx0"]) & (tx < p["tx1"]) & (ty >= p["ty0"]) & (ty < p["ty1"])).all())
     area = (proj["tx1"].astype(np.int64) - proj["tx0"]) * (proj["ty1"].astype(np.int64) - proj["ty0"])
-    assert np.array_equal(area[tiles > 0], tiles[tiles > 0].astype(np.int64))
+    # ... and is the whole rect, except for rects of at most 3 x 3 tiles, which may have lost tiles (rect version 4)
+    w, h = proj["tx1"].astype(np.int64) - proj["tx0"], proj["ty1"].astype(np.int64) - proj["ty0"]
+    small = (w <= 3) & (h <= 3)
+    vis = tiles > 0
+    assert np.array_equal(area[vis & ~small], tiles[vis & ~small].astype(np.int64))
+    assert bool((tiles[vis & small] <= area[vis & small]).all())
+    if os.environ.get("GS3D_TILE_MASKS") == "0" or os.environ.get("GS3D_RECT_V1") == "1":
+        assert np.array_equal(area[vis], tiles[vis].astype(np.int64))
     # per-tile counts from the rects (difference array) == counts in the sorted keys == ranges
     counts = np.bincount(tile_of, minlength=num_tiles)
     ranges = r.download_ranges(num_tiles).reshape(num_tiles, 2).astype(np.int64)
@@ -123,7 +135,13 @@ def test_fullsize_frame_matches_oracle_hash(gs, device, stream, name):
         stitched[b0 * 16:min(b1 * 16, g["height"])] = part[b0 * 16:min(b1 * 16, g["height"])]
         vis_sum += r.stats().pairs
     assert hashlib.sha256(stitched.tobytes()).hexdigest() == g[frame_key]
-    assert vis_sum == g["pairs"], "bands must emit each (tile, Gaussian) pair exactly once"
+    # bands emit every (tile, Gaussian) pair of the whole frame at most once — exactly once up to rect version 3; under
+    # version 4 a rect that a band boundary cuts down to 3 x 3 tiles or less becomes eligible for the exact tile test in
+    # that band, so a few more pairs go (the stitched image above is still the whole frame's)
+    if os.environ.get("GS3D_TILE_MASKS") == "0" or os.environ.get("GS3D_RECT_V1") == "1":
+        assert vis_sum == g["pairs"], "bands must emit each (tile, Gaussian) pair exactly once"
+    else:
+        assert 0.99 * g["pairs"] <= vis_sum <= g["pairs"], (vis_sum, g["pairs"])
     # the same buffer with the spatial order switched off: plain index order, the oracle's other hash
     buf.set_spatial_order(False)
     plain = _frame(gs, device, stream, r, buf, gt, mt, cam)
@@ -206,7 +224,10 @@ def test_sharded_path_single_gpu_4k(gs, device, stream):
         img = par.assemble(_HostTorch, gbuf.host(stream), plan)
         gbuf.buf.release()
         assert img.shape == (H, W, 4)
-        assert pairs == g["pairs"]
+        if os.environ.get("GS3D_TILE_MASKS") == "0" or os.environ.get("GS3D_RECT_V1") == "1":
+            assert pairs == g["pairs"]
+        else:      # (rects cut down to 3 x 3 tiles by a band edge lose a few more tiles in that band: rect version 4)
+            assert 0.99 * g["pairs"] <= pairs <= g["pairs"], (pairs, g["pairs"])
         assert hashlib.sha256(np.ascontiguousarray(img).tobytes()).hexdigest() == g[key], \
             "sharded frame differs (plan %s)" % (plan.bands,)
         # second round: bands re-cut to equal pairs

@@ -11,6 +11,9 @@ from test_gpu_render import _compare_frame, _mirror_order, _oracle_frame
 
 pytestmark = pytest.mark.gpu
 
+import os as _os
+ROOT_DIR = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
+
 
 def _scene(n, depth, first=31337):
     """depth: 'spread' (the generator's 2..26), 'wall' (all within 1e-4 relative of z = 9: one or two top digits),
@@ -170,3 +173,42 @@ def test_renderer_leaves_the_msd_tile_sort_when_buckets_overflow(gs, ob, device,
     for h in (r, buf):
         h.destroy()
     img.release()
+
+
+def test_tile_masks_follow_the_scene_size_unless_pinned(gs, device, stream):
+    """gs_renderer_set_tile_masks: unpinned (the tests' process pins it through GS3D_TILE_MASKS, so this runs in a child
+    without the variable), a scene whose records fit the Infinity Cache renders with rect version 3 — its preprocess
+    kernel is instruction-bound and the tile test would cost more than the pairs it saves — and a scene beyond 512 MB of
+    records with version 4; both pins override."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys; sys.path[:0] = [%r, %r]\n"
+        "import numpy as np, synth, wgpu_3dgs_core_amd as gs\n"
+        "dev = gs.Device(0); st = dev.create_stream()\n"
+        "cam = gs.camera_look_at((0, 0, 0), (0, 0, -1), (0, 1, 0), 1.0, 640, 360, 0.1, 100.0)\n"
+        "gt, mt = gs.gaussian_transform_pod(sh_deg=0), gs.model_transform_pod()\n"
+        "img = gs.Buffer(dev, size=640 * 360 * 16)\n"
+        "out = []\n"
+        "for n, pod in ((20000, gs.GaussianPod(gs.SH_NONE, gs.COV3D_ROT_SCALE)), (2500000, gs.GaussianPod(gs.SH_SINGLE, gs.COV3D_ROT_SCALE))):\n"
+        "    buf = gs.GaussiansBuffer.new_empty(dev, pod, n)\n"
+        "    for first in range(0, n, 500000):\n"
+        "        buf.update_range_with_pod(st, first, pod.from_gaussian(synth.scene(min(500000, n - first), first=first)))\n"
+        "    for mode in (-1, 0, 1):\n"
+        "        r = gs.Renderer(dev); r.set_tile_masks(mode)\n"
+        "        r.render(st, buf, gt, mt, cam, img.device_ptr())\n"
+        "        out.append((n, mode, r.sort_info().tile_masks, r.stats().pairs)); r.destroy()\n"
+        "    buf.destroy()\n"
+        "print('RESULT', out)\n" % (ROOT_DIR, os.path.join(ROOT_DIR, 'tools')))
+    env = dict(os.environ)
+    env.pop("GS3D_TILE_MASKS", None)
+    res = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert res.returncode == 0 and "RESULT" in res.stdout, res.stdout[-3000:]
+    out = eval(res.stdout.split("RESULT", 1)[1].strip())
+    by = {(n, mode): (masks, pairs) for n, mode, masks, pairs in out}
+    assert by[(20000, -1)][0] == 0 and by[(2500000, -1)][0] == 1, by          # the renderer's own choice
+    for n in (20000, 2500000):
+        assert by[(n, 0)][0] == 0 and by[(n, 1)][0] == 1, by                  # the pins
+        assert by[(n, 1)][1] < by[(n, 0)][1], by                              # version 4 emits fewer pairs
+        assert by[(n, -1)][1] == by[(n, by[(n, -1)][0])][1], by

@@ -1,6 +1,7 @@
 """The debug switches of DESIGN.md §4.4 are read once per process, so the alternative code paths they
 select (the pair-emission start table at small sizes, the ballot-based rank of the radix scatter,
-version 1 of the tile rect — for which the oracle binding switches to version 1 as well) are
+versions 1 and 3 of the tile rect — for which the oracle binding switches its version as well —, the MSD-first /
+LSD sorts, the unpacked rect format, the store policies) are
 exercised by running a subset of the parity tests in a child process per setting — one child at a
 time."""
 import os
@@ -19,6 +20,9 @@ SUBSET = "synthetic_small or emission or capacity_overflow or edge_cases or wide
                                  {"GS3D_BLEND_GROUPS": "1", "GS3D_RANGES_IN_BLEND": "1"}, {"GS3D_RECT_V1": "1"}, {"GS3D_SPATIAL_ORDER": "0"},
                                  {"GS3D_XCD_REMAP": "0", "GS3D_EVENT_FENCE": "1", "GS3D_FRAME_EVENT": "1", "GS3D_NT_LOADS": "1", "GS3D_BLOCK_LIST": "1", "GS3D_NT_SCATTER": "1",
                                   "GS3D_RANGES_SEARCH": "1", "GS3D_RANGES_IN_BLEND": "0", "GS3D_DEPTH_SORT_LARGE": "1"},
+                                 {"GS3D_TILE_MASKS": "0", "GS3D_DEPTH_MSD": "0", "GS3D_WT_STORES": "0"},
+                                 {"GS3D_DEPTH_MSD": "1", "GS3D_TILE_MSD": "1", "GS3D_WT_RECORDS": "1", "GS3D_DISABLE_FAST_RANK": "1"},
+                                 {"GS3D_RECT32": "0", "GS3D_TILE_MSD": "1"},
                                  {"GS3D_PRE_PIPELINE": "0", "GS3D_SCAN_ROWS_SMALL": "0", "GS3D_NT_LOADS": "0", "GS3D_BLOCK_LIST": "0",
                                   "GS3D_NT_SCATTER": "0", "GS3D_RANGES_SEARCH": "0", "GS3D_RANGES_IN_BLEND": "0", "GS3D_CHUNK_HIST": "0", "GS3D_EXPAND_XCD": "0"}],
                          ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))

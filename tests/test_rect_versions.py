@@ -181,3 +181,38 @@ def test_guard_leaves_the_synthetic_workloads_untouched(both_versions):
         tiles[v] = ob.preprocess(g["sh"], g["cov"], pods, gt, mt, cam)[1]
     assert np.array_equal(tiles[2], tiles[3])
     assert (int((tiles[3] > 0).sum()), int(tiles[3].sum(dtype=np.int64))) == (g["visible"], g["pairs"])
+
+
+def test_version_4_drops_tiles_of_small_rects_and_no_pixel(both_versions):
+    """Rect version 4 (round 5): rects of at most 3 x 3 tiles lose the tiles whose pixel-centre box the region
+    {power >= -(ln k + 0.1)} does not reach.  On the 1 M workload: fewer pairs (the counts of fullsize_v3.json), a
+    handful of Gaussians culled outright, every per-Gaussian count <= its version-3 count, larger rects untouched —
+    and the frame bit for bit the version-3 frame (100 k Gaussians rendered with both)."""
+    import synth
+    ob = both_versions
+    g = json.load(open(os.path.join(HERE, "golden", "fullsize_v3.json")))["1m"]
+    pods = ob.pack(g["sh"], g["cov"], synth.scene(g["n"]))
+    cam = helpers.default_camera(ob, g["width"], g["height"])
+    gt, mt = ob.gaussian_transform(sh_deg=g["sh_deg"]), ob.model_transform()
+    out = {}
+    for v in (3, 4):
+        ob.set_rect_version(v)
+        proj, tiles = ob.preprocess(g["sh"], g["cov"], pods, gt, mt, cam)
+        out[v] = (proj, np.asarray(tiles).copy(), tiles.rows.copy())
+    t3, t4, rows = out[3][1], out[4][1], out[4][2]
+    assert (int((t3 > 0).sum()), int(t3.sum(dtype=np.int64))) == (g["visible_rect_v3"], g["pairs_rect_v3"])
+    assert (int((t4 > 0).sum()), int(t4.sum(dtype=np.int64))) == (g["visible"], g["pairs"])
+    assert bool((t4 <= t3).all()) and not out[3][2].any()
+    p = out[3][0]
+    w, h = p["tx1"].astype(np.int64) - p["tx0"], p["ty1"].astype(np.int64) - p["ty0"]
+    changed = t4 != t3
+    assert bool(((w <= 3) & (h <= 3))[changed].all())                        # only small rects lose tiles
+    assert bool((rows[changed & (t4 > 0)] & 0x8000).all()) and not rows[~changed].any()
+    assert 0.04 < 1.0 - t4.sum(dtype=np.int64) / t3.sum(dtype=np.int64) < 0.10
+    small_n = 100000
+    pods_s = ob.pack(g["sh"], g["cov"], synth.scene(small_n))
+    frames = {}
+    for v in (3, 4):
+        ob.set_rect_version(v)
+        frames[v] = ob.render(g["sh"], g["cov"], pods_s, gt, mt, cam)[0]
+    assert np.array_equal(frames[3].view(np.uint32), frames[4].view(np.uint32))

@@ -14,16 +14,19 @@
 #include <vector>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
+// per-workgroup slots, plain stores: (a first version took atomicMin / atomicMax on one word per kernel — 2048 device-scope
+// atomics on one address are 24 us of serialised traffic behind a 1 us kernel, and that was the "gap")
 struct Stamps {
-    unsigned long long first_start, last_end;
+    unsigned long long start, end;
 };
+constexpr int MAX_WG = 1024;
 
 __device__ __forceinline__ void stamp_start(Stamps *s) {
-    if (threadIdx.x == 0) atomicMin(&s->first_start, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+    if (threadIdx.x == 0) s[blockIdx.x].start = __builtin_amdgcn_s_memrealtime();
 }
 __device__ __forceinline__ void stamp_end(Stamps *s) {
     __syncthreads();
-    if (threadIdx.x == 0) atomicMax(&s->last_end, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+    if (threadIdx.x == 0) s[blockIdx.x].end = __builtin_amdgcn_s_memrealtime();
 }
 
 template <int MODE>
@@ -55,6 +58,14 @@ __global__ __launch_bounds__(256) void k_probe(const uint4 *__restrict__ src, ui
     stamp_end(s);
 }
 
+// keeps the device busy for `ticks` x 10 ns so that the host is always several launches ahead: without it the gaps
+// behind short kernels are the host's launch rate (three launches take it ~25 us), not the device's boundary
+__global__ void k_pad(unsigned long long ticks, uint32_t *out) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+    if (ticks == 0x12345ull) out[0] = 1u;
+}
+
 int main(int argc, char **argv) {
     const int iters = argc > 1 ? atoi(argv[1]) : 200;
     hipStream_t st;
@@ -66,36 +77,49 @@ int main(int argc, char **argv) {
     CK(hipMalloc(&src, 174 * 16384));
     CK(hipMemset(src, 0, 174 * 16384));
     CK(hipMalloc(&out, 4096));
-    Stamps *stamps;      // [iters][3]
-    CK(hipMalloc(&stamps, (size_t)iters * 3 * sizeof(Stamps)));
-    std::vector<Stamps> h((size_t)iters * 3), init((size_t)iters * 3);
-    for (auto &x : init) { x.first_start = ~0ull; x.last_end = 0ull; }
+    Stamps *stamps;      // [iters][3][MAX_WG]
+    const size_t per = (size_t)3 * MAX_WG;
+    CK(hipMalloc(&stamps, (size_t)iters * per * sizeof(Stamps)));
+    std::vector<Stamps> h((size_t)iters * per);
     const char *names[4] = {"plain", "nt", "sc1", "sc0 sc1"};
     printf("%-8s %8s | %9s %9s %9s | %9s\n", "stores", "B", "store us", "gap dirty", "gap clean", "extra");
-    for (size_t bytes : {(size_t)0, (size_t)1 << 20, (size_t)4 << 20, (size_t)16 << 20, (size_t)64 << 20}) {
+    for (size_t bytes : {(size_t)0, (size_t)1 << 20, (size_t)4 << 20, (size_t)8 << 20, (size_t)16 << 20, (size_t)64 << 20}) {
         for (int mode = 0; mode < 4; mode++) {
-            CK(hipMemcpy(stamps, init.data(), init.size() * sizeof(Stamps), hipMemcpyHostToDevice));
+            CK(hipMemset(stamps, 0, (size_t)iters * per * sizeof(Stamps)));
             const size_t n16 = bytes / 16;
             const uint32_t grid = 1024;
             for (int i = 0; i < iters; i++) {
-                Stamps *s = stamps + (size_t)i * 3;
+                Stamps *s = stamps + (size_t)i * per;
+                hipLaunchKernelGGL(k_pad, dim3(1), dim3(64), 0, st, 4000ull, out);       // 40 us
                 switch (mode) {
                 case 0: hipLaunchKernelGGL(k_store<0>, dim3(grid), dim3(256), 0, st, dst, n16, (uint32_t)i, s); break;
                 case 1: hipLaunchKernelGGL(k_store<1>, dim3(grid), dim3(256), 0, st, dst, n16, (uint32_t)i, s); break;
                 case 2: hipLaunchKernelGGL(k_store<2>, dim3(grid), dim3(256), 0, st, dst, n16, (uint32_t)i, s); break;
                 default: hipLaunchKernelGGL(k_store<3>, dim3(grid), dim3(256), 0, st, dst, n16, (uint32_t)i, s); break;
                 }
-                hipLaunchKernelGGL(k_probe, dim3(174), dim3(256), 0, st, (const uint4 *)src, out, s + 1);
-                hipLaunchKernelGGL(k_probe, dim3(174), dim3(256), 0, st, (const uint4 *)src, out, s + 2);
+                hipLaunchKernelGGL(k_probe, dim3(174), dim3(256), 0, st, (const uint4 *)src, out, s + MAX_WG);
+                hipLaunchKernelGGL(k_probe, dim3(174), dim3(256), 0, st, (const uint4 *)src, out, s + 2 * MAX_WG);
             }
             CK(hipStreamSynchronize(st));
             CK(hipMemcpy(h.data(), stamps, h.size() * sizeof(Stamps), hipMemcpyDeviceToHost));
             std::vector<double> store_us, gap_dirty, gap_clean;
+            auto span = [&](const Stamps *s, uint32_t wgs, unsigned long long &first, unsigned long long &last) {
+                first = ~0ull;
+                last = 0ull;
+                for (uint32_t w = 0; w < wgs; w++) {
+                    if (s[w].start && s[w].start < first) first = s[w].start;
+                    if (s[w].end > last) last = s[w].end;
+                }
+            };
             for (int i = iters / 4; i < iters; i++) {
-                const Stamps *s = &h[(size_t)i * 3];
-                store_us.push_back((double)(s[0].last_end - s[0].first_start) * 0.01);
-                gap_dirty.push_back((double)((long long)s[1].first_start - (long long)s[0].last_end) * 0.01);
-                gap_clean.push_back((double)((long long)s[2].first_start - (long long)s[1].last_end) * 0.01);
+                const Stamps *s = &h[(size_t)i * per];
+                unsigned long long a0, a1, b0, b1, c0, c1;
+                span(s, grid, a0, a1);
+                span(s + MAX_WG, 174, b0, b1);
+                span(s + 2 * MAX_WG, 174, c0, c1);
+                store_us.push_back((double)(a1 - a0) * 0.01);
+                gap_dirty.push_back((double)((long long)b0 - (long long)a1) * 0.01);
+                gap_clean.push_back((double)((long long)c0 - (long long)b1) * 0.01);
             }
             auto med = [](std::vector<double> &v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
             const double a = med(store_us), b = med(gap_dirty), c = med(gap_clean);

@@ -33,21 +33,24 @@ static void run(const char *name, const std::vector<uint32_t> &keys, uint32_t lo
         pk[cur[b]] = (K)keys[i];
         pv[cur[b]++] = i;
     }
-    uint32_t *d_tot, *d_v, *d_out;
+    uint32_t *d_tot, *d_start, *d_v, *d_out;
     K *d_k;
     unsigned long long *d_st;
     CK(hipMalloc(&d_tot, nb * 4));
+    CK(hipMalloc(&d_start, nb * 4));
     CK(hipMalloc(&d_k, (size_t)n * sizeof(K) + 64));
     CK(hipMalloc(&d_v, (size_t)n * 4 + 64));
     CK(hipMalloc(&d_out, (size_t)n * 4 + 64));
     CK(hipMalloc(&d_st, nb * 16 * 8));
     CK(hipMemset(d_st, 0, nb * 16 * 8));
     CK(hipMemcpy(d_tot, totals.data(), nb * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_start, start.data(), nb * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(d_k, pk.data(), (size_t)n * sizeof(K), hipMemcpyHostToDevice));
     CK(hipMemcpy(d_v, pv.data(), (size_t)n * 4, hipMemcpyHostToDevice));
     gs::BucketSortIO io;
     memset(&io, 0, sizeof(io));
     io.totals = d_tot;
+    io.starts = d_start;
     io.nb = nb;
     io.keys_in = d_k;
     io.vals_in = d_v;
@@ -84,7 +87,7 @@ static void run(const char *name, const std::vector<uint32_t> &keys, uint32_t lo
         if (q[i] && q[i - 1]) printf("  %s %.2f", phase[i], (double)(q[i] - q[i - 1]) * 0.01);
     unsigned long long last = q[9] ? q[9] : q[4];
     printf("   total %.2f us\n", (double)(last - q[0]) * 0.01);
-    CK(hipFree(d_tot)); CK(hipFree(d_k)); CK(hipFree(d_v)); CK(hipFree(d_out)); CK(hipFree(d_st));
+    CK(hipFree(d_tot)); CK(hipFree(d_start)); CK(hipFree(d_k)); CK(hipFree(d_v)); CK(hipFree(d_out)); CK(hipFree(d_st));
 }
 
 int main(int argc, char **argv) {

@@ -1182,6 +1182,10 @@ class Renderer:
         """gs_renderer_set_sort_mode: 1 MSD-first, 0 LSD passes, -1 the renderer chooses (default)."""
         _check(_L.gs_renderer_set_sort_mode(self._h, int(depth_msd), int(tile_msd)))
 
+    def set_tile_masks(self, mode=-1):
+        """gs_renderer_set_tile_masks: 1 / 0 pin tile rect version 4 / 3, -1 the renderer chooses (by scene size)."""
+        _check(_L.gs_renderer_set_tile_masks(self._h, int(mode)))
+
     def render(self, stream, gaussians, gaussian_transform, model_transform, camera,
                rgba_device_ptr, band=None, check=True):
         """gs_render_frame.  check=True (the validated use: tests, one-off renders) waits for the

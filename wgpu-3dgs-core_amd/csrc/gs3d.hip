@@ -1493,12 +1493,14 @@ struct gs_renderer {
     uint32_t depth_bucket_seen = 0;       // newest reported bucket size the mode was chosen from (diagnostic)
     bool tile_msd = false;                // the tile sort of the last frame was MSD-first
     int depth_msd_req = -1, tile_msd_req = -1;   // gs_renderer_set_sort_mode: -1 = the renderer chooses
+    int tile_masks_req = -1;              // gs_renderer_set_tile_masks
+    bool tile_masks = false;              // the last frame ran tile rect version 4
     uint64_t tile_msd_fail_d = 0;         // pair count at which the MSD-first tile sort last reported an oversized bucket (0: never)
     bool state_tile_bmax_dirty = false;   // FrameState::tile_bucket_max holds a value of an MSD-first frame
     uint32_t cull_last_gen = 0, cull_last_groups = 0;   // frame / group count of the last k_block_cull (status tags)
     DevArray dkeys[2], dvals[2];          // (depth bits - bias, mirror slot), capacity N
     DevArray tkeys[2], tvals[2];          // (tile id, mirror slot), capacity pair_capacity
-    DevArray ghist, digit_totals;
+    DevArray ghist, digit_totals, bucket_starts;
     gs::FrameResult *results;             // pinned, [2]: one per frame parity
     uint32_t *host_counters;              // pinned: sizing pass total
     uint64_t pair_capacity;
@@ -1618,7 +1620,7 @@ extern "C" void gs_renderer_destroy(gs_renderer *r) {
     DevArray *arrs[] = {&r->recs, &r->depth, &r->rect, &r->sorted_rect, &r->exp_sums, &r->cursors, &r->chunk_tiles, &r->chunk_vis,
                         &r->state, &r->zero_region, &r->scan_tmp, &r->block_list, &r->cull_status, &r->chunk_hist, &r->dkeys[0], &r->dkeys[1], &r->dvals[0],
                         &r->dvals[1], &r->tkeys[0], &r->tkeys[1], &r->tvals[0], &r->tvals[1], &r->ghist,
-                        &r->digit_totals};
+                        &r->digit_totals, &r->bucket_starts};
     for (DevArray *a : arrs) dev_free(*a);
     if (r->host_counters) (void)hipHostFree(r->host_counters);
     if (r->results) (void)hipHostFree(r->results);
@@ -1745,8 +1747,16 @@ extern "C" gs_status gs_renderer_sort_info(gs_renderer *r, gs_sort_info *out) {
     out->depth_msd = r->depth_msd ? 1u : 0u;
     out->depth_bucket_max = fr.gen == r->gen ? fr.depth_bucket_max : 0u;
     out->tile_msd = r->tile_msd ? 1u : 0u;
+    out->tile_masks = r->tile_masks ? 1u : 0u;
     if (r->tile_msd && r->state.ptr)      // (the result block carries the PREVIOUS frame's: read this frame's from the device)
         GS_HIP(hipMemcpy(&out->tile_bucket_max, &((gs::FrameState *)r->state.ptr)->tile_bucket_max, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return GS_OK;
+}
+
+extern "C" gs_status gs_renderer_set_tile_masks(gs_renderer *r, int32_t mode) {
+    if (!r) return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "null renderer");
+    if (mode < -1 || mode > 1) return fail(GS_ERR_INVALID_ARGUMENT, (uint64_t)(int64_t)mode, 0, 0, "tile mask modes are -1, 0 or 1");
+    r->tile_masks_req = mode;
     return GS_OK;
 }
 
@@ -1825,11 +1835,19 @@ static void make_frame_consts(const gs_gaussian_transform_pod *gt, const gs_mode
     {
         static const bool rect_v1 = std::getenv("GS3D_RECT_V1") && std::getenv("GS3D_RECT_V1")[0] == '1';
         fc.clip_rect = gt->flags[0] == GS_DISPLAY_SPLAT && !rect_v1 ? 1u : 0u;
+        // rect version 4: small rects lose the tiles their splat cannot reach.  GS3D_TILE_MASKS=0: version 3
+        // (make_frame_consts only records that the display mode allows it; gs_render_frame decides: gs_renderer_set_tile_masks)
+        fc.tile_masks = fc.clip_rect;
     }
     fc.ellipse_pmin = -0.5f * (fc.max_std_dev * fc.max_std_dev);
     {   // packed 4-byte tile rects while both tile counts fit 8 bits (images up to 4096 px); GS3D_RECT32=0: always uint2
         static const bool rect32_off = std::getenv("GS3D_RECT32") && std::getenv("GS3D_RECT32")[0] == '0';
-        fc.rect32 = !rect32_off && fc.tiles_x <= 256u && fc.tiles_y <= 256u ? 1u : 0u;
+        fc.rect32 = !rect32_off && fc.tiles_x <= 256u && fc.tiles_y <= 256u && fc.tiles_x * fc.tiles_y <= 32768u ? 1u : 0u;
+        // write-through stores of the 16-byte-per-lane outputs (gs::store16).  GS3D_WT_STORES=0/1
+        static const int wt_env = std::getenv("GS3D_WT_STORES") ? std::atoi(std::getenv("GS3D_WT_STORES")) : 1;
+        fc.wt_stores = wt_env != 0 ? 1u : 0u;
+        static const int wtr_env = std::getenv("GS3D_WT_RECORDS") ? std::atoi(std::getenv("GS3D_WT_RECORDS")) : 0;
+        fc.wt_records = (uint32_t)wtr_env & 3u;
     }
     // block culling gain (see block_is_culled): size^2 |W R_m S_m|_2^2, the squared SPECTRAL norm of the linear part
     // whatever the caller's view and model matrices are: the largest eigenvalue of A = (WS)^T (WS), in double by the
@@ -1926,6 +1944,7 @@ static thread_local uint32_t *t_rank_fault = nullptr;
 static thread_local uint32_t t_watch = 0;
 static thread_local uint32_t *t_bucket_max = nullptr;
 static thread_local bool t_top_pass = false;
+static thread_local uint32_t *t_bucket_starts = nullptr;    // the MSD-first sorts' scatter pass writes every bucket's start here
 
 // one scatter launch (FAST_RANK chosen by the device probe); KO = type of the keys the pass writes
 template <typename KI, typename KO, int RB, bool COMPACT, int ITEMS>
@@ -1941,13 +1960,13 @@ static void launch_scatter(const gs_device *dev, hipStream_t st, uint32_t sgrid,
     uint32_t *bmax = t_top_pass ? t_bucket_max : nullptr;
     if (t_rank_fault)      // (null outside a frame and once the device has dropped to the ballot-based rank)
         hipLaunchKernelGGL((gs::k_sort_scatter<KI, true, RB, COMPACT, ITEMS, KO>), dim3(sgrid), dim3(gs::SORT_THREADS), 0, st, kin, vin,
-                           kout, ko_shift, vout, psc, shift, digit_mask, ghist, totals, cv, vo, pnb, xr_nt, t_rank_fault, t_watch, bmax);
+                           kout, ko_shift, vout, psc, shift, digit_mask, ghist, totals, cv, vo, pnb, xr_nt, t_rank_fault, t_watch, bmax, t_bucket_starts);
     else if (dev->lds_atomic_ordered.load(std::memory_order_relaxed))
         hipLaunchKernelGGL((gs::k_sort_scatter<KI, true, RB, COMPACT, ITEMS, KO>), dim3(sgrid), dim3(gs::SORT_THREADS), 0, st, kin, vin,
-                           kout, ko_shift, vout, psc, shift, digit_mask, ghist, totals, cv, vo, pnb, xr_nt, (uint32_t *)nullptr, 0u, bmax);
+                           kout, ko_shift, vout, psc, shift, digit_mask, ghist, totals, cv, vo, pnb, xr_nt, (uint32_t *)nullptr, 0u, bmax, t_bucket_starts);
     else
         hipLaunchKernelGGL((gs::k_sort_scatter<KI, false, RB, COMPACT, ITEMS, KO>), dim3(sgrid), dim3(gs::SORT_THREADS), 0, st, kin, vin,
-                           kout, ko_shift, vout, psc, shift, digit_mask, ghist, totals, cv, vo, pnb, xr_nt, (uint32_t *)nullptr, 0u, bmax);
+                           kout, ko_shift, vout, psc, shift, digit_mask, ghist, totals, cv, vo, pnb, xr_nt, (uint32_t *)nullptr, 0u, bmax, t_bucket_starts);
 }
 
 // one radix pass: histogram -> row scan -> scatter
@@ -2102,14 +2121,18 @@ static gs_status run_depth_msd_items(gs_renderer *r, hipStream_t st, const SortC
     const uint32_t pnb = (uint32_t)(((uint64_t)cp.dense_count + TILE - 1) / TILE);
     GS_TRY(dev_reserve(r->ghist, (size_t)pnb * R * 4));
     GS_TRY(dev_reserve(r->digit_totals, R * 4));
+    GS_TRY(dev_reserve(r->bucket_starts, R * 4));
     uint32_t sgrid = 0;
     const uint32_t xr = xcd_span_for(pnb, sgrid);
     const gs::SortCount psc{cp.dense_count, cp.dense_count_dev};
+    t_bucket_starts = (uint32_t *)r->bucket_starts.ptr;
     launch_pass<uint32_t, uint32_t, RB, true, ITEMS>(dev, st, sgrid, cp.dense_keys, (const uint32_t *)nullptr, (uint32_t *)r->dkeys[1].ptr, 0u,
                                                      (uint32_t *)r->dvals[1].ptr, psc, low_bits, R - 1u, r->ghist, r->digit_totals,
                                                      cp.chunk_vis, cp.visible_out, pnb, xr, cp.chunk_hist, R / 2u);
+    t_bucket_starts = nullptr;
     gs::BucketSortIO io;
     io.totals = (const uint32_t *)r->digit_totals.ptr;
+    io.starts = (const uint32_t *)r->bucket_starts.ptr;
     io.nb = top_range < R ? top_range : R;          // digits past the far plane's cannot occur (their totals are zero)
     io.keys_in = r->dkeys[1].ptr;
     io.vals_in = (const uint32_t *)r->dvals[1].ptr;
@@ -2159,12 +2182,16 @@ static gs_status run_tile_msd_items(gs_renderer *r, hipStream_t st, const gs::Ex
         hipLaunchKernelGGL((gs::k_pairs_emit<uint16_t, RB, ITEMS, false>), dim3(sgrid), dim3(gs::SORT_THREADS), 0, st, src, R - 1u,
                            (uint32_t *)r->ghist.ptr, (uint16_t *)r->tkeys[0].ptr, pnb, xr, low_bits);
     launch_scan_rows<(int)TILE>(R, st, (uint32_t *)r->ghist.ptr, pnb, tc, (uint32_t *)r->digit_totals.ptr);
+    GS_TRY(dev_reserve(r->bucket_starts, R * 4));
+    t_bucket_starts = (uint32_t *)r->bucket_starts.ptr;
     launch_scatter<uint16_t, uint16_t, RB, false, ITEMS>(dev, st, sgrid, (const uint16_t *)r->tkeys[0].ptr, (const uint32_t *)r->tvals[0].ptr,
                                                          (uint16_t *)r->tkeys[1].ptr, 0u, (uint32_t *)r->tvals[1].ptr, tc, low_bits, R - 1u,
                                                          (const uint32_t *)r->ghist.ptr, (const uint32_t *)r->digit_totals.ptr,
                                                          (const uint32_t *)nullptr, (uint32_t *)nullptr, pnb, xr);
+    t_bucket_starts = nullptr;
     gs::BucketSortIO io;
     io.totals = (const uint32_t *)r->digit_totals.ptr;
+    io.starts = (const uint32_t *)r->bucket_starts.ptr;
     io.nb = ((num_tiles - 1u) >> low_bits) + 1u;
     io.keys_in = r->tkeys[1].ptr;
     io.vals_in = (const uint32_t *)r->tvals[1].ptr;
@@ -2524,6 +2551,19 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
     gs::FrameConsts fc;
     make_frame_consts(gt, mt, cam, band_ty0, band_ty1, fc);
     size_t n64 = gs_gaussians_buffer_len(g);
+    {
+        // Tile rect version 4: pinned by the caller or the environment, otherwise on where the preprocess kernel waits for
+        // HBM long enough to hide the test's ~120 instructions per Gaussian: records of 200 bytes or more (f32 SH) in a
+        // scene beyond the Infinity Cache.  Same-box A/B, frame time with / without (gpurun_out/r05i/ab_masks3.txt): 10 M x
+        // 224 B at 4K 1.521 / 1.558 ms, at 1080p 0.926-0.951 / 0.926-0.959 (tile sort -12 us); 50 M x 144 B 3.37-3.45 /
+        // 3.31-3.37 (preprocess +65..130 us, tile sort -20..55); 1 M x 48 B 0.318 / 0.320 (preprocess +5 us).
+        static const int masks_env = std::getenv("GS3D_TILE_MASKS") ? std::atoi(std::getenv("GS3D_TILE_MASKS")) : -1;
+        const int pinned = r->tile_masks_req >= 0 ? r->tile_masks_req : masks_env;
+        const uint64_t pod_bytes = (uint64_t)gs::pod_words(g->sh, g->cov) * 4u;
+        const bool want = pinned >= 0 ? pinned != 0 : pod_bytes >= 200u && (uint64_t)n64 * pod_bytes > (512ull << 20);
+        fc.tile_masks = fc.tile_masks && want ? 1u : 0u;
+        r->tile_masks = fc.tile_masks != 0u;
+    }
     if (n64 > 0xfffffff0ull) return fail(GS_ERR_INVALID_ARGUMENT, n64, 0, 0, "too many Gaussians");
     uint32_t n = (uint32_t)n64;
     uint32_t nchunks = (n + gs::PP_CHUNK - 1) / gs::PP_CHUNK;
@@ -2905,6 +2945,7 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
         eo.sb_bound = exp_grid / gs::EXP_SB + 1;
         eo.rect32 = fc.rect32;
         eo.flags_dev = r->flags_target;
+        eo.wt_stores = fc.wt_stores;
         // Where a wave of k_pairs_emit starts: found by the wave itself (a search over the super-chunk
         // sums: one step per 256 of them) or looked up in a table that k_pairs_cursors writes first.
         // The table costs a launch and wins once the search needs more than one step (A/B on one box:
@@ -3131,14 +3172,25 @@ extern "C" gs_status gs_renderer_download_projected(gs_renderer *r, gs_projected
     if (!total) return GS_OK;
     std::vector<uint32_t> recs(total * gs::REC_WORDS);
     std::vector<uint2> rect(total);
+    std::vector<uint32_t> kept(total);      // tiles of the rect that the frame emits pairs for (all of them, or — rect version 4 — fewer)
     GS_TRY(download_sync(r, recs.data(), r->recs.ptr, total * 4 * gs::REC_WORDS));
     GS_TRY(download_slot_depths(r, total, depth));
     if (r->rect32) {
         std::vector<uint32_t> packed(total);
         GS_TRY(download_sync(r, packed.data(), r->rect.ptr, total * 4));
-        for (size_t k = 0; k < total; k++) gs::rect_unpack32(packed[k], rect[k].x, rect[k].y);   // (culled slots: never looked at)
+        for (size_t k = 0; k < total; k++) {      // (culled slots: never looked at)
+            uint32_t rows;
+            gs::rect_unpack32(packed[k], r->tiles_x ? r->tiles_x : 1u, rect[k].x, rect[k].y, rows);
+            kept[k] = gs::rect_count32(packed[k]);
+        }
     } else {
-        GS_TRY(download_sync(r, rect.data(), r->rect.ptr, total * 8));
+        std::vector<uint2> raw(total);
+        GS_TRY(download_sync(r, raw.data(), r->rect.ptr, total * 8));
+        for (size_t k = 0; k < total; k++) {
+            uint32_t rows;
+            gs::rect_unpack64(raw[k], rect[k].x, rect[k].y, rows);
+            kept[k] = gs::rect_count64(raw[k]);
+        }
     }
     for (size_t slot = 0; slot < total; slot++) {
         const size_t i = slot_map[slot];   // Gaussian index of this slot
@@ -3146,9 +3198,7 @@ extern "C" gs_status gs_renderer_download_projected(gs_renderer *r, gs_projected
         // a slot absent from the depth keys is culled (its chunk may even have been block-culled,
         // in which case its per-slot arrays are stale)
         const bool vis = depth[slot] != 0xffffffffu;
-        uint32_t w = (rect[slot].y & 0xffffu) - (rect[slot].x & 0xffffu),
-                 h = (rect[slot].y >> 16) - (rect[slot].x >> 16);
-        if (tiles_out) tiles_out[i] = vis ? w * h : 0u;
+        if (tiles_out) tiles_out[i] = vis ? kept[slot] : 0u;
         if (proj_out) {
             gs_projected &p = proj_out[i];
             if (vis) {

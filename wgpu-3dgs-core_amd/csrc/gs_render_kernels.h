@@ -50,22 +50,66 @@ struct FrameConsts {
     uint32_t clip_rect;            // display mode Splat: the tile rect is clipped to the splat's visible box
     float cull_gain;               // block culling: size^2 * |R_m S_m|_F^2 * (fx^2 (1+limx^2) + fy^2 (1+limy^2)); 0 = off
     float ellipse_pmin;            // display mode Ellipse: -max_std_dev^2 / 2
-    uint32_t rect32;               // tile rects are stored packed in 4 bytes (at most 256 tiles along either axis)
+    uint32_t rect32;               // tile rects are stored packed in 4 bytes (at most 256 tiles along either axis, 32768 in all)
+    uint32_t tile_masks;           // rect version 4: the exact tile test for rects of at most 3 x 3 tiles (needs clip_rect)
+    uint32_t wt_stores;            // store16 mode of the frame's 16-byte-per-lane outputs (pairs, image): 1 = write-through
+    uint32_t wt_records;           // store16 mode of the preprocess kernel's blend records
 };
 
-// Tile rect of a visible Gaussian.  Two storage formats: uint2 (x0 | y0 << 16, x1 | y1 << 16; any image)
-// and, while the image has at most 256 x 256 tiles (4096 px), ONE word x0 | y0 << 8 | (w - 1) << 16 |
-// (h - 1) << 24 — 4 bytes less per visible Gaussian written by preprocess, written again in depth order
-// by k_expand_count and read by k_pairs_emit.  A packed rect is never empty; culled slots are
-// recognised by their depth key, not by their rect.
-__host__ __device__ inline uint32_t rect_pack32(uint32_t r0, uint32_t r1) {
-    const uint32_t x0 = r0 & 0xffffu, y0 = r0 >> 16, x1 = r1 & 0xffffu, y1 = r1 >> 16;
-    return x0 | (y0 << 8) | ((x1 - x0 - 1u) << 16) | ((y1 - y0 - 1u) << 24);
+// Tile rect of a visible Gaussian.  Since version 4 a rect of at most 3 x 3 tiles may have lost the
+// tiles its splat cannot reach: `rows` = 0x8000 | 4 bits per tile row, (first kept column) | (kept columns) << 2.
+// Two storage formats.  (1) uint2, any image: x = x0 | y0 << 16; y = x1 | y1 << 16, or — tiles dropped — (row code |
+// (w - 1) << 12 | (h - 1) << 14) << 16 with the low half 0 (x1 is never 0).  (2) ONE word while the image has at
+// most 256 tiles along either axis and 32768 in all (1080p, 4K): masked << 31 | origin << 16 | payload, origin = y0 *
+// tiles_x + x0 (what the pair generator needs anyway), payload = (w - 1) | (h - 1) << 8, or row code | (w - 1) << 12 |
+// (h - 1) << 14 — 4 bytes less per visible Gaussian written by preprocess, written again in depth order by
+// k_expand_count and read by k_pairs_emit.  Culled slots are recognised by their depth key, not by their rect.
+__host__ __device__ inline uint32_t rect_small_code(uint32_t r0, uint32_t r1, uint32_t rows) {
+    const uint32_t w = (r1 & 0xffffu) - (r0 & 0xffffu), h = (r1 >> 16) - (r0 >> 16);
+    return (rows & 0xfffu) | ((w - 1u) << 12) | ((h - 1u) << 14);
 }
-__host__ __device__ inline void rect_unpack32(uint32_t p, uint32_t &r0, uint32_t &r1) {
-    const uint32_t x0 = p & 0xffu, y0 = (p >> 8) & 0xffu, w = ((p >> 16) & 0xffu) + 1u, h = (p >> 24) + 1u;
+__host__ __device__ inline uint32_t rect_pack32(uint32_t r0, uint32_t r1, uint32_t rows, uint32_t tiles_x) {
+    const uint32_t x0 = r0 & 0xffffu, y0 = r0 >> 16, x1 = r1 & 0xffffu, y1 = r1 >> 16;
+    const uint32_t origin = y0 * tiles_x + x0;
+    if (rows & 0x8000u) return 0x80000000u | (origin << 16) | rect_small_code(r0, r1, rows);
+    return (origin << 16) | (x1 - x0 - 1u) | ((y1 - y0 - 1u) << 8);
+}
+__host__ __device__ inline uint2 rect_pack64(uint32_t r0, uint32_t r1, uint32_t rows) {
+    uint2 r;
+    r.x = r0;
+    r.y = (rows & 0x8000u) ? rect_small_code(r0, r1, rows) << 16 : r1;
+    return r;
+}
+// kept tiles of a row code (its low 12 bits)
+__host__ __device__ inline uint32_t rect_rows_count(uint32_t code) {
+    return ((code >> 2) & 3u) + ((code >> 6) & 3u) + ((code >> 10) & 3u);
+}
+// tiles of a stored rect
+__host__ __device__ inline uint32_t rect_count32(uint32_t p) {
+    return (p >> 31) ? rect_rows_count(p) : ((p & 0xffu) + 1u) * (((p >> 8) & 0xffu) + 1u);
+}
+__host__ __device__ inline uint32_t rect_count64(uint2 r) {
+    return (r.y & 0xffffu) == 0u ? rect_rows_count(r.y >> 16)
+                                 : ((r.y & 0xffffu) - (r.x & 0xffffu)) * ((r.y >> 16) - (r.x >> 16));
+}
+// back to (x0 | y0 << 16, x1 | y1 << 16, rows) for the parity taps
+__host__ __device__ inline void rect_unpack32(uint32_t p, uint32_t tiles_x, uint32_t &r0, uint32_t &r1, uint32_t &rows) {
+    const uint32_t origin = (p >> 16) & 0x7fffu, x0 = origin % tiles_x, y0 = origin / tiles_x;
+    const uint32_t w = (p >> 31) ? ((p >> 12) & 3u) + 1u : (p & 0xffu) + 1u, h = (p >> 31) ? ((p >> 14) & 3u) + 1u : ((p >> 8) & 0xffu) + 1u;
     r0 = x0 | (y0 << 16);
     r1 = (x0 + w) | ((y0 + h) << 16);
+    rows = (p >> 31) ? 0x8000u | (p & 0xfffu) : 0u;
+}
+__host__ __device__ inline void rect_unpack64(uint2 r, uint32_t &r0, uint32_t &r1, uint32_t &rows) {
+    r0 = r.x;
+    if ((r.y & 0xffffu) == 0u && r.y != 0u) {
+        const uint32_t c = r.y >> 16, w = ((c >> 12) & 3u) + 1u, h = ((c >> 14) & 3u) + 1u;
+        r1 = ((r.x & 0xffffu) + w) | (((r.x >> 16) + h) << 16);
+        rows = 0x8000u | (c & 0xfffu);
+    } else {
+        r1 = r.y;
+        rows = 0u;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -149,6 +193,25 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_256(uint32_t v, uint32_
     total = w0 + w1 + w2 + w3;
     __syncthreads();
     return wave_off + inc - v;
+}
+
+// 16-byte store, optionally WRITE-THROUGH at agent scope (`sc1`).  A kernel that leaves B bytes dirty in the L2s makes
+// the next dependent kernel wait for their write-back: tools/mb/mb_boundary.hip measures 1.1 us for a clean boundary and
+// + B / 7 TB/s behind plain stores, up to + 2.3 us from 16 MB on; with sc1 stores the bytes leave while the kernel still
+// runs (+ 0.5 us behind 16 MB; the storing kernel itself gets 0.2-0.7 us longer).  Only for 16-byte-per-lane stores: a
+// 4-byte sc1 store is one fabric write each (MI355X_MICROARCH.md: 6 x the time per byte).
+__device__ __forceinline__ void store16(void *p, uint4 v, uint32_t mode) {       // mode: 0 plain, 1 sc1, 2 nt, 3 sc0 sc1
+    typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+    typedef uint32_t u32x4_a4_t __attribute__((ext_vector_type(4), aligned(4)));      // (records are 36 bytes apart)
+    const u32x4_t w = {v.x, v.y, v.z, v.w};
+    // s_nop 1 behind each asm store: a VMEM store of more than 64 bits followed by a VALU write of its data registers
+    // needs wait states (ISA "manually inserted wait states"), and the compiler's hazard recognizer does not see a store
+    // inside inline asm — without them the first data register was overwritten by the next instruction before the store
+    // had read it (a record's fifth word came out as the value computed right after the store).
+    if (mode == 1u) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(w) : "memory");
+    else if (mode == 2u) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(p), "v"(w) : "memory");
+    else if (mode == 3u) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(w) : "memory");
+    else *(u32x4_a4_t *)p = u32x4_a4_t{v.x, v.y, v.z, v.w};
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -683,7 +746,7 @@ __device__ const float k_ln_opacity_byte[256] = {
 // half (shade_one) reads the SH words.  project_one = both, in the order the spec gives.
 template <int SH, int COV>
 __device__ __forceinline__ uint32_t project_geom(const uint32_t *w, const FrameConsts &fc,
-                                                 uint4 rec[3], float d[3], const float *ln_tab) {
+                                                 uint4 rec[3], float d[3], const float *ln_tab, uint32_t &rows) {
     float p[3] = {u2f(w[0]), u2f(w[1]), u2f(w[2])};
     float pw[4], t[4];
     mat4_mul_point(fc.M, p, pw);
@@ -730,6 +793,8 @@ __device__ __forceinline__ uint32_t project_geom(const uint32_t *w, const FrameC
     float fy1 = clampf(floorf((my + radius) * 0.0625f) + 1.0f, lo_y, hi_y);
     // the record's quadratic form: power(dx, dy) = qa dx^2 + qb dx dy + qc dy^2
     const float qa = -0.5f * (cc * inv), qb = cb * inv, qc = -0.5f * (ca * inv);
+    bool masks_ok = false;
+    float mask_lim = 0.0f;
     if (fc.clip_rect) {
         // DESIGN.md §3.3 (rect, second step): a pixel receives alpha >= 1/255 from this splat only where
         // power >= -ln k.  The bounding box of {power >= -(ln k + 0.1)} (0.1: head room for the blend's
@@ -754,12 +819,81 @@ __device__ __forceinline__ uint32_t project_geom(const uint32_t *w, const FrameC
             fx1 = fminf(fx1, floorf(((mx + ex) - 0.5f) * 0.0625f) + 1.0f);
             fy0 = fmaxf(fy0, floorf(((my - ey) - 15.5f) * 0.0625f) + 1.0f);
             fy1 = fminf(fy1, floorf(((my + ey) - 0.5f) * 0.0625f) + 1.0f);
+            // version 4: the tile test below evaluates `power` itself and claims half of the remaining head room
+            masks_ok = fc.tile_masks != 0u && err <= 0.025f;
+            mask_lim = lim;
         }
     }
     ok = ok && (fx1 > fx0) && (fy1 > fy0);
     // NaN-safe conversions: culled lanes may carry garbage; their values are never used
     uint32_t tx0 = ok ? (uint32_t)fx0 : 0u, tx1 = ok ? (uint32_t)fx1 : 0u;
     uint32_t ty0 = ok ? (uint32_t)fy0 : 0u, ty1 = ok ? (uint32_t)fy1 : 0u;
+    uint32_t count = (tx1 - tx0) * (ty1 - ty0);
+    rows = 0u;
+    {
+        // DESIGN.md §3.3, third step (version 4): a rect of 2..3 x 2..3 tiles loses the CORNER tiles whose pixel-centre
+        // box [16 t + 0.5, 16 t + 15.5]^2 the region {power >= -(ln k + 0.1)} does not reach.  power is concave and peaks (0)
+        // at the mean; only a box lying diagonally off the mean is examined: its maximum sits on the two edges FACING the
+        // mean, one clamped parabola each — along dx = const the exponent peaks at dy = ry dx, along dy = const at dx =
+        // rx dy.  The same operations in the same order as the tests' CPU restatement.  (A first version
+        // examined all nine tiles: ~250 instructions per Gaussian, +8 us at 1 M and +120..200 us at 50 M for 0.4 % more
+        // pairs dropped than the corners alone.)
+        const uint32_t rw = tx1 - tx0, rh = ty1 - ty0;
+        const bool small = ok && masks_ok && rw >= 2u && rw <= 3u && rh >= 2u && rh <= 3u;
+        if (__any(small)) {
+            const float ry = (-0.5f * qb) / qc, rx = (-0.5f * qb) / qa, nlim = -mask_lim;
+            float dl[2][2], dh[2][2], df[2][2];      // [x / y][first / last column or row]: d range of the tile box, facing d
+            bool out[2][2];
+#pragma unroll
+            for (int a = 0; a < 2; a++)
+#pragma unroll
+                for (int e = 0; e < 2; e++) {
+                    const float m = a == 0 ? mx : my;
+                    const uint32_t t = a == 0 ? (e == 0 ? tx0 : tx1 - 1u) : (e == 0 ? ty0 : ty1 - 1u);
+                    const float b0 = (float)(16u * t) + 0.5f;
+                    dl[a][e] = m - (b0 + 15.0f);
+                    dh[a][e] = m - b0;
+                    out[a][e] = !(dl[a][e] <= 0.0f && dh[a][e] >= 0.0f);
+                    df[a][e] = dh[a][e] < 0.0f ? dh[a][e] : dl[a][e];
+                }
+            bool drop[2][2];                          // [first / last row][first / last column]
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+                for (int i = 0; i < 2; i++) {
+                    const float dx = df[0][i], dy = df[1][j];
+                    const float t0 = clampf(ry * dx, dl[1][j], dh[1][j]);
+                    const float m0 = (qc * t0 + qb * dx) * t0 + (qa * dx) * dx;
+                    const float t1 = clampf(rx * dy, dl[0][i], dh[0][i]);
+                    const float m1 = (qa * t1 + qb * dy) * t1 + (qc * dy) * dy;
+                    drop[j][i] = out[0][i] && out[1][j] && fmaxf(m0, m1) < nlim;
+                }
+            uint32_t code = 0, kept = 0;
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                const bool edge_row = j == 0 || (uint32_t)j == rh - 1u;
+                const int jj = j == 0 ? 0 : 1;
+                uint32_t first = edge_row && drop[jj][0] ? 1u : 0u;
+                const uint32_t last = edge_row && drop[jj][1] ? rw - 2u : rw - 1u;
+                uint32_t cnt = (uint32_t)j < rh && last + 1u > first ? last + 1u - first : 0u;
+                if (!cnt) first = 0u;
+                code |= (first | (cnt << 2)) << (4 * j);
+                kept += cnt;
+            }
+            if (small) {
+                ok = ok && kept != 0u;              // nothing reached: culled
+                if (kept != count) {
+                    count = kept;
+                    rows = 0x8000u | code;
+                }
+            }
+        }
+    }
+    if (!ok) {
+        tx0 = tx1 = ty0 = ty1 = 0u;
+        count = 0u;
+        rows = 0u;
+    }
 
     float dw[3] = {pw[0] - fc.cam_pos[0], pw[1] - fc.cam_pos[1], pw[2] - fc.cam_pos[2]};
     float dl = sqrtf((dw[0] * dw[0] + dw[1] * dw[1]) + dw[2] * dw[2]);
@@ -777,7 +911,7 @@ __device__ __forceinline__ uint32_t project_geom(const uint32_t *w, const FrameC
     rec[0] = make_uint4(f2u(mx), f2u(my), f2u(qa), f2u(qb));
     rec[1] = make_uint4(f2u(qc), f2u(opacity), 0u, 0u);
     rec[2] = make_uint4(0u, f2u(zv), tx0 | (ty0 << 16), tx1 | (ty1 << 16));
-    return (tx1 - tx0) * (ty1 - ty0);
+    return count;
 }
 
 template <int SH>
@@ -792,9 +926,9 @@ __device__ __forceinline__ void shade_one(const uint32_t *w, const FrameConsts &
 
 template <int SH, int COV>
 __device__ __forceinline__ uint32_t project_one(const uint32_t *w, const FrameConsts &fc,
-                                                uint4 rec[3], const float *ln_tab) {
+                                                uint4 rec[3], const float *ln_tab, uint32_t &rows) {
     float d[3];
-    uint32_t cnt = project_geom<SH, COV>(w, fc, rec, d, ln_tab);
+    uint32_t cnt = project_geom<SH, COV>(w, fc, rec, d, ln_tab, rows);
     shade_one<SH>(w, fc, d, rec);
     return cnt;
 }
@@ -937,16 +1071,17 @@ __global__ __launch_bounds__(PP_THREADS) void k_preprocess(const uint4 *__restri
                 w[4 * c + 3] = v[c].w;
             }
             uint4 rec[3];
-            const uint32_t cnt = project_one<SH, COV>(w, fc, rec, s_ln);
+            uint32_t rows;
+            const uint32_t cnt = project_one<SH, COV>(w, fc, rec, s_ln, rows);
             uint32_t *o = io.recs + (uint64_t)i * REC_WORDS;
-            *(u32x4_a4 *)(o) = u32x4_a4{rec[0].x, rec[0].y, rec[0].z, rec[0].w};
-            *(u32x4_a4 *)(o + 4) = u32x4_a4{rec[1].x, rec[1].y, rec[1].z, rec[1].w};
+            store16(o, rec[0], fc.wt_records);
+            store16(o + 4, rec[1], fc.wt_records);
             o[8] = rec[2].x;
             const uint32_t key = cnt ? rec[2].y - io.key_bias : 0xffffffffu;
             io.depth[i] = key;
             if (cnt) atomicAdd(&s_dhist[(key >> io.digit_shift) & io.digit_mask], 1u);
-            if (fc.rect32) ((uint32_t *)io.rect)[i] = cnt ? rect_pack32(rec[2].z, rec[2].w) : 0u;
-            else io.rect[i] = cnt ? make_uint2(rec[2].z, rec[2].w) : make_uint2(0u, 0u);
+            if (fc.rect32) ((uint32_t *)io.rect)[i] = cnt ? rect_pack32(rec[2].z, rec[2].w, rows, fc.tiles_x) : 0u;
+            else io.rect[i] = cnt ? rect_pack64(rec[2].z, rec[2].w, rows) : make_uint2(0u, 0u);
             local += cnt;
             local_vis += cnt ? 1u : 0u;
         }
@@ -1049,7 +1184,8 @@ __global__ __launch_bounds__(PP_THREADS) void k_preprocess_banded(const uint4 *_
             }
             uint4 rec[3];
             float d[3];
-            const uint32_t cnt = project_geom<SH, COV>(w, fc, rec, d, s_ln);
+            uint32_t rows;
+            const uint32_t cnt = project_geom<SH, COV>(w, fc, rec, d, s_ln, rows);
             if (cnt) {
                 constexpr int S0 = 1, S1 = G0 - 1;   // SH-only chunks (G0.. were loaded above)
                 if constexpr (S1 >= S0) {
@@ -1071,11 +1207,11 @@ __global__ __launch_bounds__(PP_THREADS) void k_preprocess_banded(const uint4 *_
             if (cnt || !fc.mask_culled_records) {
                 // (the rect of a culled Gaussian is never read: its key says "culled")
                 uint32_t *o = io.recs + (uint64_t)oi * REC_WORDS;
-                *(u32x4_a4 *)(o) = u32x4_a4{rec[0].x, rec[0].y, rec[0].z, rec[0].w};
-                *(u32x4_a4 *)(o + 4) = u32x4_a4{rec[1].x, rec[1].y, rec[1].z, rec[1].w};
+                store16(o, rec[0], fc.wt_records);
+                store16(o + 4, rec[1], fc.wt_records);
                 o[8] = rec[2].x;
-                if (fc.rect32) ((uint32_t *)io.rect)[oi] = cnt ? rect_pack32(rec[2].z, rec[2].w) : 0u;
-                else io.rect[oi] = make_uint2(rec[2].z, rec[2].w);
+                if (fc.rect32) ((uint32_t *)io.rect)[oi] = cnt ? rect_pack32(rec[2].z, rec[2].w, rows, fc.tiles_x) : 0u;
+                else io.rect[oi] = rect_pack64(rec[2].z, rec[2].w, rows);
             }
             if (cnt) {
                 key = rec[2].y - io.key_bias;
@@ -1268,6 +1404,7 @@ struct ExpandIO {
     uint32_t rect32;                 // rect / sorted_rect hold packed 4-byte rects (rect_pack32)
     uint32_t *flags_dev;             // optional device copy of the frame flags (null: none)
     uint32_t xcd_chunk;              // k_expand_count: workgroup -> span order (0: dispatch order)
+    uint32_t wt_stores;              // k_pairs_emit stores its pairs write-through (store16)
 };
 
 // Expansion, part 1: gather the tile rects into depth order (the only random access of the key
@@ -1329,8 +1466,8 @@ __global__ __launch_bounds__(EXP_CHUNK) void k_expand_count(ExpandIO io) {
     for (uint32_t c = 0; c < EXP_COUNT_CHUNKS; c++) {
         const uint64_t j = (uint64_t)(first_chunk + c) * EXP_CHUNK + threadIdx.x;
         uint32_t v;
-        if constexpr (RECT32) v = j < v_count ? (((rp[c] >> 16) & 0xffu) + 1u) * ((rp[c] >> 24) + 1u) : 0u;
-        else v = ((r[c].y & 0xffffu) - (r[c].x & 0xffffu)) * ((r[c].y >> 16) - (r[c].x >> 16));
+        if constexpr (RECT32) v = j < v_count ? rect_count32(rp[c]) : 0u;
+        else v = rect_count64(r[c]);
         v = wave_reduce_add(v);
         if (lane == 0) s_red[c][wid] = v;
     }
@@ -1665,7 +1802,8 @@ __device__ __forceinline__ void scatter_ranked(ScatterShared<K, RB, ITEMS> &sh, 
                                                const uint32_t *__restrict__ ghist,
                                                const uint32_t *__restrict__ digit_totals,
                                                uint32_t *__restrict__ visible_out, uint32_t *rank_fault = nullptr,
-                                               uint32_t watch_round = 0u, uint32_t *bucket_max_out = nullptr) {
+                                               uint32_t watch_round = 0u, uint32_t *bucket_max_out = nullptr,
+                                               uint32_t *bucket_start_out = nullptr) {
     constexpr int R = 1 << RB;
     constexpr int DPT = R / SORT_THREADS;        // digits per thread: thread t owns digits [t*DPT, t*DPT+DPT)
     auto &s_wave_hist = sh.wave_hist;
@@ -1777,6 +1915,8 @@ __device__ __forceinline__ void scatter_ranked(ScatterShared<K, RB, ITEMS> &sh, 
         for (int q = 0; q < DPT; q++) {
             const uint32_t digit = tid * DPT + q;
             s_delta[digit] = digit_base + (digit <= digit_mask ? gh[q] : 0u) - bin0[q];
+            // the MSD-first sorts: where every digit's bucket starts, for k_bucket_sort (tile 0 writes the table)
+            if (bucket_start_out && block == 0u && digit <= digit_mask) bucket_start_out[digit] = digit_base;
             digit_base += tot[q];
         }
         if constexpr (COMPACT)
@@ -1858,7 +1998,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
     uint32_t *__restrict__ vals_out, SortCount sc, uint32_t shift, uint32_t digit_mask,
     const uint32_t *__restrict__ ghist, const uint32_t *__restrict__ digit_totals,
     const uint32_t *__restrict__ chunk_vis, uint32_t *__restrict__ visible_out, uint32_t num_tiles,
-    uint32_t xcd_chunk_nt, uint32_t *rank_fault, uint32_t watch, uint32_t *bucket_max_out) {
+    uint32_t xcd_chunk_nt, uint32_t *rank_fault, uint32_t watch, uint32_t *bucket_max_out, uint32_t *bucket_start_out) {
     constexpr int TILE = SORT_THREADS * ITEMS;
     __shared__ ScatterShared<K, RB, ITEMS> sh;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
@@ -1925,7 +2065,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
     uint32_t *rf = rank_fault && block == watch % live_tiles ? rank_fault : (uint32_t *)nullptr;
     scatter_ranked<K, FAST_RANK, RB, COMPACT, ITEMS, KO>(sh, key, val, in_tile, block, num_tiles, keys_out, ko_shift, vals_out,
                                                          shift, digit_mask, ghist, digit_totals, visible_out, rf,
-                                                         (watch / live_tiles) % (uint32_t)ITEMS, bucket_max_out);
+                                                         (watch / live_tiles) % (uint32_t)ITEMS, bucket_max_out, bucket_start_out);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1974,6 +2114,7 @@ constexpr uint32_t BKT_CAP_SMALL = BucketCfg<BKT_THREADS_SMALL>::CAP;
 
 struct BucketSortIO {
     const uint32_t *totals;     // [nb] bucket sizes = digit totals of the scatter pass that made the buckets
+    const uint32_t *starts;     // [nb] where every bucket starts (written by tile 0 of that scatter pass)
     uint32_t nb;                // buckets (<= BKT_THREADS = 1024: the 10-bit top digit) = grid size
     const void *keys_in;        // [count] keys after the top-digit scatter (u32, or u16 tile ids)
     const uint32_t *vals_in;
@@ -2341,50 +2482,31 @@ __global__ __launch_bounds__(T) void k_bucket_sort(BucketSortIO io) {
                   "the waves' counters are cleared with whole rounds of T threads; one thread per digit");
     __shared__ BucketShared<RB, T> sh;
     const uint32_t tid = threadIdx.x, bucket = blockIdx.x;
-    // bucket start = sum of the sizes in front of it; the same walk counts the non-empty buckets in front
-    uint32_t v[PER], mine = 0, mine_nz = 0;
-#pragma unroll
-    for (uint32_t q = 0; q < PER; q++) {
-        const uint32_t i = tid * PER + q;
-        v[q] = i < io.nb ? io.totals[i] : 0u;
-        mine += v[q];
-        mine_nz += v[q] != 0u ? 1u : 0u;
-    }
-    uint32_t all, nz_all;
-    uint32_t excl = block_exclusive_scan_t<T>(mine, sh.scan, all);
-    uint32_t nz_excl = block_exclusive_scan_t<T>(mine_nz, sh.scan, nz_all);
-    if (tid == bucket / PER) {
-#pragma unroll
-        for (uint32_t q = 0; q < PER; q++) {
-            if (q == bucket % PER) {
-                sh.bcast[0] = v[q];
-                sh.bcast[1] = excl;
-                sh.bcast[2] = nz_excl;
-            }
-            excl += v[q];
-            nz_excl += v[q] != 0u ? 1u : 0u;
-        }
-    }
+    // (round 5, first version: every workgroup scanned the bucket sizes itself — two block scans over 1024 values, ~1 us
+    // in front of every bucket; the scatter pass has the starts in registers anyway and writes them)
+    const uint32_t size = io.totals[bucket], start = io.starts[bucket];
     if (bucket == 0u && io.bucket_max) {
         uint32_t m = 0;
 #pragma unroll
-        for (uint32_t q = 0; q < PER; q++) m = v[q] > m ? v[q] : m;
+        for (uint32_t q = 0; q < PER; q++) {
+            const uint32_t i = tid * PER + q;
+            const uint32_t v = i < io.nb ? io.totals[i] : 0u;
+            m = v > m ? v : m;
+        }
         m = wave_reduce_max(m);
-        if ((tid & 63u) == 0u) sh.wave_hist[0][tid >> 6] = m;
+        if ((tid & 63u) == 0u) sh.scan[tid >> 6] = m;
         __syncthreads();
         if (tid == 0u) {
             uint32_t mm = 0;
 #pragma unroll
-            for (int w = 0; w < WAVES; w++) mm = sh.wave_hist[0][w] > mm ? sh.wave_hist[0][w] : mm;
+            for (int w = 0; w < WAVES; w++) mm = sh.scan[w] > mm ? sh.scan[w] : mm;
             *io.bucket_max = mm;
         }
+        __syncthreads();
     }
-    __syncthreads();
-    const uint32_t size = sh.bcast[0], start = sh.bcast[1], nz_index = sh.bcast[2];
-    __syncthreads();
     if (size == 0u) return;
-    // the watchdog samples one NON-EMPTY bucket per frame, the next one every frame
-    uint32_t *rf = io.rank_fault && nz_index == io.watch % nz_all ? io.rank_fault : (uint32_t *)nullptr;
+    // the watchdog samples every 16th bucket, a different sixteenth every frame
+    uint32_t *rf = io.rank_fault && ((bucket + io.watch) & 15u) == 0u ? io.rank_fault : (uint32_t *)nullptr;
     if (size <= 4u * T) bucket_sort_fast<K, RB, T, 4, FAST_RANK>(sh, io, bucket, start, size, rf);
     else if (size <= 8u * T) bucket_sort_fast<K, RB, T, 8, FAST_RANK>(sh, io, bucket, start, size, rf);
     else if (size <= 16u * T) bucket_sort_fast<K, RB, T, 16, FAST_RANK>(sh, io, bucket, start, size, rf);
@@ -2556,7 +2678,7 @@ constexpr int GEN_BATCH = WAVE * GEN_PER;     // = EXP_CHUNK: a batch is one chu
 static_assert(GEN_BATCH == EXP_CHUNK, "the cursor hands out chunk starts");
 
 // per Gaussian of the batch: first slot (signed, relative to the wave's first), id, tile id of the rect origin, rect
-// width.  PACKED (rect_pack32: width <= 256, origin < 2^22): 12 bytes instead of 16 — with the staging below a
+// width — or the row code of a small rect with dropped tiles.  PACKED (rect_pack32: width <= 256, origin < 2^15): 12 bytes instead of 16 — with the staging below a
 // workgroup of k_pairs_emit then needs 38 KB of LDS instead of 52, four per CU instead of three (the kernel is
 // bound by the latency of its dependent loads times its occupancy, NOTES.md Part II).
 template <bool PACKED>
@@ -2569,17 +2691,19 @@ struct PairGenTab {
 };
 template <>
 struct PairGenTab<true> {
-    uint2 so[GEN_BATCH];               // first slot, origin | (width - 1) << 24
+    uint2 so[GEN_BATCH];               // first slot, origin (15 bits: the packed rects' limit) | shape << 15
     uint32_t gid[GEN_BATCH];
-    __device__ __forceinline__ void put(uint32_t i, uint32_t start, uint32_t g, uint32_t origin, uint32_t w) {
-        so[i] = make_uint2(start, origin | ((w - 1u) << 24));
+    // shape: the rect's width (<= 256), or 0x10000 | row code for a small rect that lost tiles (rect version 4)
+    __device__ __forceinline__ void put(uint32_t i, uint32_t start, uint32_t g, uint32_t origin, uint32_t shape) {
+        so[i] = make_uint2(start, origin | (shape << 15));
         gid[i] = g;
     }
     __device__ __forceinline__ uint4 get(uint32_t i) const {
         const uint2 a = so[i];
-        return make_uint4(a.x, gid[i], a.y & 0xffffffu, (a.y >> 24) + 1u);
+        return make_uint4(a.x, gid[i], a.y & 0x7fffu, a.y >> 15);
     }
 };
+constexpr uint32_t PAIR_SHAPE_ROWS = 0x10000u;       // PairGenTab shape: a row code, not a width
 
 template <typename K, int NSLOTS, bool RECT32>
 struct PairGenShared {                 // LDS private to one wave
@@ -2643,16 +2767,19 @@ __device__ __forceinline__ void pair_generate(const ExpandIO &io, uint32_t v_cou
 #pragma unroll
         for (int k = 0; k < GEN_PER; k++) {
             const bool live = j + GEN_PER * lane + k < v_count;
+            // w[k]: the rect's width, or PAIR_SHAPE_ROWS | row code when tiles of a small rect were dropped (rect version 4)
             if constexpr (RECT32) {
                 const uint32_t pk = k == 0 ? ra.x : k == 1 ? ra.y : k == 2 ? ra.z : ra.w;
-                w[k] = ((pk >> 16) & 0xffu) + 1u;
-                cnt[k] = live ? __umul24(w[k], (pk >> 24) + 1u) : 0u;
-                origin[k] = __umul24((pk >> 8) & 0xffu, io.tiles_x) + (pk & 0xffu);
+                const bool masked = (pk >> 31) != 0u;
+                w[k] = masked ? PAIR_SHAPE_ROWS | (pk & 0xfffu) : (pk & 0xffu) + 1u;
+                cnt[k] = live ? rect_count32(pk) : 0u;
+                origin[k] = (pk >> 16) & 0x7fffu;
             } else {
                 const uint32_t r0 = k == 0 ? ra.x : k == 1 ? ra.z : k == 2 ? rb.x : rb.z;
                 const uint32_t r1 = k == 0 ? ra.y : k == 1 ? ra.w : k == 2 ? rb.y : rb.w;
-                w[k] = (r1 & 0xffffu) - (r0 & 0xffffu);
-                cnt[k] = live ? __umul24(w[k], (r1 >> 16) - (r0 >> 16)) : 0u;
+                const bool masked = (r1 & 0xffffu) == 0u;          // (x1 is never 0; an all-zero entry past V counts 0 tiles)
+                w[k] = masked ? PAIR_SHAPE_ROWS | ((r1 >> 16) & 0xfffu) : (r1 & 0xffffu) - (r0 & 0xffffu);
+                cnt[k] = live ? rect_count64(make_uint2(r0, r1)) : 0u;
                 origin[k] = __umul24(r0 >> 16, io.tiles_x) + (r0 & 0xffffu);
             }
             mine += cnt[k];
@@ -2707,14 +2834,22 @@ __device__ __forceinline__ void pair_generate(const ExpandIO &io, uint32_t v_cou
 #pragma unroll
                 for (int k = 0; k < GEN_PER; k++) {
                     const uint32_t local = (uint32_t)(s0 + k - (int32_t)ot[k].x);
+                    const uint32_t shape = ot[k].w, width = shape & 0xffffu;
                     // row = local / width without the integer division: local < 2^22 and width < 2^16 are
                     // exact in f32, the estimate is off by at most one either way, fixed up exactly
-                    uint32_t row = (uint32_t)((float)local * __builtin_amdgcn_rcpf((float)ot[k].w));
-                    const uint32_t rem = local - __umul24(row, ot[k].w);
+                    uint32_t row = (uint32_t)((float)local * __builtin_amdgcn_rcpf((float)width));
+                    const uint32_t rem = local - __umul24(row, width);
                     if ((int32_t)rem < 0) row--;
-                    else if (rem >= ot[k].w) row++;
+                    else if (rem >= width) row++;
                     // tile = origin + row * tiles_x + col, col = local - row * width
-                    tile[k] = ot[k].z + local + __umul24(row, io.tiles_x - ot[k].w);
+                    uint32_t t = ot[k].z + local + __umul24(row, io.tiles_x - width);
+                    // a small rect that lost tiles: row j keeps cnt_j columns from first_j on (4 bits per row)
+                    const uint32_t c0 = (shape >> 2) & 3u, c01 = c0 + ((shape >> 6) & 3u);
+                    const uint32_t mrow = (local >= c0 ? 1u : 0u) + (local >= c01 ? 1u : 0u);
+                    const uint32_t before = mrow == 0u ? 0u : mrow == 1u ? c0 : c01;
+                    const uint32_t first = (shape >> (4u * mrow)) & 3u;
+                    const uint32_t mt = ot[k].z + __umul24(mrow, io.tiles_x) + first + (local - before);
+                    tile[k] = (shape & PAIR_SHAPE_ROWS) ? mt : t;
                     gid[k] = ot[k].y;
                 }
 #pragma unroll
@@ -2810,10 +2945,11 @@ __global__ __launch_bounds__(SORT_THREADS) void k_pairs_emit(ExpandIO io, uint32
         K *kout = tkeys + o0;
         if (n_slots == NSLOTS) {
 #pragma unroll
-            for (uint32_t q0 = 0; q0 < NSLOTS / 4; q0 += WAVE) ((uint4 *)vout)[q0 + lane] = ((const uint4 *)sh.vals)[q0 + lane];
+            for (uint32_t q0 = 0; q0 < NSLOTS / 4; q0 += WAVE)
+                store16((uint4 *)vout + q0 + lane, ((const uint4 *)sh.vals)[q0 + lane], io.wt_stores);
 #pragma unroll
             for (uint32_t q0 = 0; q0 < NSLOTS * sizeof(K) / 16; q0 += WAVE)
-                ((uint4 *)kout)[q0 + lane] = ((const uint4 *)sh.keys)[q0 + lane];
+                store16((uint4 *)kout + q0 + lane, ((const uint4 *)sh.keys)[q0 + lane], io.wt_stores);
         } else {
             for (uint32_t q = lane; q < n_slots; q += WAVE) {
                 vout[q] = sh.vals[q];
@@ -3299,7 +3435,7 @@ __global__ __launch_bounds__(BLEND_THREADS) void k_blend(uint32_t *__restrict__ 
         o.y = __builtin_fmaf(T.x, fc.bg[1], C1.x);
         o.z = __builtin_fmaf(T.x, fc.bg[2], C2.x);
         o.w = 1.0f - T.x;
-        rgba[(uint64_t)py0 * fc.width + px] = o;
+        store16(rgba + (uint64_t)py0 * fc.width + px, make_uint4(f2u(o.x), f2u(o.y), f2u(o.z), f2u(o.w)), fc.wt_stores);
     }
     if (in1) {
         float4 o;
@@ -3307,7 +3443,7 @@ __global__ __launch_bounds__(BLEND_THREADS) void k_blend(uint32_t *__restrict__ 
         o.y = __builtin_fmaf(T.y, fc.bg[1], C1.y);
         o.z = __builtin_fmaf(T.y, fc.bg[2], C2.y);
         o.w = 1.0f - T.y;
-        rgba[(uint64_t)py1 * fc.width + px] = o;
+        store16(rgba + (uint64_t)py1 * fc.width + px, make_uint4(f2u(o.x), f2u(o.y), f2u(o.z), f2u(o.w)), fc.wt_stores);
     }
 }
 
@@ -3599,7 +3735,7 @@ __global__ __launch_bounds__(BLEND_THREADS) void k_blend_grouped(uint32_t *__res
         o.y = __builtin_fmaf(T.x, fc.bg[1], C1.x);
         o.z = __builtin_fmaf(T.x, fc.bg[2], C2.x);
         o.w = 1.0f - T.x;
-        rgba[(uint64_t)py0 * fc.width + px] = o;
+        store16(rgba + (uint64_t)py0 * fc.width + px, make_uint4(f2u(o.x), f2u(o.y), f2u(o.z), f2u(o.w)), fc.wt_stores);
     }
     if (in1) {
         float4 o;
@@ -3607,7 +3743,7 @@ __global__ __launch_bounds__(BLEND_THREADS) void k_blend_grouped(uint32_t *__res
         o.y = __builtin_fmaf(T.y, fc.bg[1], C1.y);
         o.z = __builtin_fmaf(T.y, fc.bg[2], C2.y);
         o.w = 1.0f - T.y;
-        rgba[(uint64_t)py1 * fc.width + px] = o;
+        store16(rgba + (uint64_t)py1 * fc.width + px, make_uint4(f2u(o.x), f2u(o.y), f2u(o.z), f2u(o.w)), fc.wt_stores);
     }
 }
 
