@@ -135,13 +135,13 @@ def test_fullsize_frame_matches_oracle_hash(gs, device, stream, name):
         stitched[b0 * 16:min(b1 * 16, g["height"])] = part[b0 * 16:min(b1 * 16, g["height"])]
         vis_sum += r.stats().pairs
     assert hashlib.sha256(stitched.tobytes()).hexdigest() == g[frame_key]
-    # bands emit every (tile, Gaussian) pair of the whole frame at most once — exactly once up to rect version 3; under
-    # version 4 a rect that a band boundary cuts down to 3 x 3 tiles or less becomes eligible for the exact tile test in
-    # that band, so a few more pairs go (the stitched image above is still the whole frame's)
+    # bands emit every (tile, Gaussian) pair of the whole frame exactly once up to rect version 3; under version 4 a band
+    # boundary changes which rects are 2..3 x 2..3 tiles (a 2 x 2 rect cut in two keeps all four tiles, a 4 x 3 one cut in
+    # two may lose corners), so the sum moves by a fraction of a percent either way — the stitched image above does not
     if os.environ.get("GS3D_TILE_MASKS") == "0" or os.environ.get("GS3D_RECT_V1") == "1":
         assert vis_sum == g["pairs"], "bands must emit each (tile, Gaussian) pair exactly once"
     else:
-        assert 0.99 * g["pairs"] <= vis_sum <= g["pairs"], (vis_sum, g["pairs"])
+        assert abs(vis_sum - g["pairs"]) <= 0.01 * g["pairs"], (vis_sum, g["pairs"])
     # the same buffer with the spatial order switched off: plain index order, the oracle's other hash
     buf.set_spatial_order(False)
     plain = _frame(gs, device, stream, r, buf, gt, mt, cam)
@@ -226,8 +226,8 @@ def test_sharded_path_single_gpu_4k(gs, device, stream):
         assert img.shape == (H, W, 4)
         if os.environ.get("GS3D_TILE_MASKS") == "0" or os.environ.get("GS3D_RECT_V1") == "1":
             assert pairs == g["pairs"]
-        else:      # (rects cut down to 3 x 3 tiles by a band edge lose a few more tiles in that band: rect version 4)
-            assert 0.99 * g["pairs"] <= pairs <= g["pairs"], (pairs, g["pairs"])
+        else:      # (a band edge changes which rects are eligible for rect version 4's corner test)
+            assert abs(pairs - g["pairs"]) <= 0.01 * g["pairs"], (pairs, g["pairs"])
         assert hashlib.sha256(np.ascontiguousarray(img).tobytes()).hexdigest() == g[key], \
             "sharded frame differs (plan %s)" % (plan.bands,)
         # second round: bands re-cut to equal pairs

@@ -108,7 +108,16 @@ def test_oracle_image_matches_witness(ob, name):
     ref = WIT["%s/image" % name]
     err = np.abs(rgba.astype(np.float64) - ref)
     assert err.max() <= IMAGE_TOL, "oracle frame differs from the float64 witness by %g" % err.max()
-    assert abs(d - int(WIT["%s/pairs" % name])) <= 0.01 * d   # pair count up to borderline rects
+    # the witness counts the pairs of the CLIPPED rect (version 3); version 4 then drops unreachable corner tiles of small
+    # rects, which the witness — a renderer in float64, not a pair counter — does not restate: same image, fewer pairs
+    old = ob.rect_version()
+    try:
+        ob.set_rect_version(3 if old >= 3 else old)
+        rgba3, d3, _, _ = ob.render(ob.SH_SINGLE, ob.COV_ROT_SCALE, pods, gt, mt, cam)
+    finally:
+        ob.set_rect_version(old)
+    assert abs(d3 - int(WIT["%s/pairs" % name])) <= 0.01 * d3   # pair count up to borderline rects
+    assert d <= d3 and np.array_equal(rgba3.view(np.uint32), rgba.view(np.uint32))
 
 
 @pytest.mark.gpu
