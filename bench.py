@@ -341,6 +341,9 @@ def run_workload(gs, synth, torch, dist, dev, stream, rank, world, wl, steps, wa
                per_rank_ms=per_rank, render_ms_per_rank=render_ms, gather_ms_per_rank=gather_ms,
                bands=plan.bands, band_plan=plan_kind, skipped_band_flags=skipped_bands,
                rank_lanes=len(rank_lanes[0]) if rank_lanes[0] else 1)
+    si = r.sort_info()      # what the renderer chose for this workload
+    out["sort_info"] = dict(depth_msd=int(si.depth_msd), depth_bucket_max=int(si.depth_bucket_max),
+                            bucket_capacity=int(si.bucket_capacity), tile_msd=int(si.tile_msd), tile_masks=int(si.tile_masks))
     if samples:
         out["frame_ms"] = dict(samples=len(samples), median=samples[len(samples) // 2], min=samples[0],
                                p95=samples[min(len(samples) - 1, int(0.95 * len(samples)))], max=samples[-1],
@@ -370,7 +373,7 @@ def stage_models(wl, res):
     tpasses = -(-tile_bits // 8)
     tkey = 2 if tiles <= 65536 else 4
     dpasses = max(res["sort_passes"] - tpasses, 1)
-    rb = 4 if tiles_x <= 256 and tiles_y <= 256 else 8          # packed tile rects
+    rb = 4 if tiles_x <= 256 and tiles_y <= 256 and tiles <= 32768 else 8     # packed tile rects
     rect_writers = v if wl["sh"] != 3 else n                    # the two-phase kernel masks the rects of culled lanes
     # depth sort: pass 0 reads the N dense keys twice and writes V x (4 + 4); pass p > 0 reads its keys for the
     # histogram, keys + slots for the scatter, writes keys + slots; the pass before the last writes 2-byte keys,
@@ -383,12 +386,19 @@ def stage_models(wl, res):
         kin = 2 if p == dpasses - 1 else 4
         kout = 0 if p == dpasses - 1 else (2 if p == dpasses - 2 else 4)
         depth += v * kin + v * (kin + 4) + v * (kout + 4)
+    depth_what = ("pass 0 reads the N dense keys once (scatter) + 1 B per slot of per-chunk histogram rows and writes V x (key + 4 B); each further "
+                  "pass reads its keys (hist) and keys + slots (scatter) and writes them; 2-byte keys into the last pass")
+    if (res.get("sort_info") or {}).get("depth_msd"):
+        # MSD-first: the top-digit scatter (N dense keys + 2 B per slot of 1024-bin histogram rows in, V x 8 B out), then the
+        # bucket kernel reads V x 8 B and writes the V slots; the low digits never leave the CU
+        depth = n * 4 + n * 2 + v * 8 + v * 8 + v * 4
+        depth_what = ("MSD-first: one compacting scatter on the top 10 bits (N dense keys + 2 B per slot of histogram rows in, V x 8 B out), "
+                      "k_bucket_sort reads V x 8 B, sorts the low bits on the CU and writes the V slots; latency-bound at this size (4 launches)")
     models = {
         "preprocess": (n * wl["payload"] + v * 36 + n * 4 + rect_writers * rb + (n if chunk_hist else 0),
                        "read N x payload; write 36-B records of the V visible, 4-B keys of all N (+ 1 B per slot of digit histogram), %d-B rects of the %s"
                        % (rb, "V visible" if wl["sh"] != 3 else "N"),),
-        "depth_sort": (depth, "pass 0 reads the N dense keys once (scatter) + 1 B per slot of per-chunk histogram rows and writes V x (key + 4 B); each further "
-                              "pass reads its keys (hist) and keys + slots (scatter) and writes them; 2-byte keys into the last pass"),
+        "depth_sort": (depth, depth_what),
         "expand": (v * (4 + rb) + v * rb,
                    "k_expand_count: V x (4-B slot + %d-B rect gather) -> V x %d B (the pairs themselves are produced "
                    "by the first kernel of the tile sort); sector waste of the gather not modelled" % (rb, rb)),
@@ -870,7 +880,7 @@ def main():
         def summary(w, rr, name=None):
             d = {"workload": w["label"], "value": w["n"] / (rr["ms_per_frame"] * 1e-3) / 1e6, "unit": "Msplats/s",
                  "ms_per_step": rr["ms_per_frame"], "frame_ms": rr.get("frame_ms"), "visible": rr["visible"],
-                 "pairs": rr["pairs"], "launches_per_frame": rr["launches"], "stages_ms": rr["stages_ms"],
+                 "pairs": rr["pairs"], "launches_per_frame": rr["launches"], "sort_info": rr.get("sort_info"), "stages_ms": rr["stages_ms"],
                  "stage_models": stage_models(w, rr), "frame_bytes": frame_bytes_object(name, w, rr)}
             if rr["stages_ms"]:
                 pre = rr["stages_ms"]["preprocess"]
@@ -906,7 +916,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": wl["label"], "gaussians": wl["n"], "visible": res["visible"],
-                       "pairs": res["pairs"], "sort_passes": res["sort_passes"],
+                       "pairs": res["pairs"], "sort_passes": res["sort_passes"], "sort_info": res.get("sort_info"),
                        "launches_per_frame": res["launches"],
                        "parallelism": "tile-row bands x%d + one %s all-gather (%s), %d frames in flight per rank" % (
                            world, "RCCL" if backend == "nccl" else "%s (rehearsal, host-staged)" % backend, res["band_plan"],

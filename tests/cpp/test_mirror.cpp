@@ -185,6 +185,37 @@ int main() {
         REQUIRE(r.wait_frame().flags == 0 && r2.wait_frame().flags == 0);
         REQUIRE(img2.download<float>(s2) == px && img.download<float>(s) == px);
     }
+    {   // round 5: the sorts and the tile rect version are pinned per renderer; every combination renders the same frame;
+        // gs3d::FrameRing hands the frames to three lanes and waits per lane; a stream may be destroyed under a renderer
+        for (int depth_msd = 0; depth_msd <= 1; depth_msd++)
+            for (int masks = 0; masks <= 1; masks++) {
+                Renderer rv(dev);
+                rv.set_sort_mode(depth_msd, depth_msd);
+                rv.set_tile_masks(masks);
+                Buffer imgv(dev, (size_t)cam.width * cam.height * 16);
+                rv.render(s, rbuf, gt, mt, cam, (float *)imgv.device_ptr());
+                REQUIRE(rv.wait_frame().flags == 0);
+                const gs_sort_info si = rv.sort_info();
+                REQUIRE(si.depth_msd == (uint32_t)depth_msd && si.tile_masks == (uint32_t)masks && si.bucket_capacity >= 16384u);
+                REQUIRE(imgv.download<float>(s) == px);
+            }
+        try { r.set_sort_mode(2, 0); REQUIRE(false); } catch (const Error &e) { REQUIRE(e.status == GS_ERR_INVALID_ARGUMENT); }
+        FrameRing ring(dev, 3);
+        std::vector<Buffer> imgs;
+        for (size_t k = 0; k < ring.size(); k++) imgs.emplace_back(dev, (size_t)cam.width * cam.height * 16);
+        for (int i = 0; i < 7; i++) REQUIRE(ring.render(rbuf, gt, mt, cam, (float *)imgs[i % 3].device_ptr()) == (size_t)(i % 3));
+        for (size_t k = 0; k < ring.size(); k++) {
+            REQUIRE(ring.wait(k).flags == 0);
+            REQUIRE(imgs[k].download<float>(ring.stream(k)) == px);
+        }
+        Renderer rs(dev);
+        {
+            Stream tmp(dev);
+            rs.render(tmp, rbuf, gt, mt, cam, (float *)img.device_ptr());
+        }                                               // the stream is gone: its end-of-frame event was recorded on the way out
+        rs.render(s, rbuf, gt, mt, cam, (float *)img.device_ptr());
+        REQUIRE(rs.wait_frame().flags == 0 && img.download<float>(s) == px);
+    }
     double sum = 0; for (float v : px) sum += v;
     REQUIRE(st.gaussians == 15 && std::isfinite(sum));
     std::printf("cpp mirror OK: visible %llu pairs %llu checksum %.6f\n", (unsigned long long)st.visible, (unsigned long long)st.pairs, sum);

@@ -1029,3 +1029,39 @@ def test_two_frames_in_flight_on_priority_streams(gs, ob, device):
     img0.release()
     s0.close()
     buf.destroy()
+
+
+def test_renderer_survives_the_stream_of_its_last_frame(gs, ob, device):
+    """the end-of-frame event is recorded lazily, on the PREVIOUS stream, when a renderer moves to another
+    stream — which failed for good once the caller had destroyed that stream.  gs_stream_destroy now records the event
+    on its way out: frames on a new stream, wait_frame and the taps keep working, and the frame is the oracle's."""
+    import synth
+    g = synth.scene(20000, first=321)
+    pod = gs.GaussianPod(gs.SH_NONE, gs.COV3D_ROT_SCALE)
+    pods = pod.from_gaussian(g)
+    gt, mt = gs.gaussian_transform_pod(sh_deg=0), gs.model_transform_pod()
+    cam = helpers.default_camera(gs, 640, 360)
+    buf = gs.GaussiansBuffer.new_with_pods(device, pod, pods)
+    img = gs.Buffer(device, size=cam.height * cam.width * 16)
+    r = gs.Renderer(device)
+    a = device.create_stream()
+    r.render(a, buf, gt, mt, cam, img.device_ptr(), check=False)      # only enqueued
+    a.close()                                                          # the stream goes away under the renderer
+    assert r.wait_frame().flags == 0                                   # ... which waits on the event instead
+    assert r.stats().visible > 0
+    b = device.create_stream()
+    for _ in range(3):
+        assert r.render(b, buf, gt, mt, cam, img.device_ptr()).flags == 0
+    c = device.create_stream()
+    r.render(c, buf, gt, mt, cam, img.device_ptr(), check=False)
+    c.close()
+    r.render(b, buf, gt, mt, cam, img.device_ptr(), check=False)       # ordered behind the frame of the dead stream
+    b.synchronize()
+    rgba = img.download(b, np.float32).reshape(cam.height, cam.width, 4)
+    o = ob.render(pod.sh, pod.cov, pods, ob.gaussian_transform(sh_deg=0), ob.model_transform(), helpers.copy_camera(cam, ob.Camera),
+                  order=_mirror_order(ob, buf, b, pod.sh, pod.cov, pods))[0]
+    assert np.array_equal(rgba.view(np.uint32), o.view(np.uint32))
+    r.destroy()
+    buf.destroy()
+    img.release()
+    b.close()

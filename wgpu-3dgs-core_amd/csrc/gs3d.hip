@@ -1495,6 +1495,7 @@ struct gs_renderer {
     int depth_msd_req = -1, tile_msd_req = -1;   // gs_renderer_set_sort_mode: -1 = the renderer chooses
     int tile_masks_req = -1;              // gs_renderer_set_tile_masks
     bool tile_masks = false;              // the last frame ran tile rect version 4
+    bool wt_pairs = true;                 // k_pairs_emit stores write-through (gs::store16)
     uint64_t tile_msd_fail_d = 0;         // pair count at which the MSD-first tile sort last reported an oversized bucket (0: never)
     bool state_tile_bmax_dirty = false;   // FrameState::tile_bucket_max holds a value of an MSD-first frame
     uint32_t cull_last_gen = 0, cull_last_groups = 0;   // frame / group count of the last k_block_cull (status tags)
@@ -1844,8 +1845,10 @@ static void make_frame_consts(const gs_gaussian_transform_pod *gt, const gs_mode
         static const bool rect32_off = std::getenv("GS3D_RECT32") && std::getenv("GS3D_RECT32")[0] == '0';
         fc.rect32 = !rect32_off && fc.tiles_x <= 256u && fc.tiles_y <= 256u && fc.tiles_x * fc.tiles_y <= 32768u ? 1u : 0u;
         // write-through stores of the 16-byte-per-lane outputs (gs::store16).  GS3D_WT_STORES=0/1
-        static const int wt_env = std::getenv("GS3D_WT_STORES") ? std::atoi(std::getenv("GS3D_WT_STORES")) : 1;
-        fc.wt_stores = wt_env != 0 ? 1u : 0u;
+        // GS3D_WT_STORES: bit 0 = the pairs of k_pairs_emit, bit 1 = the image
+        static const int wt_env = std::getenv("GS3D_WT_STORES") ? std::atoi(std::getenv("GS3D_WT_STORES")) : 3;
+        fc.wt_stores = (wt_env & 2) ? 1u : 0u;
+        fc.wt_pairs = (wt_env & 1) ? 1u : 0u;
         static const int wtr_env = std::getenv("GS3D_WT_RECORDS") ? std::atoi(std::getenv("GS3D_WT_RECORDS")) : 0;
         fc.wt_records = (uint32_t)wtr_env & 3u;
     }
@@ -2563,6 +2566,7 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
         const bool want = pinned >= 0 ? pinned != 0 : pod_bytes >= 200u && (uint64_t)n64 * pod_bytes > (512ull << 20);
         fc.tile_masks = fc.tile_masks && want ? 1u : 0u;
         r->tile_masks = fc.tile_masks != 0u;
+        r->wt_pairs = fc.wt_pairs != 0u;
     }
     if (n64 > 0xfffffff0ull) return fail(GS_ERR_INVALID_ARGUMENT, n64, 0, 0, "too many Gaussians");
     uint32_t n = (uint32_t)n64;
@@ -2945,7 +2949,7 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
         eo.sb_bound = exp_grid / gs::EXP_SB + 1;
         eo.rect32 = fc.rect32;
         eo.flags_dev = r->flags_target;
-        eo.wt_stores = fc.wt_stores;
+        eo.wt_stores = r->wt_pairs ? 1u : 0u;
         // Where a wave of k_pairs_emit starts: found by the wave itself (a search over the super-chunk
         // sums: one step per 256 of them) or looked up in a table that k_pairs_cursors writes first.
         // The table costs a launch and wins once the search needs more than one step (A/B on one box:

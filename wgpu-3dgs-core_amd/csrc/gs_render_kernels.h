@@ -53,6 +53,7 @@ struct FrameConsts {
     uint32_t rect32;               // tile rects are stored packed in 4 bytes (at most 256 tiles along either axis, 32768 in all)
     uint32_t tile_masks;           // rect version 4: the exact tile test for rects of at most 3 x 3 tiles (needs clip_rect)
     uint32_t wt_stores;            // store16 mode of the frame's 16-byte-per-lane outputs (pairs, image): 1 = write-through
+    uint32_t wt_pairs;             // ... of k_pairs_emit's pairs (host-side copy of the switch: the kernel takes it through ExpandIO)
     uint32_t wt_records;           // store16 mode of the preprocess kernel's blend records
 };
 
