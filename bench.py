@@ -343,7 +343,8 @@ def run_workload(gs, synth, torch, dist, dev, stream, rank, world, wl, steps, wa
                rank_lanes=len(rank_lanes[0]) if rank_lanes[0] else 1)
     si = r.sort_info()      # what the renderer chose for this workload
     out["sort_info"] = dict(depth_msd=int(si.depth_msd), depth_bucket_max=int(si.depth_bucket_max),
-                            bucket_capacity=int(si.bucket_capacity), tile_msd=int(si.tile_msd), tile_masks=int(si.tile_masks))
+                            bucket_capacity=int(si.bucket_capacity), tile_msd=int(si.tile_msd), tile_masks=int(si.tile_masks),
+                            rounds=int(si.rounds), round1=int(si.round1), tiles_done=int(si.tiles_done))
     if samples:
         out["frame_ms"] = dict(samples=len(samples), median=samples[len(samples) // 2], min=samples[0],
                                p95=samples[min(len(samples) - 1, int(0.95 * len(samples)))], max=samples[-1],
@@ -418,6 +419,22 @@ def stage_models(wl, res):
     else:
         models["ranges"] = (d * tkey + tiles * 8, "k_tile_ranges: D keys read, tile ranges written")
     out = {}
+    if (res.get("sort_info") or {}).get("rounds") == 2:
+        # A two-round frame (DESIGN.md §4.2 "rounds"): `pairs` counts what both rounds emitted; the stage events bracket
+        # round 1's expansion, tile sort and ranges, and "blend" holds round 1's blend + the whole of round 2.  The byte
+        # models above describe one pass over V and D and do not apply; preprocess and depth sort are unchanged.
+        si = res["sort_info"]
+        for k in ("expand", "tile_sort", "ranges"):
+            models.pop(k, None)
+            out[k] = dict(bound="two_rounds", ms=st[k], note="round 1 only (the nearest %d visible Gaussians)" % si["round1"])
+        for k, (b, what) in models.items():
+            ms = st[k]
+            gbs = b / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            out[k] = dict(bound="hbm", model_bytes=b, model=what, ms=ms, achieved_gbs=gbs, frac=gbs / HBM_PEAK_GBS)
+        out["blend"] = dict(bound="two_rounds", ms=st["blend"], pairs=d, pixels=px,
+                            note="round 1's blend (%d of %d tiles finished), the slot bits and the compaction of round 2, its "
+                                 "expansion, tile sort and resumed blend" % (si["tiles_done"], tiles))
+        return out
     in_blend = os.environ.get("GS3D_RANGES_IN_BLEND")
     if (in_blend == "1") if in_blend in ("0", "1") else tiles > 16384:     # gs3d.hip: the rule that picks the range path
         # the blend workgroups find their own range (blend_tile_range): there is no range kernel to price

@@ -250,7 +250,10 @@ pub struct gs_sort_info {
     pub tile_msd: u32,
     pub tile_bucket_max: u32,
     pub tile_masks: u32,
-    pub reserved: [u32; 2],
+    pub rounds: u32,
+    pub round1: u32,
+    pub tiles_done: u32,
+    pub reserved: u32,
 }
 
 #[link(name = "gs3d_hip")]
@@ -364,6 +367,7 @@ extern "C" {
     pub fn gs_renderer_sort_info(r: *mut gs_renderer, out: *mut gs_sort_info) -> gs_status;
     pub fn gs_renderer_set_sort_mode(r: *mut gs_renderer, depth_msd: i32, tile_msd: i32) -> gs_status;
     pub fn gs_renderer_set_tile_masks(r: *mut gs_renderer, mode: i32) -> gs_status;
+    pub fn gs_renderer_set_rounds(r: *mut gs_renderer, mode: i32, first_round: u32) -> gs_status;
     pub fn gs_renderer_download_projected(r: *mut gs_renderer, proj_out: *mut gs_projected, tiles_touched_out: *mut u32, n: usize) -> gs_status;
     pub fn gs_renderer_download_sorted(r: *mut gs_renderer, keys_out: *mut u64, idx_out: *mut u32, capacity: u64, pairs_out: *mut u64) -> gs_status;
     pub fn gs_renderer_download_ranges(r: *mut gs_renderer, ranges_out: *mut u32, num_tiles: usize) -> gs_status;

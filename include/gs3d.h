@@ -647,7 +647,10 @@ typedef struct gs_sort_info {
     uint32_t tile_msd;           /* the same for the tile sort */
     uint32_t tile_bucket_max;
     uint32_t tile_masks;         /* 1: the last frame dropped unreachable tiles from small rects (tile rect version 4), 0: version 3 */
-    uint32_t reserved[2];
+    uint32_t rounds;             /* rounds the last frame took: 1, or 2 (gs_renderer_set_rounds) */
+    uint32_t round1;             /* two rounds: the nearest visible Gaussians its first round covered */
+    uint32_t tiles_done;         /* two rounds: tiles the first round finished (every pixel at its final colour) */
+    uint32_t reserved;
 } gs_sort_info;
 gs_status gs_renderer_sort_info(gs_renderer *r, gs_sort_info *out);
 /* Pins the choice for the following frames: 1 MSD-first, 0 LSD passes, -1 the renderer chooses (default; the
@@ -660,6 +663,16 @@ gs_status gs_renderer_set_sort_mode(gs_renderer *r, int32_t depth_msd, int32_t t
  * it is on for records of 200 bytes or more (f32 SH) in scenes beyond the 256 MiB Infinity Cache; 1 / 0 pin it
  * (GS3D_TILE_MASKS=0/1 pins it for every renderer of the process). */
 gs_status gs_renderer_set_tile_masks(gs_renderer *r, int32_t mode);
+/* Two-round frames (DESIGN.md 4.2 "rounds"; no reference item: the stages are the viewer's).  A deep scene finishes most
+ * of its tiles on the nearest fraction of its Gaussians; the rest is emitted, sorted and staged for nothing.  With two
+ * rounds the frame of the nearest `first_round` visible Gaussians (0: a quarter of what the previous frame saw) is
+ * rendered first; its blend marks the finished tiles and leaves the pixel state of the others in the image; the second
+ * round drops every Gaussian whose rect (at most 3 x 3 tiles) lies in finished tiles and resumes the blend.  The image is
+ * the single round's bit for bit; `pairs` of the frame result counts what was emitted (fewer), and the sorted / range
+ * taps (gs_renderer_download_sorted, _ranges) refuse such a frame (GS_ERR_INVALID_ARGUMENT).  A frame flagged SKIPPED by its
+ * second round has part of the first round's state in the image.  mode: 1 / 0 pin two rounds / one, -1 the renderer chooses
+ * (GS3D_ROUNDS=0/1 and GS3D_ROUND1=<count> pin it for every renderer of the process). */
+gs_status gs_renderer_set_rounds(gs_renderer *r, int32_t mode, uint32_t first_round);
 
 /* Parity taps on the last frame (blocking).  Sizes: N records / N counts; D keys / D indices;
  * tiles_x*tiles_y*2 ranges. */

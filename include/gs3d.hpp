@@ -465,6 +465,7 @@ class Renderer {
     gs_sort_info sort_info() { gs_sort_info si; check(gs_renderer_sort_info(h_, &si)); return si; }
     void set_sort_mode(int32_t depth_msd, int32_t tile_msd = -1) { check(gs_renderer_set_sort_mode(h_, depth_msd, tile_msd)); }
     void set_tile_masks(int32_t mode) { check(gs_renderer_set_tile_masks(h_, mode)); }
+    void set_rounds(int32_t mode, uint32_t first_round = 0) { check(gs_renderer_set_rounds(h_, mode, first_round)); }
     // sharded frames: a DEVICE word that receives every following frame's flags in stream order (nullptr: off)
     void set_frame_flags_target(uint32_t *device_word) { check(gs_renderer_set_frame_flags_target(h_, device_word)); }
   private:

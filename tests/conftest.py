@@ -14,6 +14,10 @@ for p in (ROOT, os.path.join(ROOT, "tools")):
 # enough that its test is free (gs_renderer_set_tile_masks), so the parity tests pin it for the whole process — product and
 # oracle binding read the same variable (GS3D_TILE_MASKS=0 runs both on version 3).
 os.environ.setdefault("GS3D_TILE_MASKS", "1")
+# Two-round frames (gs_renderer_set_rounds) emit fewer pairs than the oracle counts and refuse the pair / range taps: the
+# parity tests pin one round; tests/test_gpu_rounds.py pins two through the API and checks the renderer's own choice in
+# a child process without the variable.
+os.environ.setdefault("GS3D_ROUNDS", "0")
 
 
 def pytest_configure(config):

@@ -124,8 +124,10 @@ static int run(Device &dev, Stream &s, size_t n, uint32_t sh_deg, uint32_t W, ui
         Sha256 frame;
         frame.update(px.data(), px.size() * 4);
         const std::string got = frame.hex();
-        std::printf("%s order: visible %llu pairs %llu launches %u  %.4f ms/frame  sha256 %s\n", spatial ? "spatial" : "index",
-                    (unsigned long long)fr.visible, (unsigned long long)fr.pairs, fr.launches, ms, got.c_str());
+        const gs_sort_info si = r.sort_info();
+        std::printf("%s order: visible %llu pairs %llu launches %u rounds %u (first %u, %u tiles finished)  %.4f ms/frame  sha256 %s\n",
+                    spatial ? "spatial" : "index", (unsigned long long)fr.visible, (unsigned long long)fr.pairs, fr.launches, si.rounds,
+                    si.round1, si.tiles_done, ms, got.c_str());
         REQUIRE(got == (spatial ? frame_sha : frame_sha_index));
     }
     // Frames in flight across the boundary (gs3d::FrameRing): three renderers on three stream

@@ -65,11 +65,13 @@ def test_cpp_fullsize_on_the_runtime_the_library_is_built_for(name):
         exe = ge.build_cpp_fullsize_test()
     env = dict(os.environ)
     env.pop("LD_PRELOAD", None)
+    env.pop("GS3D_ROUNDS", None)          # the renderer's own choice: the 10 M frames take two rounds from the second frame on
     res = subprocess.run([exe, str(g["n"]), str(g["sh"]), str(g["cov"]), str(g["sh_deg"]), str(g["width"]), str(g["height"]),
                           g["scene_sha256"], g["frame_sha256"], g["frame_sha256_index_order"]],
                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900, env=env)
     print(res.stdout)
     assert res.returncode == 0 and "cpp fullsize OK" in res.stdout, res.stdout[-3000:]
+    assert ("rounds 2" in res.stdout) == (name == "10m"), res.stdout[-3000:]
     # the process ran on the system runtime, not on torch's bundled copy
     first = res.stdout.splitlines()[0]
     assert first.startswith("HIP headers"), first

@@ -1186,6 +1186,11 @@ class Renderer:
         """gs_renderer_set_tile_masks: 1 / 0 pin tile rect version 4 / 3, -1 the renderer chooses (by scene size)."""
         _check(_L.gs_renderer_set_tile_masks(self._h, int(mode)))
 
+    def set_rounds(self, mode=-1, first_round=0):
+        """gs_renderer_set_rounds: 1 two-round frames (the nearest `first_round` visible Gaussians first, the rest without
+        what lies in finished tiles), 0 one round, -1 the renderer chooses."""
+        _check(_L.gs_renderer_set_rounds(self._h, int(mode), int(first_round)))
+
     def render(self, stream, gaussians, gaussian_transform, model_transform, camera,
                rgba_device_ptr, band=None, check=True):
         """gs_render_frame.  check=True (the validated use: tests, one-off renders) waits for the

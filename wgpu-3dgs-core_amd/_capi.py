@@ -49,7 +49,7 @@ class FrameResult(C.Structure):
 
 class SortInfo(C.Structure):
     _fields_ = [("depth_msd", u32), ("depth_bucket_max", u32), ("bucket_capacity", u32), ("tile_msd", u32),
-                ("tile_bucket_max", u32), ("tile_masks", u32), ("reserved", u32 * 2)]
+                ("tile_bucket_max", u32), ("tile_masks", u32), ("rounds", u32), ("round1", u32), ("tiles_done", u32), ("reserved", u32)]
 
 
 class BundleDesc(C.Structure):
@@ -187,6 +187,7 @@ SIGNATURES = {
     "gs_renderer_sort_info": (i32, [vp, vp]),
     "gs_renderer_set_sort_mode": (i32, [vp, i32, i32]),
     "gs_renderer_set_tile_masks": (i32, [vp, i32]),
+    "gs_renderer_set_rounds": (i32, [vp, i32, u32]),
     "gs_render_frame": (i32, [vp, vp, vp, vp, vp, vp, u32, u32, vp]),
     "gs_renderer_download_projected": (i32, [vp, vp, vp, sz]),
     "gs_renderer_download_sorted": (i32, [vp, vp, vp, u64, vp]),

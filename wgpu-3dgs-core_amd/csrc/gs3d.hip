@@ -1481,6 +1481,7 @@ struct FrameShape {
 
 struct gs_renderer {
     gs_device *dev;
+    DevArray order_r2, keep_bits, r2_scan;         // two-round frames: mirror slots of the Gaussians round 2 keeps, in depth order; one bit per slot
     DevArray recs, depth, rect, sorted_rect, exp_sums, cursors, chunk_tiles, chunk_vis, state, zero_region, scan_tmp, block_list;
     DevArray cull_status;                 // k_block_cull: one (tag << 10 | count) word per group of 256 blocks
     DevArray chunk_hist;                  // [chunks][256] first-digit histogram of every chunk's depth keys (PreOut::chunk_hist)
@@ -1495,6 +1496,21 @@ struct gs_renderer {
     int depth_msd_req = -1, tile_msd_req = -1;   // gs_renderer_set_sort_mode: -1 = the renderer chooses
     int tile_masks_req = -1;              // gs_renderer_set_tile_masks
     bool tile_masks = false;              // the last frame ran tile rect version 4
+    bool two_round = false;               // the last frame took two rounds (its taps hold round 2 only)
+    int rounds_req = -1;                  // gs_renderer_set_rounds: -1 the renderer decides, 0 one round, 1 two
+    uint32_t round1_req = 0;              // ... Gaussians of round 1 (0: a quarter of the visible ones)
+    uint32_t round1 = 0;                  // Gaussians the last two-round frame's first round covered
+    // what the renderer's own choice of the rounds rests on: the pair count of a single-round frame of this shape (the
+    // sizing pass's, or the newest single-round report with the visible count it came with), the rounds of the frames
+    // behind the two result blocks, and the feedback state (the length of round 1 is scaled up while round 1 finishes
+    // too few tiles; past 3.4 x the renderer stays with one round until the shape changes)
+    uint64_t full_pairs = 0;
+    uint32_t full_pairs_v = 0, rounds_epoch = 0, rounds_fb_gen = 0;
+    uint8_t done_rounds[2] = {1, 1};
+    float round_scale = 1.0f;
+    bool rounds_off = false;
+    bool auto_deep = false;               // the renderer's last own choice (kept while no report is available)
+    uint64_t auto_k = 0;
     bool wt_pairs = true;                 // k_pairs_emit stores write-through (gs::store16)
     uint64_t tile_msd_fail_d = 0;         // pair count at which the MSD-first tile sort last reported an oversized bucket (0: never)
     bool state_tile_bmax_dirty = false;   // FrameState::tile_bucket_max holds a value of an MSD-first frame
@@ -1619,7 +1635,7 @@ extern "C" void gs_renderer_destroy(gs_renderer *r) {
     }
     (void)sync_last_frame(r);   // kernels of the last frame write pinned memory
     DevArray *arrs[] = {&r->recs, &r->depth, &r->rect, &r->sorted_rect, &r->exp_sums, &r->cursors, &r->chunk_tiles, &r->chunk_vis,
-                        &r->state, &r->zero_region, &r->scan_tmp, &r->block_list, &r->cull_status, &r->chunk_hist, &r->dkeys[0], &r->dkeys[1], &r->dvals[0],
+                        &r->state, &r->zero_region, &r->order_r2, &r->keep_bits, &r->r2_scan, &r->scan_tmp, &r->block_list, &r->cull_status, &r->chunk_hist, &r->dkeys[0], &r->dkeys[1], &r->dvals[0],
                         &r->dvals[1], &r->tkeys[0], &r->tkeys[1], &r->tvals[0], &r->tvals[1], &r->ghist,
                         &r->digit_totals, &r->bucket_starts};
     for (DevArray *a : arrs) dev_free(*a);
@@ -1749,6 +1765,9 @@ extern "C" gs_status gs_renderer_sort_info(gs_renderer *r, gs_sort_info *out) {
     out->depth_bucket_max = fr.gen == r->gen ? fr.depth_bucket_max : 0u;
     out->tile_msd = r->tile_msd ? 1u : 0u;
     out->tile_masks = r->tile_masks ? 1u : 0u;
+    out->rounds = r->two_round ? 2u : 1u;
+    out->round1 = r->two_round ? r->round1 : 0u;
+    out->tiles_done = r->two_round && fr.gen == r->gen ? fr.tiles_done : 0u;
     if (r->tile_msd && r->state.ptr)      // (the result block carries the PREVIOUS frame's: read this frame's from the device)
         GS_HIP(hipMemcpy(&out->tile_bucket_max, &((gs::FrameState *)r->state.ptr)->tile_bucket_max, sizeof(uint32_t), hipMemcpyDeviceToHost));
     return GS_OK;
@@ -1758,6 +1777,14 @@ extern "C" gs_status gs_renderer_set_tile_masks(gs_renderer *r, int32_t mode) {
     if (!r) return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "null renderer");
     if (mode < -1 || mode > 1) return fail(GS_ERR_INVALID_ARGUMENT, (uint64_t)(int64_t)mode, 0, 0, "tile mask modes are -1, 0 or 1");
     r->tile_masks_req = mode;
+    return GS_OK;
+}
+
+extern "C" gs_status gs_renderer_set_rounds(gs_renderer *r, int32_t mode, uint32_t first_round) {
+    if (!r) return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "null renderer");
+    if (mode < -1 || mode > 1) return fail(GS_ERR_INVALID_ARGUMENT, (uint64_t)(int64_t)mode, 0, 0, "round modes are -1, 0 or 1");
+    r->rounds_req = mode;
+    r->round1_req = first_round;
     return GS_OK;
 }
 
@@ -2587,7 +2614,7 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
     uint64_t hist_d[2] = {0, 0};
     uint32_t hist_gen[2] = {0, 0};
     uint32_t hist_v[2] = {0, 0};
-    uint32_t hist_bmax[2] = {0, 0}, hist_tmax[2] = {0, 0};
+    uint32_t hist_bmax[2] = {0, 0}, hist_tmax[2] = {0, 0}, hist_tdone[2] = {0, 0}, hist_topen[2] = {0, 0};
     for (int i = 0; i < 2; i++) {
         if (frame_event) {
             if (!r->done_valid[i] || hipEventQuery(r->done[i]) != hipSuccess) continue;
@@ -2601,13 +2628,15 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
         const uint64_t f_pairs = fr.pairs_total;
         const uint32_t f_vis = fr.visible;
         const uint32_t f_flags = fr.flags;
-        const uint32_t f_bmax = fr.depth_bucket_max, f_tmax = fr.tile_bucket_max;
+        const uint32_t f_bmax = fr.depth_bucket_max, f_tmax = fr.tile_bucket_max, f_tdone = fr.tiles_done, f_topen = fr.tiles_open;
         if (__atomic_load_n(&fr.gen, __ATOMIC_ACQUIRE) != r->done_gen[i] || f_pairs > 0xfffffff0ull) continue;
         hist_d[i] = f_pairs;
         hist_gen[i] = r->done_gen[i];
         hist_v[i] = f_vis;
         hist_bmax[i] = f_bmax;
         hist_tmax[i] = f_tmax;
+        hist_tdone[i] = f_tdone;
+        hist_topen[i] = f_topen;
         if (f_flags & gs::FRAME_FLAG_RANK_FAULT) rank_fault_seen = true;
         // grow when the last measured D leaves less than 1/8 of head room
         if (f_pairs + f_pairs / 8 > r->pair_capacity && capacity_for(f_pairs) > want_capacity)
@@ -2723,6 +2752,7 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
             }
             r->done_gen[gen & 1u] = gen;
             r->done_shape[gen & 1u] = r->shape_epoch;
+            r->done_rounds[gen & 1u] = r->two_round ? 2 : 1;
         }
     } done_guard{r, st, gen, frame_event};
     gs::FrameState *state = (gs::FrameState *)r->state.ptr;
@@ -2773,7 +2803,33 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
     }
     r->depth_msd = depth_msd;
 
-    gs::TileKeys tile_keys{nullptr, nullptr, 0u, 0u};   // null keys: the blend reads its ranges from the range array
+    gs::TileKeys tile_keys{nullptr, nullptr, 0u, 0u, 0u, nullptr, nullptr};   // null keys: the blend reads its ranges from the range array
+    // GS3D_BLEND_GROUPS = 1 (half-tile lists), 2 (8x8 blocks) or 4 (8x4 blocks, default)
+    static const int groups = std::getenv("GS3D_BLEND_GROUPS") ? std::atoi(std::getenv("GS3D_BLEND_GROUPS")) : 4;
+    uint32_t band_tiles = (fc.band_ty1 - fc.band_ty0) * fc.tiles_x;
+    // The blend launch of one round (0: the frame's only one).
+    auto launch_blend = [&](uint32_t round) -> gs_status {
+        if (!band_tiles) return GS_OK;
+        typedef void (*blend_fn)(uint32_t *, const uint32_t *, const uint32_t *, gs::FrameConsts, float4 *,
+                                 const gs::FrameState *, gs::TileKeys);
+        static const blend_fn tbl[3][3] = {
+            {gs::k_blend<0>, gs::k_blend_grouped<0, 2>, gs::k_blend_grouped<0, 4>},
+            {gs::k_blend<1>, gs::k_blend_grouped<1, 2>, gs::k_blend_grouped<1, 4>},
+            {gs::k_blend<2>, gs::k_blend_grouped<2, 2>, gs::k_blend_grouped<2, 4>}};
+        static const blend_fn tbl_rounds[3][2] = {{gs::k_blend_grouped<0, 2, true>, gs::k_blend_grouped<0, 4, true>},
+                                                  {gs::k_blend_grouped<1, 2, true>, gs::k_blend_grouped<1, 4, true>},
+                                                  {gs::k_blend_grouped<2, 2, true>, gs::k_blend_grouped<2, 4, true>}};
+        if (round != 0u && groups == 1) return fail(GS_ERR_INVALID_ARGUMENT, round, 0, 0, "two-round frames need the grouped blend");
+        const blend_fn blend = round != 0u ? tbl_rounds[mode][groups == 2 ? 0 : 1] : tbl[mode][groups == 1 ? 0 : groups == 2 ? 1 : 2];
+        tile_keys.round = round;
+        hipLaunchKernelGGL(blend, dim3(band_tiles), dim3(gs::BLEND_THREADS), 0, st,
+                           (uint32_t *)r->zero_region.ptr, (const uint32_t *)r->tvals[r->tsorted_side].ptr,
+                           (const uint32_t *)r->recs.ptr, fc, (float4 *)rgba, (const gs::FrameState *)r->state.ptr, tile_keys);
+        GS_HIP(hipGetLastError());
+        r->launches++;
+        return GS_OK;
+    };
+    r->two_round = false;
     if (n == 0) {
         // nothing to project: clear the ranges, blend the background
         GS_TRY(dev_reserve(r->zero_region, (size_t)num_tiles * 8));
@@ -2790,9 +2846,15 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
         // expansion's super-chunk sums
         const size_t ranges_words = (size_t)num_tiles * 2;                                   // even: keeps the u64 sums aligned
         const size_t esb_words = 2 * ((size_t)exp_grid / gs::EXP_SB + 1);                    // u64 super-chunk sums of the expansion
-        GS_TRY(dev_reserve(r->zero_region, (ranges_words + esb_words) * 4));
+        const size_t done_words = ((size_t)num_tiles + 31) / 32 + 1;                        // two-round frames: finished tiles
+        // (a two-round frame needs the sums of both rounds and the bits; cleared in every frame: ~1 KB)
+        const size_t zero_words = ranges_words + 2 * esb_words + 2 * done_words;
+        GS_TRY(dev_reserve(r->zero_region, zero_words * 4));
         uint32_t *zero = (uint32_t *)r->zero_region.ptr;
         uint32_t *esb = zero + ranges_words;
+        uint32_t *esb2 = esb + esb_words;
+        uint32_t *done_bits = esb2 + esb_words;
+        uint32_t *open_bits = done_bits + done_words;
 
         if (!sizing && want_capacity > r->pair_capacity) GS_TRY(reserve_pairs(r, want_capacity, wide));
         if (!sizing) GS_TRY(reserve_pairs(r, r->pair_capacity, wide));   // key width may have changed
@@ -2823,7 +2885,7 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
         po.chunk_tiles = (uint32_t *)r->chunk_tiles.ptr;
         po.chunk_vis = (uint32_t *)r->chunk_vis.ptr;
         po.zero_ptr = zero;
-        po.zero_words = (uint32_t)(ranges_words + esb_words);
+        po.zero_words = (uint32_t)zero_words;
         po.key_bias = near_bits;
         po.block_bounds = (const float *)g->block_bounds;
         po.chunk_hist = (uint32_t *)r->chunk_hist.ptr;
@@ -2890,6 +2952,8 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
                 return fail(GS_ERR_PAIR_OVERFLOW, n, 0, 0,
                             "the frame needs more than 2^32 (tile, Gaussian) pairs; pair indices are 32-bit");
             }
+            r->full_pairs = d;              // (the visible count it belongs to comes with the frame's report)
+            r->full_pairs_v = 0;
             const uint64_t cap = capacity_for(d) > want_capacity ? capacity_for(d) : want_capacity;
             GS_TRY(reserve_pairs(r, cap, wide));
         }
@@ -2931,168 +2995,269 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
                 GS_TRY((run_sort_rb<uint32_t, gs::RADIX_BITS>(r->dev, k2, v2, r->ghist, r->digit_totals, dc, dbits, &cp, st,
                                                               dside, dpasses, r->launches)));
         }
-        mark(ST_EXPAND);
 
-        // ---- pairs in depth order ----
-        gs::ExpandIO eo;
-        eo.order = (const uint32_t *)r->dvals[dside].ptr;
-        eo.rect = (const uint2 *)r->rect.ptr;
-        eo.sorted_rect = (uint2 *)r->sorted_rect.ptr;
-        eo.sums = (uint32_t *)r->exp_sums.ptr;
-        eo.sb_sums = (unsigned long long *)esb;
-        eo.tvals = (uint32_t *)r->tvals[0].ptr;
-        eo.state = state;
-        eo.result = result;
-        eo.capacity = capacity;
-        eo.tiles_x = fc.tiles_x;
-        eo.gen = gen;
-        eo.sb_bound = exp_grid / gs::EXP_SB + 1;
-        eo.rect32 = fc.rect32;
-        eo.flags_dev = r->flags_target;
-        eo.wt_stores = r->wt_pairs ? 1u : 0u;
-        // Where a wave of k_pairs_emit starts: found by the wave itself (a search over the super-chunk
-        // sums: one step per 256 of them) or looked up in a table that k_pairs_cursors writes first.
-        // The table costs a launch and wins once the search needs more than one step (A/B on one box:
-        // 1 M 0.369 vs 0.366 ms, 10 M 1.227 vs 1.226, 50 M 4.60 vs 4.80).  GS3D_CURSOR_KERNEL=0/1 forces.
-        static const int cursor_env = std::getenv("GS3D_CURSOR_KERNEL") ? std::atoi(std::getenv("GS3D_CURSOR_KERNEL")) : -1;
-        const bool cursor_kernel = cursor_env >= 0 ? cursor_env != 0 : eo.sb_bound > 256u;
-        eo.cursors = cursor_kernel ? (gs::PairCursorRec *)r->cursors.ptr : nullptr;
-        // XCD-aware span order of the gather: XCD x takes C consecutive spans of every group of 8 C, so that its L2
-        // serves part of the gather (neighbours in depth order are often neighbours in the mirror).  Same-box sweep
-        // (gpurun_out/r04q/ab*.log): C = 0 / 16 / 64 / 256 / 1024 -> 58.3 / 53.3 / 49.1 / 54.3 / 90.6 us at 10 M, 261 / 258 /
-        // 231 / 228 / 293 us at 50 M, 12.0 / - / 10.5 / 21 / 26 us at 1 M.  GS3D_EXPAND_XCD=<C> forces, 0 = dispatch order.
-        static const int exp_xcd = std::getenv("GS3D_EXPAND_XCD") ? std::atoi(std::getenv("GS3D_EXPAND_XCD")) : 64;
-        uint32_t count_grid = (exp_grid + gs::EXP_COUNT_CHUNKS - 1) / gs::EXP_COUNT_CHUNKS;
-        eo.xcd_chunk = 0;
-        if (exp_xcd > 0 && count_grid >= 256u) {
-            eo.xcd_chunk = (uint32_t)exp_xcd;
-            count_grid = 8u * eo.xcd_chunk * ((count_grid + 8u * eo.xcd_chunk - 1u) / (8u * eo.xcd_chunk));
-        }
-        if (eo.rect32)
-            hipLaunchKernelGGL(gs::k_expand_count<true>, dim3(count_grid), dim3(gs::EXP_CHUNK), 0, st, eo);
-        else
-            hipLaunchKernelGGL(gs::k_expand_count<false>, dim3(count_grid), dim3(gs::EXP_CHUNK), 0, st, eo);
-        r->launches++;
-        if (cursor_kernel) {
-            hipLaunchKernelGGL(gs::k_pairs_cursors, dim3(eo.sb_bound), dim3(gs::EXP_SB), 0, st, eo);
-            r->launches++;
-        }
-        GS_HIP(hipGetLastError());
-        mark(ST_TSORT);
-
-        // ---- stable sort on the tile id alone (pairs are generated in depth order by its first pass) ----
+        // ---- pairs in depth order, tile sort, tile ranges: once per round ----
         int tside = 0;
         uint32_t tpasses = 0;
-        const gs::SortCount tc{capacity, &state->pairs};
-        // Which tile sort (gs_renderer::tile_msd).  MSD-first needs u16 tile ids with more than 10 bits; its buckets are
-        // 2^(bits - 10) consecutive tiles, so what decides is the pair count: up to an average of a quarter of the register
-        // path's capacity per bucket it is tried, and a frame that reports a bucket beyond the capacity (FrameResult::
-        // tile_bucket_max, one frame late) sends the renderer back to the LSD passes until the pair count has dropped by
-        // a quarter below the count that failed.
-        bool tile_msd = false;
-        if (!wide && tile_bits > (uint32_t)gs::MSD_TOP_BITS && capacity != 0u) {
-            static const int tmsd_env = std::getenv("GS3D_TILE_MSD") ? std::atoi(std::getenv("GS3D_TILE_MSD")) : -1;
-            const int pinned = r->tile_msd_req >= 0 ? r->tile_msd_req : tmsd_env;
-            const int newer = hist_gen[0] > hist_gen[1] ? 0 : 1;
-            // pairs this frame is expected to hold: the newest report of this shape, else what sized the buffers
-            const uint64_t d_est = !sizing && hist_gen[newer] && r->done_shape[newer] == r->shape_epoch ? hist_d[newer]
-                                                                                                         : (uint64_t)capacity * 4u / 5u;
-            if (!sizing && hist_gen[newer] && r->done_shape[newer] == r->shape_epoch && hist_tmax[newer] > gs::BKT_CAP_SMALL)
-                r->tile_msd_fail_d = d_est ? d_est : 1u;
-            if (sizing) r->tile_msd_fail_d = 0;
-            // Measured at 1 M (gpurun_out/r05c/kt_1m.txt): the 1020 buckets of ~2 500 pairs cost the bucket kernel 22 us (one
-            // 1024-thread workgroup with 157 KB of LDS per bucket: four rounds of workgroups whose fixed costs dominate) and
-            // the 10-bit first pass 6 us more than the 7-bit one — 60 us against the LSD sort's 55.  So the renderer does
-            // not choose it by itself (GS3D_TILE_MSD_AUTO=1 lets it); pinned, it is exact (tests/test_gpu_msd_sort.py).
-            static const bool tile_auto = std::getenv("GS3D_TILE_MSD_AUTO") && std::getenv("GS3D_TILE_MSD_AUTO")[0] == '1';
-            if (pinned >= 0)
-                tile_msd = pinned != 0;
+        // round: 0 the frame's only one; 1: the nearest `limit` Gaussians of the depth order; 2: the survivors of
+        // k_round2_write (order_r2)
+        auto pairs_round = [&](uint32_t round, uint32_t limit, uint32_t *esb_r) -> gs_status {
+            if (round <= 1u) mark(ST_EXPAND);
+            gs::ExpandIO eo;
+            eo.order = round == 2u ? (const uint32_t *)r->order_r2.ptr : (const uint32_t *)r->dvals[dside].ptr;
+            eo.rect = (const uint2 *)r->rect.ptr;
+            eo.sorted_rect = (uint2 *)r->sorted_rect.ptr;
+            eo.count_dev = round == 2u ? &state->round2_visible : &state->visible;
+            eo.limit = limit;
+            eo.round = round;
+            eo.sums = (uint32_t *)r->exp_sums.ptr;
+            eo.sb_sums = (unsigned long long *)esb_r;
+            eo.tvals = (uint32_t *)r->tvals[0].ptr;
+            eo.state = state;
+            eo.result = result;
+            eo.capacity = capacity;
+            eo.tiles_x = fc.tiles_x;
+            eo.gen = gen;
+            eo.sb_bound = exp_grid / gs::EXP_SB + 1;
+            eo.rect32 = fc.rect32;
+            eo.flags_dev = r->flags_target;
+            eo.wt_stores = r->wt_pairs ? 1u : 0u;
+            // Where a wave of k_pairs_emit starts: found by the wave itself (a search over the super-chunk
+            // sums: one step per 256 of them) or looked up in a table that k_pairs_cursors writes first.
+            // The table costs a launch and wins once the search needs more than one step (A/B on one box:
+            // 1 M 0.369 vs 0.366 ms, 10 M 1.227 vs 1.226, 50 M 4.60 vs 4.80).  GS3D_CURSOR_KERNEL=0/1 forces.
+            static const int cursor_env = std::getenv("GS3D_CURSOR_KERNEL") ? std::atoi(std::getenv("GS3D_CURSOR_KERNEL")) : -1;
+            const bool cursor_kernel = cursor_env >= 0 ? cursor_env != 0 : eo.sb_bound > 256u;
+            eo.cursors = cursor_kernel ? (gs::PairCursorRec *)r->cursors.ptr : nullptr;
+            // XCD-aware span order of the gather: XCD x takes C consecutive spans of every group of 8 C, so that its L2
+            // serves part of the gather (neighbours in depth order are often neighbours in the mirror).  Same-box sweep
+            // (gpurun_out/r04q/ab*.log): C = 0 / 16 / 64 / 256 / 1024 -> 58.3 / 53.3 / 49.1 / 54.3 / 90.6 us at 10 M, 261 / 258 /
+            // 231 / 228 / 293 us at 50 M, 12.0 / - / 10.5 / 21 / 26 us at 1 M.  GS3D_EXPAND_XCD=<C> forces, 0 = dispatch order.
+            static const int exp_xcd = std::getenv("GS3D_EXPAND_XCD") ? std::atoi(std::getenv("GS3D_EXPAND_XCD")) : 64;
+            uint32_t count_grid = (exp_grid + gs::EXP_COUNT_CHUNKS - 1) / gs::EXP_COUNT_CHUNKS;
+            eo.xcd_chunk = 0;
+            if (exp_xcd > 0 && count_grid >= 256u) {
+                eo.xcd_chunk = (uint32_t)exp_xcd;
+                count_grid = 8u * eo.xcd_chunk * ((count_grid + 8u * eo.xcd_chunk - 1u) / (8u * eo.xcd_chunk));
+            }
+            if (eo.rect32)
+                hipLaunchKernelGGL(gs::k_expand_count<true>, dim3(count_grid), dim3(gs::EXP_CHUNK), 0, st, eo);
             else
-                tile_msd = tile_auto && d_est <= (uint64_t)gs::BKT_CAP_SMALL * 256u &&
-                           (r->tile_msd_fail_d == 0 || d_est < r->tile_msd_fail_d - r->tile_msd_fail_d / 4u);
-        }
-        r->tile_msd = tile_msd;
-        if (tile_msd) {
-            t_bucket_max = nullptr;
-            if (tile_bits > (uint32_t)gs::MSD_TOP_BITS + 6u) return fail(GS_ERR_INVALID_ARGUMENT, tile_bits, 0, 0, "tile id bits");
-            GS_TRY((run_tile_msd_items<gs::SortCfg<uint16_t>::ITEMS>(r, st, eo, tc, tile_bits, num_tiles, zero, &state->tile_bucket_max,
-                                                                          tpasses)));
+                hipLaunchKernelGGL(gs::k_expand_count<false>, dim3(count_grid), dim3(gs::EXP_CHUNK), 0, st, eo);
+            r->launches++;
+            if (cursor_kernel) {
+                hipLaunchKernelGGL(gs::k_pairs_cursors, dim3(eo.sb_bound), dim3(gs::EXP_SB), 0, st, eo);
+                r->launches++;
+            }
+            GS_HIP(hipGetLastError());
+            if (round <= 1u) mark(ST_TSORT);
+
+            // ---- stable sort on the tile id alone (pairs are generated in depth order by its first pass) ----
             tside = 0;
-        } else {
-            // (a frame whose tile sort is LSD reports no bucket size: the next result must not carry a stale one)
-            if (r->state_tile_bmax_dirty) GS_HIP(hipMemsetAsync(&state->tile_bucket_max, 0, sizeof(uint32_t), st));
-            void *k2[2] = {r->tkeys[0].ptr, r->tkeys[1].ptr};
-            void *v2[2] = {r->tvals[0].ptr, r->tvals[1].ptr};
-            const gs::ExpandIO *src = &eo;
-            if (wide)
-                GS_TRY((run_sort_rb<uint32_t, gs::RADIX_BITS>(r->dev, k2, v2, r->ghist, r->digit_totals, tc, tile_bits, nullptr,
-                                                              st, tside, tpasses, r->launches, src)));
-            else
-                GS_TRY((run_sort_rb<uint16_t, gs::RADIX_BITS>(r->dev, k2, v2, r->ghist, r->digit_totals, tc, tile_bits, nullptr,
-                                                              st, tside, tpasses, r->launches, src)));
+            const gs::SortCount tc{capacity, &state->pairs};
+            // Which tile sort (gs_renderer::tile_msd).  MSD-first needs u16 tile ids with more than 10 bits; its buckets are
+            // 2^(bits - 10) consecutive tiles, so what decides is the pair count: up to an average of a quarter of the register
+            // path's capacity per bucket it is tried, and a frame that reports a bucket beyond the capacity (FrameResult::
+            // tile_bucket_max, one frame late) sends the renderer back to the LSD passes until the pair count has dropped by
+            // a quarter below the count that failed.
+            bool tile_msd = false;
+            if (!wide && tile_bits > (uint32_t)gs::MSD_TOP_BITS && capacity != 0u && round == 0u) {
+                static const int tmsd_env = std::getenv("GS3D_TILE_MSD") ? std::atoi(std::getenv("GS3D_TILE_MSD")) : -1;
+                const int pinned = r->tile_msd_req >= 0 ? r->tile_msd_req : tmsd_env;
+                const int newer = hist_gen[0] > hist_gen[1] ? 0 : 1;
+                // pairs this frame is expected to hold: the newest report of this shape, else what sized the buffers
+                const uint64_t d_est = !sizing && hist_gen[newer] && r->done_shape[newer] == r->shape_epoch ? hist_d[newer]
+                                                                                                             : (uint64_t)capacity * 4u / 5u;
+                if (!sizing && hist_gen[newer] && r->done_shape[newer] == r->shape_epoch && hist_tmax[newer] > gs::BKT_CAP_SMALL)
+                    r->tile_msd_fail_d = d_est ? d_est : 1u;
+                if (sizing) r->tile_msd_fail_d = 0;
+                // Measured at 1 M (gpurun_out/r05c/kt_1m.txt): the 1020 buckets of ~2 500 pairs cost the bucket kernel 22 us (one
+                // 1024-thread workgroup with 157 KB of LDS per bucket: four rounds of workgroups whose fixed costs dominate) and
+                // the 10-bit first pass 6 us more than the 7-bit one — 60 us against the LSD sort's 55.  So the renderer does
+                // not choose it by itself (GS3D_TILE_MSD_AUTO=1 lets it); pinned, it is exact (tests/test_gpu_msd_sort.py).
+                static const bool tile_auto = std::getenv("GS3D_TILE_MSD_AUTO") && std::getenv("GS3D_TILE_MSD_AUTO")[0] == '1';
+                if (pinned >= 0)
+                    tile_msd = pinned != 0;
+                else
+                    tile_msd = tile_auto && d_est <= (uint64_t)gs::BKT_CAP_SMALL * 256u &&
+                               (r->tile_msd_fail_d == 0 || d_est < r->tile_msd_fail_d - r->tile_msd_fail_d / 4u);
+            }
+            r->tile_msd = tile_msd;
+            if (tile_msd) {
+                t_bucket_max = nullptr;
+                if (tile_bits > (uint32_t)gs::MSD_TOP_BITS + 6u) return fail(GS_ERR_INVALID_ARGUMENT, tile_bits, 0, 0, "tile id bits");
+                GS_TRY((run_tile_msd_items<gs::SortCfg<uint16_t>::ITEMS>(r, st, eo, tc, tile_bits, num_tiles, zero, &state->tile_bucket_max,
+                                                                              tpasses)));
+                tside = 0;
+            } else {
+                // (a frame whose tile sort is LSD reports no bucket size: the next result must not carry a stale one)
+                if (r->state_tile_bmax_dirty) GS_HIP(hipMemsetAsync(&state->tile_bucket_max, 0, sizeof(uint32_t), st));
+                void *k2[2] = {r->tkeys[0].ptr, r->tkeys[1].ptr};
+                void *v2[2] = {r->tvals[0].ptr, r->tvals[1].ptr};
+                const gs::ExpandIO *src = &eo;
+                if (wide)
+                    GS_TRY((run_sort_rb<uint32_t, gs::RADIX_BITS>(r->dev, k2, v2, r->ghist, r->digit_totals, tc, tile_bits, nullptr,
+                                                                  st, tside, tpasses, r->launches, src)));
+                else
+                    GS_TRY((run_sort_rb<uint16_t, gs::RADIX_BITS>(r->dev, k2, v2, r->ghist, r->digit_totals, tc, tile_bits, nullptr,
+                                                                  st, tside, tpasses, r->launches, src)));
+            }
+            r->state_tile_bmax_dirty = tile_msd;
+            if (round <= 1u) mark(ST_RANGES);
+            // Tile ranges, three ways (the MSD-first tile sort has written them already: k_bucket_sort).  (1) One pass over the sorted keys (k_tile_ranges).  (2) A 32-ary search per tile
+            // (k_tile_ranges_search) once reading every key again costs more than a few dependent probes per tile: from
+            // a pair capacity of 8 M (GS3D_RANGES_SEARCH=0/1 forces).  (3) The same search run by the blend workgroups
+            // themselves (blend_tile_range_wg): no launch in front of the blend, but a workgroup that waits for its
+            // probes is occupancy the VALU-bound blend misses — same-box A/B (gpurun_out/r04l/ab.log): blend +3.5 us at
+            // 1 M and 10 M, +10 us at 4K, +12 us at 50 M against 6.8 / 10.5 / 35 / 19 us of range kernel saved: frames
+            // +1.5 % at 1 M, +-0 at 10 M, -0.5 % at 50 M, -2.3 % at 4K.  It is taken where it pays: images of more than
+            // 16384 tiles, where neither stand-alone kernel is cheap (GS3D_RANGES_IN_BLEND=0/1 forces).
+            static const int in_blend_env = std::getenv("GS3D_RANGES_IN_BLEND") ? std::atoi(std::getenv("GS3D_RANGES_IN_BLEND")) : -1;
+            // (a two-round frame: always — the range array is cleared once per frame, and a launch per round is saved)
+            const bool ranges_in_blend = round != 0u || (in_blend_env >= 0 ? in_blend_env != 0 : num_tiles > 16384u);
+            static const int ranges_env = std::getenv("GS3D_RANGES_SEARCH") ? std::atoi(std::getenv("GS3D_RANGES_SEARCH")) : -1;
+            const bool ranges_search = ranges_env >= 0 ? ranges_env != 0 : capacity >= (8u << 20);
+            if (tile_msd) {
+                // nothing to do
+            } else if (capacity && ranges_in_blend) {
+                tile_keys.keys = r->tkeys[tside].ptr;
+                tile_keys.count_dev = &state->pairs;
+                tile_keys.count_bound = capacity;
+                tile_keys.wide = wide ? 1u : 0u;
+            } else if (capacity && ranges_search) {
+                if (wide)
+                    hipLaunchKernelGGL(gs::k_tile_ranges_search<uint32_t>, dim3((num_tiles + 3u) / 4u), dim3(256), 0, st,
+                                       (const uint32_t *)r->tkeys[tside].ptr, tc, zero, num_tiles);
+                else
+                    hipLaunchKernelGGL(gs::k_tile_ranges_search<uint16_t>, dim3((num_tiles + 3u) / 4u), dim3(256), 0, st,
+                                       (const uint16_t *)r->tkeys[tside].ptr, tc, zero, num_tiles);
+                GS_HIP(hipGetLastError());
+                r->launches++;
+            } else if (capacity) {
+                if (wide)
+                    hipLaunchKernelGGL(gs::k_tile_ranges<uint32_t>, dim3((uint32_t)(((uint64_t)capacity + 1023) / 1024)), dim3(256), 0, st,
+                                       (const uint32_t *)r->tkeys[tside].ptr, tc, zero);
+                else
+                    hipLaunchKernelGGL(gs::k_tile_ranges<uint16_t>, dim3((uint32_t)(((uint64_t)capacity + 2047) / 2048)), dim3(256), 0, st,
+                                       (const uint16_t *)r->tkeys[tside].ptr, tc, zero);
+                GS_HIP(hipGetLastError());
+                r->launches++;
+            }
+            return GS_OK;
+        };
+        // ---- one round, or two (DESIGN.md §4.2 "rounds") ----
+        // A deep scene finishes most of its tiles on the nearest fraction of its Gaussians; everything behind them is
+        // emitted, sorted and staged for nothing.  Two rounds: the frame of the nearest K visible Gaussians first, whose
+        // blend leaves a bit per finished tile and the pixel state of the others; then the rest, without the Gaussians whose
+        // (small) rect lies in finished tiles, resumed by the same blend.  The image is the single round's, bit for bit: a
+        // tile's list is the concatenation of its two lists, and a dropped Gaussian touches finished pixels only.
+        static const int rounds_env = std::getenv("GS3D_ROUNDS") ? std::atoi(std::getenv("GS3D_ROUNDS")) : -1;
+        static const long round1_env = std::getenv("GS3D_ROUND1") ? std::atol(std::getenv("GS3D_ROUND1")) : 0;
+        uint32_t round_k = 0;
+        bool two_round = false;
+        if (r->rounds_epoch != r->shape_epoch) {      // a new shape: the feedback starts over
+            r->rounds_epoch = r->shape_epoch;
+            r->round_scale = 1.0f;
+            r->rounds_off = false;
+            r->auto_deep = false;
+            r->auto_k = 0;
         }
-        r->state_tile_bmax_dirty = tile_msd;
-        mark(ST_RANGES);
-        // Tile ranges, three ways (the MSD-first tile sort has written them already: k_bucket_sort).  (1) One pass over the sorted keys (k_tile_ranges).  (2) A 32-ary search per tile
-        // (k_tile_ranges_search) once reading every key again costs more than a few dependent probes per tile: from
-        // a pair capacity of 8 M (GS3D_RANGES_SEARCH=0/1 forces).  (3) The same search run by the blend workgroups
-        // themselves (blend_tile_range_wg): no launch in front of the blend, but a workgroup that waits for its
-        // probes is occupancy the VALU-bound blend misses — same-box A/B (gpurun_out/r04l/ab.log): blend +3.5 us at
-        // 1 M and 10 M, +10 us at 4K, +12 us at 50 M against 6.8 / 10.5 / 35 / 19 us of range kernel saved: frames
-        // +1.5 % at 1 M, +-0 at 10 M, -0.5 % at 50 M, -2.3 % at 4K.  It is taken where it pays: images of more than
-        // 16384 tiles, where neither stand-alone kernel is cheap (GS3D_RANGES_IN_BLEND=0/1 forces).
-        static const int in_blend_env = std::getenv("GS3D_RANGES_IN_BLEND") ? std::atoi(std::getenv("GS3D_RANGES_IN_BLEND")) : -1;
-        const bool ranges_in_blend = in_blend_env >= 0 ? in_blend_env != 0 : num_tiles > 16384u;
-        static const int ranges_env = std::getenv("GS3D_RANGES_SEARCH") ? std::atoi(std::getenv("GS3D_RANGES_SEARCH")) : -1;
-        const bool ranges_search = ranges_env >= 0 ? ranges_env != 0 : capacity >= (8u << 20);
-        if (tile_msd) {
-            // nothing to do
-        } else if (capacity && ranges_in_blend) {
-            tile_keys.keys = r->tkeys[tside].ptr;
-            tile_keys.count_dev = &state->pairs;
-            tile_keys.count_bound = capacity;
-            tile_keys.wide = wide ? 1u : 0u;
-        } else if (capacity && ranges_search) {
-            if (wide)
-                hipLaunchKernelGGL(gs::k_tile_ranges_search<uint32_t>, dim3((num_tiles + 3u) / 4u), dim3(256), 0, st,
-                                   (const uint32_t *)r->tkeys[tside].ptr, tc, zero, num_tiles);
-            else
-                hipLaunchKernelGGL(gs::k_tile_ranges_search<uint16_t>, dim3((num_tiles + 3u) / 4u), dim3(256), 0, st,
-                                   (const uint16_t *)r->tkeys[tside].ptr, tc, zero, num_tiles);
-            GS_HIP(hipGetLastError());
-            r->launches++;
-        } else if (capacity) {
-            if (wide)
-                hipLaunchKernelGGL(gs::k_tile_ranges<uint32_t>, dim3((uint32_t)(((uint64_t)capacity + 1023) / 1024)), dim3(256), 0, st,
-                                   (const uint32_t *)r->tkeys[tside].ptr, tc, zero);
-            else
-                hipLaunchKernelGGL(gs::k_tile_ranges<uint16_t>, dim3((uint32_t)(((uint64_t)capacity + 2047) / 2048)), dim3(256), 0, st,
-                                   (const uint16_t *)r->tkeys[tside].ptr, tc, zero);
-            GS_HIP(hipGetLastError());
-            r->launches++;
+        if (capacity && band_tiles && groups != 1 && n > 4096u) {
+            const int newer = hist_gen[0] > hist_gen[1] ? 0 : 1;
+            const bool have = !sizing && hist_gen[newer] && r->done_shape[newer] == r->shape_epoch;
+            const uint32_t v_est = have ? hist_v[newer] : n;
+            if (have && r->done_rounds[newer] == 1) {
+                r->full_pairs = hist_d[newer];
+                r->full_pairs_v = hist_v[newer];
+            }
+            // pairs a single round would emit now: the measured count, scaled with the visible Gaussians since
+            const double d_full = r->full_pairs_v ? (double)r->full_pairs * (double)v_est / (double)r->full_pairs_v : (double)r->full_pairs;
+            // The renderer's own choice.  Measured (same-box A/B, gpurun_out/r05r): 10 M at 1080p (2 970 pairs per tile) -9 %,
+            // at 4K (1 716) -8 %, 50 M (14 800) -24 %; the 1 M scene (296 pairs per tile) finishes its tiles only at the end of
+            // their lists.  Round 1 is given ~400 pairs per tile — the frames above are within 1 % of their best from half to
+            // twice that — and a frame takes two rounds when that is at most a third of its Gaussians and the pairs to save
+            // outweigh the dozen launches of a second round.
+            const double per_tile = d_full / (double)band_tiles;
+            double k_auto = per_tile > 0.0 ? (double)v_est * 400.0 / per_tile * (double)r->round_scale : 0.0;
+            if (have && r->done_rounds[newer] == 2 && hist_gen[newer] != r->rounds_fb_gen) {
+                // feedback: a round 1 that finishes less than 60 % of the tiles it has pairs for was too short (or the scene
+                // does not occlude)
+                r->rounds_fb_gen = hist_gen[newer];
+                if ((uint64_t)hist_tdone[newer] * 10u < ((uint64_t)hist_tdone[newer] + hist_topen[newer]) * 6u) {
+                    r->round_scale *= 1.5f;
+                    if (r->round_scale > 3.4f) r->rounds_off = true;
+                }
+            }
+            bool deep = have && !r->rounds_off && d_full >= 12.0e6 && per_tile >= 1200.0 && k_auto * 3.0 <= (double)v_est;
+            if (!have && !sizing && r->rounds_epoch == r->shape_epoch) {
+                // frames in flight: no finished report to consult (both result blocks belong to frames still running):
+                // what the last frame with a report decided stands
+                deep = r->auto_deep && !r->rounds_off;
+                k_auto = (double)r->auto_k;
+            }
+            r->auto_deep = deep;
+            r->auto_k = (uint64_t)k_auto;
+            const int pinned = r->rounds_req >= 0 ? r->rounds_req : rounds_env;
+            two_round = pinned >= 0 ? pinned != 0 : deep;
+            const uint64_t k = r->round1_req ? r->round1_req : round1_env > 0 ? (uint64_t)round1_env : pinned > 0 && !deep ? v_est / 4u : (uint64_t)k_auto;
+            round_k = (uint32_t)((k + 2047u) / 2048u * 2048u < n ? (k + 2047u) / 2048u * 2048u : 0u);
+            if (round_k == 0u) two_round = false;
+        }
+        r->two_round = two_round;
+        r->round1 = round_k;
+        if (!two_round) {
+            GS_TRY(pairs_round(0u, 0xffffffffu, esb));
+        } else {
+            tile_keys.done = done_bits;
+            tile_keys.open = open_bits;
+            GS_TRY(pairs_round(1u, round_k, esb));
+            mark(ST_BLEND);
+            GS_TRY(launch_blend(1u));
+            {
+                GS_TRY(dev_reserve(r->order_r2, (nn + 1024) * 4));      // (its largest size at once; padded like the sorts' values)
+                gs::Round2IO ro;
+                ro.order = (const uint32_t *)r->dvals[dside].ptr + round_k;
+                ro.rect = (const uint2 *)r->rect.ptr;
+                ro.done = done_bits;
+                ro.open = open_bits;
+                ro.order_out = (uint32_t *)r->order_r2.ptr;
+                ro.state = state;
+                ro.first = round_k;
+                ro.groups = (n - round_k + gs::R2_GROUP - 1u) / gs::R2_GROUP;
+                ro.tiles_x = fc.tiles_x;
+                ro.num_tiles = num_tiles;
+                // (per-slot arrays cover whole chunks: nslots; a list frame's live in list space, bounded by the same)
+                ro.slots = (uint32_t)nslots;
+                GS_TRY(dev_reserve(r->keep_bits, nslots / 8 + 64));
+                ro.keep_bits = (uint32_t *)r->keep_bits.ptr;
+                const uint32_t bits_grid = (uint32_t)((nslots + 256u * gs::R2_SLOT_ITEMS - 1u) / (256u * gs::R2_SLOT_ITEMS));
+                {
+                    typedef void (*bits_fn)(gs::Round2IO);
+                    static const bits_fn tbl[2][2] = {{gs::k_round2_slot_bits<false, false>, gs::k_round2_slot_bits<false, true>},
+                                                      {gs::k_round2_slot_bits<true, false>, gs::k_round2_slot_bits<true, true>}};
+                    const bool lds = done_words <= gs::R2_LDS_WORDS;
+                    hipLaunchKernelGGL(tbl[fc.rect32 ? 1 : 0][lds ? 1 : 0], dim3(bits_grid), dim3(256), 0, st, ro);
+                }
+                GS_TRY(dev_reserve(r->r2_scan, (size_t)ro.groups * (2 * 4 + 32 * 8) + 64));
+                ro.masks = (unsigned long long *)r->r2_scan.ptr;
+                ro.counts = (uint32_t *)(ro.masks + (size_t)ro.groups * 32);
+                ro.offsets = ro.counts + ro.groups;
+                hipLaunchKernelGGL(gs::k_round2_count, dim3(ro.groups), dim3(256), 0, st, ro);
+                gs::ScanJob js{ro.counts, ro.offsets, &state->round2_visible, ro.groups, nullptr};
+                hipLaunchKernelGGL(gs::k_scan_chunks, dim3(1), dim3(1024), 0, st, js, js);
+                hipLaunchKernelGGL(gs::k_round2_write, dim3(ro.groups), dim3(256), 0, st, ro);
+                r->launches += 3;
+                GS_HIP(hipGetLastError());
+                r->launches++;
+            }
+            GS_TRY(pairs_round(2u, 0xffffffffu, esb2));
         }
         r->sort_passes = dpasses + tpasses;
         r->dsorted_side = dside;
         r->tsorted_side = tside;
     }
-    mark(ST_BLEND);
-    uint32_t band_tiles = (fc.band_ty1 - fc.band_ty0) * fc.tiles_x;
-    if (band_tiles) {
-        // GS3D_BLEND_GROUPS = 1 (half-tile lists), 2 (8x8 blocks) or 4 (8x4 blocks, default)
-        static const int groups = std::getenv("GS3D_BLEND_GROUPS") ? std::atoi(std::getenv("GS3D_BLEND_GROUPS")) : 4;
-        typedef void (*blend_fn)(uint32_t *, const uint32_t *, const uint32_t *, gs::FrameConsts, float4 *,
-                                 const gs::FrameState *, gs::TileKeys);
-        static const blend_fn tbl[3][3] = {
-            {gs::k_blend<0>, gs::k_blend_grouped<0, 2>, gs::k_blend_grouped<0, 4>},
-            {gs::k_blend<1>, gs::k_blend_grouped<1, 2>, gs::k_blend_grouped<1, 4>},
-            {gs::k_blend<2>, gs::k_blend_grouped<2, 2>, gs::k_blend_grouped<2, 4>}};
-        const blend_fn blend = tbl[mode][groups == 1 ? 0 : groups == 2 ? 1 : 2];
-        hipLaunchKernelGGL(blend, dim3(band_tiles), dim3(gs::BLEND_THREADS), 0, st,
-                           (uint32_t *)r->zero_region.ptr, (const uint32_t *)r->tvals[r->tsorted_side].ptr,
-                           (const uint32_t *)r->recs.ptr, fc, (float4 *)rgba, (const gs::FrameState *)state, tile_keys);
-        GS_HIP(hipGetLastError());
-        r->launches++;
-    }
+    if (!r->two_round) mark(ST_BLEND);
+    GS_TRY(launch_blend(r->two_round ? 2u : 0u));
     mark(ST_FRAME);
     if (timing) {
         (void)hipEventRecord(r->ev[ST_COUNT], st);
@@ -3223,6 +3388,8 @@ extern "C" gs_status gs_renderer_download_projected(gs_renderer *r, gs_projected
 extern "C" gs_status gs_renderer_download_sorted(gs_renderer *r, uint64_t *keys_out, uint32_t *idx_out,
                                                  uint64_t capacity, uint64_t *pairs_out) {
     if (!r) return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "null renderer");
+    if (r->have_frame && r->two_round)
+        return fail(GS_ERR_INVALID_ARGUMENT, 2, 0, 0, "the last frame took two rounds: its pair arrays hold the second round only");
     GS_TRY(use_device(r->dev));
     GS_HIP(sync_last_frame(r));
     uint64_t d = r->have_frame ? last_result(r).pairs_total : 0;
@@ -3256,6 +3423,8 @@ extern "C" gs_status gs_renderer_download_ranges(gs_renderer *r, uint32_t *range
     if (!r || !ranges_out) return fail(GS_ERR_INVALID_ARGUMENT, 0, 0, 0, "null argument");
     if (num_tiles > (size_t)r->tiles_x * r->tiles_y)
         return fail(GS_ERR_INVALID_ARGUMENT, num_tiles, 0, 0, "too many tiles");
+    if (r->have_frame && r->two_round)
+        return fail(GS_ERR_INVALID_ARGUMENT, 2, 0, 0, "the last frame took two rounds: its tile ranges are the second round's");
     GS_TRY(use_device(r->dev));
     return download_sync(r, ranges_out, r->zero_region.ptr, num_tiles * 8);
 }

@@ -232,6 +232,10 @@ struct FrameState {
     uint32_t rank_fault;     // watchdog of the LDS-atomic rank (scatter_ranked): set when block 0 of a radix pass finds a rank
                              // that is not the ballot-based one; published with the frame flags, cleared by the host
     uint32_t rank_inject;    // test hook (GS3D_TEST_RANK_FAULT=1): added to the expected rank, so the watchdog fires
+    uint32_t pairs_round1;       // two-round frames: the pairs of round 1 (round 2's publication adds them)
+    uint32_t round2_visible;     // ... the Gaussians k_round2_write kept for round 2
+    uint32_t tiles_done;         // ... tiles round 1 finished (counted by k_round2_count; 0 in a single-round frame)
+    uint32_t tiles_open;         // ... tiles round 1 left unfinished although it had pairs for them
     uint32_t depth_bucket_max;   // largest top-digit bucket of the depth sort (k_bucket_sort, or the LSD sort's last pass)
     uint32_t tile_bucket_max;    // the same for the tile sort (k_bucket_sort)
 };
@@ -250,7 +254,9 @@ struct FrameResult {
     uint32_t depth_bucket_max;   // FrameState::depth_bucket_max: feeds the host's choice of the depth sort (MSD-first / LSD)
     uint32_t tile_bucket_max;    // FrameState::tile_bucket_max as the PREVIOUS frame of the renderer left it (the tile sort
                                  // runs behind the kernel that publishes this block); 0 = that frame's tile sort was LSD
-    uint32_t pad[1];
+    uint32_t tiles_done;         // two-round frames: tiles finished by round 1 (feeds the host's choice of round 1's length)
+    uint32_t tiles_open;         // ... tiles round 1 had pairs for and did not finish
+    uint32_t pad[3];
 };
 
 // One thread publishes a frame's result to pinned host memory.  `gen` goes LAST, behind a
@@ -259,7 +265,7 @@ struct FrameResult {
 // also finds that generation's counts.
 __device__ __forceinline__ void publish_result(FrameResult *r, uint32_t visible, uint64_t pairs_total, uint32_t flags,
                                                uint32_t gen, uint32_t *flags_dev = nullptr, uint32_t depth_bucket_max = 0u,
-                                               uint32_t tile_bucket_max = 0u) {
+                                               uint32_t tile_bucket_max = 0u, uint32_t tiles_done = 0u, uint32_t tiles_open = 0u) {
     // optional copy of the flags in DEVICE memory (gs_renderer_set_frame_flags_target): a sharded frame
     // carries it inside its band's gather chunk, so every rank learns from the one all-gather whether
     // any band was skipped
@@ -269,6 +275,8 @@ __device__ __forceinline__ void publish_result(FrameResult *r, uint32_t visible,
     r->flags = flags;
     r->depth_bucket_max = depth_bucket_max;
     r->tile_bucket_max = tile_bucket_max;
+    r->tiles_done = tiles_done;
+    r->tiles_open = tiles_open;
     __hip_atomic_store(&r->gen, gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
@@ -1406,6 +1414,15 @@ struct ExpandIO {
     uint32_t *flags_dev;             // optional device copy of the frame flags (null: none)
     uint32_t xcd_chunk;              // k_expand_count: workgroup -> span order (0: dispatch order)
     uint32_t wt_stores;              // k_pairs_emit stores its pairs write-through (store16)
+    // How many Gaussians `order` holds: *count_dev (FrameState::visible, or ::round2_visible for the second round of a
+    // two-round frame), at most `limit` (round 1 of a two-round frame: the nearest K).
+    const uint32_t *count_dev;
+    uint32_t limit;
+    uint32_t round;                  // 0: the frame's only round; 1: first of two (publishes nothing); 2: second (publishes both)
+    __device__ __forceinline__ uint32_t visible() const {      // Gaussians of this round
+        const uint32_t v = *count_dev;
+        return v < limit ? v : limit;
+    }
 };
 
 // Expansion, part 1: gather the tile rects into depth order (the only random access of the key
@@ -1420,7 +1437,7 @@ static_assert(EXP_SB % EXP_COUNT_CHUNKS == 0, "a count workgroup must not stradd
 template <bool RECT32>
 __global__ __launch_bounds__(EXP_CHUNK) void k_expand_count(ExpandIO io) {
     __shared__ uint32_t s_red[EXP_COUNT_CHUNKS][4];
-    const uint32_t v_count = io.state->visible;
+    const uint32_t v_count = io.visible();
     // XCD-aware order (io.xcd_chunk, as in the radix passes): consecutive workgroups go round-robin to the 8 XCDs,
     // each with its own L2; neighbours in depth order are neighbours in space often enough (one 64-byte sector holds
     // the rects of 16 consecutive mirror slots) that giving one XCD a run of consecutive spans lets its L2 serve part
@@ -1481,6 +1498,185 @@ __global__ __launch_bounds__(EXP_CHUNK) void k_expand_count(ExpandIO io) {
 #pragma unroll
         for (int d = 1; d < (int)EXP_COUNT_CHUNKS; d <<= 1) all += __shfl_xor((unsigned long long)all, d, WAVE);
         if (c == 0 && all) atomicAdd(io.sb_sums + first_chunk / EXP_SB, (unsigned long long)all);
+    }
+}
+
+// Round 2 of a two-round frame (DESIGN.md §4.2 "rounds"): which of the visible Gaussians behind the nearest K can still
+// colour a pixel?  A Gaussian whose rect (at most 3 x 3 tiles; of a rect that lost tiles to the exact test, version 4,
+// only the kept ones) lies entirely in tiles that round 1 finished cannot, and is dropped; larger rects are few and stay.
+// Two kernels.  k_round2_slot_bits answers the question for EVERY output slot, in slot order — a stream over the rect
+// array instead of a gather in depth order (a first version gathered: 495 us at 50 M, a 200 MB array read by random
+// 4-byte accesses) — and leaves one bit per slot (N / 8 bytes: 6 MB at 50 M, which the caches hold); slots of culled
+// Gaussians hold stale rects and get a meaningless bit that nobody reads.  k_round2_count / _write then walk the depth
+// order behind K, gather the bits and write the survivors' slots to `order_out`, still in depth order.
+struct Round2IO {
+    const uint32_t *order;           // [V - K] mirror slots in depth order behind round 1's
+    const uint2 *rect;               // [slots] tile rects by slot
+    const uint32_t *done;            // one bit per tile, + 1 word
+    const uint32_t *open;            // one bit per tile: round 1 had pairs for it and did not finish it
+    uint32_t *keep_bits;             // [slots / 32 + 2] one bit per slot: this Gaussian can still colour a pixel
+    uint32_t *order_out;             // [<= V - K]
+    FrameState *state;
+    unsigned long long *masks;       // [groups * 32] ballots of the kept Gaussians, by group, chunk and wave
+    uint32_t *counts, *offsets;      // [groups] kept Gaussians per group, and their exclusive prefix (k_scan_chunks)
+    uint32_t first;                  // K
+    uint32_t groups;                 // = grid size of k_round2_count / _write
+    uint32_t tiles_x, num_tiles;
+    uint32_t slots;                  // entries of `rect` (a multiple of 1024)
+};
+constexpr uint32_t R2_CHUNKS = 8;
+constexpr uint32_t R2_GROUP = R2_CHUNKS * 256u;
+constexpr uint32_t R2_SLOT_ITEMS = 8;                         // k_round2_slot_bits: slots per thread (2048 per workgroup)
+constexpr uint32_t R2_LDS_WORDS = 2048;                       // ... bit words it keeps in LDS (images of up to 65 504 tiles)
+
+// Per tile row the three bits come out of the two words around the row's first tile (the bit array is padded by a word);
+// all six loads are issued unconditionally (rows outside the rect read word 0 and need nothing; a stale rect may point
+// anywhere: its bit index is clamped into the array).  LDS: the workgroup first copies the bit array (at most
+// R2_LDS_WORDS words) into LDS — from global memory the kernel was bound by its 3 divergent 8-byte loads per slot (118 us
+// at 50 M).
+template <bool RECT32, bool LDS>
+__global__ __launch_bounds__(256) void k_round2_slot_bits(Round2IO io) {
+    __shared__ uint32_t s_done[LDS ? R2_LDS_WORDS : 1];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t base = (blockIdx.x * 256u + (threadIdx.x & ~63u)) * R2_SLOT_ITEMS;      // first slot of this wave
+    uint32_t origin[R2_SLOT_ITEMS], w[R2_SLOT_ITEMS], h[R2_SLOT_ITEMS], rows[R2_SLOT_ITEMS];
+    if constexpr (LDS) {
+        const uint32_t words = (io.num_tiles + 31u) / 32u + 1u;     // <= R2_LDS_WORDS (host)
+        for (uint32_t q = threadIdx.x; q < words; q += 256u) s_done[q] = io.done[q];
+        __syncthreads();
+    }
+    const uint32_t *done = LDS ? s_done : io.done;
+#pragma unroll
+    for (uint32_t i = 0; i < R2_SLOT_ITEMS; i++) {
+        uint32_t slot = base + i * 64u + lane;
+        slot = slot < io.slots ? slot : io.slots - 1u;               // (the last workgroup: slots is a multiple of 1024)
+        if constexpr (RECT32) {
+            const uint32_t p = ((const uint32_t *)io.rect)[slot];
+            const bool masked = (p >> 31) != 0u;
+            origin[i] = (p >> 16) & 0x7fffu;
+            w[i] = masked ? ((p >> 12) & 3u) + 1u : (p & 0xffu) + 1u;
+            h[i] = masked ? ((p >> 14) & 3u) + 1u : ((p >> 8) & 0xffu) + 1u;
+            rows[i] = masked ? 0x8000u | (p & 0xfffu) : 0u;
+        } else {
+            uint32_t r0, r1;
+            rect_unpack64(io.rect[slot], r0, r1, rows[i]);
+            origin[i] = __umul24(r0 >> 16, io.tiles_x) + (r0 & 0xffffu);
+            w[i] = (r1 & 0xffffu) - (r0 & 0xffffu);
+            h[i] = (r1 >> 16) - (r0 >> 16);
+        }
+    }
+    uint32_t lo[R2_SLOT_ITEMS][3], hi[R2_SLOT_ITEMS][3], need[R2_SLOT_ITEMS][3], sh[R2_SLOT_ITEMS][3];
+#pragma unroll
+    for (uint32_t i = 0; i < R2_SLOT_ITEMS; i++) {
+        const bool small = w[i] >= 1u && h[i] >= 1u && w[i] <= 3u && h[i] <= 3u;
+#pragma unroll
+        for (uint32_t j = 0; j < 3u; j++) {
+            const bool in = small && j < h[i];
+            uint32_t bit = in ? origin[i] + j * io.tiles_x : 0u;
+            bit = bit < io.num_tiles ? bit : io.num_tiles - 1u;
+            // columns of row j that count: the rect's, or — a rect that lost tiles to the exact test — the kept ones
+            const uint32_t rf = (rows[i] >> (4u * j)) & 3u, rc = (rows[i] >> (4u * j + 2u)) & 3u;
+            const uint32_t cols = (rows[i] & 0x8000u) ? ((1u << rc) - 1u) << rf : (1u << (w[i] & 3u)) - 1u;
+            need[i][j] = in ? cols : (small ? 0u : 8u);      // (not small: a bit that is never there)
+            sh[i][j] = bit & 31u;
+            lo[i][j] = done[bit >> 5];
+            hi[i][j] = done[(bit >> 5) + 1u];
+        }
+    }
+#pragma unroll
+    for (uint32_t i = 0; i < R2_SLOT_ITEMS; i++) {
+        bool all = true;
+#pragma unroll
+        for (uint32_t j = 0; j < 3u; j++) {
+            const uint32_t got = (uint32_t)((((uint64_t)hi[i][j] << 32) | lo[i][j]) >> sh[i][j]) & 7u;
+            all = all && (got & need[i][j]) == need[i][j];
+        }
+        const uint64_t m = __builtin_amdgcn_ballot_w64(!all);
+        if (lane == 0u && base + i * 64u < io.slots)
+            *(uint2 *)(io.keep_bits + ((base + i * 64u) >> 5)) = make_uint2((uint32_t)m, (uint32_t)(m >> 32));
+    }
+}
+
+// The survivors in depth order: an ordered compaction in three launches — k_round2_count gathers the bits of a group of
+// 2048 Gaussians, leaves their ballots (one 64-bit word per wave and chunk) and the group's count; k_scan_chunks turns the
+// counts into offsets and the total (FrameState::round2_visible); k_round2_write places the slots.  (A single pass with a
+// decoupled look-back over one status word per group was 325 us at 50 M: the 2048 resident workgroups finish together,
+// so every one of them walks back over ~2000 words, 64 per dependent round trip, before it meets an inclusive prefix.)
+// Workgroup 0 of the count kernel also counts the tiles round 1 finished (::tiles_done) for the host.
+__global__ __launch_bounds__(256) void k_round2_count(Round2IO io) {
+    __shared__ uint32_t s_cnt[4], s_open[4];
+    const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+    const uint32_t g = blockIdx.x;
+    const uint32_t v = io.state->visible;
+    const uint32_t count = v > io.first ? v - io.first : 0u;
+    const uint64_t j0 = (uint64_t)g * R2_GROUP + threadIdx.x;
+    uint32_t slot[R2_CHUNKS];
+#pragma unroll
+    for (uint32_t c = 0; c < R2_CHUNKS; c++) {
+        const uint64_t j = j0 + c * 256u;
+        slot[c] = j < count ? io.order[j] : 0xffffffffu;
+    }
+    uint32_t word[R2_CHUNKS];
+#pragma unroll
+    for (uint32_t c = 0; c < R2_CHUNKS; c++)      // (no branch around a gather: see k_expand_count)
+        word[c] = io.keep_bits[(slot[c] != 0xffffffffu ? slot[c] : 0u) >> 5];
+    uint32_t mine = 0;
+#pragma unroll
+    for (uint32_t c = 0; c < R2_CHUNKS; c++) {
+        const uint64_t m = __builtin_amdgcn_ballot_w64(slot[c] != 0xffffffffu && ((word[c] >> (slot[c] & 31u)) & 1u) != 0u);
+        mine += (uint32_t)__popcll(m);
+        if (lane == 0u) io.masks[((uint64_t)g * R2_CHUNKS + c) * 4u + wid] = m;      // item order: chunk-major, wave-minor
+    }
+    if (lane == 0u) s_cnt[wid] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0u) io.counts[g] = (s_cnt[0] + s_cnt[1]) + (s_cnt[2] + s_cnt[3]);
+    if (g == 0u) {
+        // tiles finished by round 1, and tiles it had pairs for and left open (bits past the last tile are never set)
+        uint32_t n = 0, o = 0;
+        for (uint32_t q = threadIdx.x; q < (io.num_tiles + 31u) / 32u; q += 256u) {
+            n += (uint32_t)__popc(io.done[q]);
+            o += (uint32_t)__popc(io.open[q]);
+        }
+        n = wave_reduce_add(n);
+        o = wave_reduce_add(o);
+        __syncthreads();
+        if (lane == 0u) {
+            s_cnt[wid] = n;
+            s_open[wid] = o;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0u) {
+            io.state->tiles_done = (s_cnt[0] + s_cnt[1]) + (s_cnt[2] + s_cnt[3]);
+            io.state->tiles_open = (s_open[0] + s_open[1]) + (s_open[2] + s_open[3]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_round2_write(Round2IO io) {
+    const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+    const uint32_t g = blockIdx.x;
+    const uint32_t v = io.state->visible;
+    const uint32_t count = v > io.first ? v - io.first : 0u;
+    if ((uint64_t)g * R2_GROUP >= count) return;
+    const uint64_t j0 = (uint64_t)g * R2_GROUP + threadIdx.x;
+    // every wave scans the group's 32 ballots for itself (lane l: chunk l / 4, wave l % 4)
+    const uint64_t mall = lane < R2_CHUNKS * 4u ? io.masks[(uint64_t)g * (R2_CHUNKS * 4u) + lane] : 0ull;
+    const uint32_t base = io.offsets[g];
+    const uint32_t pc = (uint32_t)__popcll(mall);
+    const uint32_t excl = wave_inclusive_scan(pc, lane) - pc;
+    uint32_t slot[R2_CHUNKS];
+#pragma unroll
+    for (uint32_t c = 0; c < R2_CHUNKS; c++) {       // all loads first (the padded array is readable past `count`)
+        const uint64_t j = j0 + c * 256u;
+        slot[c] = io.order[j < count ? j : 0u];
+    }
+#pragma unroll
+    for (uint32_t c = 0; c < R2_CHUNKS; c++) {
+        const uint32_t src = c * 4u + wid;
+        const uint64_t m = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(mall >> 32), (int)src, WAVE) << 32) |
+                           (uint32_t)__shfl((int)(uint32_t)mall, (int)src, WAVE);
+        const uint32_t off = (uint32_t)__shfl((int)excl, (int)src, WAVE);
+        if ((m >> lane) & 1ull) io.order_out[base + off + mbcnt(m)] = slot[c];
     }
 }
 
@@ -2630,6 +2826,24 @@ struct PairCursorRec {
     unsigned long long prefix;
 };
 
+// One thread publishes the round's pair count: FrameState::pairs (clamped to the capacity) and ::overflow for the kernels
+// behind it and — unless this is round 1 of a two-round frame — the frame result.  A two-round frame is skipped as a
+// whole when either round exceeds the capacity (round 1's blend has then left the image untouched, round 2's does too).
+__device__ __forceinline__ void publish_pairs(const ExpandIO &io, uint64_t d) {
+    uint32_t over = d > (uint64_t)io.capacity ? 1u : 0u;
+    io.state->pairs = over ? io.capacity : (uint32_t)d;
+    if (io.round == 2u) over |= io.state->overflow;          // round 1 did not fit
+    io.state->overflow = over;
+    if (io.round == 1u) {
+        io.state->pairs_round1 = d > 0xffffffffull ? 0xffffffffu : (uint32_t)d;
+        return;
+    }
+    const uint64_t total = d + (io.round == 2u ? (uint64_t)io.state->pairs_round1 : 0ull);
+    publish_result(io.result, io.state->visible, total,
+                   (over ? FRAME_FLAG_PAIR_OVERFLOW | FRAME_FLAG_SKIPPED : 0u) | (io.state->rank_fault ? FRAME_FLAG_RANK_FAULT : 0u), io.gen,
+                   io.flags_dev, io.state->depth_bucket_max, io.state->tile_bucket_max, io.round == 2u ? io.state->tiles_done : 0u, io.round == 2u ? io.state->tiles_open : 0u);
+}
+
 // Grid: sb_bound workgroups of EXP_SB threads.  Workgroup 0 also publishes D (clamped to the pair
 // capacity), the overflow flag and the frame result.
 __global__ __launch_bounds__(EXP_SB) void k_pairs_cursors(ExpandIO io) {
@@ -2637,7 +2851,7 @@ __global__ __launch_bounds__(EXP_SB) void k_pairs_cursors(ExpandIO io) {
     __shared__ unsigned long long s_before[2], s_all[2], s_wave0;
     const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
     const uint32_t sb = blockIdx.x;
-    const uint32_t v_count = io.state->visible;
+    const uint32_t v_count = io.visible();
     const uint32_t nchunks = (uint32_t)(((uint64_t)v_count + EXP_CHUNK - 1) / EXP_CHUNK);
     uint64_t before = 0, all = 0;
     for (uint32_t q = threadIdx.x; q < io.sb_bound; q += EXP_SB) {
@@ -2657,13 +2871,7 @@ __global__ __launch_bounds__(EXP_SB) void k_pairs_cursors(ExpandIO io) {
     }
     __syncthreads();
     const uint64_t d = s_all[0] + s_all[1];
-    if (sb == 0u && threadIdx.x == 0u) {
-        const uint32_t over = d > (uint64_t)io.capacity ? (FRAME_FLAG_PAIR_OVERFLOW | FRAME_FLAG_SKIPPED) : 0u;
-        io.state->pairs = over ? io.capacity : (uint32_t)d;
-        io.state->overflow = over ? 1u : 0u;
-        publish_result(io.result, v_count, d, over | (io.state->rank_fault ? FRAME_FLAG_RANK_FAULT : 0u), io.gen, io.flags_dev,
-                           io.state->depth_bucket_max, io.state->tile_bucket_max);
-    }
+    if (sb == 0u && threadIdx.x == 0u) publish_pairs(io, d);
     if (v == 0ull) return;
     const uint64_t p = s_before[0] + s_before[1] + (wid ? s_wave0 : 0ull) + incl - v;   // pairs in front of chunk c
     const uint64_t end = p + v < (uint64_t)io.capacity ? p + v : (uint64_t)io.capacity;
@@ -2898,7 +3106,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_pairs_emit(ExpandIO io, uint32
     __shared__ uint32_t s_hist[COPIES][R];
     __shared__ PairGenShared<K, NSLOTS, RECT32> s_gen[4];
     const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
-    const uint32_t v_count = io.state->visible;
+    const uint32_t v_count = io.visible();
     const uint32_t block = scatter_tile_of(blockIdx.x, xcd_chunk);   // as the scatter and the histograms
     const uint64_t o0 = (uint64_t)block * TILE + wid * NSLOTS;
     PairCursor cur;
@@ -2921,13 +3129,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_pairs_emit(ExpandIO io, uint32
         cur = pair_cursor(io, v_count, o0, lane);
         const uint64_t d = cur.total;
         count = d > (uint64_t)io.capacity ? io.capacity : (uint32_t)d;
-        if (block == 0u && threadIdx.x == 0u) {
-            const uint32_t over = d > (uint64_t)io.capacity ? (FRAME_FLAG_PAIR_OVERFLOW | FRAME_FLAG_SKIPPED) : 0u;
-            io.state->pairs = count;
-            io.state->overflow = over ? 1u : 0u;
-            publish_result(io.result, v_count, d, over | (io.state->rank_fault ? FRAME_FLAG_RANK_FAULT : 0u), io.gen, io.flags_dev,
-                           io.state->depth_bucket_max, io.state->tile_bucket_max);
-        }
+        if (block == 0u && threadIdx.x == 0u) publish_pairs(io, d);
     }
     if ((uint64_t)block * TILE >= count) return;      // the same D in every wave: block-uniform
 #pragma unroll
@@ -3185,6 +3387,12 @@ struct TileKeys {
     const uint32_t *count_dev;    // D (FrameState.pairs)
     uint32_t count_bound;         // pair capacity
     uint32_t wide;
+    // Two-round frames (DESIGN.md §4.2 "rounds"): round 1 blends the nearest Gaussians and leaves (C, +-T) in the image for the
+    // tiles that are not finished (-T: the pixel itself is), a bit in `done` for those that are (their pixels are final);
+    // round 2 returns at once for the done tiles and resumes the others.  0: the frame's only round.
+    uint32_t round;
+    uint32_t *done;               // [tiles / 32 + 1], zeroed per frame
+    uint32_t *open;               // [tiles / 32 + 1], zeroed per frame: tiles round 1 had pairs for and did not finish
 };
 __device__ __forceinline__ void blend_tile_range(const TileKeys &tk, uint32_t *__restrict__ ranges, uint32_t tile,
                                                  uint32_t lane, bool writer, uint32_t &start, uint32_t &end) {
@@ -3479,7 +3687,8 @@ __device__ __forceinline__ bool splat_touches_rect2(float mx, float my, float ca
 // with the index of a null record whose exponent test never passes, so lanes whose list is shorter
 // than the wave's longest simply idle.  Results are bit-identical to k_blend: culling only removes
 // (splat, block) pairs whose alpha is below 1/255 at every pixel of the block.
-template <int MODE, int G>
+// ROUNDS: the instantiation of two-round frames (TileKeys::round = 1 / 2); the single-round one carries none of it.
+template <int MODE, int G, bool ROUNDS = false>
 __global__ __launch_bounds__(BLEND_THREADS) void k_blend_grouped(uint32_t *__restrict__ ranges,
                                                                  const uint32_t *__restrict__ idx,
                                                                  const uint32_t *__restrict__ recs,
@@ -3511,15 +3720,30 @@ __global__ __launch_bounds__(BLEND_THREADS) void k_blend_grouped(uint32_t *__res
     const uint32_t my_list = wid * G + gi;
     const float tx0 = (float)(tx * 16u) + 0.5f, ty0 = (float)(ty * 16u) + 0.5f;   // tile origin, pixel centres
 
+    if (ROUNDS && tk.round == 2u && ((tk.done[tile >> 5] >> (tile & 31u)) & 1u)) return;      // finished in round 1, pixels final
     uint32_t start, end;
     __shared__ uint32_t s_range[2];
     blend_tile_range_wg(tk, ranges, tile, lane, wid, s_range, start, end);
     f32x2 T = {1.0f, 1.0f}, C0 = {0.0f, 0.0f}, C1 = {0.0f, 0.0f}, C2 = {0.0f, 0.0f};
     const bool in0 = px < fc.width && py0 < fc.height, in1 = px < fc.width && py1 < fc.height;
     constexpr float DEAD = 1.0e15f;           // finished / out-of-image pixels are parked far away (see k_blend)
-    f32x2 pyf = {in0 ? (float)py0 + 0.5f : DEAD, in1 ? (float)py1 + 0.5f : DEAD};
+    bool live0 = in0, live1 = in1;
+    if (ROUNDS && tk.round == 2u) {
+        // resume: the pixel's state as round 1 left it
+        if (in0) {
+            const float4 s = rgba[(uint64_t)py0 * fc.width + px];
+            C0.x = s.x; C1.x = s.y; C2.x = s.z; T.x = fabsf(s.w);
+            live0 = s.w > 0.0f;
+        }
+        if (in1) {
+            const float4 s = rgba[(uint64_t)py1 * fc.width + px];
+            C0.y = s.x; C1.y = s.y; C2.y = s.z; T.y = fabsf(s.w);
+            live1 = s.w > 0.0f;
+        }
+    }
+    f32x2 pyf = {live0 ? (float)py0 + 0.5f : DEAD, live1 ? (float)py1 + 0.5f : DEAD};
     uint32_t remaining = __builtin_amdgcn_readfirstlane(
-        (uint32_t)__popcll(__ballot(in0)) + (uint32_t)__popcll(__ballot(in1)));
+        (uint32_t)__popcll(__ballot(live0)) + (uint32_t)__popcll(__ballot(live1)));
     if (tid == 0) {   // the null record: power = 0 everywhere, pmin = 1 -> "power >= pmin" never holds
         *(float4 *)(s_rec + NULL_REC * (RS / 4)) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         *(float4 *)(s_rec + NULL_REC * (RS / 4) + 4) = make_float4(0.0f, 1.0f, 0.0f, 0.0f);
@@ -3729,6 +3953,24 @@ __global__ __launch_bounds__(BLEND_THREADS) void k_blend_grouped(uint32_t *__res
             }
 #undef GS_BLEND_STEP
         }
+    }
+    if (ROUNDS && tk.round == 1u) {
+        // (s_alive: a wave that left the loop through its break wrote 0 and writes 0 again; otherwise two barriers
+        // lie between the loop's last read and this write)
+        if (lane == 0) s_alive[wid] = remaining;
+        __syncthreads();
+        if ((s_alive[0] | s_alive[1]) != 0u) {
+            // not finished: the raw state, for round 2 to resume from (T >= 1e-4 > 0 always; -T = this pixel is finished)
+            if (in0)
+                store16(rgba + (uint64_t)py0 * fc.width + px,
+                        make_uint4(f2u(C0.x), f2u(C1.x), f2u(C2.x), f2u(pyf.x == DEAD ? -T.x : T.x)), fc.wt_stores);
+            if (in1)
+                store16(rgba + (uint64_t)py1 * fc.width + px,
+                        make_uint4(f2u(C0.y), f2u(C1.y), f2u(C2.y), f2u(pyf.y == DEAD ? -T.y : T.y)), fc.wt_stores);
+            if (tid == 0 && end > start) atomicOr(tk.open + (tile >> 5), 1u << (tile & 31u));
+            return;
+        }
+        if (tid == 0) atomicOr(tk.done + (tile >> 5), 1u << (tile & 31u));
     }
     if (in0) {
         float4 o;
