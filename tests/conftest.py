@@ -18,6 +18,10 @@ os.environ.setdefault("GS3D_TILE_MASKS", "1")
 # parity tests pin one round; tests/test_gpu_rounds.py pins two through the API and checks the renderer's own choice in
 # a child process without the variable.
 os.environ.setdefault("GS3D_ROUNDS", "0")
+# ... and two-round frames are PARTITIONED from a renderer's second frame on (by default only from 32 M Gaussians): the
+# first frame of every renderer in tests/test_gpu_rounds.py compacts round 2 out of the full depth order, the following
+# ones sort each round's side of the depth threshold.
+os.environ.setdefault("GS3D_ROUND_PARTITION", "1")
 
 
 def pytest_configure(config):

@@ -200,6 +200,23 @@ int main() {
                 REQUIRE(imgv.download<float>(s) == px);
             }
         try { r.set_sort_mode(2, 0); REQUIRE(false); } catch (const Error &e) { REQUIRE(e.status == GS_ERR_INVALID_ARGUMENT); }
+        {   // two-round frames: the nearest 8192 Gaussians first — three frames (the first compacts round 2 out of the depth
+            // order; the others may sort each round on its own): the same image, fewer or as many pairs, the taps refuse
+            Renderer rr(dev);
+            rr.set_rounds(1, 8192);
+            Buffer imgr(dev, (size_t)cam.width * cam.height * 16);
+            const gs_frame_result one = r.wait_frame();
+            for (int i = 0; i < 3; i++) {
+                rr.render(s, rbuf, gt, mt, cam, (float *)imgr.device_ptr());
+                const gs_frame_result two = rr.wait_frame();
+                const gs_sort_info si = rr.sort_info();
+                if (one.gaussians > 8192u + 4096u) REQUIRE(si.rounds == 2u && si.round1 == 8192u);
+                REQUIRE(two.flags == 0 && two.visible == one.visible && two.pairs <= one.pairs);
+                REQUIRE(imgr.download<float>(s) == px);
+            }
+            try { rr.set_rounds(2); REQUIRE(false); } catch (const Error &e) { REQUIRE(e.status == GS_ERR_INVALID_ARGUMENT); }
+            rr.set_rounds(-1);
+        }
         FrameRing ring(dev, 3);
         std::vector<Buffer> imgs;
         for (size_t k = 0; k < ring.size(); k++) imgs.emplace_back(dev, (size_t)cam.width * cam.height * 16);

@@ -18,7 +18,7 @@ python3 - "$OUT" <<'PY'
 import csv, glob, sys
 f = glob.glob(sys.argv[1] + "/trace/**/*kernel_stats.csv", recursive=True)
 rows = list(csv.DictReader(open(f[0])))
-frames = max(int(r["Calls"]) for r in rows if r["Name"].startswith("void gs::k_blend") or "k_blend" in r["Name"])
+frames = max(int(r["Calls"]) for r in rows if "k_preprocess" in r["Name"])      # once per frame whatever the rounds
 tot = 0.0
 print("frames traced: %d" % frames)
 for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"])):

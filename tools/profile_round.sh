@@ -38,7 +38,7 @@ for wl in ("1m", "10m", "10m-nocull"):
 # whole-frame HBM traffic: every kernel of one frame, fetch + write per launch x launches per frame
 for wl in ("1m", "10m", "10m-nocull"):
     rows = json.load(open(os.path.join(out, "%s_%s_summary.json" % (tag, wl))))
-    frames = max([r["calls"] for r in rows if r["kernel"].startswith("k_blend")] or [0])
+    frames = max([r["calls"] for r in rows if r["kernel"].startswith("k_preprocess")] or [0])      # (once per frame whatever the rounds)
     if not frames:
         continue
     fetch = write = 0.0

@@ -1481,7 +1481,7 @@ struct FrameShape {
 
 struct gs_renderer {
     gs_device *dev;
-    DevArray order_r2, keep_bits, r2_scan;         // two-round frames: mirror slots of the Gaussians round 2 keeps, in depth order; one bit per slot
+    DevArray order_r2, keep_bits, r2_scan, box_table;         // two-round frames: mirror slots of the Gaussians round 2 keeps, in depth order; one bit per slot
     DevArray recs, depth, rect, sorted_rect, exp_sums, cursors, chunk_tiles, chunk_vis, state, zero_region, scan_tmp, block_list;
     DevArray cull_status;                 // k_block_cull: one (tag << 10 | count) word per group of 256 blocks
     DevArray chunk_hist;                  // [chunks][256] first-digit histogram of every chunk's depth keys (PreOut::chunk_hist)
@@ -1635,7 +1635,7 @@ extern "C" void gs_renderer_destroy(gs_renderer *r) {
     }
     (void)sync_last_frame(r);   // kernels of the last frame write pinned memory
     DevArray *arrs[] = {&r->recs, &r->depth, &r->rect, &r->sorted_rect, &r->exp_sums, &r->cursors, &r->chunk_tiles, &r->chunk_vis,
-                        &r->state, &r->zero_region, &r->order_r2, &r->keep_bits, &r->r2_scan, &r->scan_tmp, &r->block_list, &r->cull_status, &r->chunk_hist, &r->dkeys[0], &r->dkeys[1], &r->dvals[0],
+                        &r->state, &r->zero_region, &r->order_r2, &r->keep_bits, &r->r2_scan, &r->box_table, &r->scan_tmp, &r->block_list, &r->cull_status, &r->chunk_hist, &r->dkeys[0], &r->dkeys[1], &r->dvals[0],
                         &r->dvals[1], &r->tkeys[0], &r->tkeys[1], &r->tvals[0], &r->tvals[1], &r->ghist,
                         &r->digit_totals, &r->bucket_starts};
     for (DevArray *a : arrs) dev_free(*a);
@@ -1975,6 +1975,8 @@ static thread_local uint32_t t_watch = 0;
 static thread_local uint32_t *t_bucket_max = nullptr;
 static thread_local bool t_top_pass = false;
 static thread_local uint32_t *t_bucket_starts = nullptr;    // the MSD-first sorts' scatter pass writes every bucket's start here
+// ... and which side of a partitioned two-round frame's depth threshold the COMPACT pass keeps (gs::CompactPred; default: all)
+static thread_local gs::CompactPred t_compact_pred;
 
 // one scatter launch (FAST_RANK chosen by the device probe); KO = type of the keys the pass writes
 template <typename KI, typename KO, int RB, bool COMPACT, int ITEMS>
@@ -1988,15 +1990,26 @@ static void launch_scatter(const gs_device *dev, hipStream_t st, uint32_t sgrid,
     const bool nt = !COMPACT && (nt_env >= 0 ? nt_env != 0 : (uint64_t)psc.count * (sizeof(KI) + 4u) > (32ull << 20));
     const uint32_t xr_nt = xr | (nt ? 0x80000000u : 0u);
     uint32_t *bmax = t_top_pass ? t_bucket_max : nullptr;
-    if (t_rank_fault)      // (null outside a frame and once the device has dropped to the ballot-based rank)
-        hipLaunchKernelGGL((gs::k_sort_scatter<KI, true, RB, COMPACT, ITEMS, KO>), dim3(sgrid), dim3(gs::SORT_THREADS), 0, st, kin, vin,
-                           kout, ko_shift, vout, psc, shift, digit_mask, ghist, totals, cv, vo, pnb, xr_nt, t_rank_fault, t_watch, bmax, t_bucket_starts);
-    else if (dev->lds_atomic_ordered.load(std::memory_order_relaxed))
-        hipLaunchKernelGGL((gs::k_sort_scatter<KI, true, RB, COMPACT, ITEMS, KO>), dim3(sgrid), dim3(gs::SORT_THREADS), 0, st, kin, vin,
-                           kout, ko_shift, vout, psc, shift, digit_mask, ghist, totals, cv, vo, pnb, xr_nt, (uint32_t *)nullptr, 0u, bmax, t_bucket_starts);
-    else
-        hipLaunchKernelGGL((gs::k_sort_scatter<KI, false, RB, COMPACT, ITEMS, KO>), dim3(sgrid), dim3(gs::SORT_THREADS), 0, st, kin, vin,
-                           kout, ko_shift, vout, psc, shift, digit_mask, ghist, totals, cv, vo, pnb, xr_nt, (uint32_t *)nullptr, 0u, bmax, t_bucket_starts);
+    // FAST_RANK: chosen by the device probe and the frame's watchdog (t_rank_fault: null outside a frame and once the device
+    // has dropped to the ballot-based rank); PRED: a partitioned two-round frame's compacting pass (t_compact_pred)
+    auto go = [&](auto fast_tag, auto pred_tag, uint32_t *rf, uint32_t watch) {
+        constexpr bool FAST = decltype(fast_tag)::value, PRED = decltype(pred_tag)::value;
+        hipLaunchKernelGGL((gs::k_sort_scatter<KI, FAST, RB, COMPACT, ITEMS, KO, PRED>), dim3(sgrid), dim3(gs::SORT_THREADS), 0, st, kin, vin,
+                           kout, ko_shift, vout, psc, shift, digit_mask, ghist, totals, cv, vo, pnb, xr_nt, rf, watch, bmax, t_bucket_starts,
+                           PRED ? t_compact_pred : gs::CompactPred());
+    };
+    const bool fast = t_rank_fault || dev->lds_atomic_ordered.load(std::memory_order_relaxed);
+    uint32_t *rf = t_rank_fault;
+    const uint32_t watch = t_rank_fault ? t_watch : 0u;
+    if constexpr (COMPACT) {
+        if (t_compact_pred.tau_dev) {
+            if (fast) go(std::true_type(), std::true_type(), rf, watch);
+            else go(std::false_type(), std::true_type(), (uint32_t *)nullptr, 0u);
+            return;
+        }
+    }
+    if (fast) go(std::true_type(), std::false_type(), rf, watch);
+    else go(std::false_type(), std::false_type(), (uint32_t *)nullptr, 0u);
 }
 
 // one radix pass: histogram -> row scan -> scatter
@@ -2018,9 +2031,19 @@ static void launch_pass(const gs_device *dev, hipStream_t st, uint32_t sgrid, co
             summed = true;
         }
     }
-    if (!summed)
-        hipLaunchKernelGGL((gs::k_sort_hist<KI, RB, COMPACT, ITEMS>), dim3(sgrid), dim3(gs::SORT_THREADS), 0, st, kin, psc, shift,
-                           digit_mask, (uint32_t *)ghist.ptr, cv, pnb, xr);
+    if (!summed) {
+        bool done = false;
+        if constexpr (COMPACT) {
+            if (t_compact_pred.tau_dev) {
+                hipLaunchKernelGGL((gs::k_sort_hist<KI, RB, COMPACT, ITEMS, true>), dim3(sgrid), dim3(gs::SORT_THREADS), 0, st, kin, psc, shift,
+                                   digit_mask, (uint32_t *)ghist.ptr, cv, pnb, xr, t_compact_pred);
+                done = true;
+            }
+        }
+        if (!done)
+            hipLaunchKernelGGL((gs::k_sort_hist<KI, RB, COMPACT, ITEMS>), dim3(sgrid), dim3(gs::SORT_THREADS), 0, st, kin, psc, shift,
+                               digit_mask, (uint32_t *)ghist.ptr, cv, pnb, xr, gs::CompactPred());
+    }
     (void)R;
     launch_scan_rows<TILE>(digit_mask + 1u, st, (uint32_t *)ghist.ptr, pnb, psc, (uint32_t *)digit_totals.ptr);   // live rows only
     launch_scatter<KI, KO, RB, COMPACT, ITEMS>(dev, st, sgrid, kin, vin, kout, ko_shift, vout, psc, shift, digit_mask,
@@ -2134,6 +2157,26 @@ static uint32_t xcd_span_for(uint32_t pnb, uint32_t &sgrid) {
     }
     sgrid = xr ? 8u * xr * ((pnb + 8u * xr - 1u) / (8u * xr)) : pnb;
     return xr;
+}
+
+// The histogram half of that pass on its own (partitioned two-round frames: gs::k_round_threshold needs the totals of the top
+// digit before any sort runs): the chunk rows of the preprocess kernel summed per tile, the rows scanned; digit_totals
+// holds the 1024 totals afterwards.
+template <int ITEMS>
+static gs_status run_top_digit_totals(gs_renderer *r, hipStream_t st, uint32_t dense_count, const uint32_t *dense_count_dev) {
+    constexpr int RB = gs::MSD_TOP_BITS;
+    constexpr uint32_t R = 1u << RB, TILE = (uint32_t)(gs::SORT_THREADS * ITEMS);
+    const uint32_t pnb = (uint32_t)(((uint64_t)dense_count + TILE - 1) / TILE);
+    GS_TRY(dev_reserve(r->ghist, (size_t)pnb * R * 4));
+    GS_TRY(dev_reserve(r->digit_totals, R * 4));
+    uint32_t sgrid = 0;
+    const uint32_t xr = xcd_span_for(pnb, sgrid);
+    const gs::SortCount psc{dense_count, dense_count_dev};
+    hipLaunchKernelGGL((gs::k_sort_hist_chunks<RB, ITEMS>), dim3(sgrid), dim3(gs::SORT_THREADS), 0, st, (const uint32_t *)r->chunk_hist.ptr, psc,
+                       R - 1u, (uint32_t *)r->ghist.ptr, (const uint32_t *)r->chunk_vis.ptr, pnb, xr, R / 2u);
+    launch_scan_rows<(int)TILE>(R, st, (uint32_t *)r->ghist.ptr, pnb, psc, (uint32_t *)r->digit_totals.ptr);
+    GS_HIP(hipGetLastError());
+    return GS_OK;
 }
 
 // The frame's depth sort, MSD-first (round 5; gs_render_kernels.h, "Bucket sort"): ONE compacting scatter pass on the TOP
@@ -2830,6 +2873,82 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
         return GS_OK;
     };
     r->two_round = false;
+    // ---- one round, or two (DESIGN.md §4.2 "rounds"): decided before anything is launched, because a partitioned frame
+    //      changes what the preprocess kernel counts and what the depth sorts see ----
+    // A deep scene finishes most of its tiles on the nearest fraction of its Gaussians; everything behind them is
+    // emitted, sorted and staged for nothing.  Two rounds: the frame of the nearest K visible Gaussians first, whose
+    // blend leaves a bit per finished tile and the pixel state of the others; then the rest, without the Gaussians whose
+    // (small) rect lies in finished tiles, resumed by the same blend.  The image is the single round's, bit for bit: a
+    // tile's list is the concatenation of its two lists, and a dropped Gaussian touches finished pixels only.
+    static const int rounds_env = std::getenv("GS3D_ROUNDS") ? std::atoi(std::getenv("GS3D_ROUNDS")) : -1;
+    static const long round1_env = std::getenv("GS3D_ROUND1") ? std::atol(std::getenv("GS3D_ROUND1")) : 0;
+    uint32_t round_k = 0;
+    bool two_round = false;
+    if (r->rounds_epoch != r->shape_epoch) {      // a new shape: the feedback starts over
+        r->rounds_epoch = r->shape_epoch;
+        r->round_scale = 1.0f;
+        r->rounds_off = false;
+        r->auto_deep = false;
+        r->auto_k = 0;
+    }
+    if (band_tiles && groups != 1 && n > 4096u) {
+        const int newer = hist_gen[0] > hist_gen[1] ? 0 : 1;
+        const bool have = !sizing && hist_gen[newer] && r->done_shape[newer] == r->shape_epoch;
+        const uint32_t v_est = have ? hist_v[newer] : n;
+        if (have && r->done_rounds[newer] == 1) {
+            r->full_pairs = hist_d[newer];
+            r->full_pairs_v = hist_v[newer];
+        }
+        // pairs a single round would emit now: the measured count, scaled with the visible Gaussians since
+        const double d_full = r->full_pairs_v ? (double)r->full_pairs * (double)v_est / (double)r->full_pairs_v : (double)r->full_pairs;
+        // The renderer's own choice.  Measured (same-box A/B, gpurun_out/r05r): 10 M at 1080p (2 970 pairs per tile) -9 %,
+        // at 4K (1 716) -8 %, 50 M (14 800) -24 %; the 1 M scene (296 pairs per tile) finishes its tiles only at the end of
+        // their lists.  Round 1 is given ~400 pairs per tile — the frames above are within 1 % of their best from half to
+        // twice that — and a frame takes two rounds when that is at most a third of its Gaussians and the pairs to save
+        // outweigh the dozen launches of a second round.
+        const double per_tile = d_full / (double)band_tiles;
+        double k_auto = per_tile > 0.0 ? (double)v_est * 400.0 / per_tile * (double)r->round_scale : 0.0;
+        if (have && r->done_rounds[newer] == 2 && hist_gen[newer] != r->rounds_fb_gen) {
+            // feedback: a round 1 that finishes less than 60 % of the tiles it has pairs for was too short (or the scene
+            // does not occlude)
+            r->rounds_fb_gen = hist_gen[newer];
+            if ((uint64_t)hist_tdone[newer] * 10u < ((uint64_t)hist_tdone[newer] + hist_topen[newer]) * 6u) {
+                r->round_scale *= 1.5f;
+                if (r->round_scale > 3.4f) r->rounds_off = true;
+            }
+        }
+        bool deep = have && !r->rounds_off && d_full >= 12.0e6 && per_tile >= 1200.0 && k_auto * 3.0 <= (double)v_est;
+        if (!have && !sizing && r->rounds_epoch == r->shape_epoch) {
+            // frames in flight: no finished report to consult (both result blocks belong to frames still running):
+            // what the last frame with a report decided stands
+            deep = r->auto_deep && !r->rounds_off;
+            k_auto = (double)r->auto_k;
+        }
+        r->auto_deep = deep;
+        r->auto_k = (uint64_t)k_auto;
+        const int pinned = r->rounds_req >= 0 ? r->rounds_req : rounds_env;
+        two_round = pinned >= 0 ? pinned != 0 : deep;
+        const uint64_t k = r->round1_req ? r->round1_req : round1_env > 0 ? (uint64_t)round1_env : pinned > 0 && !deep ? v_est / 4u : (uint64_t)k_auto;
+        round_k = (uint32_t)((k + 2047u) / 2048u * 2048u < n ? (k + 2047u) / 2048u * 2048u : 0u);
+        if (round_k == 0u) two_round = false;
+    }
+    // A two-round frame is PARTITIONED when the depth keys have a top digit to cut at (and the frame is not the one that
+    // sizes the pair buffers): the preprocess kernel counts the top 10 bits of every key, k_round_threshold picks the digit
+    // boundary with at least round_k Gaussians in front of it, and each round's depth sort — LSD passes whose compacting
+    // first pass takes only its side of the boundary (gs::CompactPred) — sorts what that round renders: the nearest ones,
+    // then what k_round2_slot_bits keeps of the rest.  Otherwise round 2 is compacted out of the full depth order
+    // (k_round2_count / _write).
+    // Measured (same-box A/B, gpurun_out/r05t/ab3.txt): 50 M 2.42 against 2.53 ms (depth-sort stage 0.318 against 0.462: a
+    // threshold + two sorts whose first pass streams the 200 MB of dense keys for 1-2 M survivors, against one full sort +
+    // the compaction), 10 M 0.908 against 0.865 (two first passes of ~50 us each at their launch-bound floors cost more than
+    // the full sort of 7 M keys saves) — so from 32 M Gaussians; GS3D_ROUND_PARTITION=0/1 forces.
+    static const int partition_env = std::getenv("GS3D_ROUND_PARTITION") ? std::atoi(std::getenv("GS3D_ROUND_PARTITION")) : -1;
+    const bool partition = two_round && !sizing && dbits > (uint32_t)gs::MSD_TOP_BITS && n < (1u << 30) &&
+                           (partition_env >= 0 ? partition_env != 0 : n >= (32u << 20));
+    if (partition) {
+        depth_msd = false;
+        r->depth_msd = false;
+    }
     if (n == 0) {
         // nothing to project: clear the ranges, blend the background
         GS_TRY(dev_reserve(r->zero_region, (size_t)num_tiles * 8));
@@ -2889,9 +3008,10 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
         po.key_bias = near_bits;
         po.block_bounds = (const float *)g->block_bounds;
         po.chunk_hist = (uint32_t *)r->chunk_hist.ptr;
-        po.digit_mask = depth_msd ? (1u << gs::MSD_TOP_BITS) - 1u : first_digit_mask(dbits, depth_radix_bits(dbits));
-        po.digit_shift = depth_msd ? msd_low_bits : 0u;
-        po.hist_words = depth_msd ? (1u << gs::MSD_TOP_BITS) / 2u : (uint32_t)gs::PP_THREADS;
+        const bool top_hist = depth_msd || partition;      // the chunk rows count the TOP 10 bits (else the LSD sort's first digit)
+        po.digit_mask = top_hist ? (1u << gs::MSD_TOP_BITS) - 1u : first_digit_mask(dbits, depth_radix_bits(dbits));
+        po.digit_shift = top_hist ? msd_low_bits : 0u;
+        po.hist_words = top_hist ? (1u << gs::MSD_TOP_BITS) / 2u : (uint32_t)gs::PP_THREADS;
         po.block_list = nullptr;
         po.block_count = nullptr;
         // Block list (k_block_cull): one thread per block tests it, the survivors are handed to the first
@@ -2966,48 +3086,79 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
         //      compacts (count V stays on the device, grids from N) ----
         int dside = 0;
         uint32_t dpasses = 0;
-        {
+        // pred: which Gaussians the compacting first pass takes (all visible ones; or one side of a partitioned frame's
+        // threshold); their count goes to *visible_out
+        auto depth_sort = [&](const gs::CompactPred &pred, uint32_t *visible_out) -> gs_status {
             void *k2[2] = {r->dkeys[0].ptr, r->dkeys[1].ptr};
             void *v2[2] = {r->dvals[0].ptr, r->dvals[1].ptr};
             SortCompact cp;
             cp.dense_keys = (const uint32_t *)r->depth.ptr;
             cp.chunk_vis = (const uint32_t *)r->chunk_vis.ptr;
-            cp.visible_out = &state->visible;
+            cp.visible_out = visible_out;
             cp.dense_count = n;
             cp.dense_count_dev = r->list_mode ? &state->list_slots : nullptr;   // list frame: only the surviving blocks' slots
-            cp.chunk_hist = (const uint32_t *)r->chunk_hist.ptr;
-            const gs::SortCount dc{n, &state->visible};
+            // (a partitioned frame's chunk rows count the top digit of ALL visible keys: its passes count their own)
+            cp.chunk_hist = pred.tau_dev ? nullptr : (const uint32_t *)r->chunk_hist.ptr;
+            const gs::SortCount dc{n, visible_out};
+            t_compact_pred = pred;
+            struct PredScope {
+                ~PredScope() { t_compact_pred = gs::CompactPred(); }
+            } pred_scope;
+            uint32_t passes = 0;
             if (depth_msd) {
                 // scratch of the bucket kernel's chunked path: the LSD sort's side 0 keys and the (not yet written)
                 // depth-ordered rects — the dense keys themselves stay intact for the parity taps
                 const uint32_t top_range = ((far_bits - near_bits) >> msd_low_bits) + 1u;
                 if (n >= (4u << 20))
                     GS_TRY((run_depth_msd_items<gs::SortCfg<uint32_t>::ITEMS_LARGE>(r, st, cp, dbits, top_range, r->dkeys[0].ptr,
-                                                                                  r->sorted_rect.ptr, &state->depth_bucket_max, dpasses)));
+                                                                                  r->sorted_rect.ptr, &state->depth_bucket_max, passes)));
                 else
                     GS_TRY((run_depth_msd_items<gs::SortCfg<uint32_t>::ITEMS>(r, st, cp, dbits, top_range, r->dkeys[0].ptr,
-                                                                            r->sorted_rect.ptr, &state->depth_bucket_max, dpasses)));
+                                                                            r->sorted_rect.ptr, &state->depth_bucket_max, passes)));
                 dside = 0;
             } else if (depth_radix_bits(dbits) == (uint32_t)gs::RADIX_BITS_MAX)
                 GS_TRY((run_sort_rb<uint32_t, gs::RADIX_BITS_MAX>(r->dev, k2, v2, r->ghist, r->digit_totals, dc, dbits, &cp,
-                                                                  st, dside, dpasses, r->launches)));
+                                                                  st, dside, passes, r->launches)));
             else
                 GS_TRY((run_sort_rb<uint32_t, gs::RADIX_BITS>(r->dev, k2, v2, r->ghist, r->digit_totals, dc, dbits, &cp, st,
-                                                              dside, dpasses, r->launches)));
+                                                              dside, passes, r->launches)));
+            dpasses += passes;
+            return GS_OK;
+        };
+        gs::CompactPred pred1;                  // round 1 of a partitioned frame: the keys in front of the threshold
+        if (partition) {
+            // the totals of the top digit (the histogram half of the MSD-first sort's pass), then the cut
+            if (n >= (4u << 20))
+                GS_TRY((run_top_digit_totals<gs::SortCfg<uint32_t>::ITEMS_LARGE>(r, st, n, r->list_mode ? &state->list_slots : nullptr)));
+            else
+                GS_TRY((run_top_digit_totals<gs::SortCfg<uint32_t>::ITEMS>(r, st, n, r->list_mode ? &state->list_slots : nullptr)));
+            gs::ThresholdIO ti;
+            ti.totals = (const uint32_t *)r->digit_totals.ptr;
+            ti.state = state;
+            ti.target = round_k;
+            ti.low_bits = msd_low_bits;
+            hipLaunchKernelGGL(gs::k_round_threshold, dim3(1), dim3(512), 0, st, ti);
+            GS_HIP(hipGetLastError());
+            r->launches += 3;
+            GS_TRY(dev_reserve(r->keep_bits, nslots / 8 + 64));
+            pred1.tau_dev = &state->depth_tau;
+            pred1.keep_bits = (const uint32_t *)r->keep_bits.ptr;      // (side 0 loads and ignores them)
+            pred1.side = 0u;
         }
+        GS_TRY(depth_sort(pred1, partition ? &state->round1_visible : &state->visible));
 
         // ---- pairs in depth order, tile sort, tile ranges: once per round ----
         int tside = 0;
         uint32_t tpasses = 0;
         // round: 0 the frame's only one; 1: the nearest `limit` Gaussians of the depth order; 2: the survivors of
         // k_round2_write (order_r2)
-        auto pairs_round = [&](uint32_t round, uint32_t limit, uint32_t *esb_r) -> gs_status {
+        auto pairs_round = [&](uint32_t round, const uint32_t *order, const uint32_t *count_dev, uint32_t limit, uint32_t *esb_r) -> gs_status {
             if (round <= 1u) mark(ST_EXPAND);
             gs::ExpandIO eo;
-            eo.order = round == 2u ? (const uint32_t *)r->order_r2.ptr : (const uint32_t *)r->dvals[dside].ptr;
+            eo.order = order;
             eo.rect = (const uint2 *)r->rect.ptr;
             eo.sorted_rect = (uint2 *)r->sorted_rect.ptr;
-            eo.count_dev = round == 2u ? &state->round2_visible : &state->visible;
+            eo.count_dev = count_dev;
             eo.limit = limit;
             eo.round = round;
             eo.sums = (uint32_t *)r->exp_sums.ptr;
@@ -3145,76 +3296,22 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
             }
             return GS_OK;
         };
-        // ---- one round, or two (DESIGN.md §4.2 "rounds") ----
-        // A deep scene finishes most of its tiles on the nearest fraction of its Gaussians; everything behind them is
-        // emitted, sorted and staged for nothing.  Two rounds: the frame of the nearest K visible Gaussians first, whose
-        // blend leaves a bit per finished tile and the pixel state of the others; then the rest, without the Gaussians whose
-        // (small) rect lies in finished tiles, resumed by the same blend.  The image is the single round's, bit for bit: a
-        // tile's list is the concatenation of its two lists, and a dropped Gaussian touches finished pixels only.
-        static const int rounds_env = std::getenv("GS3D_ROUNDS") ? std::atoi(std::getenv("GS3D_ROUNDS")) : -1;
-        static const long round1_env = std::getenv("GS3D_ROUND1") ? std::atol(std::getenv("GS3D_ROUND1")) : 0;
-        uint32_t round_k = 0;
-        bool two_round = false;
-        if (r->rounds_epoch != r->shape_epoch) {      // a new shape: the feedback starts over
-            r->rounds_epoch = r->shape_epoch;
-            r->round_scale = 1.0f;
-            r->rounds_off = false;
-            r->auto_deep = false;
-            r->auto_k = 0;
-        }
-        if (capacity && band_tiles && groups != 1 && n > 4096u) {
-            const int newer = hist_gen[0] > hist_gen[1] ? 0 : 1;
-            const bool have = !sizing && hist_gen[newer] && r->done_shape[newer] == r->shape_epoch;
-            const uint32_t v_est = have ? hist_v[newer] : n;
-            if (have && r->done_rounds[newer] == 1) {
-                r->full_pairs = hist_d[newer];
-                r->full_pairs_v = hist_v[newer];
-            }
-            // pairs a single round would emit now: the measured count, scaled with the visible Gaussians since
-            const double d_full = r->full_pairs_v ? (double)r->full_pairs * (double)v_est / (double)r->full_pairs_v : (double)r->full_pairs;
-            // The renderer's own choice.  Measured (same-box A/B, gpurun_out/r05r): 10 M at 1080p (2 970 pairs per tile) -9 %,
-            // at 4K (1 716) -8 %, 50 M (14 800) -24 %; the 1 M scene (296 pairs per tile) finishes its tiles only at the end of
-            // their lists.  Round 1 is given ~400 pairs per tile — the frames above are within 1 % of their best from half to
-            // twice that — and a frame takes two rounds when that is at most a third of its Gaussians and the pairs to save
-            // outweigh the dozen launches of a second round.
-            const double per_tile = d_full / (double)band_tiles;
-            double k_auto = per_tile > 0.0 ? (double)v_est * 400.0 / per_tile * (double)r->round_scale : 0.0;
-            if (have && r->done_rounds[newer] == 2 && hist_gen[newer] != r->rounds_fb_gen) {
-                // feedback: a round 1 that finishes less than 60 % of the tiles it has pairs for was too short (or the scene
-                // does not occlude)
-                r->rounds_fb_gen = hist_gen[newer];
-                if ((uint64_t)hist_tdone[newer] * 10u < ((uint64_t)hist_tdone[newer] + hist_topen[newer]) * 6u) {
-                    r->round_scale *= 1.5f;
-                    if (r->round_scale > 3.4f) r->rounds_off = true;
-                }
-            }
-            bool deep = have && !r->rounds_off && d_full >= 12.0e6 && per_tile >= 1200.0 && k_auto * 3.0 <= (double)v_est;
-            if (!have && !sizing && r->rounds_epoch == r->shape_epoch) {
-                // frames in flight: no finished report to consult (both result blocks belong to frames still running):
-                // what the last frame with a report decided stands
-                deep = r->auto_deep && !r->rounds_off;
-                k_auto = (double)r->auto_k;
-            }
-            r->auto_deep = deep;
-            r->auto_k = (uint64_t)k_auto;
-            const int pinned = r->rounds_req >= 0 ? r->rounds_req : rounds_env;
-            two_round = pinned >= 0 ? pinned != 0 : deep;
-            const uint64_t k = r->round1_req ? r->round1_req : round1_env > 0 ? (uint64_t)round1_env : pinned > 0 && !deep ? v_est / 4u : (uint64_t)k_auto;
-            round_k = (uint32_t)((k + 2047u) / 2048u * 2048u < n ? (k + 2047u) / 2048u * 2048u : 0u);
-            if (round_k == 0u) two_round = false;
-        }
+        if (!capacity) two_round = false;
         r->two_round = two_round;
         r->round1 = round_k;
         if (!two_round) {
-            GS_TRY(pairs_round(0u, 0xffffffffu, esb));
+            GS_TRY(pairs_round(0u, (const uint32_t *)r->dvals[dside].ptr, &state->visible, 0xffffffffu, esb));
         } else {
             tile_keys.done = done_bits;
             tile_keys.open = open_bits;
-            GS_TRY(pairs_round(1u, round_k, esb));
+            if (partition)
+                GS_TRY(pairs_round(1u, (const uint32_t *)r->dvals[dside].ptr, &state->round1_visible, 0xffffffffu, esb));
+            else
+                GS_TRY(pairs_round(1u, (const uint32_t *)r->dvals[dside].ptr, &state->visible, round_k, esb));
             mark(ST_BLEND);
             GS_TRY(launch_blend(1u));
             {
-                GS_TRY(dev_reserve(r->order_r2, (nn + 1024) * 4));      // (its largest size at once; padded like the sorts' values)
+                if (!partition) GS_TRY(dev_reserve(r->order_r2, (nn + 1024) * 4));      // (its largest size at once; padded like the sorts' values)
                 gs::Round2IO ro;
                 ro.order = (const uint32_t *)r->dvals[dside].ptr + round_k;
                 ro.rect = (const uint2 *)r->rect.ptr;
@@ -3235,22 +3332,42 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
                     typedef void (*bits_fn)(gs::Round2IO);
                     static const bits_fn tbl[2][2] = {{gs::k_round2_slot_bits<false, false>, gs::k_round2_slot_bits<false, true>},
                                                       {gs::k_round2_slot_bits<true, false>, gs::k_round2_slot_bits<true, true>}};
-                    const bool lds = done_words <= gs::R2_LDS_WORDS;
-                    hipLaunchKernelGGL(tbl[fc.rect32 ? 1 : 0][lds ? 1 : 0], dim3(bits_grid), dim3(256), 0, st, ro);
+                    GS_TRY(dev_reserve(r->box_table, ((size_t)num_tiles + 8) * 2));
+                    ro.box_table = (const uint16_t *)r->box_table.ptr;
+                    hipLaunchKernelGGL(gs::k_round2_box_table, dim3((num_tiles + 255u) / 256u), dim3(256), 0, st, (const uint32_t *)done_bits,
+                                       (uint16_t *)r->box_table.ptr, fc.tiles_x, fc.tiles_y);
+                    r->launches++;
+                    const bool lds = num_tiles <= gs::R2_LDS_TILES;
+                    const size_t lds_bytes = lds ? ((size_t)num_tiles + 7) / 8 * 16 : 0;
+                    const uint32_t persistent = bits_grid < 1024u ? bits_grid : 1024u;      // (4 / 2 workgroups per CU at 1080p / 4K)
+                    hipLaunchKernelGGL(tbl[fc.rect32 ? 1 : 0][lds ? 1 : 0], dim3(persistent), dim3(256), lds_bytes, st, ro);
                 }
-                GS_TRY(dev_reserve(r->r2_scan, (size_t)ro.groups * (2 * 4 + 32 * 8) + 64));
-                ro.masks = (unsigned long long *)r->r2_scan.ptr;
-                ro.counts = (uint32_t *)(ro.masks + (size_t)ro.groups * 32);
-                ro.offsets = ro.counts + ro.groups;
-                hipLaunchKernelGGL(gs::k_round2_count, dim3(ro.groups), dim3(256), 0, st, ro);
-                gs::ScanJob js{ro.counts, ro.offsets, &state->round2_visible, ro.groups, nullptr};
-                hipLaunchKernelGGL(gs::k_scan_chunks, dim3(1), dim3(1024), 0, st, js, js);
-                hipLaunchKernelGGL(gs::k_round2_write, dim3(ro.groups), dim3(256), 0, st, ro);
-                r->launches += 3;
                 GS_HIP(hipGetLastError());
                 r->launches++;
+                if (partition) {
+                    // the depth sort of what is left: keys behind the threshold whose slot bit is set
+                    gs::CompactPred pred2;
+                    pred2.tau_dev = &state->depth_tau;
+                    pred2.keep_bits = (const uint32_t *)r->keep_bits.ptr;
+                    pred2.side = 1u;
+                    GS_TRY(depth_sort(pred2, &state->round2_visible));
+                    hipLaunchKernelGGL(gs::k_round2_tiles, dim3(1), dim3(256), 0, st, ro);
+                    r->launches++;
+                } else {
+                    GS_TRY(dev_reserve(r->r2_scan, (size_t)ro.groups * (2 * 4 + 32 * 8) + 64));
+                    ro.masks = (unsigned long long *)r->r2_scan.ptr;
+                    ro.counts = (uint32_t *)(ro.masks + (size_t)ro.groups * 32);
+                    ro.offsets = ro.counts + ro.groups;
+                    hipLaunchKernelGGL(gs::k_round2_count, dim3(ro.groups), dim3(256), 0, st, ro);
+                    gs::ScanJob js{ro.counts, ro.offsets, &state->round2_visible, ro.groups, nullptr};
+                    hipLaunchKernelGGL(gs::k_scan_chunks, dim3(1), dim3(1024), 0, st, js, js);
+                    hipLaunchKernelGGL(gs::k_round2_write, dim3(ro.groups), dim3(256), 0, st, ro);
+                    r->launches += 3;
+                }
+                GS_HIP(hipGetLastError());
             }
-            GS_TRY(pairs_round(2u, 0xffffffffu, esb2));
+            GS_TRY(pairs_round(2u, partition ? (const uint32_t *)r->dvals[dside].ptr : (const uint32_t *)r->order_r2.ptr, &state->round2_visible,
+                               0xffffffffu, esb2));
         }
         r->sort_passes = dpasses + tpasses;
         r->dsorted_side = dside;

@@ -236,6 +236,8 @@ struct FrameState {
     uint32_t round2_visible;     // ... the Gaussians k_round2_write kept for round 2
     uint32_t tiles_done;         // ... tiles round 1 finished (counted by k_round2_count; 0 in a single-round frame)
     uint32_t tiles_open;         // ... tiles round 1 left unfinished although it had pairs for them
+    uint32_t round1_visible;     // partitioned two-round frames: the Gaussians in front of the depth threshold (round 1 sorts only them)
+    uint32_t depth_tau;          // ... the threshold: round 1 = keys < tau, round 2 = keys >= tau (k_round_threshold)
     uint32_t depth_bucket_max;   // largest top-digit bucket of the depth sort (k_bucket_sort, or the LSD sort's last pass)
     uint32_t tile_bucket_max;    // the same for the tile sort (k_bucket_sort)
 };
@@ -1504,7 +1506,8 @@ __global__ __launch_bounds__(EXP_CHUNK) void k_expand_count(ExpandIO io) {
 // Round 2 of a two-round frame (DESIGN.md §4.2 "rounds"): which of the visible Gaussians behind the nearest K can still
 // colour a pixel?  A Gaussian whose rect (at most 3 x 3 tiles; of a rect that lost tiles to the exact test, version 4,
 // only the kept ones) lies entirely in tiles that round 1 finished cannot, and is dropped; larger rects are few and stay.
-// Two kernels.  k_round2_slot_bits answers the question for EVERY output slot, in slot order — a stream over the rect
+// k_round2_box_table first condenses the finished-tile bits into one entry per tile: "is the w x h box at this origin
+// finished?".  k_round2_slot_bits then answers the question for EVERY output slot, in slot order — a stream over the rect
 // array instead of a gather in depth order (a first version gathered: 495 us at 50 M, a 200 MB array read by random
 // 4-byte accesses) — and leaves one bit per slot (N / 8 bytes: 6 MB at 50 M, which the caches hold); slots of culled
 // Gaussians hold stale rects and get a meaningless bit that nobody reads.  k_round2_count / _write then walk the depth
@@ -1514,6 +1517,7 @@ struct Round2IO {
     const uint2 *rect;               // [slots] tile rects by slot
     const uint32_t *done;            // one bit per tile, + 1 word
     const uint32_t *open;            // one bit per tile: round 1 had pairs for it and did not finish it
+    const uint16_t *box_table;       // [tiles, padded to 8] k_round2_box_table
     uint32_t *keep_bits;             // [slots / 32 + 2] one bit per slot: this Gaussian can still colour a pixel
     uint32_t *order_out;             // [<= V - K]
     FrameState *state;
@@ -1527,73 +1531,87 @@ struct Round2IO {
 constexpr uint32_t R2_CHUNKS = 8;
 constexpr uint32_t R2_GROUP = R2_CHUNKS * 256u;
 constexpr uint32_t R2_SLOT_ITEMS = 8;                         // k_round2_slot_bits: slots per thread (2048 per workgroup)
-constexpr uint32_t R2_LDS_WORDS = 2048;                       // ... bit words it keeps in LDS (images of up to 65 504 tiles)
+constexpr uint32_t R2_LDS_TILES = 32768;                      // ... tiles whose box table it keeps in LDS (the packed rects' limit)
 
-// Per tile row the three bits come out of the two words around the row's first tile (the bit array is padded by a word);
-// all six loads are issued unconditionally (rows outside the rect read word 0 and need nothing; a stale rect may point
-// anywhere: its bit index is clamped into the array).  LDS: the workgroup first copies the bit array (at most
-// R2_LDS_WORDS words) into LDS — from global memory the kernel was bound by its 3 divergent 8-byte loads per slot (118 us
-// at 50 M).
+// Per tile t, nine bits: bit (h - 1) * 3 + (w - 1) = "every tile of the w x h box whose origin is t is finished" (tiles
+// past the image edge count as finished: no rect reaches them).  One thread per tile; 16 bits per tile.
+__global__ __launch_bounds__(256) void k_round2_box_table(const uint32_t *__restrict__ done, uint16_t *__restrict__ table,
+                                                          uint32_t tiles_x, uint32_t tiles_y) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= tiles_x * tiles_y) return;
+    const uint32_t x0 = t % tiles_x, y0 = t / tiles_x;
+    uint32_t row[3];          // per row j: bit i = tiles (x0 .. x0 + i, y0 + j) all finished
+#pragma unroll
+    for (uint32_t j = 0; j < 3u; j++) {
+        uint32_t run = 1u, bits = 0u;
+#pragma unroll
+        for (uint32_t i = 0; i < 3u; i++) {
+            const bool inside = x0 + i < tiles_x && y0 + j < tiles_y;
+            const uint32_t q = inside ? (y0 + j) * tiles_x + x0 + i : 0u;
+            const uint32_t d = inside ? (done[q >> 5] >> (q & 31u)) & 1u : 1u;
+            run &= d;
+            bits |= run << i;
+        }
+        row[j] = bits;
+    }
+    const uint32_t h1 = row[0], h2 = h1 & row[1], h3 = h2 & row[2];
+    table[t] = (uint16_t)(h1 | (h2 << 3) | (h3 << 6));
+}
+
+// One bit per output slot: "this Gaussian can still colour a pixel" = its rect is larger than 3 x 3 tiles or its box is
+// not finished.  (A rect that lost tiles to the exact test, version 4, is judged by its whole box: conservative — it may
+// keep a Gaussian whose open tile is one it does not touch.)  LDS: the workgroup first copies the table into LDS.  A
+// first version tested the tiles' bits row by row (3 divergent 8-byte loads and ~100 instructions per slot: 114 us at
+// 50 M, from global memory or LDS alike); the table makes it one 2-byte lookup.  A stale rect may point anywhere: its
+// origin is clamped into the table.
 template <bool RECT32, bool LDS>
 __global__ __launch_bounds__(256) void k_round2_slot_bits(Round2IO io) {
-    __shared__ uint32_t s_done[LDS ? R2_LDS_WORDS : 1];
+    // (dynamic LDS: 2 bytes per tile, padded to 16 — 16 KB at 1080p, 64 KB at 4K; the workgroups are persistent, so the
+    // table is copied a few hundred times per frame, not once per 2048 slots)
+    extern __shared__ __attribute__((aligned(16))) uint16_t s_table[];
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t base = (blockIdx.x * 256u + (threadIdx.x & ~63u)) * R2_SLOT_ITEMS;      // first slot of this wave
-    uint32_t origin[R2_SLOT_ITEMS], w[R2_SLOT_ITEMS], h[R2_SLOT_ITEMS], rows[R2_SLOT_ITEMS];
     if constexpr (LDS) {
-        const uint32_t words = (io.num_tiles + 31u) / 32u + 1u;     // <= R2_LDS_WORDS (host)
-        for (uint32_t q = threadIdx.x; q < words; q += 256u) s_done[q] = io.done[q];
+        const uint4 *src = (const uint4 *)io.box_table;
+        uint4 *dst = (uint4 *)s_table;
+        for (uint32_t q = threadIdx.x; q < (io.num_tiles + 7u) / 8u; q += 256u) dst[q] = src[q];
         __syncthreads();
     }
-    const uint32_t *done = LDS ? s_done : io.done;
+    const uint16_t *table = LDS ? s_table : io.box_table;
+    const uint32_t span = 256u * R2_SLOT_ITEMS;
+    for (uint32_t first = blockIdx.x * span; first < io.slots; first += gridDim.x * span) {
+    const uint32_t base = first + (threadIdx.x & ~63u) * R2_SLOT_ITEMS;      // first slot of this wave
+    uint32_t p[R2_SLOT_ITEMS];
+    uint2 pr[R2_SLOT_ITEMS];
 #pragma unroll
     for (uint32_t i = 0; i < R2_SLOT_ITEMS; i++) {
         uint32_t slot = base + i * 64u + lane;
-        slot = slot < io.slots ? slot : io.slots - 1u;               // (the last workgroup: slots is a multiple of 1024)
+        slot = slot < io.slots ? slot : io.slots - 1u;               // (the last span: slots is a multiple of 1024)
+        if constexpr (RECT32) p[i] = ((const uint32_t *)io.rect)[slot];
+        else pr[i] = io.rect[slot];
+    }
+#pragma unroll
+    for (uint32_t i = 0; i < R2_SLOT_ITEMS; i++) {
+        uint32_t origin, w, h;
         if constexpr (RECT32) {
-            const uint32_t p = ((const uint32_t *)io.rect)[slot];
-            const bool masked = (p >> 31) != 0u;
-            origin[i] = (p >> 16) & 0x7fffu;
-            w[i] = masked ? ((p >> 12) & 3u) + 1u : (p & 0xffu) + 1u;
-            h[i] = masked ? ((p >> 14) & 3u) + 1u : ((p >> 8) & 0xffu) + 1u;
-            rows[i] = masked ? 0x8000u | (p & 0xfffu) : 0u;
+            const bool masked = (p[i] >> 31) != 0u;
+            origin = (p[i] >> 16) & 0x7fffu;
+            w = masked ? ((p[i] >> 12) & 3u) + 1u : (p[i] & 0xffu) + 1u;
+            h = masked ? ((p[i] >> 14) & 3u) + 1u : ((p[i] >> 8) & 0xffu) + 1u;
         } else {
-            uint32_t r0, r1;
-            rect_unpack64(io.rect[slot], r0, r1, rows[i]);
-            origin[i] = __umul24(r0 >> 16, io.tiles_x) + (r0 & 0xffffu);
-            w[i] = (r1 & 0xffffu) - (r0 & 0xffffu);
-            h[i] = (r1 >> 16) - (r0 >> 16);
+            uint32_t r0, r1, rows;
+            rect_unpack64(pr[i], r0, r1, rows);
+            origin = __umul24(r0 >> 16, io.tiles_x) + (r0 & 0xffffu);
+            w = (r1 & 0xffffu) - (r0 & 0xffffu);
+            h = (r1 >> 16) - (r0 >> 16);
         }
-    }
-    uint32_t lo[R2_SLOT_ITEMS][3], hi[R2_SLOT_ITEMS][3], need[R2_SLOT_ITEMS][3], sh[R2_SLOT_ITEMS][3];
-#pragma unroll
-    for (uint32_t i = 0; i < R2_SLOT_ITEMS; i++) {
-        const bool small = w[i] >= 1u && h[i] >= 1u && w[i] <= 3u && h[i] <= 3u;
-#pragma unroll
-        for (uint32_t j = 0; j < 3u; j++) {
-            const bool in = small && j < h[i];
-            uint32_t bit = in ? origin[i] + j * io.tiles_x : 0u;
-            bit = bit < io.num_tiles ? bit : io.num_tiles - 1u;
-            // columns of row j that count: the rect's, or — a rect that lost tiles to the exact test — the kept ones
-            const uint32_t rf = (rows[i] >> (4u * j)) & 3u, rc = (rows[i] >> (4u * j + 2u)) & 3u;
-            const uint32_t cols = (rows[i] & 0x8000u) ? ((1u << rc) - 1u) << rf : (1u << (w[i] & 3u)) - 1u;
-            need[i][j] = in ? cols : (small ? 0u : 8u);      // (not small: a bit that is never there)
-            sh[i][j] = bit & 31u;
-            lo[i][j] = done[bit >> 5];
-            hi[i][j] = done[(bit >> 5) + 1u];
-        }
-    }
-#pragma unroll
-    for (uint32_t i = 0; i < R2_SLOT_ITEMS; i++) {
-        bool all = true;
-#pragma unroll
-        for (uint32_t j = 0; j < 3u; j++) {
-            const uint32_t got = (uint32_t)((((uint64_t)hi[i][j] << 32) | lo[i][j]) >> sh[i][j]) & 7u;
-            all = all && (got & need[i][j]) == need[i][j];
-        }
-        const uint64_t m = __builtin_amdgcn_ballot_w64(!all);
+        const bool small = w >= 1u && h >= 1u && w <= 3u && h <= 3u;
+        origin = origin < io.num_tiles ? origin : io.num_tiles - 1u;
+        const uint32_t e = table[origin];
+        const bool finished = small && ((e >> (((h - 1u) & 3u) * 3u + ((w - 1u) & 3u))) & 1u) != 0u;
+        const uint64_t m = __builtin_amdgcn_ballot_w64(!finished);
         if (lane == 0u && base + i * 64u < io.slots)
             *(uint2 *)(io.keep_bits + ((base + i * 64u) >> 5)) = make_uint2((uint32_t)m, (uint32_t)(m >> 32));
+    }
     }
 }
 
@@ -1603,6 +1621,28 @@ __global__ __launch_bounds__(256) void k_round2_slot_bits(Round2IO io) {
 // decoupled look-back over one status word per group was 325 us at 50 M: the 2048 resident workgroups finish together,
 // so every one of them walks back over ~2000 words, 64 per dependent round trip, before it meets an inclusive prefix.)
 // Workgroup 0 of the count kernel also counts the tiles round 1 finished (::tiles_done) for the host.
+// tiles finished by round 1, and tiles it had pairs for and left open (bits past the last tile are never set): one
+// workgroup of 256 threads, for the host's feedback (FrameState::tiles_done / tiles_open)
+__device__ __forceinline__ void round2_count_tiles(const Round2IO &io, uint32_t *s_cnt, uint32_t *s_open) {
+    const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+    uint32_t n = 0, o = 0;
+    for (uint32_t q = threadIdx.x; q < (io.num_tiles + 31u) / 32u; q += 256u) {
+        n += (uint32_t)__popc(io.done[q]);
+        o += (uint32_t)__popc(io.open[q]);
+    }
+    n = wave_reduce_add(n);
+    o = wave_reduce_add(o);
+    if (lane == 0u) {
+        s_cnt[wid] = n;
+        s_open[wid] = o;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0u) {
+        io.state->tiles_done = (s_cnt[0] + s_cnt[1]) + (s_cnt[2] + s_cnt[3]);
+        io.state->tiles_open = (s_open[0] + s_open[1]) + (s_open[2] + s_open[3]);
+    }
+}
+
 __global__ __launch_bounds__(256) void k_round2_count(Round2IO io) {
     __shared__ uint32_t s_cnt[4], s_open[4];
     const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
@@ -1631,25 +1671,15 @@ __global__ __launch_bounds__(256) void k_round2_count(Round2IO io) {
     __syncthreads();
     if (threadIdx.x == 0u) io.counts[g] = (s_cnt[0] + s_cnt[1]) + (s_cnt[2] + s_cnt[3]);
     if (g == 0u) {
-        // tiles finished by round 1, and tiles it had pairs for and left open (bits past the last tile are never set)
-        uint32_t n = 0, o = 0;
-        for (uint32_t q = threadIdx.x; q < (io.num_tiles + 31u) / 32u; q += 256u) {
-            n += (uint32_t)__popc(io.done[q]);
-            o += (uint32_t)__popc(io.open[q]);
-        }
-        n = wave_reduce_add(n);
-        o = wave_reduce_add(o);
         __syncthreads();
-        if (lane == 0u) {
-            s_cnt[wid] = n;
-            s_open[wid] = o;
-        }
-        __syncthreads();
-        if (threadIdx.x == 0u) {
-            io.state->tiles_done = (s_cnt[0] + s_cnt[1]) + (s_cnt[2] + s_cnt[3]);
-            io.state->tiles_open = (s_open[0] + s_open[1]) + (s_open[2] + s_open[3]);
-        }
+        round2_count_tiles(io, s_cnt, s_open);
     }
+}
+
+// the same count for a partitioned frame (whose round 2 is compacted by its depth sort): one workgroup
+__global__ __launch_bounds__(256) void k_round2_tiles(Round2IO io) {
+    __shared__ uint32_t s_cnt[4], s_open[4];
+    round2_count_tiles(io, s_cnt, s_open);
 }
 
 __global__ __launch_bounds__(256) void k_round2_write(Round2IO io) {
@@ -1677,6 +1707,52 @@ __global__ __launch_bounds__(256) void k_round2_write(Round2IO io) {
                            (uint32_t)__shfl((int)(uint32_t)mall, (int)src, WAVE);
         const uint32_t off = (uint32_t)__shfl((int)excl, (int)src, WAVE);
         if ((m >> lane) & 1ull) io.order_out[base + off + mbcnt(m)] = slot[c];
+    }
+}
+
+// Partitioned two-round frames: where to cut the depth order.  The preprocess kernel counted the TOP 10 bits of every
+// visible Gaussian's depth key per 1024-slot chunk (PreOut::chunk_hist in its MSD-first layout); k_sort_hist_chunks and
+// the row scan of the MSD-first sort turn the rows into the 1024 digit totals (a first version added the rows up with one
+// global atomic per bin and workgroup: 230 us at 50 M — 763 atomics on each of 1024 addresses), and this kernel — one
+// workgroup — turns the totals into the threshold: the first digit boundary with at least `target` Gaussians in front of
+// it (FrameState::depth_tau = that digit << low_bits; everything in front: round 1, sorted and rendered first; the rest
+// waits for k_round2_slot_bits).  It also publishes V (FrameState::visible), which no depth sort of such a frame counts.
+struct ThresholdIO {
+    const uint32_t *totals;          // [1024] Gaussians per top digit
+    FrameState *state;
+    uint32_t target;                 // Gaussians wanted in round 1
+    uint32_t low_bits;               // key bits below the top digit
+};
+__global__ __launch_bounds__(512) void k_round_threshold(ThresholdIO io) {
+    __shared__ uint32_t s_tot[1024];
+    __shared__ uint32_t s_wave[8];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t t0 = io.totals[2u * tid], t1 = io.totals[2u * tid + 1u];
+    const uint32_t lane = tid & 63u, wid = tid >> 6;
+    const uint32_t incl = wave_inclusive_scan(t0 + t1, lane);
+    if (lane == 63u) s_wave[wid] = incl;
+    __syncthreads();
+    uint32_t before = 0, all = 0;
+#pragma unroll
+    for (uint32_t q = 0; q < 8u; q++) {
+        before += q < wid ? s_wave[q] : 0u;
+        all += s_wave[q];
+    }
+    const uint32_t i1 = before + incl, i0 = i1 - t1;      // Gaussians with digit <= 2t / <= 2t + 1
+    s_tot[2u * tid] = i0;
+    s_tot[2u * tid + 1u] = i1;
+    __syncthreads();
+    // the cut: the smallest digit d with (Gaussians of digits <= d) >= target -> tau = (d + 1) << low_bits
+    const bool hit0 = i0 >= io.target && (tid == 0u || s_tot[2u * tid - 1u] < io.target);
+    const bool hit1 = i1 >= io.target && i0 < io.target;
+    if (hit0 || hit1) {
+        const uint32_t d = 2u * tid + (hit0 ? 0u : 1u);
+        const uint64_t tau = (uint64_t)(d + 1u) << io.low_bits;
+        io.state->depth_tau = tau >= 0xffffffffull ? 0xffffffffu : (uint32_t)tau;
+    }
+    if (tid == 0u) {
+        if (all < io.target) io.state->depth_tau = 0xffffffffu;      // fewer visible Gaussians than wanted: all of them in round 1
+        io.state->visible = all;
     }
 }
 
@@ -1725,19 +1801,32 @@ struct SortCount {
 // partitioned (key, slot) list of the V visible ones, and workgroup 0 publishes V.
 constexpr uint32_t SORT_INVALID_KEY = 0xffffffffu;
 
+// Which elements of a COMPACT pass count (partitioned two-round frames, DESIGN.md §4.2 "rounds"): all visible ones
+// (tau_dev == null), those in front of the depth threshold (side 0: key < *tau_dev), or those behind it that can
+// still colour a pixel (side 1: key >= *tau_dev and the slot's bit in keep_bits, k_round2_slot_bits).  The rest is treated
+// exactly like a culled Gaussian, so each round sorts only what it renders.
+struct CompactPred {
+    const uint32_t *tau_dev = nullptr;
+    const uint32_t *keep_bits = nullptr;
+    uint32_t side = 0;
+};
+
 // ghist layout: [digit][block] (digit-major, row stride = the grid size) so that the row scan reads
 // contiguous memory.  Tile ids and depth exponents are highly repetitive, so neighbouring lanes
 // often hit the same bin; the private copies (lane & (COPIES-1)) cut the same-address LDS atomic
 // serialisation.
-template <typename K, int RB, bool COMPACT, int ITEMS>
+template <typename K, int RB, bool COMPACT, int ITEMS, bool PRED = false>
 __global__ __launch_bounds__(SORT_THREADS) void k_sort_hist(const K *__restrict__ keys, SortCount sc,
                                                             uint32_t shift, uint32_t digit_mask,
                                                             uint32_t *__restrict__ ghist,
                                                             const uint32_t *__restrict__ chunk_vis, uint32_t num_blocks,
-                                                            uint32_t xcd_chunk) {
+                                                            uint32_t xcd_chunk, CompactPred pred = CompactPred()) {
     constexpr uint32_t TILE = SORT_THREADS * ITEMS;
     constexpr int R = 1 << RB;
     constexpr int COPIES = 2048 / R;   // 8 KiB of private copies: 8 x 256 or 4 x 512 bins
+    static_assert(!PRED || COMPACT, "the predicate belongs to the compacting pass");
+    uint32_t tau = 0;
+    if constexpr (PRED) tau = *pred.tau_dev;
     constexpr int DPT = R / SORT_THREADS;
     static_assert(!COMPACT || (sizeof(K) == 4 && TILE % PP_CHUNK == 0), "compacting pass: u32 keys, whole chunks per tile");
     const uint32_t count = sc.get();
@@ -1775,6 +1864,12 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_hist(const K *__restrict_
         }
 #pragma unroll
         for (int v = 0; v < VECS; v++) qv[v] = src[(ok[v] ? v : 0) * SORT_THREADS + threadIdx.x];
+        uint32_t kb[PRED ? VECS : 1];        // a partitioned frame: the words holding the four slots' keep bits (loaded
+                                             // unconditionally — keep_bits is always a readable array —, used by side 1)
+        if constexpr (PRED) {
+#pragma unroll
+            for (int v = 0; v < VECS; v++) kb[v] = pred.keep_bits[(base + ((uint32_t)v * SORT_THREADS + threadIdx.x) * 4u) >> 5];
+        }
         __builtin_amdgcn_sched_barrier(0);   // every load is issued before the first pin / use
 #pragma unroll
         for (int v = 0; v < VECS; v++) asm volatile("" : "+v"(qv[v].x), "+v"(qv[v].y), "+v"(qv[v].z), "+v"(qv[v].w));
@@ -1789,8 +1884,13 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_hist(const K *__restrict_
                 if constexpr (sizeof(K) == 2) k = (K)(w[e >> 1] >> (16 * (e & 1)));
                 else if constexpr (sizeof(K) == 4) k = (K)w[e];
                 else k = (K)(((uint64_t)w[2 * e + 1] << 32) | w[2 * e]);
-                if (!COMPACT || (uint32_t)k != SORT_INVALID_KEY)
-                    atomicAdd(&s_hist[copy][(uint32_t)(k >> shift) & digit_mask], 1u);
+                bool live = true;
+                if constexpr (COMPACT) live = (uint32_t)k != SORT_INVALID_KEY;
+                if constexpr (PRED) {
+                    const uint32_t slot = base + ((uint32_t)v * SORT_THREADS + threadIdx.x) * 4u + (uint32_t)e;
+                    live = pred.side == 0u ? (uint32_t)k < tau : live && (uint32_t)k >= tau && ((kb[v] >> (slot & 31u)) & 1u) != 0u;
+                }
+                if (live) atomicAdd(&s_hist[copy][(uint32_t)(k >> shift) & digit_mask], 1u);
             }
         }
     } else {
@@ -1801,7 +1901,12 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_hist(const K *__restrict_
             if (i < valid) {
                 const K key = keys[base + i];
                 bool ok = true;
-                if constexpr (COMPACT) ok = (uint32_t)key != SORT_INVALID_KEY && chunk_vis[(base + i) >> 10] != 0u;
+                if constexpr (COMPACT) {
+                    ok = (uint32_t)key != SORT_INVALID_KEY && chunk_vis[(base + i) >> 10] != 0u;
+                    if constexpr (PRED)
+                        ok = pred.side == 0u ? ok && (uint32_t)key < tau
+                                             : ok && (uint32_t)key >= tau && ((pred.keep_bits[(base + i) >> 5] >> ((base + i) & 31u)) & 1u) != 0u;
+                }
                 if (ok) atomicAdd(&s_hist[copy][(uint32_t)(key >> shift) & digit_mask], 1u);
             }
         }
@@ -2189,13 +2294,14 @@ __device__ __forceinline__ void scatter_ranked(ScatterShared<K, RB, ITEMS> &sh, 
     }
 }
 
-template <typename K, bool FAST_RANK, int RB, bool COMPACT, int ITEMS, typename KO = K>
+template <typename K, bool FAST_RANK, int RB, bool COMPACT, int ITEMS, typename KO = K, bool PRED = false>
 __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
     const K *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, KO *__restrict__ keys_out, uint32_t ko_shift,
     uint32_t *__restrict__ vals_out, SortCount sc, uint32_t shift, uint32_t digit_mask,
     const uint32_t *__restrict__ ghist, const uint32_t *__restrict__ digit_totals,
     const uint32_t *__restrict__ chunk_vis, uint32_t *__restrict__ visible_out, uint32_t num_tiles,
-    uint32_t xcd_chunk_nt, uint32_t *rank_fault, uint32_t watch, uint32_t *bucket_max_out, uint32_t *bucket_start_out) {
+    uint32_t xcd_chunk_nt, uint32_t *rank_fault, uint32_t watch, uint32_t *bucket_max_out, uint32_t *bucket_start_out,
+    CompactPred pred = CompactPred()) {
     constexpr int TILE = SORT_THREADS * ITEMS;
     __shared__ ScatterShared<K, RB, ITEMS> sh;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
@@ -2253,9 +2359,31 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(
             const K raw = __builtin_nontemporal_load(&keys_in[tile_base + (ok ? e : 0u)]);
             key[k] = ok ? raw : (K)~(K)0;
             val[k] = tile_base + e;
+
         } else {
             key[k] = ok ? keys_in[tile_base + e] : (K)~(K)0;
             val[k] = ok ? vals_in[tile_base + e] : 0u;
+        }
+    }
+    if constexpr (PRED) {
+        // A partitioned frame: this round's side of the depth threshold only — the other elements become "culled".  The
+        // keep bits of the wave's 64 slots per round are two consecutive words (loaded unconditionally, all rounds back
+        // to back: keep_bits is always a readable array; side 0 ignores them).
+        static_assert(COMPACT, "the predicate belongs to the compacting pass");
+        const uint32_t tau = *pred.tau_dev;
+        uint32_t word[ITEMS];
+#pragma unroll
+        for (int k = 0; k < ITEMS; k++) {
+            uint32_t e = wave_off + (uint32_t)k * WAVE + lane;
+            e = e < in_tile ? e : 0u;
+            word[k] = pred.keep_bits[(tile_base + e) >> 5];
+        }
+#pragma unroll
+        for (int k = 0; k < ITEMS; k++) {
+            const uint32_t kk = (uint32_t)key[k];
+            const bool mine = pred.side == 0u ? kk < tau
+                                              : kk >= tau && kk != SORT_INVALID_KEY && ((word[k] >> (lane & 31u)) & 1u) != 0u;
+            key[k] = mine ? key[k] : (K)~(K)0;
         }
     }
     // the watchdog's sample of this pass: tile (watch mod live tiles), round (watch / live tiles) mod ITEMS
