@@ -1507,8 +1507,11 @@ struct gs_renderer {
     uint64_t full_pairs = 0;
     uint32_t full_pairs_v = 0, rounds_epoch = 0, rounds_fb_gen = 0;
     uint8_t done_rounds[2] = {1, 1};
+    uint32_t done_round_k[2] = {0, 0};
     float round_scale = 1.0f;
     bool rounds_off = false;
+    uint64_t round_cap = 0;               // the pair bound the last two-round frame used for its grids (0: the buffers' capacity)
+    uint32_t round_cap_k = 0;             // ... and the length of round 1 it was measured with
     bool auto_deep = false;               // the renderer's last own choice (kept while no report is available)
     uint64_t auto_k = 0;
     bool wt_pairs = true;                 // k_pairs_emit stores write-through (gs::store16)
@@ -2657,7 +2660,7 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
     uint64_t hist_d[2] = {0, 0};
     uint32_t hist_gen[2] = {0, 0};
     uint32_t hist_v[2] = {0, 0};
-    uint32_t hist_bmax[2] = {0, 0}, hist_tmax[2] = {0, 0}, hist_tdone[2] = {0, 0}, hist_topen[2] = {0, 0};
+    uint32_t hist_bmax[2] = {0, 0}, hist_tmax[2] = {0, 0}, hist_tdone[2] = {0, 0}, hist_topen[2] = {0, 0}, hist_rmax[2] = {0, 0};
     for (int i = 0; i < 2; i++) {
         if (frame_event) {
             if (!r->done_valid[i] || hipEventQuery(r->done[i]) != hipSuccess) continue;
@@ -2671,7 +2674,7 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
         const uint64_t f_pairs = fr.pairs_total;
         const uint32_t f_vis = fr.visible;
         const uint32_t f_flags = fr.flags;
-        const uint32_t f_bmax = fr.depth_bucket_max, f_tmax = fr.tile_bucket_max, f_tdone = fr.tiles_done, f_topen = fr.tiles_open;
+        const uint32_t f_bmax = fr.depth_bucket_max, f_tmax = fr.tile_bucket_max, f_tdone = fr.tiles_done, f_topen = fr.tiles_open, f_rmax = fr.round_pairs_max;
         if (__atomic_load_n(&fr.gen, __ATOMIC_ACQUIRE) != r->done_gen[i] || f_pairs > 0xfffffff0ull) continue;
         hist_d[i] = f_pairs;
         hist_gen[i] = r->done_gen[i];
@@ -2680,6 +2683,7 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
         hist_tmax[i] = f_tmax;
         hist_tdone[i] = f_tdone;
         hist_topen[i] = f_topen;
+        hist_rmax[i] = f_rmax;
         if (f_flags & gs::FRAME_FLAG_RANK_FAULT) rank_fault_seen = true;
         // grow when the last measured D leaves less than 1/8 of head room
         if (f_pairs + f_pairs / 8 > r->pair_capacity && capacity_for(f_pairs) > want_capacity)
@@ -2796,6 +2800,7 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
             r->done_gen[gen & 1u] = gen;
             r->done_shape[gen & 1u] = r->shape_epoch;
             r->done_rounds[gen & 1u] = r->two_round ? 2 : 1;
+            r->done_round_k[gen & 1u] = r->two_round ? r->round1 : 0u;
         }
     } done_guard{r, st, gen, frame_event};
     gs::FrameState *state = (gs::FrameState *)r->state.ptr;
@@ -3079,7 +3084,25 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
         }
         if (!(r->shape == shape)) r->shape_epoch++;
         r->shape = shape;
-        const uint32_t capacity = (uint32_t)r->pair_capacity;
+        // A two-round frame sizes its grids — and bounds each round — by what a ROUND emitted last time, not by the single-round
+        // pair count that sized the buffers (50 M: 3 M pairs per round in buffers for 150 M: the emission's and the tile sort's
+        // 37 000 mostly empty workgroups cost 20-40 us per kernel): twice the larger round of the newest two-round report, with
+        // the usual head room.  A round that still outgrows it skips the frame like any pair overflow (the next one has the
+        // report); the first two-round frame of a shape, and any frame without a report, use the buffers' capacity.
+        uint32_t capacity = (uint32_t)r->pair_capacity;
+        if (two_round) {
+            const int newer = hist_gen[0] > hist_gen[1] ? 0 : 1;
+            uint64_t want = 0;
+            // (only a report of a frame whose round 1 was as long as this one's says anything about this frame's rounds)
+            if (!sizing && hist_gen[newer] && r->done_shape[newer] == r->shape_epoch && r->done_rounds[newer] == 2 && hist_rmax[newer] &&
+                r->done_round_k[newer] == round_k)
+                want = capacity_for(2ull * hist_rmax[newer]);
+            else if (!sizing && !hist_gen[newer] && r->round_cap && r->round_cap_k == round_k)
+                want = r->round_cap;          // frames in flight: the last bound stands
+            if (want && want < capacity) capacity = (uint32_t)want;
+            r->round_cap = want;
+            r->round_cap_k = round_k;
+        }
         mark(ST_DSORT);
 
         // ---- depth sort of the visible Gaussians; its first pass reads the dense per-slot keys and

@@ -258,7 +258,8 @@ struct FrameResult {
                                  // runs behind the kernel that publishes this block); 0 = that frame's tile sort was LSD
     uint32_t tiles_done;         // two-round frames: tiles finished by round 1 (feeds the host's choice of round 1's length)
     uint32_t tiles_open;         // ... tiles round 1 had pairs for and did not finish
-    uint32_t pad[3];
+    uint32_t round_pairs_max;    // ... the larger of the two rounds' pair counts (what the next two-round frame's grids are sized for)
+    uint32_t pad[2];
 };
 
 // One thread publishes a frame's result to pinned host memory.  `gen` goes LAST, behind a
@@ -267,7 +268,8 @@ struct FrameResult {
 // also finds that generation's counts.
 __device__ __forceinline__ void publish_result(FrameResult *r, uint32_t visible, uint64_t pairs_total, uint32_t flags,
                                                uint32_t gen, uint32_t *flags_dev = nullptr, uint32_t depth_bucket_max = 0u,
-                                               uint32_t tile_bucket_max = 0u, uint32_t tiles_done = 0u, uint32_t tiles_open = 0u) {
+                                               uint32_t tile_bucket_max = 0u, uint32_t tiles_done = 0u, uint32_t tiles_open = 0u,
+                                               uint32_t round_pairs_max = 0u) {
     // optional copy of the flags in DEVICE memory (gs_renderer_set_frame_flags_target): a sharded frame
     // carries it inside its band's gather chunk, so every rank learns from the one all-gather whether
     // any band was skipped
@@ -279,6 +281,7 @@ __device__ __forceinline__ void publish_result(FrameResult *r, uint32_t visible,
     r->tile_bucket_max = tile_bucket_max;
     r->tiles_done = tiles_done;
     r->tiles_open = tiles_open;
+    r->round_pairs_max = round_pairs_max;
     __hip_atomic_store(&r->gen, gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
@@ -2969,7 +2972,8 @@ __device__ __forceinline__ void publish_pairs(const ExpandIO &io, uint64_t d) {
     const uint64_t total = d + (io.round == 2u ? (uint64_t)io.state->pairs_round1 : 0ull);
     publish_result(io.result, io.state->visible, total,
                    (over ? FRAME_FLAG_PAIR_OVERFLOW | FRAME_FLAG_SKIPPED : 0u) | (io.state->rank_fault ? FRAME_FLAG_RANK_FAULT : 0u), io.gen,
-                   io.flags_dev, io.state->depth_bucket_max, io.state->tile_bucket_max, io.round == 2u ? io.state->tiles_done : 0u, io.round == 2u ? io.state->tiles_open : 0u);
+                   io.flags_dev, io.state->depth_bucket_max, io.state->tile_bucket_max, io.round == 2u ? io.state->tiles_done : 0u, io.round == 2u ? io.state->tiles_open : 0u,
+                   io.round == 2u ? (d > (uint64_t)io.state->pairs_round1 ? (d > 0xffffffffull ? 0xffffffffu : (uint32_t)d) : io.state->pairs_round1) : 0u);
 }
 
 // Grid: sb_bound workgroups of EXP_SB threads.  Workgroup 0 also publishes D (clamped to the pair
