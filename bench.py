@@ -329,6 +329,7 @@ def run_workload(gs, synth, torch, dist, dev, stream, rank, world, wl, steps, wa
         raise RuntimeError("bench.py: a frame was skipped or flagged (per-band flags %s; bit 0/1 = pair capacity exceeded / "
                            "skipped, bit 2 = radix rank watchdog): the timed region did not render every frame" % skipped_bands)
     checksum = float(img[:H].double().sum().item())
+    fr = r.wait_frame()          # the LAST frame's result: its launches are a steady-state frame's (two rounds take ~36, the sizing frame 20)
     visible, pairs = int(st.visible), int(st.pairs)
     if world > 1:   # totals over the bands
         t = torch.tensor([pairs], dtype=torch.float64, device="cuda")
