@@ -103,6 +103,21 @@ def test_two_rounds_with_and_without_tile_masks(gs, ob, device, stream, masks, s
         assert fr2.pairs < fr1.pairs
 
 
+@pytest.mark.parametrize("W,H", [(240, 160), (387, 144), (16, 16)])
+def test_two_rounds_on_small_images(gs, ob, device, stream, W, H):
+    """150 / 225 / 1 tiles: a tile sort of ONE pass (or none) leaves the sorted pairs on the other side of its ping-pong
+    buffers than the two passes of the larger tests (found by tools/soak_rounds.py: round 1's blend read the side the
+    PREVIOUS frame had left its pairs on)."""
+    g = _deep_scene(60000, first=123, scale=1.5)
+    pod, pods, ogt, omt, ocam, gt, mt, cam = _setup(gs, ob, g, W, H, gs.SH_NONE, gs.COV3D_ROT_SCALE)
+    buf = gs.GaussiansBuffer.new_with_pods(device, pod, pods)
+    want = ob.render(gs.SH_NONE, gs.COV3D_ROT_SCALE, pods, ogt, omt, ocam, order=buf.download_order(stream))[0]
+    for k in (2048, 16384):
+        r2, fr2, two = _render(gs, device, stream, buf, gt, mt, cam, k, frames=3)
+        assert r2.sort_info().rounds == 2
+        assert np.array_equal(two.view(np.uint32), want.view(np.uint32)), "K = %d" % k
+
+
 def test_two_rounds_in_a_band_and_over_several_frames(gs, ob, device, stream):
     """a rank's band (tile rows 5..14) and the steady state: frames 2.. size their first round from the previous frame's
     visible count (first_round = 0)"""

@@ -3317,6 +3317,7 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
                 GS_HIP(hipGetLastError());
                 r->launches++;
             }
+            r->tsorted_side = tside;          // (launch_blend reads the pairs of THIS round: round 1's blend runs before the frame ends)
             return GS_OK;
         };
         if (!capacity) two_round = false;
