@@ -118,6 +118,32 @@ def test_two_rounds_on_small_images(gs, ob, device, stream, W, H):
         assert np.array_equal(two.view(np.uint32), want.view(np.uint32)), "K = %d" % k
 
 
+def test_round_2_is_skipped_when_round_1_finishes_every_tile(gs, ob, device, stream):
+    """k_round2_gate: a view the scene covers with opaque splats — after a long enough round 1 all 920 tiles are finished,
+    round 2's kernels return at once (the frame's pair count is round 1's) and the image is still the oracle's; one tile
+    short of that, round 2 runs."""
+    g = _deep_scene(150000, first=31, opacity=255, scale=5.0)
+    W, H = 640, 360
+    pod, pods, ogt, omt, ocam, gt, mt, cam = _setup(gs, ob, g, W, H, gs.SH_NONE, gs.COV3D_ROT_SCALE)
+    buf = gs.GaussiansBuffer.new_with_pods(device, pod, pods)
+    want = ob.render(gs.SH_NONE, gs.COV3D_ROT_SCALE, pods, ogt, omt, ocam, order=buf.download_order(stream))[0]
+    seen = set()
+    for k in (8192, 32768, 65536):
+        r2, fr2, two = _render(gs, device, stream, buf, gt, mt, cam, k, frames=3)
+        si = r2.sort_info()
+        assert si.rounds == 2
+        assert np.array_equal(two.view(np.uint32), want.view(np.uint32)), "K = %d" % k
+        seen.add(si.tiles_done == 40 * 23)
+        if si.tiles_done == 40 * 23:
+            # everything round 2 could have emitted was dropped
+            one = gs.Renderer(device)
+            one.set_rounds(0)
+            img = gs.Buffer(device, size=W * H * 16)
+            one.render(stream, buf, gt, mt, cam, img.device_ptr())
+            assert fr2.pairs < one.wait_frame().pairs
+    assert seen == {False, True}, "the scene must finish every tile for the longest round 1 only: %s" % seen
+
+
 def test_two_rounds_in_a_band_and_over_several_frames(gs, ob, device, stream):
     """a rank's band (tile rows 5..14) and the steady state: frames 2.. size their first round from the previous frame's
     visible count (first_round = 0)"""

@@ -3111,7 +3111,7 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
         uint32_t dpasses = 0;
         // pred: which Gaussians the compacting first pass takes (all visible ones; or one side of a partitioned frame's
         // threshold); their count goes to *visible_out
-        auto depth_sort = [&](const gs::CompactPred &pred, uint32_t *visible_out) -> gs_status {
+        auto depth_sort = [&](const gs::CompactPred &pred, uint32_t *visible_out, const uint32_t *dense_dev = nullptr) -> gs_status {
             void *k2[2] = {r->dkeys[0].ptr, r->dkeys[1].ptr};
             void *v2[2] = {r->dvals[0].ptr, r->dvals[1].ptr};
             SortCompact cp;
@@ -3119,7 +3119,8 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
             cp.chunk_vis = (const uint32_t *)r->chunk_vis.ptr;
             cp.visible_out = visible_out;
             cp.dense_count = n;
-            cp.dense_count_dev = r->list_mode ? &state->list_slots : nullptr;   // list frame: only the surviving blocks' slots
+            // list frame: only the surviving blocks' slots; round 2 of a partitioned frame: none when the gate found nothing left
+            cp.dense_count_dev = dense_dev ? dense_dev : r->list_mode ? &state->list_slots : nullptr;
             // (a partitioned frame's chunk rows count the top digit of ALL visible keys: its passes count their own)
             cp.chunk_hist = pred.tau_dev ? nullptr : (const uint32_t *)r->chunk_hist.ptr;
             const gs::SortCount dc{n, visible_out};
@@ -3358,9 +3359,11 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
                                                       {gs::k_round2_slot_bits<true, false>, gs::k_round2_slot_bits<true, true>}};
                     GS_TRY(dev_reserve(r->box_table, ((size_t)num_tiles + 8) * 2));
                     ro.box_table = (const uint16_t *)r->box_table.ptr;
+                    hipLaunchKernelGGL(gs::k_round2_gate, dim3(1), dim3(256), 0, st, ro, band_tiles, n,
+                                       r->list_mode ? (const uint32_t *)&state->list_slots : (const uint32_t *)nullptr);
                     hipLaunchKernelGGL(gs::k_round2_box_table, dim3((num_tiles + 255u) / 256u), dim3(256), 0, st, (const uint32_t *)done_bits,
-                                       (uint16_t *)r->box_table.ptr, fc.tiles_x, fc.tiles_y);
-                    r->launches++;
+                                       (uint16_t *)r->box_table.ptr, fc.tiles_x, fc.tiles_y, (const gs::FrameState *)state);
+                    r->launches += 2;
                     const bool lds = num_tiles <= gs::R2_LDS_TILES;
                     const size_t lds_bytes = lds ? ((size_t)num_tiles + 7) / 8 * 16 : 0;
                     const uint32_t persistent = bits_grid < 1024u ? bits_grid : 1024u;      // (4 / 2 workgroups per CU at 1080p / 4K)
@@ -3374,9 +3377,7 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
                     pred2.tau_dev = &state->depth_tau;
                     pred2.keep_bits = (const uint32_t *)r->keep_bits.ptr;
                     pred2.side = 1u;
-                    GS_TRY(depth_sort(pred2, &state->round2_visible));
-                    hipLaunchKernelGGL(gs::k_round2_tiles, dim3(1), dim3(256), 0, st, ro);
-                    r->launches++;
+                    GS_TRY(depth_sort(pred2, &state->round2_visible, &state->round2_dense));
                 } else {
                     GS_TRY(dev_reserve(r->r2_scan, (size_t)ro.groups * (2 * 4 + 32 * 8) + 64));
                     ro.masks = (unsigned long long *)r->r2_scan.ptr;

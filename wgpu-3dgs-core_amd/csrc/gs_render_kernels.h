@@ -236,6 +236,8 @@ struct FrameState {
     uint32_t round2_visible;     // ... the Gaussians k_round2_write kept for round 2
     uint32_t tiles_done;         // ... tiles round 1 finished (counted by k_round2_count; 0 in a single-round frame)
     uint32_t tiles_open;         // ... tiles round 1 left unfinished although it had pairs for them
+    uint32_t round2_skip;        // ... 1: round 1 finished EVERY tile of the band — round 2 has nothing to do (k_round2_gate)
+    uint32_t round2_dense;       // ... slots the compacting pass of round 2's depth sort walks (0 when round 2 is skipped)
     uint32_t round1_visible;     // partitioned two-round frames: the Gaussians in front of the depth threshold (round 1 sorts only them)
     uint32_t depth_tau;          // ... the threshold: round 1 = keys < tau, round 2 = keys >= tau (k_round_threshold)
     uint32_t depth_bucket_max;   // largest top-digit bucket of the depth sort (k_bucket_sort, or the LSD sort's last pass)
@@ -1539,7 +1541,8 @@ constexpr uint32_t R2_LDS_TILES = 32768;                      // ... tiles whose
 // Per tile t, nine bits: bit (h - 1) * 3 + (w - 1) = "every tile of the w x h box whose origin is t is finished" (tiles
 // past the image edge count as finished: no rect reaches them).  One thread per tile; 16 bits per tile.
 __global__ __launch_bounds__(256) void k_round2_box_table(const uint32_t *__restrict__ done, uint16_t *__restrict__ table,
-                                                          uint32_t tiles_x, uint32_t tiles_y) {
+                                                          uint32_t tiles_x, uint32_t tiles_y, const FrameState *state) {
+    if (state->round2_skip) return;
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     if (t >= tiles_x * tiles_y) return;
     const uint32_t x0 = t % tiles_x, y0 = t / tiles_x;
@@ -1573,6 +1576,7 @@ __global__ __launch_bounds__(256) void k_round2_slot_bits(Round2IO io) {
     // table is copied a few hundred times per frame, not once per 2048 slots)
     extern __shared__ __attribute__((aligned(16))) uint16_t s_table[];
     const uint32_t lane = threadIdx.x & 63u;
+    if (io.state->round2_skip) return;
     if constexpr (LDS) {
         const uint4 *src = (const uint4 *)io.box_table;
         uint4 *dst = (uint4 *)s_table;
@@ -1623,7 +1627,6 @@ __global__ __launch_bounds__(256) void k_round2_slot_bits(Round2IO io) {
 // counts into offsets and the total (FrameState::round2_visible); k_round2_write places the slots.  (A single pass with a
 // decoupled look-back over one status word per group was 325 us at 50 M: the 2048 resident workgroups finish together,
 // so every one of them walks back over ~2000 words, 64 per dependent round trip, before it meets an inclusive prefix.)
-// Workgroup 0 of the count kernel also counts the tiles round 1 finished (::tiles_done) for the host.
 // tiles finished by round 1, and tiles it had pairs for and left open (bits past the last tile are never set): one
 // workgroup of 256 threads, for the host's feedback (FrameState::tiles_done / tiles_open)
 __device__ __forceinline__ void round2_count_tiles(const Round2IO &io, uint32_t *s_cnt, uint32_t *s_open) {
@@ -1647,9 +1650,13 @@ __device__ __forceinline__ void round2_count_tiles(const Round2IO &io, uint32_t 
 }
 
 __global__ __launch_bounds__(256) void k_round2_count(Round2IO io) {
-    __shared__ uint32_t s_cnt[4], s_open[4];
+    __shared__ uint32_t s_cnt[4];
     const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
     const uint32_t g = blockIdx.x;
+    if (io.state->round2_skip) {          // (k_round2_gate) nothing is left: count 0, no ballots
+        if (threadIdx.x == 0u) io.counts[g] = 0u;
+        return;
+    }
     const uint32_t v = io.state->visible;
     const uint32_t count = v > io.first ? v - io.first : 0u;
     const uint64_t j0 = (uint64_t)g * R2_GROUP + threadIdx.x;
@@ -1673,19 +1680,25 @@ __global__ __launch_bounds__(256) void k_round2_count(Round2IO io) {
     if (lane == 0u) s_cnt[wid] = mine;
     __syncthreads();
     if (threadIdx.x == 0u) io.counts[g] = (s_cnt[0] + s_cnt[1]) + (s_cnt[2] + s_cnt[3]);
-    if (g == 0u) {
-        __syncthreads();
-        round2_count_tiles(io, s_cnt, s_open);
+}
+
+// The gate of round 2, one workgroup, right behind round 1's blend: counts the tiles (FrameState::tiles_done / tiles_open, for
+// the host's feedback) and — when round 1 finished EVERY tile of the band, as it does for a view the scene covers —
+// declares round 2 empty: the box table, the slot bits and the compaction return at once, round 2's Gaussian count
+// comes out as 0 and every kernel behind it exits on that count (10 M: ~110 us of round 2 become ~13 empty launches).
+__global__ __launch_bounds__(256) void k_round2_gate(Round2IO io, uint32_t band_tiles, uint32_t dense, const uint32_t *dense_dev) {
+    __shared__ uint32_t s_cnt[4], s_open[4];
+    round2_count_tiles(io, s_cnt, s_open);
+    if (threadIdx.x == 0u) {
+        const uint32_t done = (s_cnt[0] + s_cnt[1]) + (s_cnt[2] + s_cnt[3]);
+        const uint32_t skip = done == band_tiles ? 1u : 0u;
+        io.state->round2_skip = skip;
+        io.state->round2_dense = skip ? 0u : (dense_dev ? *dense_dev : dense);
     }
 }
 
-// the same count for a partitioned frame (whose round 2 is compacted by its depth sort): one workgroup
-__global__ __launch_bounds__(256) void k_round2_tiles(Round2IO io) {
-    __shared__ uint32_t s_cnt[4], s_open[4];
-    round2_count_tiles(io, s_cnt, s_open);
-}
-
 __global__ __launch_bounds__(256) void k_round2_write(Round2IO io) {
+    if (io.state->round2_skip) return;
     const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
     const uint32_t g = blockIdx.x;
     const uint32_t v = io.state->visible;
