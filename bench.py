@@ -345,7 +345,8 @@ def run_workload(gs, synth, torch, dist, dev, stream, rank, world, wl, steps, wa
     si = r.sort_info()      # what the renderer chose for this workload
     out["sort_info"] = dict(depth_msd=int(si.depth_msd), depth_bucket_max=int(si.depth_bucket_max),
                             bucket_capacity=int(si.bucket_capacity), tile_msd=int(si.tile_msd), tile_masks=int(si.tile_masks),
-                            rounds=int(si.rounds), round1=int(si.round1), tiles_done=int(si.tiles_done))
+                            rounds=int(si.rounds), round1=int(si.round1), tiles_done=int(si.tiles_done),
+                            partitioned=int(si.partitioned))
     if samples:
         out["frame_ms"] = dict(samples=len(samples), median=samples[len(samples) // 2], min=samples[0],
                                p95=samples[min(len(samples) - 1, int(0.95 * len(samples)))], max=samples[-1],
@@ -425,6 +426,11 @@ def stage_models(wl, res):
         # round 1's expansion, tile sort and ranges, and "blend" holds round 1's blend + the whole of round 2.  The byte
         # models above describe one pass over V and D and do not apply; preprocess and depth sort are unchanged.
         si = res["sort_info"]
+        if si.get("partitioned"):
+            # each round's depth sort takes only its side of a depth threshold: the stage is the threshold + round 1's sort
+            models.pop("depth_sort", None)
+            out["depth_sort"] = dict(bound="two_rounds", ms=st["depth_sort"], note="threshold + the sort of round 1's %d Gaussians only "
+                                     "(first pass streams the N dense keys); round 2's sort is part of `blend`" % si["round1"])
         for k in ("expand", "tile_sort", "ranges"):
             models.pop(k, None)
             out[k] = dict(bound="two_rounds", ms=st[k], note="round 1 only (the nearest %d visible Gaussians)" % si["round1"])

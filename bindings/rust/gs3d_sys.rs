@@ -253,7 +253,7 @@ pub struct gs_sort_info {
     pub rounds: u32,
     pub round1: u32,
     pub tiles_done: u32,
-    pub reserved: u32,
+    pub partitioned: u32,
 }
 
 #[link(name = "gs3d_hip")]

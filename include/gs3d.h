@@ -650,7 +650,7 @@ typedef struct gs_sort_info {
     uint32_t rounds;             /* rounds the last frame took: 1, or 2 (gs_renderer_set_rounds) */
     uint32_t round1;             /* two rounds: the nearest visible Gaussians its first round covered */
     uint32_t tiles_done;         /* two rounds: tiles the first round finished (every pixel at its final colour) */
-    uint32_t reserved;
+    uint32_t partitioned;        /* two rounds: 1 = each round sorted only its own side of a depth threshold */
 } gs_sort_info;
 gs_status gs_renderer_sort_info(gs_renderer *r, gs_sort_info *out);
 /* Pins the choice for the following frames: 1 MSD-first, 0 LSD passes, -1 the renderer chooses (default; the

@@ -49,7 +49,7 @@ class FrameResult(C.Structure):
 
 class SortInfo(C.Structure):
     _fields_ = [("depth_msd", u32), ("depth_bucket_max", u32), ("bucket_capacity", u32), ("tile_msd", u32),
-                ("tile_bucket_max", u32), ("tile_masks", u32), ("rounds", u32), ("round1", u32), ("tiles_done", u32), ("reserved", u32)]
+                ("tile_bucket_max", u32), ("tile_masks", u32), ("rounds", u32), ("round1", u32), ("tiles_done", u32), ("partitioned", u32)]
 
 
 class BundleDesc(C.Structure):

@@ -1497,6 +1497,7 @@ struct gs_renderer {
     int tile_masks_req = -1;              // gs_renderer_set_tile_masks
     bool tile_masks = false;              // the last frame ran tile rect version 4
     bool two_round = false;               // the last frame took two rounds (its taps hold round 2 only)
+    bool partitioned = false;             // ... and sorted each round on its own (gs_sort_info)
     int rounds_req = -1;                  // gs_renderer_set_rounds: -1 the renderer decides, 0 one round, 1 two
     uint32_t round1_req = 0;              // ... Gaussians of round 1 (0: a quarter of the visible ones)
     uint32_t round1 = 0;                  // Gaussians the last two-round frame's first round covered
@@ -1513,6 +1514,7 @@ struct gs_renderer {
     uint64_t round_cap = 0;               // the pair bound the last two-round frame used for its grids (0: the buffers' capacity)
     uint32_t round_cap_k = 0;             // ... and the length of round 1 it was measured with
     bool auto_deep = false;               // the renderer's last own choice (kept while no report is available)
+    bool auto_all_done = false;           // the newest two-round report of this shape: round 1 finished every tile (round 2 was skipped)
     uint64_t auto_k = 0;
     bool wt_pairs = true;                 // k_pairs_emit stores write-through (gs::store16)
     uint64_t tile_msd_fail_d = 0;         // pair count at which the MSD-first tile sort last reported an oversized bucket (0: never)
@@ -1771,6 +1773,7 @@ extern "C" gs_status gs_renderer_sort_info(gs_renderer *r, gs_sort_info *out) {
     out->rounds = r->two_round ? 2u : 1u;
     out->round1 = r->two_round ? r->round1 : 0u;
     out->tiles_done = r->two_round && fr.gen == r->gen ? fr.tiles_done : 0u;
+    out->partitioned = r->two_round && r->partitioned ? 1u : 0u;
     if (r->tile_msd && r->state.ptr)      // (the result block carries the PREVIOUS frame's: read this frame's from the device)
         GS_HIP(hipMemcpy(&out->tile_bucket_max, &((gs::FrameState *)r->state.ptr)->tile_bucket_max, sizeof(uint32_t), hipMemcpyDeviceToHost));
     return GS_OK;
@@ -2738,6 +2741,15 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
         GS_TRY(dev_reserve(r->dkeys[i], nn * 4));
         GS_TRY(dev_reserve(r->dvals[i], (nn + 1024) * 4));
     }
+    {
+        // The sorts' histogram rows and digit totals at the largest size any depth pass of this scene may ask for (the top-digit
+        // histogram of an MSD-first sort or of a partitioned two-round frame: 1024 rows): reserved HERE, in the frame that sizes
+        // the scene, because growing them later means a hipFree under frames in flight — a device-wide wait at best (and under
+        // rocprofv3 --pmc the 10 M bench hung in it: the first partitioned frame doubled `ghist` behind eight queued frames).
+        const size_t depth_tile = (size_t)gs::SORT_THREADS * (n >= (4u << 20) ? gs::SortCfg<uint32_t>::ITEMS_LARGE : gs::SortCfg<uint32_t>::ITEMS);
+        GS_TRY(dev_reserve(r->ghist, ((size_t)nn + depth_tile - 1) / depth_tile * ((size_t)4 << gs::MSD_TOP_BITS)));
+        GS_TRY(dev_reserve(r->digit_totals, (size_t)4 << gs::MSD_TOP_BITS));
+    }
     const uint32_t exp_grid = (n + gs::EXP_CHUNK - 1) / gs::EXP_CHUNK;   // V <= N
     GS_TRY(dev_reserve(r->exp_sums, (size_t)(exp_grid ? exp_grid : 1) * 4));
     GS_TRY(reserve_zeroed(r->state, sizeof(gs::FrameState), st));
@@ -2943,13 +2955,27 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
     // first pass takes only its side of the boundary (gs::CompactPred) — sorts what that round renders: the nearest ones,
     // then what k_round2_slot_bits keeps of the rest.  Otherwise round 2 is compacted out of the full depth order
     // (k_round2_count / _write).
-    // Measured (same-box A/B, gpurun_out/r05t/ab3.txt): 50 M 2.42 against 2.53 ms (depth-sort stage 0.318 against 0.462: a
-    // threshold + two sorts whose first pass streams the 200 MB of dense keys for 1-2 M survivors, against one full sort +
-    // the compaction), 10 M 0.908 against 0.865 (two first passes of ~50 us each at their launch-bound floors cost more than
-    // the full sort of 7 M keys saves) — so from 32 M Gaussians; GS3D_ROUND_PARTITION=0/1 forces.
+    // Measured, same-box A/B.  With a round 2 that runs (gpurun_out/r05t/ab3.txt): 50 M 2.42 against 2.53 ms (depth-sort stage
+    // 0.318 against 0.462: a threshold + two sorts whose first pass streams the 200 MB of dense keys for 1-2 M survivors,
+    // against one full sort + the compaction), 10 M 0.908 against 0.865 (two first passes of ~50 us each at their launch-bound
+    // floors cost more than the full sort of 7 M keys saves).  With a round 2 that k_round2_gate skips — round 1 finished every
+    // tile — only round 1's sort remains (gpurun_out/r05x/ab_part.txt): 10 M 0.806 against 0.817, 4K 1.29 against 1.32, 50 M 2.00
+    // against 2.15.  So: from 32 M Gaussians, or when the newest two-round report of this shape says that round 1 finished
+    // every tile (kept while no report is available); GS3D_ROUND_PARTITION=0/1 forces.
     static const int partition_env = std::getenv("GS3D_ROUND_PARTITION") ? std::atoi(std::getenv("GS3D_ROUND_PARTITION")) : -1;
+    bool partition_auto = n >= (32u << 20);
+    {
+        const int newer = hist_gen[0] > hist_gen[1] ? 0 : 1;
+        if (!sizing && hist_gen[newer] && r->done_shape[newer] == r->shape_epoch) {
+            if (r->done_rounds[newer] == 2) r->auto_all_done = hist_tdone[newer] == band_tiles && hist_topen[newer] == 0u;
+        } else if (sizing) {
+            r->auto_all_done = false;
+        }
+        partition_auto = partition_auto || r->auto_all_done;
+    }
     const bool partition = two_round && !sizing && dbits > (uint32_t)gs::MSD_TOP_BITS && n < (1u << 30) &&
-                           (partition_env >= 0 ? partition_env != 0 : n >= (32u << 20));
+                           (partition_env >= 0 ? partition_env != 0 : partition_auto);
+    r->partitioned = partition;
     if (partition) {
         depth_msd = false;
         r->depth_msd = false;
@@ -3379,7 +3405,7 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
                     pred2.side = 1u;
                     GS_TRY(depth_sort(pred2, &state->round2_visible, &state->round2_dense));
                 } else {
-                    GS_TRY(dev_reserve(r->r2_scan, (size_t)ro.groups * (2 * 4 + 32 * 8) + 64));
+                    GS_TRY(dev_reserve(r->r2_scan, ((size_t)nn / gs::R2_GROUP + 1) * (2 * 4 + 32 * 8) + 64));      // (its largest size: never regrown under frames in flight)
                     ro.masks = (unsigned long long *)r->r2_scan.ptr;
                     ro.counts = (uint32_t *)(ro.masks + (size_t)ro.groups * 32);
                     ro.offsets = ro.counts + ro.groups;
