@@ -2920,11 +2920,13 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
         const double d_full = r->full_pairs_v ? (double)r->full_pairs * (double)v_est / (double)r->full_pairs_v : (double)r->full_pairs;
         // The renderer's own choice.  Measured (same-box A/B, gpurun_out/r05r): 10 M at 1080p (2 970 pairs per tile) -9 %,
         // at 4K (1 716) -8 %, 50 M (14 800) -24 %; the 1 M scene (296 pairs per tile) finishes its tiles only at the end of
-        // their lists.  Round 1 is given ~400 pairs per tile — the frames above are within 1 % of their best from half to
-        // twice that — and a frame takes two rounds when that is at most a third of its Gaussians and the pairs to save
-        // outweigh the dozen launches of a second round.
+        // their lists.  Round 1 is given ~250 pairs per tile: the bench scenes finish EVERY tile from ~170 on (k_round2_gate
+        // then skips round 2), and a shorter round 1 is a shorter tile sort (same-box sweep, gpurun_out/r05x/ab_k.txt: 10 M
+        // 0.813 / 0.801 / 0.790 / 0.786 ms at 400 / 270 / 210 / 170 pairs per tile, 50 M 2.07 / 2.06 / 2.02 / 2.02) — and a frame
+        // takes two rounds when that is at most a third of its Gaussians and the pairs to save outweigh the launches of a
+        // second round.  The feedback below lengthens a round 1 that turns out too short.
         const double per_tile = d_full / (double)band_tiles;
-        double k_auto = per_tile > 0.0 ? (double)v_est * 400.0 / per_tile * (double)r->round_scale : 0.0;
+        double k_auto = per_tile > 0.0 ? (double)v_est * 250.0 / per_tile * (double)r->round_scale : 0.0;
         if (have && r->done_rounds[newer] == 2 && hist_gen[newer] != r->rounds_fb_gen) {
             // feedback: a round 1 that finishes less than 60 % of the tiles it has pairs for was too short (or the scene
             // does not occlude)
@@ -2932,6 +2934,10 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
             if ((uint64_t)hist_tdone[newer] * 10u < ((uint64_t)hist_tdone[newer] + hist_topen[newer]) * 6u) {
                 r->round_scale *= 1.5f;
                 if (r->round_scale > 3.4f) r->rounds_off = true;
+            } else if (hist_topen[newer] != 0u && (uint64_t)hist_topen[newer] * 10u <= (uint64_t)hist_tdone[newer] + hist_topen[newer] &&
+                       r->round_scale < 2.7f) {
+                // nearly there (at most a tenth of the tiles with pairs left open): a little longer and round 2 is skipped
+                r->round_scale *= 1.25f;
             }
         }
         bool deep = have && !r->rounds_off && d_full >= 12.0e6 && per_tile >= 1200.0 && k_auto * 3.0 <= (double)v_est;
