@@ -155,12 +155,19 @@ def run_workload(gs, synth, torch, dist, dev, stream, rank, world, wl, steps, wa
         gbuf = par.allocate_gather(torch, plan, W, "cuda")
         plan_kind = "tile rows re-cut to equal pairs (one calibration frame)"
     fr = render(check=True)          # sizes the pair buffers for this band (blocking once)
+    # ... and a few frames the validated way: the renderer picks its sorts, its rounds and their bounds per frame from the
+    # reports of finished frames, which a viewer's loop has after a handful of frames; the W warm-up frames
+    # that follow are enqueued without waiting and would otherwise start the timed region in the middle of that
+    SETTLE = 6
+    for _ in range(SETTLE):
+        render(check=True)
     if world > 1:
         nl = max(1, min(int(frames_in_flight or 1), 2))
         if nl > 1:
             rank_lanes[0] = par.lanes(torch, gs, dev, nl, first_renderer=r)
-            for rr, gs_s, ts in rank_lanes[0][1:]:      # the sizing frame of every further renderer (blocking once each)
-                rr.render(gs_s, buf, gt, mt, cam, par.band_target_ptr(gbuf, plan, rank, W), band=plan.bands[rank], check=True)
+            for rr, gs_s, ts in rank_lanes[0][1:]:      # the sizing frame of every further renderer (blocking once each), and its settling
+                for _ in range(1 + SETTLE):
+                    rr.render(gs_s, buf, gt, mt, cam, par.band_target_ptr(gbuf, plan, rank, W), band=plan.bands[rank], check=True)
             torch.cuda.synchronize()
         pipe[0] = par.FramePipeline(torch, dist, plan, rank, W, "cuda", depth=nl + 1)
         band_flags[0] = torch.zeros(world, dtype=torch.int32, device="cuda")
