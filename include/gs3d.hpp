@@ -462,6 +462,8 @@ class Renderer {
     // PairCapacityError when it exceeded the pair capacity (the next frame has larger buffers)
     gs_frame_result wait_frame() { gs_frame_result fr; check(gs_renderer_wait_frame(h_, &fr)); return fr; }
     gs_frame_stats stats() { gs_frame_stats st; check(gs_renderer_stats(h_, &st)); return st; }
+    // how the last frame sorted / how many rounds it took, and the pins of those per-frame choices (-1: the renderer decides;
+    // every setting renders the same image; gs3d.h has the details)
     gs_sort_info sort_info() { gs_sort_info si; check(gs_renderer_sort_info(h_, &si)); return si; }
     void set_sort_mode(int32_t depth_msd, int32_t tile_msd = -1) { check(gs_renderer_set_sort_mode(h_, depth_msd, tile_msd)); }
     void set_tile_masks(int32_t mode) { check(gs_renderer_set_tile_masks(h_, mode)); }
