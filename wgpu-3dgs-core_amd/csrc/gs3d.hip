@@ -1511,6 +1511,7 @@ struct gs_renderer {
     uint32_t done_round_k[2] = {0, 0};
     float round_scale = 1.0f;
     bool rounds_off = false;
+    uint32_t rounds_off_gen = 0;          // the frame that switched the rounds off (another try 512 frames later)
     uint64_t round_cap = 0;               // the pair bound the last two-round frame used for its grids (0: the buffers' capacity)
     uint32_t round_cap_k = 0;             // ... and the length of round 1 it was measured with
     bool auto_deep = false;               // the renderer's last own choice (kept while no report is available)
@@ -2933,12 +2934,20 @@ extern "C" gs_status gs_render_frame(gs_renderer *r, gs_stream *s, gs_gaussians_
             r->rounds_fb_gen = hist_gen[newer];
             if ((uint64_t)hist_tdone[newer] * 10u < ((uint64_t)hist_tdone[newer] + hist_topen[newer]) * 6u) {
                 r->round_scale *= 1.5f;
-                if (r->round_scale > 3.4f) r->rounds_off = true;
+                if (r->round_scale > 3.4f) {
+                    r->rounds_off = true;
+                    r->rounds_off_gen = r->gen;
+                }
             } else if (hist_topen[newer] != 0u && (uint64_t)hist_topen[newer] * 10u <= (uint64_t)hist_tdone[newer] + hist_topen[newer] &&
                        r->round_scale < 2.7f) {
                 // nearly there (at most a tenth of the tiles with pairs left open): a little longer and round 2 is skipped
                 r->round_scale *= 1.25f;
             }
+        }
+        if (r->rounds_off && r->gen - r->rounds_off_gen > 512u) {
+            // ... but not for ever: the camera may have moved into a view that does occlude; another try every 512 frames
+            r->rounds_off = false;
+            r->round_scale = 1.0f;
         }
         bool deep = have && !r->rounds_off && d_full >= 12.0e6 && per_tile >= 1200.0 && k_auto * 3.0 <= (double)v_est;
         if (!have && !sizing && r->rounds_epoch == r->shape_epoch) {
